@@ -1,0 +1,156 @@
+"""ctypes binding of libclx.so — the C ABI declared in ``include/clx.h``.
+
+There is deliberately NO fallback: if the library is missing, or a kernel entry
+point is called without a HIP device, an exception is raised.  The product
+path never computes on the CPU.
+"""
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_int, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclx.so")
+
+
+class ClxError(RuntimeError):
+    """A libclx entry point returned a negative status."""
+
+
+class ClxSrc(Structure):
+    """``clx_src`` (include/clx.h)."""
+
+    _fields_ = [
+        ("ptr", c_void_p),
+        ("C", c_int),
+        ("ld", c_int),
+        ("D", c_int),
+        ("H", c_int),
+        ("W", c_int),
+        ("oz", c_int),
+        ("oy", c_int),
+        ("ox", c_int),
+        ("fz", c_int),
+        ("fy", c_int),
+        ("fx", c_int),
+    ]
+
+
+class ClxConvDesc(Structure):
+    """``clx_conv_desc`` (include/clx.h)."""
+
+    _fields_ = [
+        ("nsrc", c_int),
+        ("src", ClxSrc * 2),
+        ("B", c_int),
+        ("ID", c_int),
+        ("IH", c_int),
+        ("IW", c_int),
+        ("KD", c_int),
+        ("KH", c_int),
+        ("KW", c_int),
+        ("PD", c_int),
+        ("PH", c_int),
+        ("PW", c_int),
+        ("N", c_int),
+        ("wpack", c_void_p),
+        ("bias", c_void_p),
+        ("relu", c_int),
+        ("mask", c_void_p),
+        ("ld_mask", c_int),
+        ("out", c_void_p),
+        ("ld_out", c_int),
+    ]
+
+
+_P = c_void_p
+_I = c_int
+_LL = c_longlong
+_D = c_double
+
+# name -> (restype, argtypes); mirrors include/clx.h one to one
+PROTOTYPES = {
+    "clx_last_error": (c_char_p, []),
+    "clx_abi_version": (_I, []),
+    "clx_device_count": (_I, []),
+    "clx_conv_fwd": (_I, [POINTER(ClxConvDesc), _P]),
+    "clx_conv_wgrad": (_I, [POINTER(ClxConvDesc), _P, _I, _P, _P, _P]),
+    "clx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
+    "clx_pixel_to_planar": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
+    "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_maxpool_bwd": (_I, [_P, _P, _P, _P] + [_I] * 7 + [_P] + [_I] * 8 + [_P]),
+    "clx_upsample_bwd": (_I, [_P] + [_I] * 8 + [_P, _P] + [_I] * 8 + [_P]),
+    "clx_gather_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_gather_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_oce_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _LL, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+    "clx_oce_pairs_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
+    "clx_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P]),
+    "clx_noise_stats": (_I, [_P, _P, _I, _I, _LL, _P]),
+    "clx_ms_prepare_workspace": (c_size_t, [_LL]),
+    "clx_ms_prepare": (_I, [_P, _P, _D, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "clx_ms_iterate": (_I, [_P, _I, _P, _I, _I, _D, _I, _P, _P, _P, _P]),
+    "clx_ms_assign": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "clx_cc_workspace": (c_size_t, [_LL]),
+    "clx_cc_label_filter": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "clx_edt_workspace": (c_size_t, [_LL]),
+    "clx_edt_sq": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "clx_grow_shrink": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "clx_minmax_f64": (_I, [_P, _LL, _P, _P]),
+    "clx_histogram_f64": (_I, [_P, _LL, _P, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libclx.so (once) and attach the prototypes. Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ClxError(
+            f"{LIB_PATH} is missing: build it with `python -m cellulus_amd._build` "
+            "(hipcc --offload-arch=gfx950). cellulus_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = load().clx_last_error().decode("utf-8", "replace")
+        raise ClxError(f"{what or 'libclx'} failed ({status}): {msg}")
+
+
+def stream_ptr(device=None):
+    """Raw hipStream_t of torch's current stream on `device`."""
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def require_device(t, name="tensor"):
+    if not t.is_cuda:
+        raise ClxError(
+            f"{name} lives on {t.device}: cellulus_amd kernels run on HIP devices only "
+            "(device strings 'cuda:N' denote HIP device N on ROCm); there is no CPU path."
+        )
+
+
+def call(name, *args):
+    fn = getattr(load(), name)
+    check(fn(*args), name)

@@ -1,0 +1,58 @@
+// Shared helpers for the libclx HIP sources (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/clx.h"
+
+void clx_set_error(const char* fmt, ...);
+
+#define CLX_REQUIRE(cond, ...)                \
+  do {                                        \
+    if (!(cond)) {                            \
+      clx_set_error(__VA_ARGS__);             \
+      return CLX_ERR_ARG;                     \
+    }                                         \
+  } while (0)
+
+#define CLX_CHECK_LAUNCH(name)                                           \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      clx_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return CLX_ERR_LAUNCH;                                             \
+    }                                                                    \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// n / d for 0 <= n < 2^31 with a host-prepared multiplier (Granlund–Montgomery
+// round-up form): q = (umulhi(m, n) + n) >> l.
+struct FastDiv {
+  uint32_t m, l, d;
+};
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  f.l = l;
+  f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+  return (__umulhi(f.m, n) + n) >> f.l;
+}
+
+// Bijective XCD-aware block remap: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give every XCD a contiguous range of virtual ids.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,292 @@
+// f32 MFMA implicit-GEMM convolution for gfx950 (forward and data gradient).
+//
+//   out[m][n] = act( sum_{tap, c} in[pix(m) (+) tap][c] * wpack[n][tap][c] + bias[n] )
+//
+// GEMM view: M = B*OD*OH*OW output pixels, N = output channels,
+// K = taps x Ctot.  A rows are gathered on the fly (valid / zero-padded conv,
+// optional crop offset and nearest upsample per source, two concatenated
+// sources), B rows are the K-contiguous packed weights.  Both tiles are staged
+// through LDS as [rows][32 + 4 pad] so every MFMA operand fragment is one
+// conflict-free ds_read_b128: lane (i = l&31, h = l>>5) reads k = 8q+4h..+3 of
+// row i and feeds the 4 components to 4 v_mfma_f32_32x32x2_f32 (the k order
+// inside a chunk is permuted identically for A and B, which a sum allows).
+//
+// Replaces nn.Conv{2,3}d(+ReLU) forward/backward-data of the reference U-Net
+// (cellulus/models/unet.py:24-63, funlib ConvPass) — exact f32 arithmetic.
+#include "clx_common.h"
+
+namespace {
+
+constexpr int BK = 32;       // K chunk (floats)
+constexpr int LDS_LD = 36;   // padded LDS row (floats): conflict-free b128 reads
+
+struct SrcP {
+  const float* ptr;
+  int C, ld, D, H, W, oz, oy, ox, fz, fy, fx;
+};
+
+struct ConvP {
+  int nsrc;
+  SrcP src[2];
+  int B, ID, IH, IW, KD, KH, KW, PD, PH, PW, OD, OH, OW;
+  int N, M, Ctot, Ktot;
+  FastDiv dOW, dOH, dOD;
+  const float* wpack;
+  const float* bias;
+  const float* mask;
+  float* out;
+  int relu, ld_mask, ld_out;
+  int nbm, nbn;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
+  constexpr int TM = BM / WAVES_M / 32;
+  constexpr int TN = BN / WAVES_N / 32;
+  constexpr int A_PASSES = BM / 32;
+  constexpr int B_PASSES = BN / 32;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  __shared__ float As[2][BM * LDS_LD];
+  __shared__ float Bs[2][BN * LDS_LD];
+
+  const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+  const int tile_n = v % p.nbn;
+  const int tile_m = v / p.nbn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int lrow = tid >> 3;        // 0..31
+  const int lcol = (tid & 7) * 4;   // float offset inside the 32-wide chunk
+
+  // ---- decode this thread's A rows (output pixels) once
+  int rb[A_PASSES], rz[A_PASSES], ry[A_PASSES], rx[A_PASSES];
+#pragma unroll
+  for (int j = 0; j < A_PASSES; ++j) {
+    uint32_t m = (uint32_t)(m0 + lrow + 32 * j);
+    if (m >= (uint32_t)p.M) {
+      rb[j] = -1; rz[j] = ry[j] = rx[j] = 0;
+    } else {
+      uint32_t t = fdiv(m, p.dOW);
+      rx[j] = (int)(m - t * p.OW);
+      uint32_t t2 = fdiv(t, p.dOH);
+      ry[j] = (int)(t - t2 * p.OH);
+      uint32_t t3 = fdiv(t2, p.dOD);
+      rz[j] = (int)(t2 - t3 * p.OD);
+      rb[j] = (int)t3;
+    }
+  }
+  // ---- B rows (output channels)
+  const float* wrow[B_PASSES];
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) {
+    int n = n0 + lrow + 32 * j;
+    wrow[j] = (n < p.N) ? p.wpack + (size_t)n * p.Ktot : nullptr;
+  }
+
+  // ---- K-loop state: (tap, source, channel chunk)
+  int tz = 0, ty = 0, tx = 0, tap = 0, s = 0, c0 = 0;
+  long long aoff[A_PASSES];   // float offset of the row in the current source, -1 = zero row
+  const float* sptr = p.src[0].ptr;
+  int sC = p.src[0].C, cbase = 0;
+
+  auto set_source = [&]() {
+    const SrcP& S = p.src[s];
+    sptr = S.ptr;
+    sC = S.C;
+    cbase = (s == 0) ? 0 : p.src[0].C;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) {
+      const int lz = rz[j] + tz - p.PD, ly = ry[j] + ty - p.PH, lx = rx[j] + tx - p.PW;
+      const bool ok = rb[j] >= 0 && (unsigned)lz < (unsigned)p.ID &&
+                      (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW;
+      int sz = lz + S.oz, sy = ly + S.oy, sx = lx + S.ox;
+      if (S.fz > 1) sz /= S.fz;
+      if (S.fy > 1) sy /= S.fy;
+      if (S.fx > 1) sx /= S.fx;
+      const long long pix = (((long long)rb[j] * S.D + sz) * S.H + sy) * S.W + sx;
+      aoff[j] = ok ? pix * S.ld : -1;
+    }
+  };
+
+  f32x4 ra[A_PASSES], rw[B_PASSES];
+  auto load_chunk = [&]() {
+    const int c = c0 + lcol;
+    const bool cv = c < sC;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[j] = (cv && aoff[j] >= 0) ? *reinterpret_cast<const f32x4*>(sptr + aoff[j] + c) : z;
+    }
+    const int kflat = tap * p.Ctot + cbase + c;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rw[j] = (cv && wrow[j] != nullptr) ? *reinterpret_cast<const f32x4*>(wrow[j] + kflat) : z;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j)
+      *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * j) * LDS_LD + lcol]) = ra[j];
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * j) * LDS_LD + lcol]) = rw[j];
+  };
+  // returns false when the K loop is exhausted
+  auto advance = [&]() -> bool {
+    c0 += BK;
+    if (c0 < sC) return true;
+    c0 = 0;
+    ++s;
+    if (s == p.nsrc) {
+      s = 0;
+      ++tap;
+      if (++tx == p.KW) { tx = 0; if (++ty == p.KH) { ty = 0; ++tz; } }
+      if (tz == p.KD) return false;
+    }
+    set_source();
+    return true;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_base = (wm * TM * 32 + li) * LDS_LD + 4 * lh;
+  const int b_base = (wn * TN * 32 + li) * LDS_LD + 4 * lh;
+
+  set_source();
+  load_chunk();
+  store_chunk(0);
+  __syncthreads();
+
+  int buf = 0;
+  bool more = advance();
+  while (true) {
+    if (more) load_chunk();   // global loads for the next chunk fly during the MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        af[a] = *reinterpret_cast<const f32x4*>(&As[buf][a_base + a * 32 * LDS_LD + 8 * q]);
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        bf[b] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_base + b * 32 * LDS_LD + 8 * q]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
+    }
+    if (!more) break;
+    store_chunk(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    more = advance();
+  }
+
+  // ---- epilogue: bias, ReLU, optional (mask > 0) gate, store
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + (wn * TN + b) * 32 + li;
+      const bool nv = n < p.N;
+      const float bv = (nv && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nv && m < p.M) {
+          float val = acc[a][b][r] + bv;
+          if (p.relu) val = fmaxf(val, 0.f);
+          if (p.mask) val = (p.mask[(size_t)m * p.ld_mask + n] > 0.f) ? val : 0.f;
+          p.out[(size_t)m * p.ld_out + n] = val;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+static int conv_validate(const clx_conv_desc* d, const char* who) {
+  CLX_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  CLX_REQUIRE(d->nsrc == 1 || d->nsrc == 2, "%s: nsrc must be 1 or 2", who);
+  CLX_REQUIRE(d->B > 0 && d->ID > 0 && d->IH > 0 && d->IW > 0, "%s: bad extent", who);
+  const int K[3] = {d->KD, d->KH, d->KW};
+  const int P[3] = {d->PD, d->PH, d->PW};
+  const int I[3] = {d->ID, d->IH, d->IW};
+  for (int i = 0; i < 3; ++i) {
+    CLX_REQUIRE(K[i] == 1 || K[i] == 3, "%s: kernel extent must be 1 or 3", who);
+    CLX_REQUIRE(P[i] >= 0 && P[i] < K[i], "%s: padding must be < kernel extent", who);
+    CLX_REQUIRE(I[i] + 2 * P[i] - K[i] + 1 > 0, "%s: input smaller than kernel", who);
+  }
+  for (int s = 0; s < d->nsrc; ++s) {
+    const clx_src& S = d->src[s];
+    CLX_REQUIRE(S.ptr != nullptr, "%s: null source %d", who, s);
+    CLX_REQUIRE(S.C > 0 && S.C % 4 == 0 && S.ld % 4 == 0 && S.ld >= S.C,
+                "%s: source channels/ld must be multiples of 4 (C=%d ld=%d)", who, S.C, S.ld);
+    CLX_REQUIRE(((uintptr_t)S.ptr & 15) == 0, "%s: source pointer must be 16-byte aligned", who);
+    CLX_REQUIRE(S.fz >= 1 && S.fy >= 1 && S.fx >= 1, "%s: upsample factors >= 1", who);
+    CLX_REQUIRE(S.oz >= 0 && S.oy >= 0 && S.ox >= 0, "%s: negative crop", who);
+    CLX_REQUIRE((d->ID - 1 + S.oz) / S.fz < S.D && (d->IH - 1 + S.oy) / S.fy < S.H &&
+                    (d->IW - 1 + S.ox) / S.fx < S.W,
+                "%s: source %d smaller than the logical input", who, s);
+  }
+  const long long M = (long long)d->B * (d->ID + 2 * d->PD - d->KD + 1) *
+                      (d->IH + 2 * d->PH - d->KH + 1) * (d->IW + 2 * d->PW - d->KW + 1);
+  CLX_REQUIRE(M < (1ll << 31), "%s: too many output pixels", who);
+  return CLX_OK;
+}
+
+static void fill_params(const clx_conv_desc* d, ConvP& p) {
+  p.nsrc = d->nsrc;
+  for (int s = 0; s < 2; ++s) {
+    const clx_src& S = d->src[s < d->nsrc ? s : 0];
+    p.src[s] = SrcP{S.ptr, S.C, S.ld, S.D, S.H, S.W, S.oz, S.oy, S.ox, S.fz, S.fy, S.fx};
+  }
+  p.B = d->B; p.ID = d->ID; p.IH = d->IH; p.IW = d->IW;
+  p.KD = d->KD; p.KH = d->KH; p.KW = d->KW;
+  p.PD = d->PD; p.PH = d->PH; p.PW = d->PW;
+  p.OD = d->ID + 2 * d->PD - d->KD + 1;
+  p.OH = d->IH + 2 * d->PH - d->KH + 1;
+  p.OW = d->IW + 2 * d->PW - d->KW + 1;
+  p.N = d->N;
+  p.M = d->B * p.OD * p.OH * p.OW;
+  p.Ctot = d->src[0].C + (d->nsrc == 2 ? d->src[1].C : 0);
+  p.Ktot = p.Ctot * d->KD * d->KH * d->KW;
+  p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
+  p.wpack = d->wpack; p.bias = d->bias; p.mask = d->mask; p.out = d->out;
+  p.relu = d->relu; p.ld_mask = d->ld_mask; p.ld_out = d->ld_out;
+}
+
+extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
+  int rc = conv_validate(d, "clx_conv_fwd");
+  if (rc) return rc;
+  CLX_REQUIRE(d->wpack && d->out, "clx_conv_fwd: null wpack/out");
+  CLX_REQUIRE(d->N > 0 && d->ld_out >= d->N, "clx_conv_fwd: bad N/ld_out");
+  CLX_REQUIRE(((uintptr_t)d->wpack & 15) == 0, "clx_conv_fwd: wpack must be 16-byte aligned");
+  CLX_REQUIRE(d->mask == nullptr || d->ld_mask >= d->N, "clx_conv_fwd: bad ld_mask");
+  ConvP p;
+  fill_params(d, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->N > 64) {
+    p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
+    conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn), dim3(256), 0, st>>>(p);
+  } else {
+    p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
+    conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn), dim3(256), 0, st>>>(p);
+  }
+  CLX_CHECK_LAUNCH("clx_conv_fwd");
+  return CLX_OK;
+}

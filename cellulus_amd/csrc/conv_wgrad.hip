@@ -1,0 +1,264 @@
+// f32 MFMA weight-gradient kernel for gfx950.
+//
+//   dwpack[tap][n][c] += sum_{p in slice} dy[p][n] * in[pix(p) (+) tap][c]
+//   dbias[n]          += sum_p dy[p][n]
+//
+// GEMM view per tap: rows = output channels n (from dy), cols = input channels
+// c (gathered input), contraction over the output pixels p (hundreds of
+// thousands), split over `nslices` blocks that combine with float atomics
+// (the [tap][n][c] layout makes every atomic wave-instruction two 128-byte
+// row segments — the full-rate shape of MI355X_MICROARCH "Global float
+// atomics").  Both operands are pixel-major in HBM, so the LDS tiles are
+// [32 pixels][channels] and an MFMA fragment is a conflict-free ds_read_b32.
+//
+// Replaces the autograd weight/bias gradient of nn.Conv{2,3}d on the
+// reference train step (cellulus/train.py:178).
+#include "clx_common.h"
+
+namespace {
+
+constexpr int BKP = 32;  // pixels per chunk
+
+struct SrcP {
+  const float* ptr;
+  int C, ld, D, H, W, oz, oy, ox, fz, fy, fx;
+};
+
+struct WgradP {
+  int nsrc;
+  SrcP src[2];
+  int B, ID, IH, IW, KD, KH, KW, PD, PH, PW, OD, OH, OW;
+  int N, M, Ctot;
+  FastDiv dOW, dOH, dOD;
+  const float* dy;
+  int ld_dy;
+  float* dwp;
+  float* dbias;
+  int tiles_n, tiles_c, taps, nslices, chunks_per_slice;
+};
+
+template <int BMN, int BNC, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
+  constexpr int TM = BMN / WAVES_M / 32;
+  constexpr int TN = BNC / WAVES_N / 32;
+  constexpr int A_F4 = BMN / 4, A_RPP = 256 / A_F4, A_PASSES = BKP / A_RPP;
+  constexpr int B_F4 = BNC / 4, B_RPP = 256 / B_F4, B_PASSES = BKP / B_RPP;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+
+  __shared__ float Ys[2][BKP * BMN];
+  __shared__ float Xs[2][BKP * BNC];
+
+  const int T = p.tiles_n * p.tiles_c * p.taps;
+  const int v = xcd_remap(blockIdx.x, T * p.nslices);
+  const int slice = v / T;
+  int t = v - slice * T;
+  const int tile_c = t % p.tiles_c; t /= p.tiles_c;
+  const int tile_n = t % p.tiles_n;
+  const int tap = t / p.tiles_n;
+  const int tx = tap % p.KW, ty = (tap / p.KW) % p.KH, tz = tap / (p.KW * p.KH);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+
+  // loader coordinates
+  const int a_row = tid / A_F4, a_col = (tid % A_F4) * 4;
+  const int b_row = tid / B_F4, b_col = (tid % B_F4) * 4;
+  const int n_g = tile_n * BMN + a_col;       // first of this thread's 4 dy columns
+  const bool n_ok = n_g < p.N;
+  const int c_g = tile_c * BNC + b_col;       // first of this thread's 4 input channels
+  const bool c_ok = c_g < p.Ctot;
+  const int s = (p.nsrc == 2 && c_g >= p.src[0].C) ? 1 : 0;
+  const SrcP S = p.src[s];
+  const int c_l = c_g - (s ? p.src[0].C : 0);
+
+  const int chunk0 = slice * p.chunks_per_slice;
+  int nchunks = (p.M + BKP - 1) / BKP - chunk0;
+  if (nchunks > p.chunks_per_slice) nchunks = p.chunks_per_slice;
+
+  f32x4 ra[A_PASSES], rb[B_PASSES];
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0;
+
+  auto load_chunk = [&](int chunk) {
+    const int p0 = (chunk0 + chunk) * BKP;
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) {
+      const int pp = p0 + a_row + j * A_RPP;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      ra[j] = (n_ok && pp < p.M)
+                  ? *reinterpret_cast<const f32x4*>(p.dy + (size_t)pp * p.ld_dy + n_g) : z;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      const uint32_t pp = (uint32_t)(p0 + b_row + j * B_RPP);
+      f32x4 val = {0.f, 0.f, 0.f, 0.f};
+      if (c_ok && pp < (uint32_t)p.M) {
+        uint32_t q1 = fdiv(pp, p.dOW);
+        const int ox = (int)(pp - q1 * p.OW);
+        uint32_t q2 = fdiv(q1, p.dOH);
+        const int oy = (int)(q1 - q2 * p.OH);
+        uint32_t q3 = fdiv(q2, p.dOD);
+        const int oz = (int)(q2 - q3 * p.OD);
+        const int b = (int)q3;
+        const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
+        if ((unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH &&
+            (unsigned)lx < (unsigned)p.IW) {
+          int sz = lz + S.oz, sy = ly + S.oy, sx = lx + S.ox;
+          if (S.fz > 1) sz /= S.fz;
+          if (S.fy > 1) sy /= S.fy;
+          if (S.fx > 1) sx /= S.fx;
+          const long long pix = (((long long)b * S.D + sz) * S.H + sy) * S.W + sx;
+          val = *reinterpret_cast<const f32x4*>(S.ptr + pix * S.ld + c_l);
+        }
+      }
+      rb[j] = val;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j) {
+      *reinterpret_cast<f32x4*>(&Ys[buf][(a_row + j * A_RPP) * BMN + a_col]) = ra[j];
+      if (do_bias) bsum += ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j)
+      *reinterpret_cast<f32x4*>(&Xs[buf][(b_row + j * B_RPP) * BNC + b_col]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int li = lane & 31, lh = lane >> 5;
+  const int a_base = lh * BMN + wm * TM * 32 + li;
+  const int b_base = lh * BNC + wn * TN * 32 + li;
+
+  if (nchunks > 0) {
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const bool more = ch + 1 < nchunks;
+      if (more) load_chunk(ch + 1);
+#pragma unroll
+      for (int k2 = 0; k2 < BKP / 2; ++k2) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) af[a] = Ys[buf][a_base + 2 * k2 * BMN + a * 32];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bf[b] = Xs[buf][b_base + 2 * k2 * BNC + b * 32];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+      }
+      if (more) {
+        store_chunk(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+    }
+  }
+
+  // ---- combine: float atomics into dwpack[tap][n][c]
+  float* dst = p.dwp + (size_t)tap * p.N * p.Ctot;
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int c = tile_c * BNC + (wn * TN + b) * 32 + li;
+      if (c < p.Ctot) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = tile_n * BMN + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n < p.N) atomicAdd(dst + (size_t)n * p.Ctot + c, acc[a][b][r]);
+        }
+      }
+    }
+  }
+
+  // ---- bias gradient: column sums of this block's dy rows
+  if (do_bias) {
+    __syncthreads();
+    float* red = &Ys[0][0];  // [A_RPP][BMN]
+    *reinterpret_cast<f32x4*>(&red[a_row * BMN + a_col]) = bsum;
+    __syncthreads();
+    if (tid < BMN) {
+      float sum = 0.f;
+#pragma unroll 4
+      for (int r = 0; r < A_RPP; ++r) sum += red[r * BMN + tid];
+      const int n = tile_n * BMN + tid;
+      if (n < p.N) atomicAdd(p.dbias + n, sum);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy,
+                              float* dwpack, float* dbias, clx_stream stream) {
+  CLX_REQUIRE(d && dy && dwpack, "clx_conv_wgrad: null pointer");
+  CLX_REQUIRE(d->nsrc == 1 || d->nsrc == 2, "clx_conv_wgrad: nsrc must be 1 or 2");
+  CLX_REQUIRE(d->N > 0 && d->N % 4 == 0 && ld_dy % 4 == 0 && ld_dy >= d->N,
+              "clx_conv_wgrad: N and ld_dy must be multiples of 4 (N=%d ld_dy=%d)", d->N, ld_dy);
+  CLX_REQUIRE(((uintptr_t)dy & 15) == 0, "clx_conv_wgrad: dy must be 16-byte aligned");
+  for (int s = 0; s < d->nsrc; ++s) {
+    const clx_src& S = d->src[s];
+    CLX_REQUIRE(S.ptr && S.C > 0 && S.C % 4 == 0 && S.ld % 4 == 0 && S.ld >= S.C &&
+                    ((uintptr_t)S.ptr & 15) == 0,
+                "clx_conv_wgrad: bad source %d", s);
+    CLX_REQUIRE(S.fz >= 1 && S.fy >= 1 && S.fx >= 1 && S.oz >= 0 && S.oy >= 0 && S.ox >= 0,
+                "clx_conv_wgrad: bad crop/upsample of source %d", s);
+  }
+  WgradP p;
+  p.nsrc = d->nsrc;
+  for (int s = 0; s < 2; ++s) {
+    const clx_src& S = d->src[s < d->nsrc ? s : 0];
+    p.src[s] = SrcP{S.ptr, S.C, S.ld, S.D, S.H, S.W, S.oz, S.oy, S.ox, S.fz, S.fy, S.fx};
+  }
+  p.B = d->B; p.ID = d->ID; p.IH = d->IH; p.IW = d->IW;
+  p.KD = d->KD; p.KH = d->KH; p.KW = d->KW;
+  p.PD = d->PD; p.PH = d->PH; p.PW = d->PW;
+  p.OD = d->ID + 2 * d->PD - d->KD + 1;
+  p.OH = d->IH + 2 * d->PH - d->KH + 1;
+  p.OW = d->IW + 2 * d->PW - d->KW + 1;
+  CLX_REQUIRE(p.OD > 0 && p.OH > 0 && p.OW > 0, "clx_conv_wgrad: empty output");
+  const long long M = (long long)d->B * p.OD * p.OH * p.OW;
+  CLX_REQUIRE(M < (1ll << 31), "clx_conv_wgrad: too many pixels");
+  p.N = d->N; p.M = (int)M;
+  p.Ctot = d->src[0].C + (d->nsrc == 2 ? d->src[1].C : 0);
+  p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
+  p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
+  p.taps = d->KD * d->KH * d->KW;
+
+  const bool big_n = p.N > 64, big_c = p.Ctot > 64;
+  const int bmn = big_n ? 128 : 64, bnc = big_c ? 128 : 64;
+  p.tiles_n = cdiv(p.N, bmn);
+  p.tiles_c = cdiv(p.Ctot, bnc);
+  const int T = p.tiles_n * p.tiles_c * p.taps;
+  const int total_chunks = cdiv(p.M, BKP);
+  int nslices = cdiv(2048, T);
+  const int max_slices = total_chunks / 8 > 0 ? total_chunks / 8 : 1;
+  if (nslices > max_slices) nslices = max_slices;
+  if (nslices < 1) nslices = 1;
+  p.chunks_per_slice = cdiv(total_chunks, nslices);
+  p.nslices = cdiv(total_chunks, p.chunks_per_slice);
+  const dim3 grid(T * p.nslices), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (big_n && big_c)
+    conv_wgrad_kernel<128, 128, 2, 2><<<grid, block, 0, st>>>(p);
+  else if (big_n)
+    conv_wgrad_kernel<128, 64, 4, 1><<<grid, block, 0, st>>>(p);
+  else if (big_c)
+    conv_wgrad_kernel<64, 128, 1, 4><<<grid, block, 0, st>>>(p);
+  else
+    conv_wgrad_kernel<64, 64, 2, 2><<<grid, block, 0, st>>>(p);
+  CLX_CHECK_LAUNCH("clx_conv_wgrad");
+  return CLX_OK;
+}

@@ -1,0 +1,212 @@
+// HBM-bound streaming kernels around the convolutions: max-pool forward,
+// the fused (max-pool backward + skip-gradient add + ReLU gate), the fused
+// (nearest-upsample backward + crop + ReLU gate), inference statistics.
+// All tensors are dense channels-last f32; one thread handles 4 channels of
+// one pixel (16-byte accesses, channel-contiguous => fully coalesced).
+#include "clx_common.h"
+
+namespace {
+
+inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// replaces funlib Downsample = nn.MaxPool{2,3}d(f, stride=f) [unet.py:24-51]
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   int D, int H, int W, int C4, int fz, int fy, int fx,
+                                   int OD, int OH, int OW, long long total) {
+  const int C = C4 * 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int ox = (int)(q % OW); q /= OW;
+    const int oy = (int)(q % OH); q /= OH;
+    const int oz = (int)(q % OD);
+    const long long b = q / OD;
+    f32x4 m;
+    bool first = true;
+    for (int dz = 0; dz < fz; ++dz)
+      for (int dy = 0; dy < fy; ++dy)
+        for (int dx = 0; dx < fx; ++dx) {
+          const long long pix = ((b * D + oz * fz + dz) * H + oy * fy + dy) * W + ox * fx + dx;
+          const f32x4 v = ld4(x + pix * C + c);
+          if (first) { m = v; first = false; }
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[e] = (v[e] > m[e]) ? v[e] : m[e];
+          }
+        }
+    st4(y + (i / C4) * C + c, m);
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                   const float* __restrict__ dyp, const float* __restrict__ dskip,
+                                   int ld_skip, int SD, int SH, int SW, int cz, int cy, int cx,
+                                   float* __restrict__ dxo, int D, int H, int W, int C4,
+                                   int fz, int fy, int fx, long long total) {
+  const int C = C4 * 4;
+  const int OD = D / fz, OH = H / fy, OW = W / fx;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int px = (int)(q % W); q /= W;
+    const int py = (int)(q % H); q /= H;
+    const int pz = (int)(q % D);
+    const long long b = q / D;
+    const int wz = pz / fz, wy = py / fy, wx = px / fx;
+    const f32x4 xv = ld4(x + (i / C4) * C + c);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (wz < OD && wy < OH && wx < OW) {
+      const long long win = ((b * OD + wz) * OH + wy) * OW + wx;
+      const f32x4 yv = ld4(y + win * C + c);
+      const f32x4 gv = ld4(dyp + win * C + c);
+      bool is_max[4], earlier[4] = {false, false, false, false};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) is_max[e] = (xv[e] == yv[e]);
+      // torch keeps the FIRST maximum in window scan order
+      const int rz = pz - wz * fz, ry = py - wy * fy, rx = px - wx * fx;
+      const int my = (rz * fy + ry) * fx + rx;
+      for (int k = 0; k < my; ++k) {
+        const int dx = k % fx, dy = (k / fx) % fy, dz = k / (fx * fy);
+        const long long pix = ((b * D + wz * fz + dz) * H + wy * fy + dy) * W + wx * fx + dx;
+        const f32x4 ov = ld4(x + pix * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) earlier[e] = earlier[e] || (ov[e] == yv[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] = (is_max[e] && !earlier[e]) ? gv[e] : 0.f;
+    }
+    if (dskip) {
+      const int sz = pz - cz, sy = py - cy, sx = px - cx;
+      if ((unsigned)sz < (unsigned)SD && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW) {
+        const long long sp = ((b * SD + sz) * SH + sy) * SW + sx;
+        g += ld4(dskip + sp * ld_skip + c);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = (xv[e] > 0.f) ? g[e] : 0.f;
+    st4(dxo + (i / C4) * C + c, g);
+  }
+}
+
+__global__ void upsample_bwd_kernel(const float* __restrict__ dcat, int ld_cat, int coff,
+                                    int LD, int LH, int LW, int oz, int oy, int ox,
+                                    const float* __restrict__ y, float* __restrict__ dy,
+                                    int D, int H, int W, int C4, int fz, int fy, int fx,
+                                    long long total) {
+  const int C = C4 * 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int qx = (int)(q % W); q /= W;
+    const int qy = (int)(q % H); q /= H;
+    const int qz = (int)(q % D);
+    const long long b = q / D;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int dz = 0; dz < fz; ++dz) {
+      const int lz = qz * fz + dz - oz;
+      if ((unsigned)lz >= (unsigned)LD) continue;
+      for (int dyy = 0; dyy < fy; ++dyy) {
+        const int ly = qy * fy + dyy - oy;
+        if ((unsigned)ly >= (unsigned)LH) continue;
+        for (int dx = 0; dx < fx; ++dx) {
+          const int lx = qx * fx + dx - ox;
+          if ((unsigned)lx >= (unsigned)LW) continue;
+          const long long pix = ((b * LD + lz) * LH + ly) * LW + lx;
+          g += ld4(dcat + pix * ld_cat + coff + c);
+        }
+      }
+    }
+    const f32x4 yv = ld4(y + (i / C4) * C + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = (yv[e] > 0.f) ? g[e] : 0.f;
+    st4(dy + (i / C4) * C + c, g);
+  }
+}
+
+// torch.std_mean(stack(preds), dim=0, unbiased=False); std summed over channels
+// [cellulus/models/unet.py:90-98]
+__global__ void noise_stats_kernel(const float* __restrict__ preds, float* __restrict__ out,
+                                   int T, int C, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float std_sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int t = 0; t < T; ++t) s += preds[((long long)t * C + c) * n + i];
+      const float mean = s / (float)T;
+      float v = 0.f;
+      for (int t = 0; t < T; ++t) {
+        const float d = preds[((long long)t * C + c) * n + i] - mean;
+        v += d * d;
+      }
+      out[(long long)c * n + i] = mean;
+      std_sum += sqrtf(v / (float)T);
+    }
+    out[(long long)C * n + i] = std_sum;
+  }
+}
+
+}  // namespace
+
+extern "C" int clx_maxpool_fwd(const float* x, float* y, int B, int D, int H, int W, int C,
+                               int fz, int fy, int fx, clx_stream stream) {
+  CLX_REQUIRE(x && y, "clx_maxpool_fwd: null pointer");
+  CLX_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "clx_maxpool_fwd: bad extents");
+  CLX_REQUIRE(fz >= 1 && fy >= 1 && fx >= 1, "clx_maxpool_fwd: bad factors");
+  CLX_REQUIRE(D % fz == 0 && H % fy == 0 && W % fx == 0,
+              "clx_maxpool_fwd: extent (%d,%d,%d) not divisible by factor (%d,%d,%d)", D, H, W, fz, fy, fx);
+  const int OD = D / fz, OH = H / fy, OW = W / fx;
+  const long long total = (long long)B * OD * OH * OW * (C / 4);
+  maxpool_fwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      x, y, D, H, W, C / 4, fz, fy, fx, OD, OH, OW, total);
+  CLX_CHECK_LAUNCH("clx_maxpool_fwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_maxpool_bwd(const float* x, const float* y, const float* dy_pool,
+                               const float* dskip, int ld_skip, int SD, int SH, int SW,
+                               int cz, int cy, int cx, float* dx, int B, int D, int H,
+                               int W, int C, int fz, int fy, int fx, clx_stream stream) {
+  CLX_REQUIRE(x && y && dy_pool && dx, "clx_maxpool_bwd: null pointer");
+  CLX_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "clx_maxpool_bwd: bad extents");
+  CLX_REQUIRE(D % fz == 0 && H % fy == 0 && W % fx == 0, "clx_maxpool_bwd: extent not divisible");
+  CLX_REQUIRE(dskip == nullptr || (ld_skip % 4 == 0 && ld_skip >= C), "clx_maxpool_bwd: bad ld_skip");
+  const long long total = (long long)B * D * H * W * (C / 4);
+  maxpool_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      x, y, dy_pool, dskip, ld_skip, SD, SH, SW, cz, cy, cx, dx, D, H, W, C / 4, fz, fy, fx, total);
+  CLX_CHECK_LAUNCH("clx_maxpool_bwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD, int LH,
+                                int LW, int oz, int oy, int ox, const float* y, float* dy,
+                                int B, int D, int H, int W, int C, int fz, int fy, int fx,
+                                clx_stream stream) {
+  CLX_REQUIRE(dcat && y && dy, "clx_upsample_bwd: null pointer");
+  CLX_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "clx_upsample_bwd: bad extents");
+  CLX_REQUIRE(ld_cat % 4 == 0 && coff % 4 == 0 && coff + C <= ld_cat, "clx_upsample_bwd: bad ld/coff");
+  const long long total = (long long)B * D * H * W * (C / 4);
+  upsample_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      dcat, ld_cat, coff, LD, LH, LW, oz, oy, ox, y, dy, D, H, W, C / 4, fz, fy, fx, total);
+  CLX_CHECK_LAUNCH("clx_upsample_bwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
+                               clx_stream stream) {
+  CLX_REQUIRE(preds && out && T > 0 && C > 0 && n > 0, "clx_noise_stats: bad arguments");
+  noise_stats_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
+  CLX_CHECK_LAUNCH("clx_noise_stats");
+  return CLX_OK;
+}

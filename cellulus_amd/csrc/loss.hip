@@ -1,0 +1,250 @@
+// Train-step tail kernels: embedding gather (+ coordinates), OCE pair loss with
+// its gradient, the fused gather->loss->scatter kernel and the Adam step.
+// All are HBM/L2-bound; loss sums are reduced per wavefront with DPP shuffles,
+// per block through LDS, then one f64 atomic per block.
+#include "clx_common.h"
+
+namespace {
+
+inline int grid_for(long long total, int block) {
+  long long g = (total + block - 1) / block;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// linear index of coordinate row `co` (x = last axis first) in a (Z, Y, X) grid
+__device__ __forceinline__ long long coord_index(const long long* co, int ND, int Y, int X) {
+  const long long x = co[0], y = co[1];
+  const long long z = (ND == 3) ? co[2] : 0;
+  return (z * Y + y) * X + x;
+}
+
+// UNetModel.select_and_add_coordinates [cellulus/models/unet.py:108-124]
+__global__ void gather_add_fwd_kernel(const float* __restrict__ offsets,
+                                      const long long* __restrict__ coords,
+                                      float* __restrict__ sel, int P, int ND, int Y, int X,
+                                      long long npix, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / P;
+    const long long* co = coords + i * ND;
+    const long long idx = coord_index(co, ND, Y, X);
+    const float* ob = offsets + b * ND * npix + idx;
+    for (int c = 0; c < ND; ++c) sel[i * ND + c] = ob[(long long)c * npix] + (float)co[c];
+  }
+}
+
+__global__ void gather_add_bwd_kernel(const float* __restrict__ dsel,
+                                      const long long* __restrict__ coords,
+                                      float* __restrict__ doffsets, int P, int ND, int Y, int X,
+                                      long long npix, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / P;
+    const long long* co = coords + i * ND;
+    const long long idx = coord_index(co, ND, Y, X);
+    float* ob = doffsets + b * ND * npix + idx;
+    for (int c = 0; c < ND; ++c) atomicAdd(ob + (long long)c * npix, dsel[i * ND + c]);
+  }
+}
+
+// OCELoss.forward [cellulus/criterions/oce_loss.py:45-63], per pair:
+//   d = |a - r|_2, oce = 1 - exp(-d^2 / T), reg = w |a|_2
+//   d(oce + reg)/da = (2/T) exp(-d^2/T) (a - r) + w a / |a|   (0 at zero norm)
+template <int ND>
+__device__ __forceinline__ void oce_pair(const float* a, const float* r, float T, float w,
+                                         float& oce, float& reg, float* da) {
+  float s = 0.f, na = 0.f, diff[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) {
+    diff[c] = a[c] - r[c];
+    s += diff[c] * diff[c];
+    na += a[c] * a[c];
+  }
+  const float d = sqrtf(s);
+  const float e = expf(-(d * d) / T);
+  oce = 1.f - e;
+  const float nrm = sqrtf(na);
+  reg = w * nrm;
+  const float k = 2.f * e / T;
+  const float inv = (nrm > 0.f) ? w / nrm : 0.f;
+#pragma unroll
+  for (int c = 0; c < ND; ++c) da[c] = k * diff[c] + inv * a[c];
+}
+
+__device__ __forceinline__ void block_accumulate(double oce, double reg, double* sums) {
+  __shared__ double red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    oce += __shfl_down(oce, o, 64);
+    reg += __shfl_down(reg, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = oce; red[1][wid] = reg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double o = 0., g = 0.;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { o += red[0][k]; g += red[1][k]; }
+    atomicAdd(sums + 0, o + g);
+    atomicAdd(sums + 1, o);
+    atomicAdd(sums + 2, g);
+  }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void oce_loss_kernel(const float* __restrict__ a,
+                                                       const float* __restrict__ r,
+                                                       float* __restrict__ da, double* sums,
+                                                       long long npairs, float T, float w,
+                                                       float gscale) {
+  double oce_acc = 0., reg_acc = 0.;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs;
+       i += (long long)gridDim.x * blockDim.x) {
+    float av[ND], rv[ND], g[ND], oce, reg;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) { av[c] = a[i * ND + c]; rv[c] = r[i * ND + c]; }
+    oce_pair<ND>(av, rv, T, w, oce, reg, g);
+    oce_acc += oce; reg_acc += reg;
+    if (da) {
+#pragma unroll
+      for (int c = 0; c < ND; ++c) da[i * ND + c] = gscale * g[c];
+    }
+  }
+  block_accumulate(oce_acc, reg_acc, sums);
+}
+
+// train.py:170-178 in one pass: gather anchor/reference embeddings, loss,
+// scatter-add the anchor gradient into doffsets (planar).
+template <int ND>
+__global__ __launch_bounds__(256) void oce_pairs_fused_kernel(
+    const float* __restrict__ offsets, const long long* __restrict__ anchor,
+    const long long* __restrict__ reference, float* __restrict__ doffsets, double* sums,
+    int P, int Y, int X, long long npix, long long total, float T, float w) {
+  double oce_acc = 0., reg_acc = 0.;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / P;
+    const long long* ca = anchor + i * ND;
+    const long long* cr = reference + i * ND;
+    const long long ia = coord_index(ca, ND, Y, X), ir = coord_index(cr, ND, Y, X);
+    const float* ob = offsets + b * ND * npix;
+    float av[ND], rv[ND], g[ND], oce, reg;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+      av[c] = ob[(long long)c * npix + ia] + (float)ca[c];
+      rv[c] = ob[(long long)c * npix + ir] + (float)cr[c];
+    }
+    oce_pair<ND>(av, rv, T, w, oce, reg, g);
+    oce_acc += oce; reg_acc += reg;
+    float* gb = doffsets + b * ND * npix + ia;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) atomicAdd(gb + (long long)c * npix, g[c]);
+  }
+  block_accumulate(oce_acc, reg_acc, sums);
+}
+
+// torch.optim.Adam single-tensor step order (weight_decay coupled into grad):
+//   g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g*g;
+//   denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, long long n,
+                            float one_minus_b1, float b2, float one_minus_b2, float eps,
+                            float wd, float step_size, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float pv = p[i];
+    const float gv = g[i] + wd * pv;
+    float mv = m[i];
+    mv = mv + one_minus_b1 * (gv - mv);
+    const float vv = b2 * v[i] + one_minus_b2 * gv * gv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    m[i] = mv;
+    v[i] = vv;
+    p[i] = pv - step_size * (mv / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int clx_gather_add_fwd(const float* offsets, const long long* coords, float* sel,
+                                  int B, int P, int ND, int Z, int Y, int X, clx_stream stream) {
+  CLX_REQUIRE(offsets && coords && sel, "clx_gather_add_fwd: null pointer");
+  CLX_REQUIRE(B > 0 && P >= 0 && (ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0,
+              "clx_gather_add_fwd: bad extents");
+  CLX_REQUIRE(ND == 3 || Z == 1, "clx_gather_add_fwd: Z must be 1 for 2-D");
+  if (P == 0) return CLX_OK;
+  const long long total = (long long)B * P;
+  gather_add_fwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      offsets, coords, sel, P, ND, Y, X, (long long)Z * Y * X, total);
+  CLX_CHECK_LAUNCH("clx_gather_add_fwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_gather_add_bwd(const float* dsel, const long long* coords, float* doffsets,
+                                  int B, int P, int ND, int Z, int Y, int X, clx_stream stream) {
+  CLX_REQUIRE(dsel && coords && doffsets, "clx_gather_add_bwd: null pointer");
+  CLX_REQUIRE(B > 0 && P >= 0 && (ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0,
+              "clx_gather_add_bwd: bad extents");
+  if (P == 0) return CLX_OK;
+  const long long total = (long long)B * P;
+  gather_add_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      dsel, coords, doffsets, P, ND, Y, X, (long long)Z * Y * X, total);
+  CLX_CHECK_LAUNCH("clx_gather_add_bwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_oce_loss_fwd_bwd(const float* a, const float* r, float* da, double* sums,
+                                    long long npairs, int ND, float temperature,
+                                    float reg_weight, float grad_scale, clx_stream stream) {
+  CLX_REQUIRE(a && r && sums, "clx_oce_loss_fwd_bwd: null pointer");
+  CLX_REQUIRE(npairs >= 0 && (ND == 2 || ND == 3), "clx_oce_loss_fwd_bwd: bad extents");
+  CLX_REQUIRE(temperature != 0.f, "clx_oce_loss_fwd_bwd: temperature must be non-zero");
+  if (npairs == 0) return CLX_OK;
+  const int grid = grid_for(npairs, 256);
+  if (ND == 2)
+    oce_loss_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(a, r, da, sums, npairs, temperature, reg_weight, grad_scale);
+  else
+    oce_loss_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(a, r, da, sums, npairs, temperature, reg_weight, grad_scale);
+  CLX_CHECK_LAUNCH("clx_oce_loss_fwd_bwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_oce_pairs_fused(const float* offsets, const long long* anchor,
+                                   const long long* reference, float* doffsets, double* sums,
+                                   int B, int P, int ND, int Z, int Y, int X,
+                                   float temperature, float reg_weight, clx_stream stream) {
+  CLX_REQUIRE(offsets && anchor && reference && doffsets && sums, "clx_oce_pairs_fused: null pointer");
+  CLX_REQUIRE(B > 0 && P >= 0 && (ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0,
+              "clx_oce_pairs_fused: bad extents");
+  CLX_REQUIRE(temperature != 0.f, "clx_oce_pairs_fused: temperature must be non-zero");
+  if (P == 0) return CLX_OK;
+  const long long total = (long long)B * P, npix = (long long)Z * Y * X;
+  const int grid = grid_for(total, 256);
+  if (ND == 2)
+    oce_pairs_fused_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(
+        offsets, anchor, reference, doffsets, sums, P, Y, X, npix, total, temperature, reg_weight);
+  else
+    oce_pairs_fused_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(
+        offsets, anchor, reference, doffsets, sums, P, Y, X, npix, total, temperature, reg_weight);
+  CLX_CHECK_LAUNCH("clx_oce_pairs_fused");
+  return CLX_OK;
+}
+
+extern "C" int clx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                             long long n, double lr, double beta1, double beta2, double eps,
+                             double weight_decay, int step, clx_stream stream) {
+  CLX_REQUIRE(param && grad && exp_avg && exp_avg_sq, "clx_adam_step: null pointer");
+  CLX_REQUIRE(n >= 0 && step >= 1, "clx_adam_step: bad n/step");
+  if (n == 0) return CLX_OK;
+  // host-side scalars in double, as torch computes them in Python floats
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  adam_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+      param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
+      (float)(1.0 - beta2), (float)eps, (float)weight_decay, step_size, bc2_sqrt);
+  CLX_CHECK_LAUNCH("clx_adam_step");
+  return CLX_OK;
+}

@@ -1,0 +1,473 @@
+"""Launch plan of the U-Net + head on libclx (forward, backward, inference).
+
+The topology is the one ``cellulus/models/unet.py:24-63`` requests from
+``funlib.learn.torch.models.UNet`` (valid convolutions ``[3,1,1,3]`` + ReLU per
+level, max-pool down, nearest ``constant_upsample`` up, centre-cropped skip
+concatenated *before* the upsampled tensor) followed by the 1x1 head.  funlib
+is not vendored in the reference; the restated rules (``crop_to_factor``,
+channel counts, module names) are documented in SURVEY.md §3.4.
+
+Everything device-side is channels-last f32 with channel counts padded to a
+multiple of 4; the padded channels stay zero for the life of a buffer.
+"""
+
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import _clx
+from .._clx import ClxConvDesc, ClxSrc
+
+
+def pad4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _tri(v):
+    """(z, y, x) triple from a 2- or 3-tuple (2-D data gets z = 1 / 0)."""
+    v = tuple(int(a) for a in v)
+    return v if len(v) == 3 else (None,) + v
+
+
+@dataclass
+class Source:
+    """One input of a convolution: a stored tensor seen through crop/upsample."""
+
+    tensor: str                      # buffer name
+    channels: int                    # real channels
+    crop: Tuple[int, int, int] = (0, 0, 0)
+    factor: Tuple[int, int, int] = (1, 1, 1)
+
+
+@dataclass
+class ConvLayer:
+    name: str                        # state_dict prefix, e.g. backbone.l_conv.0.conv_pass.0
+    sources: List[Source]
+    cout: int
+    kernel: Tuple[int, int, int]     # (kd, kh, kw), kd = 1 for 2-D
+    in_shape: Tuple[int, int, int]   # logical input extent (D, H, W)
+    out: str                         # output buffer name
+    relu: bool = True
+    param_index: int = -1            # index into the flat (weight, bias) list
+
+    @property
+    def cin(self):
+        return sum(s.channels for s in self.sources)
+
+    @property
+    def cin_pad(self):
+        return sum(pad4(s.channels) for s in self.sources)
+
+    @property
+    def taps(self):
+        return self.kernel[0] * self.kernel[1] * self.kernel[2]
+
+    @property
+    def out_shape(self):
+        return tuple(i - k + 1 for i, k in zip(self.in_shape, self.kernel))
+
+
+@dataclass
+class PoolOp:
+    src: str
+    out: str
+    channels: int
+    in_shape: Tuple[int, int, int]
+    factor: Tuple[int, int, int]
+
+
+@dataclass
+class Topology:
+    """Static description of the network for one input crop shape."""
+
+    nd: int
+    in_channels: int
+    out_channels: int
+    in_shape: Tuple[int, int, int]
+    convs: List[ConvLayer] = field(default_factory=list)
+    pools: List[PoolOp] = field(default_factory=list)
+    fwd_order: list = field(default_factory=list)      # ConvLayer | PoolOp in execution order
+    shapes: dict = field(default_factory=dict)         # buffer -> ((D,H,W), channels)
+    levels: int = 0
+    # per r-level: (conv0 layer, skip tensor, up tensor)
+    r_info: list = field(default_factory=list)
+    out_shape: Tuple[int, int, int] = (1, 1, 1)
+
+
+def build_topology(in_channels, out_channels, num_fmaps, fmap_inc_factor, features_in_last_layer,
+                   downsampling_factors, num_spatial_dims, spatial):
+    """Derives every layer's geometry for an input of spatial extent `spatial`."""
+    nd = num_spatial_dims
+    assert nd in (2, 3), "num_spatial_dims must be 2 or 3"
+    assert len(spatial) == nd
+    L = len(downsampling_factors)
+    factors = []
+    for f in downsampling_factors:
+        f = tuple(int(a) for a in f)
+        assert len(f) == nd, "downsampling factor rank must equal num_spatial_dims"
+        factors.append((1,) + f if nd == 2 else f)
+    shape = ((1,) + tuple(int(s) for s in spatial)) if nd == 2 else tuple(int(s) for s in spatial)
+    k3 = (1, 3, 3) if nd == 2 else (3, 3, 3)
+    k1 = (1, 1, 1)
+    pass_kernels = [k3, k1, k1, k3]
+    conv_crop = tuple(sum(k[d] - 1 for k in pass_kernels) for d in range(3))
+
+    topo = Topology(nd=nd, in_channels=in_channels, out_channels=out_channels, in_shape=shape, levels=L)
+    topo.shapes["raw"] = (shape, in_channels)
+
+    def add_pass(prefix, first_sources, first_in_shape, cout, out_prefix):
+        srcs, ishape = first_sources, first_in_shape
+        layers = []
+        for j, k in enumerate(pass_kernels):
+            name = f"{prefix}.conv_pass.{2 * j}"
+            out = f"{out_prefix}.{j}"
+            layer = ConvLayer(name=name, sources=srcs, cout=cout, kernel=k, in_shape=ishape, out=out)
+            for d in range(3):
+                if layer.out_shape[d] <= 0:
+                    raise ValueError(
+                        f"input extent {spatial} is too small for the U-Net (layer {name} would be empty)")
+            topo.convs.append(layer)
+            topo.fwd_order.append(layer)
+            topo.shapes[out] = (layer.out_shape, cout)
+            layers.append(layer)
+            srcs, ishape = [Source(out, cout)], layer.out_shape
+        return layers
+
+    # ---- left (contracting) path
+    left_out = []
+    cur, cur_c, cur_shape = "raw", in_channels, shape
+    for i in range(L + 1):
+        cout = num_fmaps * fmap_inc_factor ** i
+        layers = add_pass(f"backbone.l_conv.{i}", [Source(cur, cur_c)], cur_shape, cout, f"l{i}")
+        y, yshape = layers[-1].out, layers[-1].out_shape
+        left_out.append((y, cout, yshape))
+        if i < L:
+            f = factors[i]
+            for d in range(3):
+                if yshape[d] % f[d] != 0:
+                    raise RuntimeError(
+                        f"Can not downsample shape {yshape[3 - nd:]} with factor {f[3 - nd:]}, "
+                        f"mismatch in spatial dimension {d - (3 - nd)}")
+            pshape = tuple(s // ff for s, ff in zip(yshape, f))
+            pool = PoolOp(src=y, out=f"p{i}", channels=cout, in_shape=yshape, factor=f)
+            topo.pools.append(pool)
+            topo.fwd_order.append(pool)
+            topo.shapes[pool.out] = (pshape, cout)
+            cur, cur_c, cur_shape = pool.out, cout, pshape
+
+    # ---- right (expanding) path, bottom-up
+    crop_factors = []
+    prod = None
+    for f in factors[::-1]:
+        prod = tuple(f) if prod is None else tuple(a * b for a, b in zip(f, prod))
+        crop_factors.append(prod)
+    crop_factors = crop_factors[::-1]
+
+    below, below_c, below_shape = left_out[L]
+    topo.r_info = [None] * L
+    for i in range(L - 1, -1, -1):
+        f = factors[i]
+        up_shape = tuple(s * ff for s, ff in zip(below_shape, f))
+        # crop_to_factor: keep (size - conv_crop) a multiple of the cumulative factor
+        cf = crop_factors[i]
+        target = tuple(int(math.floor((s - c) / ff)) * ff + c for s, c, ff in zip(up_shape, conv_crop, cf))
+        for d in range(3):
+            if target[d] <= conv_crop[d] and up_shape[d] != target[d]:
+                raise RuntimeError(f"Feature map with shape {up_shape} is too small for cropping to factor")
+        up_crop = tuple((s - t) // 2 for s, t in zip(up_shape, target))
+        skip, skip_c, skip_shape = left_out[i]
+        for d in range(3):
+            if skip_shape[d] < target[d]:
+                raise RuntimeError("skip connection smaller than the upsampled feature map")
+        skip_crop = tuple((s - t) // 2 for s, t in zip(skip_shape, target))
+        cout = features_in_last_layer if i == 0 else num_fmaps * fmap_inc_factor ** i
+        srcs = [Source(skip, skip_c, crop=skip_crop),
+                Source(below, below_c, crop=up_crop, factor=f)]
+        layers = add_pass(f"backbone.r_conv.0.{i}", srcs, target, cout, f"r{i}")
+        topo.r_info[i] = dict(conv0=layers[0], skip=skip, up=below, level=i)
+        below, below_c, below_shape = layers[-1].out, cout, layers[-1].out_shape
+
+    # ---- head: 1x1 conv + ReLU + 1x1 conv (unet.py:52-63)
+    top, top_c, top_shape = below, below_c, below_shape
+    if L > 0 and top_c != features_in_last_layer:
+        raise AssertionError("internal: top level width mismatch")
+    h0 = ConvLayer(name="head.0", sources=[Source(top, top_c)], cout=features_in_last_layer,
+                   kernel=k1, in_shape=top_shape, out="h0", relu=True)
+    h1 = ConvLayer(name="head.2", sources=[Source("h0", features_in_last_layer)], cout=out_channels,
+                   kernel=k1, in_shape=top_shape, out="h1", relu=False)
+    if L == 0 and top_c != features_in_last_layer:
+        # funlib keeps num_fmaps at level 0 when there is no upsampling path; the
+        # reference head then expects features_in_last_layer inputs (a config error).
+        raise ValueError("with no downsampling, num_fmaps must equal features_in_last_layer")
+    for layer in (h0, h1):
+        topo.convs.append(layer)
+        topo.fwd_order.append(layer)
+        topo.shapes[layer.out] = (layer.out_shape, layer.cout)
+    topo.out_shape = top_shape
+    for idx, layer in enumerate(topo.convs):
+        layer.param_index = idx
+    return topo
+
+
+class UNetPlan:
+    """Executes a Topology for a fixed batch size on one HIP device."""
+
+    def __init__(self, topo: Topology, batch: int, device: torch.device, keep_activations: bool):
+        self.topo = topo
+        self.B = int(batch)
+        self.device = device
+        self.keep = keep_activations
+        self.buf = {}
+        self._alloc()
+
+    # ------------------------------------------------------------------ memory
+    def _alloc(self):
+        t = self.topo
+        for name, (shape, c) in t.shapes.items():
+            n = self.B * shape[0] * shape[1] * shape[2]
+            self.buf[name] = torch.zeros((n, pad4(c)), dtype=torch.float32, device=self.device)
+        # packed weights
+        self.wpack_fwd = {}
+        self.wpack_dgrad = {}
+        for layer in t.convs:
+            self.wpack_fwd[layer.name] = torch.empty(
+                layer.cout * layer.taps * layer.cin_pad, dtype=torch.float32, device=self.device)
+        self._packed_version = None
+        self._bwd_ready = False
+
+    def _alloc_backward(self):
+        t = self.topo
+        self.gbuf = {}
+        for name, (shape, c) in t.shapes.items():
+            if name == "raw":
+                continue
+            n = self.B * shape[0] * shape[1] * shape[2]
+            self.gbuf[name] = torch.zeros((n, pad4(c)), dtype=torch.float32, device=self.device)
+        for info in t.r_info:
+            layer = info["conv0"]
+            n = self.B * layer.in_shape[0] * layer.in_shape[1] * layer.in_shape[2]
+            self.gbuf["cat%d" % info["level"]] = torch.zeros(
+                (n, layer.cin_pad), dtype=torch.float32, device=self.device)
+        total = 0
+        self.dw_off = {}
+        for layer in t.convs:
+            self.dw_off[layer.name] = total
+            total += layer.taps * pad4(layer.cout) * layer.cin_pad
+            if layer.param_index > 0:  # first layer needs no data gradient
+                self.wpack_dgrad[layer.name] = torch.empty(
+                    layer.cin_pad * layer.taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
+        self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._bwd_ready = True
+
+    # ------------------------------------------------------------- descriptors
+    def _desc(self, layer: ConvLayer, dgrad=False):
+        d = ClxConvDesc()
+        d.nsrc = len(layer.sources)
+        t = self.topo
+        for i, s in enumerate(layer.sources):
+            shape, c = t.shapes[s.tensor]
+            src = ClxSrc()
+            src.ptr = self.buf[s.tensor].data_ptr()
+            src.C = pad4(s.channels)
+            src.ld = pad4(c)
+            src.D, src.H, src.W = shape
+            src.oz, src.oy, src.ox = s.crop
+            src.fz, src.fy, src.fx = s.factor
+            d.src[i] = src
+        d.B = self.B
+        d.ID, d.IH, d.IW = layer.in_shape
+        d.KD, d.KH, d.KW = layer.kernel
+        d.PD = d.PH = d.PW = 0
+        return d
+
+    def _expand_cin(self, layer, w):
+        """torch weight (cout, cin, taps) -> (cout, cin_gapped, taps) when a concat source is padded."""
+        if len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
+            return w, layer.cin
+        parts, c0 = [], 0
+        for s in layer.sources:
+            blk = w[:, c0:c0 + s.channels]
+            padw = pad4(s.channels) - s.channels
+            if padw:
+                blk = torch.cat([blk, blk.new_zeros(blk.shape[0], padw, blk.shape[2])], dim=1)
+            parts.append(blk)
+            c0 += s.channels
+        g = torch.cat(parts, dim=1).contiguous()
+        return g, g.shape[1]
+
+    def _compress_cin(self, layer, g):
+        """inverse of _expand_cin for gradients: (cout, cin_gapped, taps) -> (cout, cin, taps)."""
+        parts, c0 = [], 0
+        for s in layer.sources:
+            parts.append(g[:, c0:c0 + s.channels])
+            c0 += pad4(s.channels)
+        return torch.cat(parts, dim=1)
+
+    def pack_weights(self, params, version, need_dgrad):
+        """(Re)pack weights when the parameters changed (version = tuple of tensor versions)."""
+        if need_dgrad and not self._bwd_ready:
+            self._alloc_backward()
+        key = (version, need_dgrad)
+        if self._packed_version is not None and self._packed_version[0] == version and \
+                (self._packed_version[1] or not need_dgrad):
+            return
+        st = _clx.stream_ptr(self.device)
+        for layer in self.topo.convs:
+            w = params[2 * layer.param_index]
+            wv = w.detach().reshape(layer.cout, layer.cin, layer.taps)
+            if not wv.is_contiguous():
+                wv = wv.contiguous()
+            wv, cin_eff = self._expand_cin(layer, wv)
+            _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_fwd[layer.name]),
+                      layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout), 0, st)
+            if need_dgrad and layer.name in self.wpack_dgrad:
+                _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_dgrad[layer.name]),
+                          layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout), 1, st)
+        self._packed_version = key
+
+    # ----------------------------------------------------------------- forward
+    def forward(self, raw, params):
+        """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial)."""
+        t = self.topo
+        st = _clx.stream_ptr(self.device)
+        npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
+        raw = raw.contiguous()
+        _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
+                  t.in_channels, npix_in, pad4(t.in_channels), st)
+        for op in t.fwd_order:
+            if isinstance(op, ConvLayer):
+                d = self._desc(op)
+                d.N = op.cout
+                d.wpack = self.wpack_fwd[op.name].data_ptr()
+                b = params[2 * op.param_index + 1]
+                d.bias = b.data_ptr() if b is not None else None
+                d.relu = 1 if op.relu else 0
+                d.mask = None
+                d.ld_mask = 0
+                d.out = self.buf[op.out].data_ptr()
+                d.ld_out = pad4(op.cout)
+                _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+            else:
+                D, H, W = op.in_shape
+                _clx.call("clx_maxpool_fwd", _clx.ptr(self.buf[op.src]), _clx.ptr(self.buf[op.out]),
+                          self.B, D, H, W, pad4(op.channels), *op.factor, st)
+        npix_out = t.out_shape[0] * t.out_shape[1] * t.out_shape[2]
+        spatial = t.out_shape[3 - t.nd:]
+        out = torch.empty((self.B, t.out_channels) + tuple(spatial), dtype=torch.float32, device=self.device)
+        _clx.call("clx_pixel_to_planar", _clx.ptr(self.buf["h1"]), _clx.ptr(out), self.B,
+                  t.out_channels, npix_out, pad4(t.out_channels), st)
+        return out
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, dout, params, grads):
+        """dout: (B, out_channels, *out_spatial) gradient of the loss w.r.t. forward()'s result.
+        grads: list aligned with params; every entry is OVERWRITTEN with the gradient."""
+        t = self.topo
+        st = _clx.stream_ptr(self.device)
+        assert self._bwd_ready, "pack_weights(need_dgrad=True) must run before backward"
+        npix_out = t.out_shape[0] * t.out_shape[1] * t.out_shape[2]
+        dout = dout.contiguous()
+        _clx.call("clx_planar_to_pixel", _clx.ptr(dout), _clx.ptr(self.gbuf["h1"]), self.B,
+                  t.out_channels, npix_out, pad4(t.out_channels), st)
+        self.dwpack.zero_()
+        for g in grads[1::2]:
+            if g is not None:
+                g.zero_()
+
+        by_out = {layer.out: layer for layer in t.convs}
+        pool_by_out = {p.out: p for p in t.pools}
+        r_by_conv0 = {info["conv0"].name: info for info in t.r_info}
+        pending_skip = {}   # skip tensor name -> (cat gbuf name, conv0 layer)
+
+        # reverse execution order; gbuf[x] holds dL/d(pre-activation of x)
+        for op in reversed(t.fwd_order):
+            if isinstance(op, PoolOp):
+                continue  # handled when its consumer's data gradient is produced
+            layer = op
+            dy = self.gbuf[layer.out]
+            # ---- weight + bias gradient
+            d = self._desc(layer)
+            d.N = pad4(layer.cout)
+            gb = grads[2 * layer.param_index + 1]
+            off = self.dw_off[layer.name]
+            dwp = self.dwpack[off:off + layer.taps * pad4(layer.cout) * layer.cin_pad]
+            _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), pad4(layer.cout), _clx.ptr(dwp),
+                      _clx.ptr(gb) if gb is not None else None, st)
+            gw = grads[2 * layer.param_index]
+            if len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
+                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
+                          layer.taps, pad4(layer.cout), layer.cin_pad, st)
+            else:
+                tmp = torch.empty((layer.cout, layer.cin_pad, layer.taps), dtype=torch.float32,
+                                  device=self.device)
+                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(tmp), layer.cout, layer.cin_pad,
+                          layer.taps, pad4(layer.cout), layer.cin_pad, st)
+                gw.copy_(self._compress_cin(layer, tmp).reshape(gw.shape))
+            # ---- data gradient
+            if layer.param_index == 0:
+                continue
+            dd = ClxConvDesc()
+            dd.nsrc = 1
+            src = ClxSrc()
+            src.ptr = dy.data_ptr()
+            src.C = pad4(layer.cout)
+            src.ld = pad4(layer.cout)
+            src.D, src.H, src.W = layer.out_shape
+            src.oz = src.oy = src.ox = 0
+            src.fz = src.fy = src.fx = 1
+            dd.src[0] = src
+            dd.B = self.B
+            dd.ID, dd.IH, dd.IW = layer.out_shape
+            dd.KD, dd.KH, dd.KW = layer.kernel
+            dd.PD, dd.PH, dd.PW = (k - 1 for k in layer.kernel)
+            dd.N = layer.cin_pad
+            dd.wpack = self.wpack_dgrad[layer.name].data_ptr()
+            dd.bias = None
+            dd.relu = 0
+            if len(layer.sources) == 2:
+                info = r_by_conv0[layer.name]
+                cat = self.gbuf["cat%d" % info["level"]]
+                dd.mask = None
+                dd.ld_mask = 0
+                dd.out = cat.data_ptr()
+                dd.ld_out = layer.cin_pad
+                _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+                skip_s, up_s = layer.sources
+                # upsampled branch -> pre-activation gradient of the low-res tensor
+                ushape, uc = t.shapes[up_s.tensor]
+                LD, LH, LW = layer.in_shape
+                _clx.call("clx_upsample_bwd", _clx.ptr(cat), layer.cin_pad, pad4(skip_s.channels),
+                          LD, LH, LW, *up_s.crop, _clx.ptr(self.buf[up_s.tensor]),
+                          _clx.ptr(self.gbuf[up_s.tensor]), self.B, ushape[0], ushape[1], ushape[2],
+                          pad4(uc), *up_s.factor, st)
+                pending_skip[skip_s.tensor] = (cat, layer)
+            else:
+                s = layer.sources[0]
+                if s.tensor in pool_by_out:
+                    # input is a pooled tensor: dgrad -> gradient of the pool output (no gate),
+                    # then route through the max-pool, add the skip gradient, gate by ReLU.
+                    pool = pool_by_out[s.tensor]
+                    dd.mask = None
+                    dd.ld_mask = 0
+                    dd.out = self.gbuf[pool.out].data_ptr()
+                    dd.ld_out = pad4(pool.channels)
+                    _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+                    cat, rl = pending_skip.pop(pool.src)
+                    skip_s = rl.sources[0]
+                    D, H, W = pool.in_shape
+                    SD, SH, SW = rl.in_shape
+                    _clx.call("clx_maxpool_bwd", _clx.ptr(self.buf[pool.src]), _clx.ptr(self.buf[pool.out]),
+                              _clx.ptr(self.gbuf[pool.out]), _clx.ptr(cat), rl.cin_pad, SD, SH, SW,
+                              *skip_s.crop, _clx.ptr(self.gbuf[pool.src]), self.B, D, H, W,
+                              pad4(pool.channels), *pool.factor, st)
+                else:
+                    prev = by_out[s.tensor]
+                    dd.mask = self.buf[prev.out].data_ptr() if prev.relu else None
+                    dd.ld_mask = pad4(prev.cout)
+                    dd.out = self.gbuf[prev.out].data_ptr()
+                    dd.ld_out = pad4(prev.cout)
+                    _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+        assert not pending_skip

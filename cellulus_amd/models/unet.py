@@ -1,0 +1,275 @@
+"""``UNetModel`` — drop-in for ``cellulus/models/unet.py`` running on libclx.
+
+Same constructor, ``forward`` (train / infer modes), ``set_infer`` and
+``select_and_add_coordinates`` as the reference (unet.py:9-124).  Parameters
+carry the reference's ``state_dict`` names (``backbone.l_conv.<i>.conv_pass.<j>``,
+``backbone.r_conv.0.<i>.conv_pass.<j>``, ``head.0``, ``head.2``) in torch layout,
+so checkpoints interchange; the modules that own them never execute — every
+forward/backward is a sequence of HIP kernel launches driven by ``UNetPlan``.
+"""
+
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _clx
+from .plan import UNetPlan, build_topology
+
+
+class _ConvPass(nn.Module):
+    """Parameter holder named like funlib's ConvPass (conv_pass.{0,2,4,6})."""
+
+    def __init__(self, cin, cout, kernel_sizes, nd):
+        super().__init__()
+        conv = nn.Conv2d if nd == 2 else nn.Conv3d
+        layers = []
+        for k in kernel_sizes:
+            layers.append(conv(cin, cout, k))
+            layers.append(nn.ReLU())
+            cin = cout
+        self.conv_pass = nn.Sequential(*layers)
+
+
+class _Backbone(nn.Module):
+    """Parameter holder named like funlib.learn.torch.models.UNet (num_heads = 1)."""
+
+    def __init__(self, in_channels, num_fmaps, fmap_inc_factor, downsample_factors, num_fmaps_out, nd):
+        super().__init__()
+        L = len(downsample_factors)
+        ks = [(3,) * nd, (1,) * nd, (1,) * nd, (3,) * nd]
+        self.l_conv = nn.ModuleList([
+            _ConvPass(in_channels if i == 0 else num_fmaps * fmap_inc_factor ** (i - 1),
+                      num_fmaps * fmap_inc_factor ** i, ks, nd)
+            for i in range(L + 1)
+        ])
+        self.r_conv = nn.ModuleList([nn.ModuleList([
+            _ConvPass(num_fmaps * fmap_inc_factor ** i + num_fmaps * fmap_inc_factor ** (i + 1),
+                      num_fmaps_out if i == 0 else num_fmaps * fmap_inc_factor ** i, ks, nd)
+            for i in range(L)
+        ])])
+
+
+class _UNetFunction(torch.autograd.Function):
+    """autograd glue: one node for the whole network."""
+
+    @staticmethod
+    def forward(ctx, model, raw, *params):
+        plan = model._plan_for(raw, keep=True)
+        plan.pack_weights(params, model._param_version(), need_dgrad=True)
+        out = plan.forward(raw, params)
+        ctx.model = model
+        ctx.plan = plan
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, plan = ctx.model, ctx.plan
+        grads = model._grad_views()
+        plan.backward(dout, ctx.params, grads)
+        return (None, None) + tuple(grads)
+
+
+class UNetModel(nn.Module):  # type: ignore
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        num_fmaps: int,
+        fmap_inc_factor: int,
+        features_in_last_layer: int,
+        downsampling_factors: List[Tuple[int, ...]],
+        num_spatial_dims: int,
+    ):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.features_in_last_layer = features_in_last_layer
+        self.num_fmaps = num_fmaps
+        self.fmap_inc_factor = fmap_inc_factor
+        self.downsampling_factors = [tuple(f) for f in downsampling_factors]
+        self.num_spatial_dims = num_spatial_dims
+        self.mode = "train"
+        self.backbone = _Backbone(in_channels, num_fmaps, fmap_inc_factor,
+                                  self.downsampling_factors, features_in_last_layer, num_spatial_dims)
+        conv = nn.Conv2d if num_spatial_dims == 2 else nn.Conv3d
+        self.head = torch.nn.Sequential(
+            conv(self.features_in_last_layer, self.features_in_last_layer, 1),
+            nn.ReLU(),
+            conv(self.features_in_last_layer, out_channels, 1),
+        )
+        self._plans = {}
+        self._flat = None
+        self._flat_grad = None
+        self._weights_epoch = 0
+        self.max_infer_batch = 8
+
+    # ------------------------------------------------------------ plumbing
+    def _ordered_params(self):
+        """[w0, b0, w1, b1, ...] in the plan's layer order."""
+        mods = []
+        for cp in self.backbone.l_conv:
+            mods += [m for m in cp.conv_pass if isinstance(m, nn.modules.conv._ConvNd)]
+        for cp in reversed(list(self.backbone.r_conv[0])):
+            mods += [m for m in cp.conv_pass if isinstance(m, nn.modules.conv._ConvNd)]
+        mods += [self.head[0], self.head[2]]
+        out = []
+        for m in mods:
+            out += [m.weight, m.bias]
+        return out
+
+    def _param_version(self):
+        return (self._weights_epoch,) + tuple(p._version for p in self._ordered_params())
+
+    def mark_weights_changed(self):
+        """Called by optimizers that update the parameters behind torch's back."""
+        self._weights_epoch += 1
+
+    def flatten_parameters(self):
+        """Makes every parameter (and .grad) a view of one flat f32 buffer so the optimizer
+        step and the data-parallel all-reduce are single launches over contiguous memory."""
+        params = self._ordered_params()
+        dev = params[0].device
+        total = sum(p.numel() for p in params)
+        ok = self._flat is not None and self._flat.device == dev and self._flat.numel() == total
+        if ok:
+            off = 0
+            for p in params:
+                if p.data_ptr() != self._flat.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + n].view(p.shape)
+                off += n
+            self._flat = flat
+            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        return self._flat, self._flat_grad
+
+    def _grad_views(self):
+        _, fg = self.flatten_parameters()
+        views, off = [], 0
+        for p in self._ordered_params():
+            n = p.numel()
+            views.append(fg[off:off + n].view(p.shape))
+            off += n
+        return views
+
+    def attach_flat_grads(self):
+        """p.grad := view into the flat gradient buffer (used by the fused train step)."""
+        views = self._grad_views()
+        for p, g in zip(self._ordered_params(), views):
+            p.grad = g
+        return views
+
+    def _plan_for(self, raw, keep):
+        _clx.require_device(raw, "raw")
+        if raw.dtype != torch.float32:
+            raise TypeError(f"raw must be float32, got {raw.dtype}")
+        if raw.ndim != self.num_spatial_dims + 2 or raw.shape[1] != self.in_channels:
+            raise ValueError(
+                f"raw must have shape (B, {self.in_channels}, *{self.num_spatial_dims} spatial dims), "
+                f"got {tuple(raw.shape)}")
+        w = self.head[0].weight
+        if w.device != raw.device:
+            raise RuntimeError(f"model parameters are on {w.device} but raw is on {raw.device}")
+        key = (tuple(raw.shape), raw.device, bool(keep))
+        plan = self._plans.get(key)
+        if plan is None:
+            topo = build_topology(self.in_channels, self.out_channels, self.num_fmaps,
+                                  self.fmap_inc_factor, self.features_in_last_layer,
+                                  self.downsampling_factors, self.num_spatial_dims, raw.shape[2:])
+            # one plan (activation arena) per input shape; drop older ones to bound memory
+            for k in [k for k in self._plans if k[2] == bool(keep)]:
+                del self._plans[k]
+            plan = UNetPlan(topo, raw.shape[0], raw.device, keep)
+            self._plans[key] = plan
+        return plan
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to()/.cuda() re-allocates parameters: forget flat views and plans
+        self._plans = {}
+        self._flat = None
+        self._flat_grad = None
+        return super()._apply(fn, *args, **kwargs)
+
+    # ------------------------------------------------------------- forward
+    def head_forward(self, backbone_output):
+        raise NotImplementedError(
+            "cellulus_amd fuses backbone and head into one launch plan; call the model itself")
+
+    def _forward_nograd(self, raw):
+        params = self._ordered_params()
+        plan = self._plan_for(raw, keep=False)
+        plan.pack_weights(params, self._param_version(), need_dgrad=False)
+        return plan.forward(raw, params)
+
+    def forward(self, raw):
+        if self.mode == "train":
+            params = self._ordered_params()
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                self.flatten_parameters()
+                params = self._ordered_params()
+                return _UNetFunction.apply(self, raw, *params)
+            return self._forward_nograd(raw)
+        elif self.mode == "infer":
+            return self.infer_on_device(raw).cpu()
+
+    @torch.no_grad()
+    def infer_on_device(self, raw, noise=None):
+        """Infer-mode forward (unet.py:73-100) without the final D2H copy.
+
+        For every sample: 2 * num_infer_iterations salt/pepper-noised copies
+        (value 0.5 then 1.0) -> forward -> per-pixel mean and population std over
+        the copies; std summed over channels.  Returns (B, D+1, *out) on device.
+        `noise`: optional (B, 2*N, C, *spatial) uniform randoms (CPU or device);
+        default draws them with torch.rand on the CPU exactly like the reference
+        (one call per noisy copy, in the reference's order)."""
+        _clx.require_device(raw, "raw")
+        n_it = int(self.num_infer_iterations)
+        T = 2 * n_it
+        B = raw.shape[0]
+        st = _clx.stream_ptr(raw.device)
+        embeddings = []
+        for sample in range(B):
+            raw_sample = raw[sample:sample + 1]
+            if noise is None:
+                rnd = torch.stack([torch.rand(*raw_sample.shape) for _ in range(T)], dim=0)
+                rnd = rnd.reshape((T,) + tuple(raw_sample.shape[1:]))
+            else:
+                rnd = noise[sample]
+            rnd = rnd.to(raw.device, non_blocking=True)
+            vals = torch.tensor([0.5] * n_it + [1.0] * n_it, dtype=torch.float32, device=raw.device)
+            vals = vals.view((T,) + (1,) * (raw_sample.ndim - 1))
+            noisy = torch.where(rnd <= self.p_salt_pepper, vals, raw_sample.expand_as(rnd))
+            preds = []
+            step = max(1, min(T, int(self.max_infer_batch)))
+            for i in range(0, T, step):
+                preds.append(self._forward_nograd(noisy[i:i + step].contiguous()))
+            preds = torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
+            C = preds.shape[1]
+            n = preds[0, 0].numel()
+            out = torch.empty((C + 1,) + tuple(preds.shape[2:]), dtype=torch.float32, device=raw.device)
+            _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(out), T, C, n, st)
+            embeddings.append(out)
+        return torch.stack(embeddings, dim=0)
+
+    def set_infer(self, p_salt_pepper, num_infer_iterations, device):
+        self.mode = "infer"
+        self.p_salt_pepper = p_salt_pepper
+        self.num_infer_iterations = num_infer_iterations
+        self.device: torch.device = device
+
+    @staticmethod
+    def select_and_add_coordinates(outputs, coordinates):
+        """sel[b, p, c] = outputs[b, c, (z,) y, x] + coordinates[b, p, c]  (unet.py:108-124);
+        coordinate column 0 is x (last axis)."""
+        from ..criterions.oce_loss import gather_add
+
+        return gather_add(outputs, coordinates)

@@ -1,0 +1,263 @@
+/*
+ * clx.h — C ABI of libclx.so, the MI355X (gfx950) kernel library behind
+ * cellulus_amd.  Plain C: caller-owned DEVICE pointers, explicit extents, a HIP
+ * stream handle.  No allocation and no ownership transfer inside the library.
+ * Every entry point is asynchronous on `stream` and returns 0 on success or a
+ * negative clx_status; clx_last_error() returns the message of the last
+ * failure on the calling thread.
+ *
+ * The reference (funkelab/cellulus) is pure Python and has no FFI; what each
+ * entry point replaces is the *library call* the reference makes on the hot
+ * path.  The replaced call site is cited per function as
+ * `cellulus/<file>:<line>` (paths relative to the reference checkout).
+ *
+ * Tensor layout used by all kernels: channels-last ("pixel-major"):
+ *   element (b, z, y, x, c) of a (B, D, H, W) grid with C channels sits at
+ *   ptr[(((b*D + z)*H + y)*W + x) * ld + c],  ld >= C, ld % 4 == 0, C % 4 == 0
+ * (2-D data uses D == 1).  The reference's NCHW tensors are converted at the
+ * model boundary with clx_planar_to_pixel / clx_pixel_to_planar.
+ */
+#ifndef CLX_H
+#define CLX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* clx_stream; /* hipStream_t */
+
+enum clx_status {
+  CLX_OK = 0,
+  CLX_ERR_ARG = -1,    /* invalid argument / unsupported shape */
+  CLX_ERR_LAUNCH = -2, /* HIP launch or runtime failure */
+  CLX_ERR_WORKSPACE = -3
+};
+
+const char* clx_last_error(void);
+/* Library/ABI version (bumped when a signature changes). */
+int clx_abi_version(void);
+/* Number of HIP devices visible to the library (0 = none; not an error). */
+int clx_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Convolution (valid, stride 1, kernel extent 1 or 3 per dim)              */
+/* replaces: nn.Conv{2,3}d + nn.ReLU inside funlib ConvPass and the 1x1     */
+/* head (cellulus/models/unet.py:24-63), their autograd backward            */
+/* (cellulus/train.py:178), nn.Upsample(nearest) + centre-crop + torch.cat  */
+/* of the U-Net's right path (fused into the A-operand gather).             */
+/* ------------------------------------------------------------------------ */
+
+/* One input source of a convolution.  The convolution reads a *logical* input
+ * grid of extent (ID, IH, IW); logical voxel l of source s is stored at grid
+ * position ((l + o) / f) of the source's (D, H, W) array — `o` is a crop
+ * offset, `f` a nearest-neighbour upsampling factor (1 = none). */
+typedef struct clx_src {
+  const float* ptr;
+  int C;          /* channels taken from this source (multiple of 4) */
+  int ld;         /* floats between consecutive pixels */
+  int D, H, W;    /* stored grid extent */
+  int oz, oy, ox; /* crop offset (in logical = upsampled coordinates) */
+  int fz, fy, fx; /* nearest upsample factor per dim, >= 1 */
+} clx_src;
+
+typedef struct clx_conv_desc {
+  int nsrc;       /* 1 or 2; channels of src[0] come first (torch.cat order) */
+  clx_src src[2];
+  int B;
+  int ID, IH, IW; /* logical input extent */
+  int KD, KH, KW; /* kernel extent, each 1 or 3 */
+  int PD, PH, PW; /* zero padding per side (0 for the valid forward conv) */
+  int N;          /* output channels actually computed (<= ld_out) */
+  const float* wpack; /* [N][KD*KH*KW][Ctot] packed weights (clx_pack_weights) */
+  const float* bias;  /* [N] or NULL */
+  int relu;           /* epilogue: max(0, .) */
+  const float* mask;  /* optional [M][ld_mask]: out *= (mask > 0) (ReLU backward) */
+  int ld_mask;
+  float* out;         /* [M][ld_out], M = B*OD*OH*OW, O = I + 2P - K + 1 */
+  int ld_out;
+} clx_conv_desc;
+
+/* out = act(conv(in) + bias).  f32 MFMA implicit GEMM (M = output pixels,
+ * N = output channels, K = taps x channels). Also used for the data gradient
+ * (PD = K-1, weights packed with CLX_PACK_DGRAD). */
+int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream);
+
+/* Weight gradient of the convolution described by `d` (d->out/bias/relu/mask/
+ * wpack ignored): dwpack[tap][n][c] += sum_p dy[p][n] * in[p (+) tap][c],
+ * dbias[n] += sum_p dy[p][n]  (dbias may be NULL).  Both outputs are
+ * ACCUMULATED with float atomics (split-K): zero them first.
+ * dy: [M][ld_dy] gradient w.r.t. the pre-activation output. */
+int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy,
+                   float* dwpack, float* dbias, clx_stream stream);
+
+enum clx_pack_mode {
+  CLX_PACK_FWD = 0,   /* w[n][c][tap] -> wp[n][tap][cpad]               */
+  CLX_PACK_DGRAD = 1  /* w[n][c][tap] -> wp[c][flip(tap)][npad] (rows c < cpad) */
+};
+/* Repack torch-layout conv weights w (Cout, Cin, taps) for clx_conv_fwd.
+ * cin_pad/cout_pad >= real extents (multiples of 4), padding is zero-filled.
+ * FWD:   wp is [Cout][taps][cin_pad].
+ * DGRAD: wp is [cin_pad][taps][cout_pad] with the taps reversed. */
+int clx_pack_weights(const float* w, float* wp, int cout, int cin, int taps,
+                     int cin_pad, int cout_pad, int mode, clx_stream stream);
+/* dw[n][c][tap] = dwpack[tap][n][c] for n < cout, c < cin  (wgrad output ->
+ * torch layout). dwpack is [taps][rows][cin_pad], rows >= cout. */
+int clx_unpack_wgrad(const float* dwpack, float* dw, int cout, int cin, int taps,
+                     int rows, int cin_pad, clx_stream stream);
+
+/* (B, C, n) planar <-> (B, n, ld) pixel-major; channels c >= C of the
+ * pixel-major side are written as zero / ignored. */
+int clx_planar_to_pixel(const float* planar, float* pixel, int B, int C,
+                        long long n, int ld, clx_stream stream);
+int clx_pixel_to_planar(const float* pixel, float* planar, int B, int C,
+                        long long n, int ld, clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Max pooling / upsample backward (funlib Downsample / Upsample,           */
+/* cellulus/models/unet.py:24-51)                                           */
+/* ------------------------------------------------------------------------ */
+/* y = maxpool(x), window = stride = (fz, fy, fx); extents must divide. */
+int clx_maxpool_fwd(const float* x, float* y, int B, int D, int H, int W, int C,
+                    int fz, int fy, int fx, clx_stream stream);
+/* Gradient w.r.t. the PRE-activation of the tensor x that feeds both the
+ * max-pool and the cropped skip connection:
+ *   g[p][c]  = (x[p][c] is the first maximum of its window ? dy_pool[win][c] : 0)
+ *            + (p inside the crop ? dskip[p - crop][c] : 0)
+ *   dx[p][c] = g * (x[p][c] > 0)
+ * dskip may be NULL. dskip has extent (SD, SH, SW), pixel stride ld_skip and
+ * sits at offset (cz, cy, cx) inside x's grid. */
+int clx_maxpool_bwd(const float* x, const float* y, const float* dy_pool,
+                    const float* dskip, int ld_skip, int SD, int SH, int SW,
+                    int cz, int cy, int cx, float* dx, int B, int D, int H,
+                    int W, int C, int fz, int fy, int fx, clx_stream stream);
+/* Backward of nearest upsample (+ crop) into the PRE-activation gradient of the
+ * low-resolution tensor y (extent D,H,W; C channels):
+ *   dy[q][c] = (sum over the f-block of dcat[(q*f + r) - o][coff + c]) * (y > 0)
+ * dcat: gradient of the concatenated tensor, logical extent (LD, LH, LW),
+ * pixel stride ld_cat, channel offset coff; o = crop offset. */
+int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD, int LH,
+                     int LW, int oz, int oy, int ox, const float* y, float* dy,
+                     int B, int D, int H, int W, int C, int fz, int fy, int fx,
+                     clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Embedding gather, OCE loss, Adam                                         */
+/* ------------------------------------------------------------------------ */
+/* sel[b][p][c] = offsets[b][c][coord...] + coord[b][p][c]
+ * replaces UNetModel.select_and_add_coordinates (cellulus/models/unet.py:108-124).
+ * offsets: planar (B, ND, [Z,] Y, X) f32; coords: (B, P, ND) int64, column 0
+ * indexes the LAST spatial axis. */
+int clx_gather_add_fwd(const float* offsets, const long long* coords, float* sel,
+                       int B, int P, int ND, int Z, int Y, int X, clx_stream stream);
+/* doffsets[b][c][coord] += dsel[b][p][c]  (float atomics; zero doffsets first) */
+int clx_gather_add_bwd(const float* dsel, const long long* coords, float* doffsets,
+                       int B, int P, int ND, int Z, int Y, int X, clx_stream stream);
+/* OCE loss forward + gradient, replaces OCELoss.forward
+ * (cellulus/criterions/oce_loss.py:45-63) and its autograd backward:
+ *   d = |a - r|, oce = sum(1 - exp(-d^2/T)), reg = w * sum |a|
+ *   da = (2/T) exp(-d^2/T) (a - r) + w a/|a|      (0 where the norm is 0)
+ * a, r: (npairs, ND) f32. sums[0..2] += (loss, oce, reg) in f64 (zero first).
+ * da may be NULL (forward only); grad_scale multiplies da. */
+int clx_oce_loss_fwd_bwd(const float* a, const float* r, float* da, double* sums,
+                         long long npairs, int ND, float temperature,
+                         float reg_weight, float grad_scale, clx_stream stream);
+/* Fused train-step tail: gather(anchor), gather(reference), OCE loss, and the
+ * scatter-add of the anchor gradient straight into doffsets (planar, zeroed by
+ * the caller). Equivalent to the three calls above composed as in
+ * cellulus/train.py:170-178. */
+int clx_oce_pairs_fused(const float* offsets, const long long* anchor,
+                        const long long* reference, float* doffsets, double* sums,
+                        int B, int P, int ND, int Z, int Y, int X,
+                        float temperature, float reg_weight, clx_stream stream);
+/* torch.optim.Adam(lr, betas, eps, weight_decay) single step with coupled L2
+ * (cellulus/train.py:80-82,179) over flat buffers of n floats.
+ * step = 1-based step count AFTER increment. */
+int clx_adam_step(float* param, const float* grad, float* exp_avg,
+                  float* exp_avg_sq, long long n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step,
+                  clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Inference statistics (cellulus/models/unet.py:90-98)                     */
+/* ------------------------------------------------------------------------ */
+/* preds: (T, C, n) planar predictions of T noisy forwards of one sample.
+ * out: (C+1, n): out[c] = mean_t preds[t][c], out[C] = sum_c std_t (population
+ * std, torch.std_mean(unbiased=False)). */
+int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
+                    clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Mean-shift clustering (cellulus/utils/mean_shift.py:6-121 ->             */
+/* sklearn.cluster.MeanShift.fit/predict), float64                          */
+/* ------------------------------------------------------------------------ */
+/* Adds pixel coordinates to the embedding IN PLACE (the reference mutates its
+ * argument, mean_shift.py:15-32), builds the foreground mask std < threshold
+ * and compacts foreground pixels in raster order:
+ *   emb:  (ND, [Z,] Y, X) f64, channel 0 += x, 1 += y, 2 += z
+ *   X:    (nfg, ND) f64 out,  index: (nfg) int32 raster index of each fg pixel
+ *   nfg_out: device int32, number of foreground pixels
+ * workspace: clx_ms_prepare_workspace(npix) bytes. */
+size_t clx_ms_prepare_workspace(long long npix);
+int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
+                   int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
+                   void* workspace, clx_stream stream);
+/* Flat-kernel mean-shift of every seed over the fit points until
+ * |shift| <= 1e-3*bandwidth or max_iter (sklearn _mean_shift_single_seed).
+ * fit: (nfit, ND) f64; seeds: (nseeds, ND) f64; outputs centers (nseeds, ND)
+ * f64, counts (nseeds) int32 = members within bandwidth of the final query,
+ * iters (nseeds) int32. */
+int clx_ms_iterate(const double* fit, int nfit, const double* seeds, int nseeds,
+                   int ND, double bandwidth, int max_iter, double* centers,
+                   int* counts, int* iters, clx_stream stream);
+/* labels[index[i]] = 1 + argmin_k |X[i] - centers[k]|  (first minimum);
+ * labels (npix) int32 must be zero-filled by the caller (background = 0). */
+int clx_ms_assign(const double* X, const int* index, int nfg,
+                  const double* centers, int ncenters, int ND, int* labels,
+                  clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Connected components + size filter (cellulus/utils/misc.py:11-25 ->      */
+/* skimage.measure.label, full connectivity, background 0)                  */
+/* ------------------------------------------------------------------------ */
+size_t clx_cc_workspace(long long npix);
+/* out[p] = raster-order component id (1..ncomp) of the maximal equal-value
+ * 8-/26-connected region containing p, 0 for seg[p]==0. Components with fewer
+ * than min_size pixels are removed first (min_size <= 0: keep all — and, as in
+ * the reference, min_size == 0 means "return seg unchanged": the caller
+ * handles that case). ncomp_out: device int32. */
+int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X,
+                        int min_size, int* ncomp_out, void* workspace,
+                        clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Exact squared Euclidean distance transform (scipy distance_transform_edt */
+/* as used by cellulus/segment.py:41-51)                                    */
+/* ------------------------------------------------------------------------ */
+size_t clx_edt_workspace(long long npix);
+/* out[p] = min over q with in[q]==0 of |p-q|^2 (int32; "infinite" when the
+ * image has no zero pixel is reported as INT32_MAX/2). */
+int clx_edt_sq(const unsigned char* in, int* out, int Z, int Y, int X,
+               void* workspace, clx_stream stream);
+/* segment "cell" post-processing in one call (segment.py:41-51):
+ *   d1 = edt(seg==0); grown = d1 < grow; d2 = edt(grown); seg[d2 < shrink] = 0 */
+int clx_grow_shrink(int* seg, int Z, int Y, int X, int grow, int shrink,
+                    void* workspace /* 2*clx_edt_workspace + npix */,
+                    clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
+/* Otsu histogram (skimage.filters.threshold_otsu, cellulus/detect.py:88-91) */
+/* ------------------------------------------------------------------------ */
+/* minmax[0..1] = min, max of x (f64, n elements). */
+int clx_minmax_f64(const double* x, long long n, double* minmax, clx_stream stream);
+/* numpy.histogram(x, bins=nbins, range=(edges[0], edges[nbins])) with the
+ * caller-supplied edges (np.linspace) — counts (nbins) int64, zeroed by caller. */
+int clx_histogram_f64(const double* x, long long n, const double* edges,
+                      int nbins, long long* counts, clx_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLX_H */

@@ -1,0 +1,210 @@
+"""Oracle (test infrastructure): CPU restatement of the U-Net + head, the
+embedding gather and the OCE loss in plain PyTorch fp32.
+
+Follows:
+  * cellulus/models/unet.py:24-63   (backbone arguments, 1x1 head)
+  * cellulus/models/unet.py:69-100  (train / infer forward)
+  * cellulus/models/unet.py:108-124 (select_and_add_coordinates)
+  * cellulus/criterions/oce_loss.py:45-63 (OCE loss)
+  * funlib.learn.torch.models.UNet @ f36decaf (pyproject.toml:30) — NOT present
+    under /root/reference; restated from its published architecture (ConvPass =
+    valid Conv + ReLU per kernel size, MaxPool down, nearest Upsample,
+    crop_to_factor, centre-cropped skip concatenated before the upsampled
+    tensor).  PARITY UNPINNED for the backbone topology: the reference holds no
+    golden vector for it; only the (crop - 16) output-shape contract
+    (cellulus/datasets/zarr_dataset.py:94) is pinned.
+The head, the infer-mode noise loop, the gather and the loss are pinned against
+the real reference classes by tests/golden (see tests/golden/make_golden.py).
+"""
+
+import math
+
+import torch
+import torch.nn as nn
+
+
+class ConvPass(nn.Module):
+    def __init__(self, cin, cout, kernel_sizes, nd):
+        super().__init__()
+        conv = {2: nn.Conv2d, 3: nn.Conv3d}[nd]
+        layers = []
+        for k in kernel_sizes:
+            layers.append(conv(cin, cout, k))       # padding="valid"
+            layers.append(nn.ReLU())
+            cin = cout
+        self.conv_pass = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.conv_pass(x)
+
+
+class Downsample(nn.Module):
+    def __init__(self, factor, nd):
+        super().__init__()
+        self.factor = tuple(factor)
+        self.nd = nd
+        pool = {2: nn.MaxPool2d, 3: nn.MaxPool3d}[nd]
+        self.down = pool(self.factor, stride=self.factor)
+
+    def forward(self, x):
+        for d in range(1, self.nd + 1):
+            if x.size()[-d] % self.factor[-d] != 0:
+                raise RuntimeError(
+                    "Can not downsample shape %s with factor %s, mismatch in spatial dimension %d"
+                    % (x.size(), self.factor, self.nd - d))
+        return self.down(x)
+
+
+class Upsample(nn.Module):
+    def __init__(self, factor, nd, crop_factor, next_conv_kernel_sizes):
+        super().__init__()
+        self.nd = nd
+        self.crop_factor = crop_factor
+        self.next_conv_kernel_sizes = next_conv_kernel_sizes
+        self.up = nn.Upsample(scale_factor=tuple(factor), mode="nearest")
+
+    def crop_to_factor(self, x, factor, kernel_sizes):
+        shape = x.size()
+        spatial = shape[-self.nd:]
+        conv_crop = tuple(sum(ks[d] - 1 for ks in kernel_sizes) for d in range(self.nd))
+        ns = (int(math.floor(float(s - c) / f)) for s, c, f in zip(spatial, conv_crop, factor))
+        target = tuple(n * f + c for n, c, f in zip(ns, conv_crop, factor))
+        if target != tuple(spatial):
+            assert all(t > c for t, c in zip(target, conv_crop)), "feature map too small"
+            return self.crop(x, target)
+        return x
+
+    def crop(self, x, shape):
+        x_target = x.size()[:-self.nd] + tuple(shape)
+        offset = tuple((a - b) // 2 for a, b in zip(x.size(), x_target))
+        slices = tuple(slice(o, o + s) for o, s in zip(offset, x_target))
+        return x[slices]
+
+    def forward(self, f_left, g_out):
+        g_up = self.up(g_out)
+        g_cropped = self.crop_to_factor(g_up, self.crop_factor, self.next_conv_kernel_sizes)
+        f_cropped = self.crop(f_left, g_cropped.size()[-self.nd:])
+        return torch.cat([f_cropped, g_cropped], dim=1)
+
+
+class OracleUNet(nn.Module):
+    """Backbone with the constructor keywords cellulus/models/unet.py:24-51 passes."""
+
+    def __init__(self, in_channels, num_fmaps, fmap_inc_factor, downsample_factors,
+                 kernel_size_down=None, kernel_size_up=None, activation="ReLU",
+                 num_fmaps_out=None, padding="valid", constant_upsample=True, **_):
+        super().__init__()
+        assert activation == "ReLU" and padding == "valid" and constant_upsample
+        nd = len(downsample_factors[0]) if len(downsample_factors) else len(kernel_size_down[0][0])
+        self.nd = nd
+        self.num_levels = len(downsample_factors) + 1
+        L = self.num_levels - 1
+        crop_factors, prod = [], None
+        for f in downsample_factors[::-1]:
+            prod = list(f) if prod is None else [a * b for a, b in zip(f, prod)]
+            crop_factors.append(prod)
+        crop_factors = crop_factors[::-1]
+        self.l_conv = nn.ModuleList([
+            ConvPass(in_channels if i == 0 else num_fmaps * fmap_inc_factor ** (i - 1),
+                     num_fmaps * fmap_inc_factor ** i, kernel_size_down[i], nd)
+            for i in range(self.num_levels)])
+        self.l_down = nn.ModuleList([Downsample(downsample_factors[i], nd) for i in range(L)])
+        self.r_up = nn.ModuleList([nn.ModuleList([
+            Upsample(downsample_factors[i], nd, crop_factors[i], kernel_size_up[i]) for i in range(L)])])
+        self.r_conv = nn.ModuleList([nn.ModuleList([
+            ConvPass(num_fmaps * fmap_inc_factor ** i + num_fmaps * fmap_inc_factor ** (i + 1),
+                     num_fmaps * fmap_inc_factor ** i if (num_fmaps_out is None or i != 0) else num_fmaps_out,
+                     kernel_size_up[i], nd)
+            for i in range(L)])])
+
+    def rec_forward(self, level, f_in):
+        i = self.num_levels - level - 1
+        f_left = self.l_conv[i](f_in)
+        if level == 0:
+            return f_left
+        g_in = self.l_down[i](f_left)
+        g_out = self.rec_forward(level - 1, g_in)
+        f_right = self.r_up[0][i](f_left, g_out)
+        return self.r_conv[0][i](f_right)
+
+    def forward(self, x):
+        return self.rec_forward(self.num_levels - 1, x)
+
+
+class OracleUNetModel(nn.Module):
+    """cellulus/models/unet.py:9-124 with the backbone above (CPU, fp32)."""
+
+    def __init__(self, in_channels, out_channels, num_fmaps, fmap_inc_factor,
+                 features_in_last_layer, downsampling_factors, num_spatial_dims):
+        super().__init__()
+        nd = num_spatial_dims
+        ks = [(3,) * nd, (1,) * nd, (1,) * nd, (3,) * nd]
+        self.backbone = OracleUNet(
+            in_channels=in_channels, num_fmaps=num_fmaps, fmap_inc_factor=fmap_inc_factor,
+            downsample_factors=[tuple(f) for f in downsampling_factors], activation="ReLU",
+            padding="valid", num_fmaps_out=features_in_last_layer,
+            kernel_size_down=[ks] * (len(downsampling_factors) + 1),
+            kernel_size_up=[ks] * len(downsampling_factors), constant_upsample=True)
+        conv = {2: nn.Conv2d, 3: nn.Conv3d}[nd]
+        self.head = nn.Sequential(conv(features_in_last_layer, features_in_last_layer, 1), nn.ReLU(),
+                                  conv(features_in_last_layer, out_channels, 1))
+        self.mode = "train"
+
+    def set_infer(self, p_salt_pepper, num_infer_iterations, device=None):
+        self.mode = "infer"
+        self.p_salt_pepper = p_salt_pepper
+        self.num_infer_iterations = num_infer_iterations
+
+    def forward(self, raw, noise=None):
+        if self.mode == "train":
+            return self.head(self.backbone(raw))
+        embeddings = []
+        for sample in range(raw.shape[0]):          # unet.py:75-98
+            raw_sample = raw[sample:sample + 1]
+            preds, t = [], 0
+            for val in [0.5, 1.0]:
+                for _ in range(self.num_infer_iterations):
+                    noisy = raw_sample.detach().clone()
+                    rnd = torch.rand(*noisy.shape) if noise is None else noise[sample, t][None]
+                    noisy[rnd <= self.p_salt_pepper] = val
+                    preds.append(self.head(self.backbone(noisy))[0].detach())
+                    t += 1
+            std, mean = torch.std_mean(torch.stack(preds, dim=0), dim=0, keepdim=False, unbiased=False)
+            std = std.sum(dim=0, keepdim=True)
+            embeddings.append(torch.cat((mean, std), dim=0))
+        return torch.stack(embeddings, dim=0)
+
+
+def select_and_add_coordinates(outputs, coordinates):
+    """cellulus/models/unet.py:108-124."""
+    selections = []
+    for output, coordinate in zip(outputs, coordinates):
+        if output.ndim == 3:
+            selection = output[:, coordinate[:, 1], coordinate[:, 0]]
+        else:
+            selection = output[:, coordinate[:, 2], coordinate[:, 1], coordinate[:, 0]]
+        selection = selection.transpose(1, 0)
+        selection = selection + coordinate
+        selections.append(selection)
+    return torch.stack(selections, dim=0)
+
+
+def oce_loss(anchor, reference, temperature, regularization_weight):
+    """cellulus/criterions/oce_loss.py:45-63 -> (loss, oce, reg)."""
+    distance = (anchor - reference.detach()).norm(2, dim=-1)
+    oce = (1 - (-distance.pow(2) / temperature).exp()).sum()
+    reg = regularization_weight * anchor.norm(2, dim=-1).sum()
+    return oce + reg, oce, reg
+
+
+def train_step(model, optimizer, raw, anchor, reference, temperature, regularization_weight):
+    """cellulus/train.py:160-180 on the CPU; returns (loss, oce, offsets)."""
+    model.train()
+    offsets = model(raw)
+    ea = select_and_add_coordinates(offsets, anchor)
+    er = select_and_add_coordinates(offsets, reference)
+    loss, oce, _ = oce_loss(ea, er, temperature, regularization_weight)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.item(), oce.item(), offsets
