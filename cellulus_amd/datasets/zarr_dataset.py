@@ -1,0 +1,183 @@
+"""`ZarrDataset` — random crops + pair coordinates, the producer side of
+``train_iteration`` (cellulus/datasets/zarr_dataset.py:12-251).
+
+The reference builds a gunpowder pipeline (ZarrSource -> RandomLocation ->
+Normalize [-> ElasticAugment]); gunpowder and zarr are absent here, so the
+pipeline is restated on numpy/scipy: uniform random sample + spatial offset,
+``float32(data) * factor`` normalisation, optional elastic deformation
+(jittered control-point grid + rotation in [0, pi/2] + scale in [0.9, 1.1],
+linear interpolation), rejection of all-zero crops (zarr_dataset.py:139-158).
+The pair sampler (`sample_coordinates`, `sample_offsets_within_radius`) follows
+zarr_dataset.py:177-251 call for call on the global numpy RNG, so seeding
+``np.random`` reproduces the reference's coordinates.
+"""
+
+import math
+import random
+from typing import Tuple
+
+import numpy as np
+from torch.utils.data import IterableDataset
+
+from ..configs import DatasetConfig
+from ..utils import zarr_io
+from .meta_data import DatasetMetaData
+
+
+def default_normalization_factor(dtype):
+    """gunpowder.Normalize(factor=None): scale integer types to [0, 1]."""
+    dtype = np.dtype(dtype)
+    if dtype == np.uint8:
+        return 1.0 / 255
+    if dtype == np.uint16:
+        return 1.0 / 65535
+    if dtype.kind == "f":
+        return 1.0
+    raise RuntimeError(f"automatic normalization is not implemented for dtype {dtype}; "
+                       "set normalization_factor")
+
+
+class ZarrDataset(IterableDataset):  # type: ignore
+    def __init__(
+        self,
+        dataset_config: DatasetConfig,
+        crop_size: Tuple[int, ...],
+        elastic_deform: bool,
+        control_point_spacing: int,
+        control_point_jitter: float,
+        density: float,
+        kappa: float,
+        normalization_factor: float,
+    ):
+        self.dataset_config = dataset_config
+        self.crop_size = tuple(crop_size)
+        self.elastic_deform = elastic_deform
+        self.control_point_spacing = control_point_spacing
+        self.control_point_jitter = control_point_jitter
+        self.normalization_factor = normalization_factor
+        self.__read_meta_data()
+        assert len(crop_size) == self.num_spatial_dims, (
+            f'"crop_size" must have the same dimension as the spatial(temporal) dimensions of the '
+            f'"{self.dataset_config.dataset_name}" dataset which is {self.num_spatial_dims}, '
+            f"but it is {crop_size}")
+        self.density = density
+        self.kappa = kappa
+        self.output_shape = tuple(int(_ - 16) for _ in self.crop_size)
+        self.unbiased_shape = tuple(int(_ - (2 * self.kappa)) for _ in self.output_shape)
+        self._array = None
+
+    def __iter__(self):
+        return iter(self.__yield_sample())
+
+    # ------------------------------------------------------------------ source
+    def _open(self):
+        if self._array is None:
+            container = zarr_io.open(self.dataset_config.container_path, "r")
+            self._array = container[self.dataset_config.dataset_name]
+            for size, crop in zip(self._array.shape[2:], self.crop_size):
+                if size < crop:
+                    raise RuntimeError(f"crop_size {self.crop_size} exceeds the dataset's spatial "
+                                       f"extent {self._array.shape[2:]}")
+        return self._array
+
+    def _random_crop(self):
+        arr = self._open()
+        s = random.randint(0, arr.shape[0] - 1)
+        factor = self.normalization_factor
+        if factor is None:
+            factor = default_normalization_factor(arr.dtype)
+        spatial = arr.shape[2:]
+        if not self.elastic_deform:
+            off = [random.randint(0, n - c) for n, c in zip(spatial, self.crop_size)]
+            sl = (s, slice(None)) + tuple(slice(o, o + c) for o, c in zip(off, self.crop_size))
+            return arr[sl].astype(np.float32) * np.float32(factor)
+        return self._elastic_crop(arr, s, factor)
+
+    def _elastic_crop(self, arr, s, factor):
+        from scipy.ndimage import map_coordinates, zoom
+
+        nd = self.num_spatial_dims
+        crop = np.asarray(self.crop_size, dtype=np.float64)
+        spatial = np.asarray(arr.shape[2:], dtype=np.float64)
+        angle = random.uniform(0, math.pi / 2)
+        scale = random.uniform(0.9, 1.1)
+        grid = np.stack(np.meshgrid(*[np.arange(c, dtype=np.float64) for c in self.crop_size],
+                                    indexing="ij"))
+        centre = (crop - 1) / 2
+        rel = grid - centre.reshape((nd,) + (1,) * nd)
+        rot = np.eye(nd)
+        c_, s_ = math.cos(angle), math.sin(angle)
+        rot[-2:, -2:] = [[c_, -s_], [s_, c_]]          # rotate in the (y, x) plane
+        rel = np.tensordot(rot, rel, axes=1) * scale
+        cp_shape = [max(2, int(math.ceil(c / self.control_point_spacing)) + 1) for c in self.crop_size]
+        for d in range(nd):
+            jitter = np.random.normal(0.0, self.control_point_jitter, size=cp_shape)
+            rel[d] += zoom(jitter, [c / p for c, p in zip(self.crop_size, cp_shape)], order=3,
+                           mode="nearest", grid_mode=False)[tuple(slice(0, c) for c in self.crop_size)]
+        lo, hi = rel.reshape(nd, -1).min(axis=1), rel.reshape(nd, -1).max(axis=1)
+        room = spatial - 1 - (hi - lo)
+        mode = "constant" if np.all(room >= 0) else "reflect"
+        origin = np.array([random.uniform(0, max(r, 0)) for r in room]) - lo
+        coords = rel + origin.reshape((nd,) + (1,) * nd)
+        data = arr[s].astype(np.float32) * np.float32(factor)
+        out = np.stack([map_coordinates(ch, coords, order=1, mode=mode, cval=0.0) for ch in data])
+        return out.astype(np.float32)
+
+    def __yield_sample(self):
+        """An infinite generator of crops."""
+        while True:
+            array_is_zero = True
+            while array_is_zero:   # reject empty crops (zarr_dataset.py:139-158)
+                sample_data = self._random_crop()
+                if np.max(sample_data) <= 0.0:
+                    continue
+                array_is_zero = False
+                anchor_samples, reference_samples = self.sample_coordinates()
+            yield sample_data, anchor_samples, reference_samples
+
+    def __read_meta_data(self):
+        meta_data = DatasetMetaData.from_dataset_config(self.dataset_config)
+        self.num_dims = meta_data.num_dims
+        self.num_spatial_dims = meta_data.num_spatial_dims
+        self.num_channels = meta_data.num_channels
+        self.num_samples = meta_data.num_samples
+        self.sample_dim = meta_data.sample_dim
+        self.channel_dim = meta_data.channel_dim
+        self.time_dim = meta_data.time_dim
+
+    def get_num_channels(self):
+        return self.num_channels
+
+    def get_num_spatial_dims(self):
+        return self.num_spatial_dims
+
+    # ------------------------------------------------------------ pair sampler
+    def sample_offsets_within_radius(self, radius, number_offsets):
+        nd = self.num_spatial_dims
+        draws = [np.random.randint(-radius, radius + 1, size=nd * number_offsets) for _ in range(nd)]
+        offsets = np.stack(draws, axis=1)
+        offsets = offsets[(offsets ** 2).sum(axis=1) < radius ** 2]
+        offsets = offsets[np.absolute(offsets).sum(axis=1) > 0]
+        if len(offsets) < number_offsets:
+            return self.sample_offsets_within_radius(radius, number_offsets)
+        return offsets[:number_offsets]
+
+    def sample_coordinates(self):
+        num_anchors = self.get_num_anchors()
+        num_references = self.get_num_references()
+        columns = [np.random.randint(self.kappa, self.output_shape[d] - self.kappa + 1, size=num_anchors)
+                   for d in range(self.num_spatial_dims)]
+        anchor_coordinates = np.stack(columns, axis=1)
+        anchor_samples = np.repeat(anchor_coordinates, num_references, axis=0)
+        offset_in_pos_radius = self.sample_offsets_within_radius(self.kappa, len(anchor_samples))
+        reference_samples = anchor_samples + offset_in_pos_radius
+        return anchor_samples, reference_samples
+
+    def get_num_anchors(self):
+        return int(self.density * self.unbiased_shape[0] * self.unbiased_shape[1])
+
+    def get_num_references(self):
+        return int(self.density * self.kappa ** 2 * np.pi)
+
+    def get_num_samples(self):
+        return self.get_num_anchors() * self.get_num_references()

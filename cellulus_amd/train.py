@@ -1,0 +1,278 @@
+"""Training driver — drop-in for ``cellulus/train.py`` (``train``,
+``train_iteration``, ``save_model``, ``save_snapshot``) on libclx.
+
+Same control flow, checkpoint dictionary (``iteration, lowest_loss,
+model_state_dict, optim_state_dict, logger_data``), file names
+(``models/best_loss.pth``, ``models/<iter:06d>.pth``, ``loss.csv``,
+``snapshots.zarr/<iter>/{raw,prediction}``) and console output as the
+reference.  What differs is underneath: ``train_iteration`` is one stream of
+HIP launches (pack -> U-Net forward -> fused gather/OCE/scatter -> backward ->
+[RCCL all-reduce SUM] -> one fused Adam launch) with a single host
+synchronisation for the two returned floats.
+
+Launched under ``torch.distributed.run`` (WORLD_SIZE > 1) it trains
+data-parallel: each rank draws its own crops, gradients are SUM-all-reduced (the
+loss is a sum over pairs, so this equals one process at the global batch);
+rank 0 alone logs, checkpoints and snapshots.
+"""
+
+import os
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from . import _clx, parallel
+from .criterions import get_loss
+from .criterions.oce_loss import OCELoss
+from .datasets import get_dataset
+from .models import get_model
+from .models.unet import UNetModel
+from .optim import Adam
+from .utils import get_logger
+from .utils import zarr_io
+
+
+def _require_hip_device(device_str):
+    device = torch.device(device_str)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise RuntimeError(
+            f"device={device_str!r}: cellulus_amd runs on HIP devices only ('cuda:N' is HIP device N "
+            "on ROCm) and none is usable here; there is no CPU path.")
+    return device
+
+
+def train(experiment_config):
+    print(experiment_config)
+    rank, world, local_rank = parallel.init_from_env()
+    is_main = rank == 0
+
+    if is_main and not os.path.exists("models"):
+        os.makedirs("models")
+
+    train_config = experiment_config.train_config
+    model_config = experiment_config.model_config
+
+    device_str = train_config.device
+    if world > 1:
+        device_str = f"cuda:{local_rank}"
+    device = _require_hip_device(device_str)
+    torch.cuda.set_device(device)
+
+    # create train dataset
+    train_dataset = get_dataset(
+        dataset_config=train_config.train_data_config,
+        crop_size=tuple(train_config.crop_size),
+        elastic_deform=train_config.elastic_deform,
+        control_point_spacing=train_config.control_point_spacing,
+        control_point_jitter=train_config.control_point_jitter,
+        density=train_config.density,
+        kappa=train_config.kappa,
+        normalization_factor=experiment_config.normalization_factor,
+    )
+
+    # create train dataloader (every rank draws its own random crops)
+    train_dataloader = torch.utils.data.DataLoader(
+        dataset=train_dataset,
+        batch_size=train_config.batch_size,
+        drop_last=True,
+        num_workers=train_config.num_workers,
+        pin_memory=True,
+    )
+
+    # set model
+    model = get_model(
+        in_channels=train_dataset.get_num_channels(),
+        out_channels=train_dataset.get_num_spatial_dims(),
+        num_fmaps=model_config.num_fmaps,
+        fmap_inc_factor=model_config.fmap_inc_factor,
+        features_in_last_layer=model_config.features_in_last_layer,
+        downsampling_factors=[tuple(factor) for factor in model_config.downsampling_factors],
+        num_spatial_dims=train_dataset.get_num_spatial_dims(),
+    )
+    model = model.to(device)
+
+    # initialize model weights
+    if model_config.initialize:
+        for _name, layer in model.named_modules():
+            if isinstance(layer, torch.nn.modules.conv._ConvNd):
+                torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+
+    # set loss
+    criterion = get_loss(
+        regularizer_weight=train_config.regularizer_weight,
+        temperature=train_config.temperature,
+        density=train_config.density,
+        num_spatial_dims=train_dataset.get_num_spatial_dims(),
+        device=device,
+    )
+
+    # set optimizer: Adam with coupled L2 (train.py:80-82)
+    flat, _ = model.flatten_parameters()
+    parallel.broadcast_(flat, src=0)
+    optimizer = Adam(model.parameters(), lr=train_config.initial_learning_rate, weight_decay=0.01)
+
+    # set logger
+    logger = get_logger(keys=["loss", "oce_loss"], title="loss")
+
+    # resume training
+    start_iteration = 0
+    lowest_loss = 1e6
+    epoch_loss = 0
+    num_iterations = 0
+    if model_config.checkpoint is not None:
+        print(f"Resuming model from {model_config.checkpoint}")
+        state = torch.load(model_config.checkpoint, map_location=device, weights_only=False)
+        start_iteration = state["iteration"] + 1
+        lowest_loss = state["lowest_loss"]
+        model.load_state_dict(state["model_state_dict"], strict=True)
+        optimizer.load_state_dict(state["optim_state_dict"])
+        logger.data = state["logger_data"]
+
+    # call `train_iteration`
+    for iteration, batch in tqdm(
+        zip(range(start_iteration, train_config.max_iterations), train_dataloader),
+        disable=not is_main,
+    ):
+        loss, oce_loss, prediction = train_iteration(
+            batch, model=model, criterion=criterion, optimizer=optimizer, device=device)
+        if not is_main:
+            continue
+        print(f"===> loss: {loss:.6f}, oce loss: {oce_loss:.6f}")
+        logger.add(key="loss", value=loss)
+        logger.add(key="oce_loss", value=oce_loss)
+        logger.write()
+        logger.plot()
+
+        # Check if lowest loss
+        epoch_loss += loss
+        num_iterations += 1
+        if iteration % train_config.save_best_model_every == 0:
+            is_lowest = epoch_loss / (num_iterations) < lowest_loss
+            lowest_loss = min(epoch_loss / num_iterations, lowest_loss)
+            if is_lowest:
+                save_model(_state(iteration, lowest_loss, model, optimizer, logger), iteration, is_lowest)
+            epoch_loss = 0
+            num_iterations = 0
+
+        # Save model at specific intervals
+        if (iteration % train_config.save_model_every == 0
+                or iteration == train_config.max_iterations - 1):
+            save_model(_state(iteration, lowest_loss, model, optimizer, logger), iteration)
+
+        # Save snapshots at specific intervals
+        if iteration % train_config.save_snapshot_every == 0:
+            save_snapshot(batch, prediction, iteration)
+    if is_main:
+        logger.plot(force=True)
+
+
+def _state(iteration, lowest_loss, model, optimizer, logger):
+    return {
+        "iteration": iteration,
+        "lowest_loss": lowest_loss,
+        "model_state_dict": model.state_dict(),
+        "optim_state_dict": optimizer.state_dict(),
+        "logger_data": logger.data,
+    }
+
+
+def train_iteration(batch, model, criterion, optimizer, device):
+    """One optimisation step (train.py:160-180): returns (loss, oce_loss, offsets)."""
+    raw, anchor_coordinates, reference_coordinates = batch
+    raw, anchor_coordinates, reference_coordinates = (
+        raw.to(device, non_blocking=True),
+        anchor_coordinates.to(device, non_blocking=True),
+        reference_coordinates.to(device, non_blocking=True),
+    )
+    model.train()
+
+    if isinstance(model, UNetModel) and isinstance(criterion, OCELoss) and model.mode == "train":
+        loss, oce_loss, offsets = _fused_step(
+            model, criterion, optimizer, raw, anchor_coordinates, reference_coordinates)
+        return loss, oce_loss, offsets
+
+    # generic autograd composition (custom model / criterion objects)
+    offsets = model(raw)
+    embeddings_anchor = model.select_and_add_coordinates(offsets, anchor_coordinates)
+    embeddings_reference = model.select_and_add_coordinates(offsets, reference_coordinates)
+    loss, oce_loss, regularization_loss = criterion(embeddings_anchor, embeddings_reference)
+    optimizer.zero_grad()
+    loss.backward()
+    if parallel.world_size() > 1:
+        for p in model.parameters():
+            if p.grad is not None:
+                parallel.all_reduce_sum_(p.grad)
+    optimizer.step()
+    return loss.item(), oce_loss.item(), offsets
+
+
+def _fused_step(model, criterion, optimizer, raw, anchor, reference):
+    """forward -> fused gather + OCE + scatter -> backward -> all-reduce -> Adam, no autograd."""
+    if raw.dtype != torch.float32:
+        raw = raw.float()
+    if anchor.dtype != torch.int64:
+        anchor = anchor.long()
+    if reference.dtype != torch.int64:
+        reference = reference.long()
+    anchor = anchor.contiguous()
+    reference = reference.contiguous()
+    device = raw.device
+    model.flatten_parameters()
+    params = model._ordered_params()
+    grads = model.attach_flat_grads()
+    plan = model._plan_for(raw, keep=True)
+    plan.pack_weights(params, model._param_version(), need_dgrad=True)
+    offsets = plan.forward(raw, params)
+
+    B, ND = offsets.shape[0], offsets.shape[1]
+    if anchor.ndim != 3 or anchor.shape != reference.shape or anchor.shape[0] != B or anchor.shape[2] != ND:
+        raise ValueError(f"coordinates must be (B={B}, P, {ND}); got {tuple(anchor.shape)} and "
+                         f"{tuple(reference.shape)}")
+    Z, Y, X = (1, offsets.shape[2], offsets.shape[3]) if ND == 2 else tuple(offsets.shape[2:])
+    sums = torch.zeros(3, dtype=torch.float64, device=device)
+    doffsets = torch.zeros_like(offsets)
+    _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
+              _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
+              float(criterion.temperature), float(criterion.regularization_weight),
+              _clx.stream_ptr(device))
+    plan.backward(doffsets, params, grads)
+    if parallel.world_size() > 1:
+        parallel.all_reduce_sum_(model._flat_grad)
+        parallel.all_reduce_sum_(sums)
+    optimizer.step()
+    host = sums.to(torch.float32).cpu()       # the step's single host synchronisation
+    return host[0].item(), host[1].item(), offsets
+
+
+def save_model(state, iteration, is_lowest=False):
+    if is_lowest:
+        file_name = os.path.join("models", "best_loss.pth")
+        torch.save(state, file_name)
+        print(f"Best model weights saved at iteration {iteration}")
+    else:
+        file_name = os.path.join("models", str(iteration).zfill(6) + ".pth")
+        torch.save(state, file_name)
+        print(f"Checkpoint saved at iteration {iteration}")
+
+
+def save_snapshot(batch, prediction, iteration):
+    """snapshots.zarr/<iteration>/{raw,prediction} with mean-subtracted offsets (train.py:194-224)."""
+    raw, anchor_coordinates, reference_coordinates = batch
+    num_spatial_dims = len(raw.shape) - 2
+    axis_names = ["s", "c"] + ["t", "z", "y", "x"][-num_spatial_dims:]
+    prediction_offset = tuple(
+        (a - b) / 2
+        for a, b in zip(raw.shape[-num_spatial_dims:], prediction.shape[-num_spatial_dims:]))
+    f = zarr_io.open("snapshots.zarr", "a")
+    f[f"{iteration}/raw"] = raw.detach().cpu().numpy()
+    f[f"{iteration}/raw"].attrs["axis_names"] = axis_names
+    f[f"{iteration}/raw"].attrs["resolution"] = [1] * num_spatial_dims
+    prediction_cpu = prediction.detach().cpu().numpy()
+    flat = np.reshape(prediction_cpu, (prediction_cpu.shape[0], prediction_cpu.shape[1], -1))
+    mean_prediction = np.mean(flat, 2)
+    prediction_cpu -= mean_prediction[(...,) + (np.newaxis,) * num_spatial_dims]
+    f[f"{iteration}/prediction"] = prediction_cpu
+    f[f"{iteration}/prediction"].attrs["axis_names"] = axis_names
+    f[f"{iteration}/prediction"].attrs["offset"] = prediction_offset
+    f[f"{iteration}/prediction"].attrs["resolution"] = [1] * num_spatial_dims

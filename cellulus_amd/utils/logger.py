@@ -1,0 +1,57 @@
+"""`Logger` — keeps the reference's outputs (``<title>.csv`` with an index column,
+``<title>.png``; cellulus/utils/logger.py:7-35) but appends instead of
+rewriting the whole history every iteration, and draws the plot only every
+``plot_every`` calls: at GPU step rates the reference's per-iteration
+CSV + PNG rewrite would dominate the step."""
+
+from typing import Dict, List
+
+
+class Logger:
+    def __init__(self, keys: List[str], title: str, plot_every: int = 100):
+        self.keys = keys
+        self.title = title
+        self.plot_every = max(1, int(plot_every))
+        self.data: Dict[str, List[float]] = {k: [] for k in keys}
+        self._written = 0
+        self._plots = 0
+        self._window = None
+        print(f"Created logger with keys: {keys}")
+
+    def add(self, key, value):
+        assert key in self.data, "Key not in data"
+        self.data[key].append(value)
+
+    def write(self):
+        """<title>.csv: header ',key1,key2', then 'row_index,value1,value2' (pandas to_csv layout)."""
+        n = min(len(v) for v in self.data.values()) if self.data else 0
+        path = self.title + ".csv"
+        if self._written == 0 or self._written > n:
+            with open(path, "w") as f:
+                f.write("," + ",".join(self.data.keys()) + "\n")
+            self._written = 0
+        if n > self._written:
+            with open(path, "a") as f:
+                for i in range(self._written, n):
+                    f.write(str(i) + "," + ",".join(repr(float(self.data[k][i])) for k in self.data) + "\n")
+            self._written = n
+
+    def plot(self, force: bool = False):
+        self._plots += 1
+        if not force and self._plots % self.plot_every != 1 and self.plot_every != 1:
+            return
+        import matplotlib
+
+        matplotlib.use("Agg", force=False)
+        import matplotlib.pyplot as plt
+
+        if self._window is None:
+            self._window = plt.subplots()
+        fig, ax = self._window
+        ax.cla()
+        for key in self.data:
+            data = self.data[key]
+            ax.plot(range(len(data)), data, marker=".")
+        ax.set_xlabel("Iteration")
+        ax.set_ylabel(self.title)
+        fig.savefig(self.title + ".png")

@@ -1,0 +1,289 @@
+"""Minimal zarr-v2 directory-store reader/writer (zarr itself is not installed).
+
+Covers what the hot path's callers need (``cellulus/datasets/meta_data.py``,
+``predict.py:103-142``, ``detect.py:18-80``, ``segment.py:19-38``,
+``train.py:194-224``): C-order arrays of bool/int/uint/float dtypes, chunked,
+``compressor`` null / zlib / gzip (Blosc chunks cannot be decoded here and raise),
+``fill_value``, ``.zattrs``.  Groups are plain directories with a ``.zgroup``.
+"""
+
+import gzip
+import io
+import itertools
+import json
+import os
+import zlib
+
+import numpy as np
+
+
+class ZarrError(RuntimeError):
+    pass
+
+
+def _json_dump(path, obj):
+    tmp = path + ".tmp"
+    with io.open(tmp, "w") as f:
+        json.dump(obj, f, indent=4)
+    os.replace(tmp, path)
+
+
+class Attributes:
+    """dict-like view of a node's .zattrs, written through on every assignment."""
+
+    def __init__(self, node_path):
+        self._path = os.path.join(node_path, ".zattrs")
+
+    def _load(self):
+        if os.path.exists(self._path):
+            with io.open(self._path) as f:
+                return json.load(f)
+        return {}
+
+    def __getitem__(self, key):
+        return self._load()[key]
+
+    def __contains__(self, key):
+        return key in self._load()
+
+    def get(self, key, default=None):
+        return self._load().get(key, default)
+
+    def __setitem__(self, key, value):
+        d = self._load()
+        if isinstance(value, np.ndarray):
+            value = value.tolist()
+        if isinstance(value, tuple):
+            value = list(value)
+        d[key] = value
+        _json_dump(self._path, d)
+
+    def asdict(self):
+        return self._load()
+
+    def keys(self):
+        return self._load().keys()
+
+
+def _decode(raw, compressor):
+    if compressor is None:
+        return raw
+    cid = compressor.get("id")
+    if cid == "zlib":
+        return zlib.decompress(raw)
+    if cid == "gzip":
+        return gzip.decompress(raw)
+    raise ZarrError(f"unsupported zarr compressor {cid!r} (only null, zlib and gzip can be read here)")
+
+
+def _encode(raw, compressor):
+    if compressor is None:
+        return raw
+    cid = compressor.get("id")
+    if cid == "zlib":
+        return zlib.compress(raw, compressor.get("level", 1))
+    if cid == "gzip":
+        return gzip.compress(raw, compressor.get("level", 1))
+    raise ZarrError(f"unsupported zarr compressor {cid!r}")
+
+
+class Array:
+    def __init__(self, path):
+        self.path = path
+        meta_path = os.path.join(path, ".zarray")
+        if not os.path.exists(meta_path):
+            raise ZarrError(f"{path} is not a zarr array")
+        with io.open(meta_path) as f:
+            m = json.load(f)
+        if m.get("zarr_format") != 2:
+            raise ZarrError("only zarr format 2 is supported")
+        if m.get("order", "C") != "C":
+            raise ZarrError("only C-order zarr arrays are supported")
+        if m.get("filters"):
+            raise ZarrError("zarr filters are not supported")
+        self.shape = tuple(m["shape"])
+        self.chunks = tuple(m["chunks"])
+        self.dtype = np.dtype(m["dtype"])
+        self.compressor = m.get("compressor")
+        self.fill_value = m.get("fill_value")
+        self.sep = m.get("dimension_separator", ".")
+        self.attrs = Attributes(path)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _fill(self):
+        fv = self.fill_value
+        if fv is None:
+            return 0
+        if isinstance(fv, str):
+            return {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}.get(fv, 0)
+        return fv
+
+    def _chunk_path(self, idx):
+        return os.path.join(self.path, self.sep.join(str(i) for i in idx))
+
+    def _read_chunk(self, idx):
+        p = self._chunk_path(idx)
+        if not os.path.exists(p):
+            return np.full(self.chunks, self._fill(), dtype=self.dtype)
+        with io.open(p, "rb") as f:
+            raw = _decode(f.read(), self.compressor)
+        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+
+    def _write_chunk(self, idx, data):
+        p = self._chunk_path(idx)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        tmp = p + ".tmp"
+        with io.open(tmp, "wb") as f:
+            f.write(_encode(np.ascontiguousarray(data, dtype=self.dtype).tobytes(), self.compressor))
+        os.replace(tmp, p)
+
+    def _normalize(self, key):
+        """index expression -> (list of slices, axes to squeeze)."""
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = key.index(Ellipsis)
+            fill = self.ndim - (len(key) - 1)
+            key = key[:i] + (slice(None),) * fill + key[i + 1:]
+        key = key + (slice(None),) * (self.ndim - len(key))
+        if len(key) != self.ndim:
+            raise IndexError("too many indices for zarr array")
+        slices, squeeze = [], []
+        for ax, (k, n) in enumerate(zip(key, self.shape)):
+            if isinstance(k, (int, np.integer)):
+                k = int(k)
+                if k < 0:
+                    k += n
+                if not 0 <= k < n:
+                    raise IndexError("index out of bounds")
+                slices.append(slice(k, k + 1))
+                squeeze.append(ax)
+            elif isinstance(k, slice):
+                start, stop, step = k.indices(n)
+                if step != 1:
+                    raise IndexError("only unit-step slices are supported")
+                slices.append(slice(start, max(stop, start)))
+            else:
+                raise IndexError("only integers, slices and Ellipsis are supported")
+        return slices, tuple(squeeze)
+
+    def __getitem__(self, key):
+        slices, squeeze = self._normalize(key)
+        out_shape = tuple(s.stop - s.start for s in slices)
+        out = np.empty(out_shape, dtype=self.dtype)
+        ranges = [range(s.start // c, (max(s.stop, s.start + 1) - 1) // c + 1) if s.stop > s.start else range(0)
+                  for s, c in zip(slices, self.chunks)]
+        for idx in itertools.product(*ranges):
+            chunk = self._read_chunk(idx)
+            src, dst = [], []
+            for i, s, c in zip(idx, slices, self.chunks):
+                lo, hi = max(s.start, i * c), min(s.stop, (i + 1) * c)
+                src.append(slice(lo - i * c, hi - i * c))
+                dst.append(slice(lo - s.start, hi - s.start))
+            out[tuple(dst)] = chunk[tuple(src)]
+        return out.squeeze(axis=squeeze) if squeeze else out
+
+    def __setitem__(self, key, value):
+        slices, squeeze = self._normalize(key)
+        region = tuple(s.stop - s.start for s in slices)
+        value = np.asarray(value)
+        if squeeze:
+            value = np.expand_dims(value, squeeze) if value.ndim == len(region) - len(squeeze) else value
+        value = np.broadcast_to(value.astype(self.dtype, copy=False), region)
+        ranges = [range(s.start // c, (max(s.stop, s.start + 1) - 1) // c + 1) if s.stop > s.start else range(0)
+                  for s, c in zip(slices, self.chunks)]
+        for idx in itertools.product(*ranges):
+            src, dst, full = [], [], True
+            for i, s, c, n in zip(idx, slices, self.chunks, self.shape):
+                lo, hi = max(s.start, i * c), min(s.stop, (i + 1) * c)
+                dst.append(slice(lo - i * c, hi - i * c))
+                src.append(slice(lo - s.start, hi - s.start))
+                if hi - lo != c:
+                    full = False
+            if full:
+                chunk = value[tuple(src)]
+            else:
+                chunk = self._read_chunk(idx).copy()
+                chunk[tuple(dst)] = value[tuple(src)]
+            self._write_chunk(idx, chunk)
+
+
+class Group:
+    def __init__(self, path, create=False):
+        self.path = path
+        if create:
+            os.makedirs(path, exist_ok=True)
+            zg = os.path.join(path, ".zgroup")
+            if not os.path.exists(zg) and not os.path.exists(os.path.join(path, ".zarray")):
+                _json_dump(zg, {"zarr_format": 2})
+        elif not os.path.isdir(path):
+            raise ZarrError(f"zarr container {path} does not exist")
+        self.attrs = Attributes(path)
+
+    def __contains__(self, name):
+        p = os.path.join(self.path, name)
+        return os.path.exists(os.path.join(p, ".zarray")) or os.path.exists(os.path.join(p, ".zgroup"))
+
+    def __getitem__(self, name):
+        p = os.path.join(self.path, name)
+        if os.path.exists(os.path.join(p, ".zarray")):
+            return Array(p)
+        if os.path.isdir(p):
+            return Group(p)
+        raise KeyError(name)
+
+    def _make_parents(self, name):
+        parts = name.strip("/").split("/")
+        cur = self.path
+        for part in parts[:-1]:
+            cur = os.path.join(cur, part)
+            Group(cur, create=True)
+        return os.path.join(cur, parts[-1])
+
+    def create_dataset(self, name, shape, dtype, chunks=None, compressor=None, fill_value=0,
+                       overwrite=True):
+        p = self._make_parents(name)
+        dtype = np.dtype(dtype)
+        shape = tuple(int(s) for s in shape)
+        if chunks is None:
+            # one chunk per leading index keeps per-sample writes cheap
+            chunks = (1,) + shape[1:] if len(shape) > 1 else shape
+        chunks = tuple(max(1, int(min(c, s))) if s > 0 else 1 for c, s in zip(chunks, shape))
+        if os.path.exists(p) and overwrite:
+            import shutil
+
+            shutil.rmtree(p)
+        os.makedirs(p, exist_ok=True)
+        meta = {
+            "zarr_format": 2,
+            "shape": list(shape),
+            "chunks": list(chunks),
+            "dtype": dtype.str,
+            "compressor": compressor,
+            "fill_value": fill_value,
+            "order": "C",
+            "filters": None,
+        }
+        _json_dump(os.path.join(p, ".zarray"), meta)
+        return Array(p)
+
+    def __setitem__(self, name, value):
+        value = np.asarray(value)
+        arr = self.create_dataset(name, shape=value.shape, dtype=value.dtype)
+        arr[...] = value
+
+
+def open(path, mode="a"):  # noqa: A001 - mirrors zarr.open
+    """zarr.open(path[, mode]) for directory stores; returns a Group (or an Array if path is one)."""
+    path = str(path)
+    if os.path.exists(os.path.join(path, ".zarray")):
+        return Array(path)
+    if mode == "r":
+        return Group(path, create=False)
+    return Group(path, create=True)

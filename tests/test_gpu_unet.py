@@ -1,8 +1,10 @@
 """GPU parity: HIP U-Net (forward, backward, infer mode) vs the CPU oracle.
 
 Tolerances: embeddings within 1e-4 absolute (BASELINE.json north_star) on
-O(1) inputs; gradients within 1e-3 relative to the tensor's max magnitude
-(f32 accumulation-order differences over up to ~10^5-term sums)."""
+O(1) inputs.  Gradients: relative L2 error < 2e-4 per parameter tensor and
+max error < 5e-3 of the tensor's max magnitude — both sides are f32 and a
+pre-activation within rounding of 0 can flip one ReLU gate, which moves single
+gradient entries by far more than accumulation-order noise does."""
 
 import numpy as np
 import pytest
@@ -73,7 +75,9 @@ def test_backward_matches_oracle(name, device):
         g_ref, g = po.grad, pm.grad.cpu()
         scale = g_ref.abs().max().item() + 1e-12
         err = (g - g_ref).abs().max().item() / scale
-        assert err < 1e-3, f"{name}: grad of {n}: rel err {err} (scale {scale})"
+        l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-12)).item()
+        assert err < 5e-3, f"{name}: grad of {n}: max rel err {err} (scale {scale})"
+        assert l2 < 2e-4, f"{name}: grad of {n}: rel L2 err {l2}"
 
 
 def test_forward_is_deterministic_and_repacks_after_weight_change(device):
