@@ -1,0 +1,181 @@
+"""Mean-shift instance clustering on libclx — drop-in for
+``cellulus/utils/mean_shift.py`` (``mean_shift_segmentation``,
+``segment_with_meanshift``, ``AnchorMeanshift``), i.e. for
+``sklearn.cluster.MeanShift(bandwidth, cluster_all=False, seeds).fit(X_red)``
+followed by ``.predict(X)``, all in float64.
+
+Device side: coordinate add + foreground compaction (raster order), the
+per-seed flat-kernel iterations, the nearest-centre assignment.  Host side
+(small, sequential by definition): the reference's ``np.random.rand``
+sub-sampling mask (same global RNG call, so seeding numpy reproduces it) and
+sklearn's sort + greedy de-duplication of converged centres.
+"""
+
+import numpy as np
+import torch
+
+from .. import _clx
+
+MAX_ITER = 300   # sklearn.cluster.MeanShift default
+
+
+def dedup_centers(centers, counts, bandwidth):
+    """sklearn MeanShift.fit post-processing (_mean_shift.py: center_intensity_dict,
+    sort by (count, centre) descending, greedy removal of centres within `bandwidth`)."""
+    centers = np.asarray(centers, dtype=np.float64)
+    counts = np.asarray(counts)
+    keep = counts > 0
+    if not keep.any():
+        raise ValueError(
+            "No point was within bandwidth=%f of any seed. Try a different seeding strategy "
+            "or increase the bandwidth." % bandwidth)
+    centers, counts = centers[keep], counts[keep]
+    # dict semantics: identical centre tuples collapse, the LAST count wins
+    _, first_idx, inverse = np.unique(centers, axis=0, return_index=True, return_inverse=True)
+    inverse = np.asarray(inverse).reshape(-1)
+    last_count = np.zeros(len(first_idx), dtype=counts.dtype)
+    last_count[inverse] = counts          # later duplicates overwrite earlier ones
+    centers = centers[first_idx]
+    counts = last_count
+    # sorted(items, key=(count, centre_tuple), reverse=True)
+    keys = tuple(centers[:, d] for d in range(centers.shape[1] - 1, -1, -1)) + (counts,)
+    order = np.lexsort(keys)[::-1]
+    centers = centers[order]
+    unique = np.ones(len(centers), dtype=bool)
+    bw2 = bandwidth * bandwidth
+    for i in range(len(centers)):
+        if unique[i]:
+            diff = centers - centers[i]
+            d2 = np.zeros(len(centers))
+            for d in range(centers.shape[1]):
+                d2 += diff[:, d] * diff[:, d]
+            unique[d2 <= bw2] = False
+            unique[i] = True
+    return centers[unique]
+
+
+def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, seeds=None):
+    """emb: (ND, *spatial) f64 device tensor (coordinates are ADDED IN PLACE, as the
+    reference does to its argument); std: (*spatial) f64 device tensor.
+    Returns (labels int32 device tensor of shape spatial — background 0 —, cluster centres)."""
+    _clx.require_device(emb, "embedding")
+    nd = emb.shape[0]
+    spatial = tuple(emb.shape[1:])
+    assert len(spatial) == nd and tuple(std.shape) == spatial
+    assert emb.dtype == torch.float64 and std.dtype == torch.float64
+    assert emb.is_contiguous() and std.is_contiguous()
+    Z, Y, X = (1,) * (3 - nd) + spatial
+    npix = Z * Y * X
+    dev = emb.device
+    st = _clx.stream_ptr(dev)
+    lib = _clx.load()
+    ws = torch.empty(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=dev)
+    pts = torch.empty((npix, nd), dtype=torch.float64, device=dev)
+    index = torch.empty(npix, dtype=torch.int32, device=dev)
+    nfg_d = torch.zeros(1, dtype=torch.int32, device=dev)
+    _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
+              _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
+    labels = torch.zeros(spatial, dtype=torch.int32, device=dev)
+    nfg = int(nfg_d.item())
+    if nfg == 0:      # mean_shift.py:83-84,92-93 -> all -1, +1 -> 0
+        return labels, np.zeros((0, nd))
+    pts = pts[:nfg]
+    if reduction_probability < 1.0:
+        keep = np.random.rand(nfg) < reduction_probability      # mean_shift.py:69
+        fit = pts[torch.from_numpy(keep).to(dev)].contiguous()
+    else:
+        fit = pts
+    if fit.shape[0] == 0:
+        raise ValueError("Found array with 0 sample(s) (shape=(0, %d)) while a minimum of 1 is "
+                         "required by MeanShift." % nd)
+    if seeds is None:
+        seeds_d = fit
+    else:
+        seeds_d = torch.as_tensor(np.ascontiguousarray(np.asarray(seeds, dtype=np.float64)), device=dev)
+        if seeds_d.ndim != 2 or seeds_d.shape[1] != nd:
+            raise ValueError(f"seeds must have shape (n, {nd})")
+    ns = seeds_d.shape[0]
+    centers = torch.empty((ns, nd), dtype=torch.float64, device=dev)
+    counts = torch.empty(ns, dtype=torch.int32, device=dev)
+    iters = torch.empty(ns, dtype=torch.int32, device=dev)
+    _clx.call("clx_ms_iterate", _clx.ptr(fit), fit.shape[0], _clx.ptr(seeds_d), ns, nd,
+              float(bandwidth), MAX_ITER, _clx.ptr(centers), _clx.ptr(counts), _clx.ptr(iters), st)
+    cluster_centers = dedup_centers(centers.cpu().numpy(), counts.cpu().numpy(), float(bandwidth))
+    cc = torch.from_numpy(np.ascontiguousarray(cluster_centers)).to(dev)
+    _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), cc.shape[0], nd,
+              _clx.ptr(labels), st)
+    return labels, cluster_centers
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise _clx.ClxError("mean-shift needs a HIP device; cellulus_amd has no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def mean_shift_segmentation(
+    embedding_mean,
+    embedding_std,
+    bandwidth,
+    min_size,
+    reduction_probability,
+    threshold,
+    seeds,
+    device=None,
+):
+    """Same contract as mean_shift.py:6-45: embedding_mean (1, ND, *spatial) float64 numpy array
+    — pixel coordinates are added to it IN PLACE, like the reference —, embedding_std
+    (*spatial); returns the int32 label map (background 0)."""
+    device = torch.device(device) if device is not None else _default_device()
+    if embedding_mean.dtype != np.float64:
+        raise TypeError("embedding_mean must be float64 (the reference reads float64 zarr data)")
+    emb = torch.from_numpy(np.ascontiguousarray(embedding_mean[0])).to(device)
+    std = torch.from_numpy(np.ascontiguousarray(embedding_std, dtype=np.float64)).to(device)
+    labels, _ = mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, seeds)
+    embedding_mean[0] = emb.cpu().numpy()      # the reference mutates its input (mean_shift.py:15-32)
+    return labels.cpu().numpy()
+
+
+def segment_with_meanshift(embedding, bandwidth, mask, reduction_probability, cluster_all, seeds):
+    """mean_shift.py:48-57 — embedding: torch (1, ND, *spatial) f64 with coordinates already
+    added; mask: (1, *spatial) bool."""
+    anchor_mean_shift = AnchorMeanshift(bandwidth, reduction_probability=reduction_probability,
+                                        cluster_all=cluster_all, seeds=seeds)
+    return anchor_mean_shift(embedding, mask=mask) + 1
+
+
+class AnchorMeanshift:
+    """mean_shift.py:60-121; `cluster_all` is accepted and — as in the reference, whose labels
+    come from MeanShift.predict — has no effect."""
+
+    def __init__(self, bandwidth, reduction_probability, cluster_all, seeds):
+        self.bandwidth = bandwidth
+        self.reduction_probability = reduction_probability
+        self.cluster_all = cluster_all
+        self.seeds = seeds
+
+    def compute_masked_ms(self, embedding, mask=None):
+        device = embedding.device if embedding.is_cuda else _default_device()
+        emb = embedding.to(device=device, dtype=torch.float64).contiguous().clone()
+        spatial = tuple(emb.shape[1:])
+        if mask is None:
+            std = torch.zeros(spatial, dtype=torch.float64, device=device)
+        else:
+            assert tuple(mask.shape) == spatial
+            m = torch.as_tensor(np.asarray(mask.cpu() if torch.is_tensor(mask) else mask)).to(device)
+            std = torch.where(m.bool(), 0.0, 2.0).to(torch.float64)
+        # coordinates were already added by the caller: undo the kernel's in-place add
+        nd = emb.shape[0]
+        for c in range(nd):
+            ax = nd - 1 - c
+            shape = [1] * nd
+            shape[ax] = spatial[ax]
+            emb[c] -= torch.arange(spatial[ax], dtype=torch.float64, device=device).view(shape)
+        labels, _ = mean_shift_on_device(emb, std, self.bandwidth, self.reduction_probability, 1.0, self.seeds)
+        return labels.cpu().numpy().astype(np.int32) - 1
+
+    def __call__(self, embedding, mask=None):
+        out = []
+        for j in range(len(embedding)):
+            out.append(self.compute_masked_ms(embedding[j], mask[j] if mask is not None else None))
+        return np.stack(out)

@@ -39,11 +39,11 @@ def test_gather_add_fwd_bwd(shape, device):
 
 
 def test_gather_known_answer(device):
-    # SURVEY.md §8c probe: out[0,0] = arange(30).view(5,6), coord (x=1, y=2) -> 14 + 1
+    # SURVEY.md §8c probe: out[0,0] = arange(30).view(5,6), coord (x=1, y=2) -> 13 + 1 = 14
     out = torch.zeros(1, 2, 5, 6)
     out[0, 0] = torch.arange(30.0).view(5, 6)
     got = UNetModel.select_and_add_coordinates(out.to(device), torch.tensor([[[1, 2]]], device=device))
-    assert got.cpu().tolist() == [[[15.0, 2.0]]]
+    assert got.cpu().tolist() == [[[14.0, 2.0]]]
 
 
 @pytest.mark.parametrize("nd", [2, 3])
