@@ -1,0 +1,115 @@
+"""Detection stage — drop-in for ``cellulus/detect.py:14-192``.
+
+Per sample: Otsu threshold of the std channel (device histogram), foreground
+mask, centred embeddings (side output), then per bandwidth the mean-shift
+clustering on the device.  Writes the same three zarr datasets as the
+reference (``detection`` uint16, ``binary-segmentation`` uint16,
+``centered-embeddings`` float64).  Samples are independent: ranks take blocks
+of samples, no collective.
+"""
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from . import parallel
+from .configs.inference_config import InferenceConfig
+from .datasets.meta_data import DatasetMetaData
+from .utils import zarr_io
+from .utils.mean_shift import mean_shift_on_device
+from .utils.otsu import threshold_otsu
+
+
+def _create(f, name, shape, dtype, nd):
+    ds = f.create_dataset(name, shape=shape, dtype=dtype)
+    ds.attrs["axis_names"] = ["s", "c"] + ["t", "z", "y", "x"][-nd:]
+    ds.attrs["resolution"] = (1,) * nd
+    ds.attrs["offset"] = (0,) * nd
+    return ds
+
+
+def peak_local_max(image):
+    """skimage.feature.peak_local_max(image) defaults (min_distance=1, exclude_border=1,
+    threshold = image.min()) restated on scipy: coordinates of strict-threshold local maxima
+    of a 3^D neighbourhood, sorted by decreasing intensity.  [unpinned: skimage is not
+    installed under the product interpreter]"""
+    from scipy.ndimage import maximum_filter
+
+    size = 3
+    mx = maximum_filter(image, size=size, mode="nearest")
+    mask = (image == mx) & (image > image.min())
+    for ax in range(image.ndim):          # exclude_border=True -> min_distance pixels
+        sl = [slice(None)] * image.ndim
+        sl[ax] = slice(0, 1)
+        mask[tuple(sl)] = False
+        sl[ax] = slice(-1, None)
+        mask[tuple(sl)] = False
+    coords = np.stack(np.nonzero(mask), axis=1)
+    order = np.argsort(-image[mask], kind="stable")
+    return coords[order]
+
+
+def detect(inference_config: InferenceConfig) -> None:
+    dataset_config = inference_config.dataset_config
+    meta = DatasetMetaData.from_dataset_config(dataset_config)
+    nd = meta.num_spatial_dims
+    device = torch.device(inference_config.device)
+    if parallel.world_size() > 1:
+        device = torch.device("cuda", torch.cuda.current_device())
+
+    f = zarr_io.open(inference_config.detection_dataset_config.container_path)
+    ds = f[inference_config.detection_dataset_config.secondary_dataset_name]
+    spatial = tuple(meta.spatial_array)
+    if parallel.rank() == 0:
+        _create(f, inference_config.detection_dataset_config.dataset_name,
+                (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
+        _create(f, "binary-segmentation", (meta.num_samples, 1, *spatial), np.uint16, nd)
+        _create(f, "centered-embeddings", (meta.num_samples, nd + 1, *spatial), float, nd)
+    if parallel.world_size() > 1:
+        torch.distributed.barrier()
+    ds_detection = f[inference_config.detection_dataset_config.dataset_name]
+    ds_binary_segmentation = f["binary-segmentation"]
+    ds_object_centered_embeddings = f["centered-embeddings"]
+
+    if inference_config.clustering == "greedy":
+        raise NotImplementedError(
+            "clustering='greedy' (cellulus/utils/greedy_cluster.py) is not part of the MI355X hot "
+            "path yet (SURVEY.md §8f-3); use clustering='meanshift'")
+
+    lo, hi = parallel.shard_range(meta.num_samples)
+    for sample in tqdm(range(lo, hi), disable=parallel.rank() != 0):
+        embeddings = ds[sample]                                  # (D+1, *spatial) float64
+        emb_d = torch.from_numpy(np.ascontiguousarray(embeddings)).to(device)
+        std_d = emb_d[-1].contiguous()
+        if inference_config.threshold is None:
+            threshold = threshold_otsu(std_d)
+        else:
+            threshold = inference_config.threshold
+        print(f"For sample {sample}, binary threshold {threshold} was used.")
+        binary_mask = embeddings[-1] < threshold
+        ds_binary_segmentation[sample, 0, ...] = binary_mask
+
+        # centred embeddings: subtract the mean of the non-zero masked offsets per channel
+        embeddings_centered = embeddings.copy()
+        masked = binary_mask[np.newaxis, ...] * embeddings[:nd]
+        for k in range(nd):
+            ck = masked[k]
+            embeddings_centered[k] -= ck[ck != 0].mean()
+        ds_object_centered_embeddings[sample] = embeddings_centered
+
+        for bandwidth_factor in range(inference_config.num_bandwidths):
+            bandwidth = inference_config.bandwidth / (2 ** bandwidth_factor)
+            if inference_config.use_seeds:
+                from scipy.ndimage import gaussian_filter
+
+                offset_magnitude = np.linalg.norm(embeddings_centered[:-1], axis=0)
+                smooth = gaussian_filter(offset_magnitude, sigma=2)
+                seeds = np.flip(peak_local_max(-smooth), 1)
+                src = torch.from_numpy(np.ascontiguousarray(embeddings_centered)).to(device)
+                mean_d, sd_d = src[:nd].contiguous().clone(), src[-1].contiguous()
+            else:
+                seeds = None
+                mean_d, sd_d = emb_d[:nd].contiguous().clone(), std_d
+            labels, _ = mean_shift_on_device(
+                mean_d, sd_d, bandwidth, inference_config.reduction_probability, threshold, seeds)
+            ds_detection[sample, bandwidth_factor, ...] = labels.cpu().numpy()

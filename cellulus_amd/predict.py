@@ -1,0 +1,93 @@
+"""Tiled embedding inference — drop-in for ``cellulus/predict.py:9-142``.
+
+The reference drives gunpowder (ZarrSource -> Normalize -> Pad(reflect) ->
+torch Predict -> ZarrWrite -> Scan).  gunpowder is absent, so the scan is
+restated: the raw image is reflect-padded by the network context
+(``(crop - out) // 2`` = 8), tiles of ``crop_size`` are visited with a stride of
+the output tile, the last tile of every axis is shifted back inside the
+image (overlaps are overwritten by the later tile, as gunpowder's Scan does),
+and every tile is the (mean, std) of ``2 * num_infer_iterations`` salt/pepper
+noised forwards (``UNetModel.infer_on_device``).  Output: float64 zarr dataset
+``(S, D+1, *spatial)`` with ``axis_names`` / ``resolution`` / ``offset``.
+
+Samples are independent units: under torch.distributed every rank predicts
+a contiguous block of samples, no collective.
+"""
+
+import itertools
+
+import numpy as np
+import torch
+
+from . import parallel
+from .configs.inference_config import InferenceConfig
+from .datasets.meta_data import DatasetMetaData
+from .datasets.zarr_dataset import default_normalization_factor
+from .models.plan import build_topology
+from .utils import zarr_io
+
+
+def tile_offsets(size, tile):
+    """Start offsets of output tiles along one axis: stride = tile, last one shifted inside."""
+    if size < tile:
+        raise RuntimeError(
+            f"image extent {size} is smaller than the network's output tile {tile}: reduce crop_size")
+    offs = list(range(0, size - tile + 1, tile))
+    if offs[-1] + tile < size:
+        offs.append(size - tile)
+    return offs
+
+
+def predict(model: torch.nn.Module, inference_config: InferenceConfig, normalization_factor: float) -> None:
+    dataset_config = inference_config.dataset_config
+    meta = DatasetMetaData.from_dataset_config(dataset_config)
+    nd = meta.num_spatial_dims
+    device = torch.device(inference_config.device)
+    if parallel.world_size() > 1:
+        device = torch.device("cuda", torch.cuda.current_device())
+    model.set_infer(p_salt_pepper=inference_config.p_salt_pepper,
+                    num_infer_iterations=inference_config.num_infer_iterations, device=device)
+
+    crop = tuple(int(c) for c in inference_config.crop_size)
+    if len(crop) != nd:
+        raise ValueError(f"crop_size must have {nd} entries, got {crop}")
+    topo = build_topology(model.in_channels, model.out_channels, model.num_fmaps, model.fmap_inc_factor,
+                          model.features_in_last_layer, model.downsampling_factors, nd, crop)
+    out_tile = tuple(topo.out_shape[3 - nd:])
+    context = tuple((c - o) // 2 for c, o in zip(crop, out_tile))
+
+    raw_ds = zarr_io.open(dataset_config.container_path, "r")[dataset_config.dataset_name]
+    factor = normalization_factor
+    if factor is None:
+        factor = default_normalization_factor(raw_ds.dtype)
+
+    f = zarr_io.open(inference_config.prediction_dataset_config.container_path)
+    ds = f.create_dataset(
+        inference_config.prediction_dataset_config.dataset_name,
+        shape=(meta.num_samples, nd + 1, *meta.spatial_array),
+        dtype=float,
+    )
+
+    spatial = tuple(meta.spatial_array)
+    offsets = [tile_offsets(s, t) for s, t in zip(spatial, out_tile)]
+    lo, hi = parallel.shard_range(meta.num_samples)
+    pad = [(0, 0)] + [(c, c) for c in context]
+    for sample in range(lo, hi):
+        raw = raw_ds[sample].astype(np.float32) * np.float32(factor)      # gp.Normalize
+        raw = np.pad(raw, pad, mode="reflect")                             # gp.Pad(mode="reflect")
+        raw_d = torch.from_numpy(raw).to(device)
+        result = torch.empty((nd + 1,) + spatial, dtype=torch.float32, device=device)
+        for off in itertools.product(*offsets):
+            in_sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, crop))
+            tile = raw_d[in_sl].unsqueeze(0).contiguous()
+            emb = model.infer_on_device(tile)[0]
+            out_sl = (slice(None),) + tuple(slice(o, o + t) for o, t in zip(off, out_tile))
+            result[out_sl] = emb
+        ds[sample] = result.cpu().numpy().astype(np.float64)
+
+    if parallel.world_size() > 1:
+        torch.distributed.barrier()
+    if parallel.rank() == 0:
+        ds.attrs["axis_names"] = ["s", "c"] + ["t", "z", "y", "x"][-nd:]
+        ds.attrs["resolution"] = (1,) * nd
+        ds.attrs["offset"] = (0,) * nd

@@ -1,0 +1,195 @@
+"""Generates tests/golden/*.npz by running the REAL reference code in the build
+container (it cannot travel to the GPU box):
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg \
+        python tests/golden/make_golden.py
+
+Importable reference modules: cellulus.criterions.oce_loss,
+cellulus.utils.mean_shift (+ installed scikit-learn), cellulus.configs, and
+cellulus.models.unet once `funlib.learn.torch.models.UNet` is stubbed with the
+oracle's backbone restatement (the head, noise loop, std_mean and gather are
+then genuine reference code).  The fixtures hold inputs (or the seeds that
+regenerate them) and the reference's outputs — data only.
+"""
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import infer_oracle as IO  # noqa: E402  (synthetic input generator only)
+from oracle.unet_oracle import OracleUNet  # noqa: E402
+
+# ---- stub the un-vendored backbone so cellulus.models.unet imports
+funlib = types.ModuleType("funlib")
+learn = types.ModuleType("funlib.learn")
+ftorch = types.ModuleType("funlib.learn.torch")
+models = types.ModuleType("funlib.learn.torch.models")
+models.UNet = OracleUNet
+sys.modules.update({"funlib": funlib, "funlib.learn": learn, "funlib.learn.torch": ftorch,
+                    "funlib.learn.torch.models": models})
+
+from cellulus.configs import ExperimentConfig  # noqa: E402
+from cellulus.criterions import get_loss  # noqa: E402
+from cellulus.models.unet import UNetModel  # noqa: E402
+from cellulus.utils.mean_shift import mean_shift_segmentation  # noqa: E402
+
+
+def g1_oce():
+    out = {}
+    for nd in (2, 3):
+        torch.manual_seed(nd)
+        a = (torch.randn(3, 200, nd) * 4)
+        r = a + torch.randn(3, 200, nd) * 3
+        a[0, 0] = 0.0
+        r[0, 1] = a[0, 1]
+        a.requires_grad_(True)
+        crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1,
+                        num_spatial_dims=nd, device=torch.device("cpu"))
+        loss, oce, reg = crit(a, r)
+        loss.backward()
+        out[f"a{nd}"] = a.detach().numpy()
+        out[f"r{nd}"] = r.numpy()
+        out[f"sums{nd}"] = np.array([loss.item(), oce.item(), reg.item()], dtype=np.float64)
+        out[f"grad{nd}"] = a.grad.numpy()
+    # known-answer vector of SURVEY.md §8c
+    a = torch.tensor([[[3.0, 4.0], [1.0, 1.0], [0.0, 0.0]]], requires_grad=True)
+    r = torch.tensor([[[0.0, 0.0], [1.0, 1.0], [2.0, 0.0]]])
+    crit = get_loss(10.0, 1e-5, 0.1, 2, torch.device("cpu"))
+    loss, oce, reg = crit(a, r)
+    loss.backward()
+    out["kat_sums"] = np.array([loss.item(), oce.item(), reg.item()])
+    out["kat_grad"] = a.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "g1_oce_loss.npz"), **out)
+
+
+def g2_gather():
+    out = {}
+    rng = np.random.default_rng(0)
+    for nd, shape in ((2, (9, 11)), (3, (5, 6, 7))):
+        offsets = torch.from_numpy(rng.standard_normal((2, nd) + shape).astype(np.float32))
+        coords = np.stack([rng.integers(0, s, size=(2, 50)) for s in shape[::-1]], axis=2).astype(np.int64)
+        sel = UNetModel.select_and_add_coordinates(offsets, torch.from_numpy(coords))
+        out[f"offsets{nd}"] = offsets.numpy()
+        out[f"coords{nd}"] = coords
+        out[f"sel{nd}"] = sel.numpy()
+    np.savez_compressed(os.path.join(HERE, "g2_gather.npz"), **out)
+
+
+def g3_unet():
+    """Reference UNetModel wrapper (real head / infer loop) around the stub backbone."""
+    out = {}
+    for nd, spatial in ((2, (36, 40)), (3, (20, 20, 24))):
+        cfg = dict(in_channels=1, out_channels=nd, num_fmaps=4, fmap_inc_factor=2,
+                   features_in_last_layer=8, downsampling_factors=[(2,) * nd], num_spatial_dims=nd)
+        torch.manual_seed(100 + nd)
+        model = UNetModel(**cfg)
+        for _n, layer in model.named_modules():
+            if isinstance(layer, torch.nn.modules.conv._ConvNd):
+                torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+        raw = torch.rand(2, 1, *spatial)
+        with torch.no_grad():
+            train_out = model(raw)
+        model.set_infer(p_salt_pepper=0.05, num_infer_iterations=2, device=torch.device("cpu"))
+        torch.manual_seed(7)
+        with torch.no_grad():
+            infer_out = model(raw)
+        for k, v in model.state_dict().items():
+            out[f"w{nd}/{k}"] = v.numpy()
+        out[f"raw{nd}"] = raw.numpy()
+        out[f"train{nd}"] = train_out.numpy()
+        out[f"infer{nd}"] = infer_out.numpy()
+    np.savez_compressed(os.path.join(HERE, "g3_unet.npz"), **out)
+
+
+def g4_mean_shift():
+    """Real reference mean_shift_segmentation (+ sklearn) on synthetic disc/ball embeddings."""
+    out = {}
+    cases = [
+        ("2d_rp1", (96, 96), dict(spacing=32, radius=9), 1.0, None, 10.0),
+        ("2d_rp05", (96, 128), dict(spacing=32, radius=9), 0.5, None, 10.0),
+        ("2d_rp02", (144, 144), dict(spacing=48, radius=12), 0.2, None, 15.0),
+        ("2d_seeds", (96, 96), dict(spacing=32, radius=9), 0.5, "grid", 10.0),
+        ("3d_rp05", (24, 40, 40), dict(spacing=20, radius=6), 0.5, None, 7.0),
+        ("2d_empty", (32, 32), dict(spacing=64, radius=0), 0.5, None, 10.0),
+    ]
+    for name, shape, kw, rp, seeds, bw in cases:
+        mean, std = IO.synthetic_embeddings(shape, seed=3, **kw)
+        if name == "2d_empty":
+            std[:] = 1.0
+        if seeds == "grid":
+            nd = len(shape)
+            seeds = np.stack(np.meshgrid(*[np.arange(16, s, 32) for s in shape[::-1]], indexing="ij"),
+                             -1).reshape(-1, nd)      # (x, y) order, integers
+        np.random.seed(11)
+        m = mean.copy()
+        labels = mean_shift_segmentation(m, std, bandwidth=bw, min_size=10,
+                                         reduction_probability=rp, threshold=0.5, seeds=seeds)
+        out[f"{name}/mean"] = mean
+        out[f"{name}/std"] = std
+        out[f"{name}/mean_after"] = m
+        out[f"{name}/labels"] = labels
+        out[f"{name}/params"] = np.array([bw, rp, 0.5, 11])
+        if seeds is not None:
+            out[f"{name}/seeds"] = seeds
+    np.savez_compressed(os.path.join(HERE, "g4_mean_shift.npz"), **out)
+
+
+def g7_configs():
+    import tomli
+
+    train_toml = b"""
+[model_config]
+num_fmaps = 256
+fmap_inc_factor = 3
+downsampling_factors = [[2,2],]
+
+[train_config.train_data_config]
+container_path = "skin.zarr"
+dataset_name = "train/raw"
+"""
+    infer_toml = b"""
+[model_config]
+num_fmaps = 256
+fmap_inc_factor = 3
+checkpoint = "models/best_loss.pth"
+
+[inference_config.dataset_config]
+container_path = "skin.zarr"
+dataset_name = "test/raw"
+
+[inference_config.prediction_dataset_config]
+container_path = "skin.zarr"
+dataset_name = "embeddings"
+
+[inference_config.detection_dataset_config]
+container_path = "skin.zarr"
+dataset_name = "detection"
+secondary_dataset_name = "embeddings"
+
+[inference_config.segmentation_dataset_config]
+container_path = "skin.zarr"
+dataset_name = "segmentation"
+secondary_dataset_name = "detection"
+"""
+    reprs = []
+    for t in (train_toml, infer_toml):
+        cfg = ExperimentConfig(experiment_name="golden", **tomli.loads(t.decode()))
+        reprs.append(repr(cfg))
+    np.savez_compressed(os.path.join(HERE, "g7_configs.npz"), train_toml=np.frombuffer(train_toml, dtype=np.uint8),
+                        infer_toml=np.frombuffer(infer_toml, dtype=np.uint8), reprs=np.array(reprs))
+
+
+if __name__ == "__main__":
+    g1_oce()
+    g2_gather()
+    g3_unet()
+    g4_mean_shift()
+    g7_configs()
+    print("golden vectors written to", HERE)

@@ -1,0 +1,334 @@
+"""CPU tier: host-side logic of cellulus_amd (no kernel is launched): configs, zarr IO,
+topology, pair sampler, centre de-duplication, evaluation, the C-ABI symbol table,
+loud failure without a HIP device, and the data-parallel wiring over gloo."""
+
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+# ------------------------------------------------------------------ C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "clx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(clx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cellulus_amd import _build, _clx
+
+    _build.build()
+    lib = ctypes.CDLL(_clx.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/clx.h but not exported"
+    assert sorted(_clx.PROTOTYPES) == declared, "ctypes prototypes and clx.h disagree"
+    assert _clx.load().clx_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    """Validation happens before any launch, so it is testable on the CPU."""
+    from cellulus_amd import _clx
+
+    lib = _clx.load()
+    d = _clx.ClxConvDesc()
+    d.nsrc = 3
+    assert lib.clx_conv_fwd(ctypes.byref(d), None) == -1
+    assert b"nsrc" in lib.clx_last_error()
+    with pytest.raises(_clx.ClxError, match="nsrc"):
+        _clx.call("clx_conv_fwd", ctypes.byref(d), None)
+    assert lib.clx_maxpool_fwd(None, None, 1, 1, 4, 4, 4, 1, 2, 2, None) == -1
+    assert lib.clx_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
+
+
+def test_product_fails_loudly_without_hip_device():
+    from cellulus_amd._clx import ClxError
+    from cellulus_amd.models import get_model
+    from cellulus_amd.utils.misc import size_filter
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    model = get_model(1, 2, 8, 3, 16, [[2, 2]], 2)
+    with pytest.raises(ClxError, match="no CPU path"):
+        model(torch.zeros(1, 1, 44, 44))
+    with pytest.raises(ClxError, match="no CPU path"):
+        size_filter(np.ones((4, 4), dtype=np.int32), 2)
+    from cellulus_amd.train import _require_hip_device
+
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _require_hip_device("cpu")
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _dirs, files in os.walk(os.path.join(ROOT, "cellulus_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+# ----------------------------------------------------------------- configs
+def test_configs_match_reference_repr_and_validators():
+    import tomli
+
+    from cellulus_amd.configs import ExperimentConfig
+
+    g = np.load(os.path.join(G, "g7_configs.npz"))
+    for key, ref in zip(("train_toml", "infer_toml"), g["reprs"]):
+        cfg = ExperimentConfig(experiment_name="golden", **tomli.loads(bytes(g[key]).decode()))
+        assert repr(cfg) == str(ref)
+    with pytest.raises(TypeError):      # object_size must be an int (tests/train.toml:2 trips this)
+        ExperimentConfig(model_config=dict(num_fmaps=8, fmap_inc_factor=2), object_size=10.0)
+    with pytest.raises(ValueError):
+        ExperimentConfig(model_config=dict(num_fmaps=8, fmap_inc_factor=2),
+                         inference_config=dict(clustering="kmeans"))
+    with pytest.raises(TypeError):
+        ExperimentConfig(model_config=dict(num_fmaps=8.0, fmap_inc_factor=2))
+
+
+# -------------------------------------------------------------------- zarr
+def test_zarr_roundtrip_and_metadata(tmp_path):
+    from cellulus_amd.configs import DatasetConfig
+    from cellulus_amd.datasets import DatasetMetaData
+    from cellulus_amd.utils import zarr_io
+
+    f = zarr_io.open(tmp_path / "c.zarr")
+    a = np.random.default_rng(0).random((3, 2, 10, 12, 14)).astype(np.float32)
+    f["train/raw"] = a
+    f["train/raw"].attrs["axis_names"] = ["s", "c", "z", "y", "x"]
+    m = DatasetMetaData.from_dataset_config(DatasetConfig(container_path=tmp_path / "c.zarr", dataset_name="train/raw"))
+    assert (m.num_samples, m.num_channels, m.num_spatial_dims, m.spatial_array) == (3, 2, 3, (10, 12, 14))
+    np.testing.assert_array_equal(zarr_io.open(tmp_path / "c.zarr", "r")["train/raw"][1, :, 2:5], a[1, :, 2:5])
+    ds = f.create_dataset("u16", shape=(2, 1, 9, 9), dtype=np.uint16, chunks=(1, 1, 4, 4),
+                          compressor={"id": "gzip", "level": 1})
+    ds[1, 0, 2:7, 3:9] = np.arange(30).reshape(5, 6)
+    assert ds[1, 0, 6, 8] == 29 and ds[0].sum() == 0
+    f["noattr"] = np.zeros((1, 1, 4, 4))
+    with pytest.raises(RuntimeError, match="axis_names"):
+        DatasetMetaData.from_dataset_config(DatasetConfig(container_path=tmp_path / "c.zarr", dataset_name="noattr"))
+    with pytest.raises(RuntimeError, match="does not contain"):
+        DatasetMetaData.from_dataset_config(DatasetConfig(container_path=tmp_path / "c.zarr", dataset_name="missing"))
+    with pytest.raises(RuntimeError, match="sample dimension"):
+        DatasetMetaData((4, 4), ["y", "x"])
+
+
+# ---------------------------------------------------------------- topology
+def test_topology_matches_oracle_shapes():
+    from cellulus_amd.models.plan import build_topology
+    from oracle.unet_oracle import OracleUNetModel
+
+    cases = [
+        (dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=3, features_in_last_layer=8,
+              downsampling_factors=[[2, 2]], num_spatial_dims=2), (60, 44)),
+        (dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=2, features_in_last_layer=8,
+              downsampling_factors=[[2, 2], [3, 3]], num_spatial_dims=2), (108, 120)),
+        # crop_to_factor is NOT a no-op here: 3x upsampling of 17 -> 51, (51-4) % 3 != 0
+        (dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=2, features_in_last_layer=8,
+              downsampling_factors=[[3, 3]], num_spatial_dims=2), (67, 67)),
+        (dict(in_channels=2, out_channels=3, num_fmaps=4, fmap_inc_factor=2, features_in_last_layer=8,
+              downsampling_factors=[[1, 2, 2]], num_spatial_dims=3), (20, 28, 32)),
+    ]
+    for cfg, spatial in cases:
+        oracle = OracleUNetModel(**cfg)
+        with torch.no_grad():
+            y = oracle(torch.zeros(1, cfg["in_channels"], *spatial))
+        topo = build_topology(spatial=spatial, **cfg)
+        assert tuple(topo.out_shape[3 - cfg["num_spatial_dims"]:]) == tuple(y.shape[2:]), (cfg, spatial)
+    # output = crop - 16 for the single 2x level (zarr_dataset.py:94)
+    assert build_topology(1, 2, 4, 3, 8, [[2, 2]], 2, (256, 256)).out_shape == (1, 240, 240)
+    with pytest.raises(RuntimeError, match="downsample"):
+        build_topology(1, 2, 4, 3, 8, [[2, 2]], 2, (45, 44))
+    with pytest.raises(ValueError, match="too small"):
+        build_topology(1, 2, 4, 3, 8, [[2, 2]], 2, (12, 12))
+
+
+def test_state_dict_names_match_reference_layout():
+    from cellulus_amd.models import get_model
+    from oracle.unet_oracle import OracleUNetModel
+
+    cfg = dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=3, features_in_last_layer=8,
+               downsampling_factors=[[2, 2], [2, 2]], num_spatial_dims=2)
+    a, b = get_model(**cfg).state_dict(), OracleUNetModel(**cfg).state_dict()
+    assert list(a) == list(b)
+    assert all(a[k].shape == b[k].shape for k in a)
+    assert "backbone.r_conv.0.1.conv_pass.6.bias" in a and "head.2.weight" in a
+
+
+# ------------------------------------------------------------ pair sampler
+def test_pair_sampler_counts_and_geometry(tmp_path):
+    from cellulus_amd.configs import DatasetConfig
+    from cellulus_amd.datasets import get_dataset
+    from cellulus_amd.utils import zarr_io
+
+    f = zarr_io.open(tmp_path / "d.zarr")
+    raw = np.random.default_rng(0).random((4, 1, 300, 280)).astype(np.float32)
+    raw[0] = 0.0                                            # an all-zero sample must be rejected
+    f["train/raw"] = raw
+    f["train/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    ds = get_dataset(DatasetConfig(container_path=tmp_path / "d.zarr", dataset_name="train/raw"),
+                     crop_size=(256, 256), elastic_deform=False, control_point_spacing=64,
+                     control_point_jitter=2.0, density=0.1, kappa=10.0, normalization_factor=1.0)
+    assert ds.get_num_anchors() == 4840 and ds.get_num_references() == 31
+    assert ds.get_num_samples() == 150040
+    np.random.seed(0)
+    it = iter(ds)
+    for _ in range(3):
+        crop, anchor, ref = next(it)
+        assert crop.shape == (1, 256, 256) and crop.dtype == np.float32 and crop.max() > 0
+        assert anchor.shape == ref.shape == (150040, 2)
+        assert anchor.min() >= 10 and anchor.max() <= 230
+        d = ref - anchor
+        assert ((d ** 2).sum(1) < 100).all() and (np.abs(d).sum(1) > 0).all()
+        assert (anchor[:31] == anchor[0]).all()             # np.repeat layout: 31 refs per anchor
+    # elastic path produces finite crops of the right shape
+    ds2 = get_dataset(DatasetConfig(container_path=tmp_path / "d.zarr", dataset_name="train/raw"),
+                      crop_size=(128, 128), elastic_deform=True, control_point_spacing=64,
+                      control_point_jitter=2.0, density=0.1, kappa=10.0, normalization_factor=None)
+    crop, _, _ = next(iter(ds2))
+    assert crop.shape == (1, 128, 128) and np.isfinite(crop).all()
+
+
+# ---------------------------------------------------------- centre de-dup
+def test_dedup_centers_equals_oracle_dict_sort_dedup():
+    from cellulus_amd.utils.mean_shift import dedup_centers
+    from oracle import infer_oracle as IO
+
+    rng = np.random.default_rng(0)
+    truth = rng.random((12, 2)) * 200
+    centers = truth[rng.integers(0, 12, size=400)] + rng.normal(0, 0.01, size=(400, 2))
+    centers[50:60] = centers[50]                       # exact duplicates (dict keys collapse)
+    counts = rng.integers(0, 50, size=400).astype(np.int32)
+    got = dedup_centers(centers, counts, 15.0)
+    # oracle's Python dict + sorted + greedy loop on the same converged centres
+    d = {}
+    for c, n in zip(centers, counts):
+        if n:
+            d[tuple(c)] = int(n)
+    items = sorted(d.items(), key=lambda t: (t[1], t[0]), reverse=True)
+    sc = np.array([t[0] for t in items])
+    uniq = np.ones(len(sc), bool)
+    for i, c in enumerate(sc):
+        if uniq[i]:
+            uniq[((sc - c) ** 2).sum(1) <= 225.0] = 0
+            uniq[i] = 1
+    np.testing.assert_array_equal(got, sc[uniq])
+    with pytest.raises(ValueError, match="bandwidth"):
+        dedup_centers(centers, np.zeros(400, dtype=np.int32), 15.0)
+    assert IO is not None
+
+
+# -------------------------------------------------------------- evaluation
+def test_pairwise_iou_equals_bruteforce_definition():
+    from cellulus_amd.evaluate import compute_F1, compute_pairwise_IoU
+
+    rng = np.random.default_rng(0)
+    pred = np.kron(rng.integers(0, 5, size=(6, 6)), np.ones((4, 4), dtype=np.int64)).astype(np.uint16)
+    gt = np.roll(pred, 2, axis=1)
+    iou, seg, n = compute_pairwise_IoU(pred, gt)
+    pids = [i for i in np.unique(pred) if i != 0]
+    gids = [i for i in np.unique(gt) if i != 0]
+    ref = np.zeros((len(pids), len(gids)))
+    iog = np.zeros_like(ref)
+    for j, p in enumerate(pids):       # cellulus/evaluate.py:72-97
+        for k, g in enumerate(gids):
+            inter = ((pred == p) & (gt == g)).sum()
+            ref[j, k] = inter / ((pred == p) | (gt == g)).sum()
+            iog[j, k] = inter / (gt == g).sum()
+    np.testing.assert_allclose(iou, ref)
+    assert n == len(gids) and abs(seg - ref[iog > 0.5].sum()) < 1e-12
+    f1, tp, fp, fn = compute_F1(iou)
+    assert 0 <= f1 <= 1 and tp + fn == len(gids)
+    assert compute_pairwise_IoU(pred, np.zeros_like(gt)) is None
+
+
+def test_tile_offsets():
+    from cellulus_amd.predict import tile_offsets
+
+    assert tile_offsets(512, 240) == [0, 240, 272]
+    assert tile_offsets(240, 240) == [0]
+    assert tile_offsets(480, 240) == [0, 240]
+    with pytest.raises(RuntimeError):
+        tile_offsets(100, 240)
+
+
+def test_logger_csv_layout(tmp_path, monkeypatch):
+    from cellulus_amd.utils import get_logger
+
+    monkeypatch.chdir(tmp_path)
+    lg = get_logger(keys=["loss", "oce_loss"], title="loss")
+    for i in range(3):
+        lg.add("loss", 1.5 * i)
+        lg.add("oce_loss", 0.5 * i)
+        lg.write()
+    lines = open("loss.csv").read().strip().split("\n")
+    assert lines[0] == ",loss,oce_loss" and lines[3].split(",")[0] == "2" and len(lines) == 4
+    assert float(lines[2].split(",")[1]) == 1.5
+
+
+# ------------------------------------------------------------- DDP (gloo)
+_DDP_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cellulus_amd import parallel
+rank, world, _ = parallel.init_from_env(backend="gloo")
+assert world == 2
+# loss is a SUM over pairs => global gradient = SUM of per-rank gradients (no averaging)
+w = torch.tensor([1.0, -2.0, 0.5])
+x = torch.arange(12.0).view(4, 3) + 1
+shard = x[rank * 2:(rank + 1) * 2]
+g = (2 * (shard @ w)[:, None] * shard).sum(0)
+flat = g.clone()
+parallel.all_reduce_sum_(flat)
+full = (2 * (x @ w)[:, None] * x).sum(0)
+assert torch.allclose(flat, full), (flat, full)
+p = torch.full((5,), float(rank))
+parallel.broadcast_(p, src=0)
+assert (p == 0).all()
+lo, hi = parallel.shard_range(7)
+assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+sums = torch.tensor([float(rank + 1)], dtype=torch.float64)
+parallel.all_reduce_sum_(sums)
+assert sums.item() == 3.0
+dist.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def test_data_parallel_wiring_gloo_world2(tmp_path):
+    script = tmp_path / "ddp.py"
+    script.write_text(_DDP_SCRIPT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+    assert parallel_shard_cover()
+
+
+def parallel_shard_cover():
+    from cellulus_amd import parallel
+
+    for n in (0, 1, 7, 8, 64):
+        for w in (1, 2, 3, 8):
+            got = []
+            for r in range(w):
+                lo, hi = parallel.shard_range(n, r, w)
+                got += list(range(lo, hi))
+            if got != list(range(n)):
+                return False
+    return True

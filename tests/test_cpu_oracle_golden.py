@@ -1,0 +1,111 @@
+"""CPU tier: the oracle (oracle/) is pinned against golden vectors produced by the
+REAL reference code (tests/golden/make_golden*.py).  No GPU, no product code."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import infer_oracle as IO
+from oracle import unet_oracle as UO
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_oce_loss_oracle_matches_reference():
+    g = _load("g1_oce_loss.npz")
+    for nd in (2, 3):
+        a = torch.from_numpy(g[f"a{nd}"]).requires_grad_(True)
+        r = torch.from_numpy(g[f"r{nd}"])
+        loss, oce, reg = UO.oce_loss(a, r, 10.0, 1e-5)
+        loss.backward()
+        np.testing.assert_allclose([loss.item(), oce.item(), reg.item()], g[f"sums{nd}"], rtol=1e-6)
+        np.testing.assert_allclose(a.grad.numpy(), g[f"grad{nd}"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(g["kat_sums"], [1.2476590872, 1.2475949526, 6.41421e-5], rtol=1e-5)
+
+
+def test_gather_oracle_matches_reference():
+    g = _load("g2_gather.npz")
+    for nd in (2, 3):
+        sel = UO.select_and_add_coordinates(torch.from_numpy(g[f"offsets{nd}"]), torch.from_numpy(g[f"coords{nd}"]))
+        np.testing.assert_array_equal(sel.numpy(), g[f"sel{nd}"])
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_unet_oracle_matches_reference_wrapper(nd):
+    """Reference UNetModel (real head + infer loop, stubbed backbone) == OracleUNetModel."""
+    g = _load("g3_unet.npz")
+    cfg = dict(in_channels=1, out_channels=nd, num_fmaps=4, fmap_inc_factor=2, features_in_last_layer=8,
+               downsampling_factors=[(2,) * nd], num_spatial_dims=nd)
+    model = UO.OracleUNetModel(**cfg)
+    sd = {k[len(f"w{nd}/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"w{nd}/")}
+    model.load_state_dict(sd, strict=True)
+    raw = torch.from_numpy(g[f"raw{nd}"])
+    with torch.no_grad():
+        out = model(raw)
+    assert out.shape == tuple(g[f"train{nd}"].shape)
+    assert tuple(out.shape[2:]) == tuple(s - 16 for s in raw.shape[2:])   # zarr_dataset.py:94
+    np.testing.assert_allclose(out.numpy(), g[f"train{nd}"], atol=1e-6)
+    model.set_infer(0.05, 2)
+    torch.manual_seed(7)
+    with torch.no_grad():
+        inf = model(raw)
+    np.testing.assert_allclose(inf.numpy(), g[f"infer{nd}"], atol=1e-6)
+
+
+MS_CASES = ["2d_rp1", "2d_rp05", "2d_rp02", "2d_seeds", "3d_rp05", "2d_empty"]
+
+
+@pytest.mark.parametrize("case", MS_CASES)
+def test_mean_shift_oracle_matches_reference(case):
+    g = _load("g4_mean_shift.npz")
+    bw, rp, thr, seed = g[f"{case}/params"]
+    mean = g[f"{case}/mean"].copy()
+    seeds = g[f"{case}/seeds"] if f"{case}/seeds" in g.files else None
+    np.random.seed(int(seed))
+    labels = IO.mean_shift_segmentation(mean, g[f"{case}/std"], bw, 10, rp, thr, seeds)
+    ref = g[f"{case}/labels"]
+    assert labels.dtype == ref.dtype == np.int32
+    np.testing.assert_array_equal(mean, g[f"{case}/mean_after"])      # in-place coordinate add
+    # cluster numbering follows sklearn's sort of near-tied centres; the PARTITION is the contract
+    np.testing.assert_array_equal(labels > 0, ref > 0)
+    np.testing.assert_array_equal(IO.label(labels), IO.label(ref))
+    # ... and on these inputs even the numbering agrees
+    np.testing.assert_array_equal(labels, ref)
+
+
+SK_CASES = ["2d_rp1", "2d_rp02", "3d_rp05", "rand2d", "noise2d", "noise3d", "zeros2d", "full2d"]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_label_and_size_filter_oracle_match_skimage(case):
+    g = _load("g5_skimage.npz")
+    seg = g[f"{case}/seg"]
+    np.testing.assert_array_equal(IO.label(seg), g[f"{case}/label"])
+    for ms in (1, 4, 30):
+        np.testing.assert_array_equal(IO.size_filter(seg.copy(), ms), g[f"{case}/size_filter_{ms}"])
+
+
+def test_otsu_oracle_matches_skimage():
+    g = _load("g5_skimage.npz")
+    for i in range(3):
+        assert IO.threshold_otsu(g[f"otsu{i}/image"]) == float(g[f"otsu{i}/threshold"])
+
+
+def test_edt_sq_matches_scipy_semantics():
+    rng = np.random.default_rng(0)
+    m = rng.random((20, 30)) < 0.9
+    d = IO.edt_sq(m)
+    assert d[~m].max() == 0 and d[m].min() >= 1
+    # no zero anywhere: scipy reports the distance to a phantom zero at index -1 of axis 0
+    ones = np.ones((4, 5), dtype=bool)
+    yy, xx = np.mgrid[0:4, 0:5]
+    np.testing.assert_array_equal(IO.edt_sq(ones), (yy + 1) ** 2 + xx ** 2)
+    ones3 = np.ones((3, 4, 5), dtype=bool)
+    zz, yy, xx = np.mgrid[0:3, 0:4, 0:5]
+    np.testing.assert_array_equal(IO.edt_sq(ones3), (zz + 1) ** 2 + yy ** 2 + xx ** 2)

@@ -1,0 +1,269 @@
+"""GPU parity of the inference-side hot path: mean-shift, connected components +
+size filter, Otsu, distance-transform grow/shrink, and the whole
+predict -> detect -> segment pipeline over zarr — against the CPU oracle and the
+golden vectors captured from the real reference (tests/golden)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cellulus_amd.utils import mean_shift as MS
+from cellulus_amd.utils.misc import label_on_device, size_filter
+from cellulus_amd.utils.otsu import histogram_on_device, threshold_otsu
+from oracle import infer_oracle as IO
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ------------------------------------------------------------------ mean shift
+MS_CASES = ["2d_rp1", "2d_rp05", "2d_rp02", "2d_seeds", "3d_rp05", "2d_empty"]
+
+
+@pytest.mark.parametrize("case", MS_CASES)
+def test_mean_shift_matches_reference_golden(case, device):
+    g = np.load(os.path.join(G, "g4_mean_shift.npz"))
+    bw, rp, thr, seed = g[f"{case}/params"]
+    mean = g[f"{case}/mean"].copy()
+    seeds = g[f"{case}/seeds"] if f"{case}/seeds" in g.files else None
+    np.random.seed(int(seed))
+    labels = MS.mean_shift_segmentation(mean, g[f"{case}/std"], float(bw), 10, float(rp), float(thr), seeds,
+                                        device=device)
+    ref = g[f"{case}/labels"]
+    assert labels.dtype == np.int32 and labels.shape == ref.shape
+    np.testing.assert_array_equal(mean, g[f"{case}/mean_after"])     # input mutated like the reference
+    np.testing.assert_array_equal(labels > 0, ref > 0)
+    # the instance PARTITION is bit-exact (ids are canonicalised by the final CC labelling)
+    np.testing.assert_array_equal(IO.label(labels), IO.label(ref))
+    np.testing.assert_array_equal(labels, ref)
+
+
+@pytest.mark.parametrize("shape,rp", [((160, 192), 0.3), ((20, 48, 40), 0.4)])
+def test_mean_shift_matches_oracle_on_fresh_inputs(shape, rp, device):
+    mean, std = IO.synthetic_embeddings(shape, spacing=40 if len(shape) == 2 else 20,
+                                        radius=11 if len(shape) == 2 else 6, seed=5)
+    bw = 13.0 if len(shape) == 2 else 7.0
+    np.random.seed(3)
+    ref = IO.mean_shift_segmentation(mean.copy(), std, bw, 10, rp, 0.5, None)
+    np.random.seed(3)
+    got = MS.mean_shift_segmentation(mean.copy(), std, bw, 10, rp, 0.5, None, device=device)
+    np.testing.assert_array_equal(IO.label(got), IO.label(ref))
+    assert got.max() == ref.max() > 4
+
+
+def test_mean_shift_kernels_match_oracle_numbers(device):
+    """centres/counts of the iteration kernel vs the C restatement, point by point."""
+    from cellulus_amd import _clx
+
+    rng = np.random.default_rng(0)
+    fit = np.concatenate([rng.normal(c, 2.0, size=(300, 2)) for c in ((10, 10), (60, 20), (30, 70))])
+    seeds = fit[::7].copy()
+    lib = IO._clib()
+    ns = len(seeds)
+    c_ref = np.empty((ns, 2)); n_ref = np.empty(ns, np.int32); i_ref = np.empty(ns, np.int32)
+    lib.ms_oracle_iterate(IO._dptr(fit), len(fit), IO._dptr(seeds), ns, 2, 6.0, 300, IO._dptr(c_ref),
+                          IO._iptr(n_ref), IO._iptr(i_ref))
+    fit_d = torch.from_numpy(fit).to(device); seeds_d = torch.from_numpy(seeds).to(device)
+    c = torch.empty((ns, 2), dtype=torch.float64, device=device)
+    n = torch.empty(ns, dtype=torch.int32, device=device)
+    it = torch.empty(ns, dtype=torch.int32, device=device)
+    _clx.call("clx_ms_iterate", _clx.ptr(fit_d), len(fit), _clx.ptr(seeds_d), ns, 2, 6.0, 300,
+              _clx.ptr(c), _clx.ptr(n), _clx.ptr(it), _clx.stream_ptr(device))
+    np.testing.assert_array_equal(n.cpu().numpy(), n_ref)
+    np.testing.assert_array_equal(it.cpu().numpy(), i_ref)
+    np.testing.assert_allclose(c.cpu().numpy(), c_ref, rtol=0, atol=1e-11)   # summation order only
+
+
+def test_mean_shift_degenerate_inputs(device):
+    mean, std = IO.synthetic_embeddings((40, 40), spacing=40, radius=8, seed=1)
+    # nothing below the threshold -> all background, no RNG draw, no error (mean_shift.py:83-84)
+    out = MS.mean_shift_segmentation(mean.copy(), np.ones_like(std), 10.0, 10, 0.5, 0.5, None, device=device)
+    assert out.shape == (40, 40) and out.max() == 0
+    # reduction keeps no point -> sklearn raises on an empty fit set
+    with pytest.raises(ValueError):
+        MS.mean_shift_segmentation(mean.copy(), std, 10.0, 10, 0.0, 0.5, None, device=device)
+    # seeds far away from every point -> "No point was within bandwidth"
+    with pytest.raises(ValueError, match="bandwidth"):
+        MS.mean_shift_segmentation(mean.copy(), std, 3.0, 10, 1.0, 0.5, np.array([[1000, 1000]]), device=device)
+    with pytest.raises(TypeError):
+        MS.mean_shift_segmentation(mean.astype(np.float32), std, 3.0, 10, 1.0, 0.5, None, device=device)
+
+
+# ------------------------------------------------------- CC / size filter / Otsu
+SK_CASES = ["2d_rp1", "2d_rp02", "3d_rp05", "rand2d", "noise2d", "noise3d", "zeros2d", "full2d"]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_label_and_size_filter_bit_exact_vs_skimage_golden(case, device):
+    g = np.load(os.path.join(G, "g5_skimage.npz"))
+    seg = g[f"{case}/seg"]
+    lab, ncomp = label_on_device(torch.from_numpy(seg).to(device), 1)
+    np.testing.assert_array_equal(lab.cpu().numpy(), g[f"{case}/label"])
+    assert int(ncomp.item()) == g[f"{case}/label"].max()
+    for ms in (1, 4, 30):
+        s = seg.copy()
+        out = size_filter(s, ms, device=device)
+        assert out.dtype == np.int64
+        np.testing.assert_array_equal(out, g[f"{case}/size_filter_{ms}"])
+        np.testing.assert_array_equal(s, g[f"{case}/seg_after_{ms}"])      # input zeroed like the reference
+    assert size_filter(seg, 0, device=device) is seg                          # misc.py:12-13
+
+
+@pytest.mark.parametrize("shape", [(512, 512), (37, 61), (48, 64, 56), (1, 1), (1, 300)])
+def test_size_filter_matches_oracle_random(shape, device):
+    rng = np.random.default_rng(sum(shape))
+    seg = (rng.random(shape) < 0.55).astype(np.int32) * rng.integers(1, 4, size=shape).astype(np.int32)
+    for ms in (1, 9, 70):
+        np.testing.assert_array_equal(size_filter(seg.copy(), ms, device=device), IO.size_filter(seg.copy(), ms))
+    # idempotence: filtering a filtered map changes nothing but (possibly) nothing at all
+    once = size_filter(seg.copy(), 9, device=device)
+    np.testing.assert_array_equal(size_filter(once.copy(), 9, device=device), once)
+
+
+def test_long_snake_component(device):
+    """A single serpentine component: worst case for union-find chains."""
+    seg = np.zeros((64, 65), dtype=np.int32)
+    seg[::2, :] = 7
+    for r in range(1, 63, 2):
+        seg[r, 64 if (r // 2) % 2 == 0 else 0] = 7
+    out = size_filter(seg.copy(), 5, device=device)
+    np.testing.assert_array_equal(out, IO.size_filter(seg.copy(), 5))
+    assert out.max() == 1
+
+
+def test_otsu_bit_exact_vs_skimage_golden(device):
+    g = np.load(os.path.join(G, "g5_skimage.npz"))
+    for i in range(3):
+        img = g[f"otsu{i}/image"]
+        got = threshold_otsu(torch.from_numpy(img).to(device))
+        assert got == float(g[f"otsu{i}/threshold"])
+        counts, edges = histogram_on_device(torch.from_numpy(img).to(device))
+        ref_counts, ref_edges = np.histogram(img.ravel(), bins=256)
+        np.testing.assert_array_equal(counts, ref_counts)
+        np.testing.assert_array_equal(edges, ref_edges)
+    assert threshold_otsu(torch.full((5, 5), 2.5, dtype=torch.float64, device=device)) == 2.5
+
+
+# ------------------------------------------------------------------ EDT
+@pytest.mark.parametrize("shape", [(64, 80), (300, 17), (20, 24, 28)])
+def test_edt_sq_bit_exact(shape, device):
+    from cellulus_amd import _clx
+
+    rng = np.random.default_rng(1)
+    for density in (0.02, 0.5, 1.0):      # 1.0: no zero anywhere -> scipy's phantom zero
+        m = (rng.random(shape) < density) if density < 1.0 else np.ones(shape, bool)
+        ref = IO.edt_sq(m)
+        Z, Y, X = (1,) * (3 - len(shape)) + tuple(shape)
+        md = torch.from_numpy(m.astype(np.uint8)).to(device)
+        out = torch.empty(shape, dtype=torch.int32, device=device)
+        ws = torch.empty(m.size * 4 + 16, dtype=torch.uint8, device=device)
+        _clx.call("clx_edt_sq", _clx.ptr(md), _clx.ptr(out), Z, Y, X, _clx.ptr(ws), _clx.stream_ptr(device))
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("shape", [(96, 96), (24, 40, 40)])
+def test_grow_shrink_bit_exact(shape, device):
+    from cellulus_amd.segment import grow_shrink_on_device
+
+    key = "2d_rp1" if len(shape) == 2 else "3d_rp05"
+    seg = np.load(os.path.join(G, "g4_mean_shift.npz"))[f"{key}/labels"]
+    for grow, shrink in ((3, 6), (1, 1), (0, 2), (5, 2)):
+        ref = IO.grow_shrink(seg, grow, shrink)
+        got = grow_shrink_on_device(torch.from_numpy(seg.copy()).to(device), grow, shrink).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+    # everything foreground after growing: scipy's phantom-zero artefact is reproduced too
+    full = np.ones(shape, dtype=np.int32)
+    np.testing.assert_array_equal(
+        grow_shrink_on_device(torch.from_numpy(full.copy()).to(device), 3, 6).cpu().numpy(),
+        IO.grow_shrink(full, 3, 6))
+
+
+# -------------------------------------------------------- end-to-end pipeline
+def _write_raw(path, nd, seed=0):
+    from cellulus_amd.utils import zarr_io
+
+    rng = np.random.default_rng(seed)
+    shape = (2, 1, 72, 80) if nd == 2 else (1, 1, 40, 44, 40)
+    raw = rng.random(shape).astype(np.float32)
+    f = zarr_io.open(path)
+    f["test/raw"] = raw
+    f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"] if nd == 2 else ["s", "c", "z", "y", "x"]
+    return raw
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_infer_pipeline_matches_oracle(nd, device, tmp_path, monkeypatch):
+    """infer(): predict -> detect -> segment over zarr vs the oracle stage by stage."""
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.infer import infer
+    from cellulus_amd.predict import tile_offsets
+    from cellulus_amd.utils import zarr_io
+    from oracle.unet_oracle import OracleUNetModel
+
+    monkeypatch.chdir(tmp_path)
+    container = str(tmp_path / "data.zarr")
+    raw = _write_raw(container, nd)
+    mcfg = dict(num_fmaps=8, fmap_inc_factor=2, features_in_last_layer=16,
+                downsampling_factors=[[2] * nd])
+    torch.manual_seed(0)
+    oracle = OracleUNetModel(in_channels=1, out_channels=nd, num_spatial_dims=nd, **mcfg)
+    os.makedirs("models", exist_ok=True)
+    torch.save({"model_state_dict": oracle.state_dict()}, "models/best_loss.pth")
+    crop = [56, 56] if nd == 2 else [36, 36, 36]
+    n_it = 2
+    cfg = ExperimentConfig(
+        model_config=dict(checkpoint="models/best_loss.pth", **mcfg),
+        object_size=12, normalization_factor=1.0,
+        inference_config=dict(
+            dataset_config=dict(container_path=container, dataset_name="test/raw"),
+            prediction_dataset_config=dict(container_path=container, dataset_name="embeddings"),
+            detection_dataset_config=dict(container_path=container, dataset_name="detection",
+                                          secondary_dataset_name="embeddings"),
+            segmentation_dataset_config=dict(container_path=container, dataset_name="segmentation",
+                                             secondary_dataset_name="detection"),
+            crop_size=crop, num_infer_iterations=n_it, p_salt_pepper=0.05,
+            reduction_probability=0.5, min_size=6, grow_distance=2, shrink_distance=3,
+            device="cuda:0"))
+    torch.manual_seed(42)
+    np.random.seed(42)
+    infer(cfg)
+    f = zarr_io.open(container, "r")
+    spatial = raw.shape[2:]
+    emb = f["embeddings"][...]
+    assert emb.dtype == np.float64 and emb.shape == (raw.shape[0], nd + 1) + spatial
+    assert f["embeddings"].attrs["axis_names"] == ["s", "c"] + ["z", "y", "x"][-nd:]
+
+    # ---- oracle predict: same tiling, same torch.rand sequence
+    oracle.set_infer(0.05, n_it)
+    out_tile = tuple(c - 16 for c in crop)
+    torch.manual_seed(42)
+    ref_emb = np.zeros_like(emb)
+    import itertools
+    for s in range(raw.shape[0]):
+        padded = np.pad(raw[s], [(0, 0)] + [(8, 8)] * nd, mode="reflect")
+        for off in itertools.product(*[tile_offsets(n, t) for n, t in zip(spatial, out_tile)]):
+            sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, crop))
+            with torch.no_grad():
+                e = oracle(torch.from_numpy(padded[sl][None]))[0].numpy()
+            ref_emb[(s, slice(None)) + tuple(slice(o, o + t) for o, t in zip(off, out_tile))] = e
+    assert np.abs(emb - ref_emb).max() < 1e-4
+
+    # ---- detect + segment, stage by stage on the pipeline's own zarr data
+    np.random.seed(42)
+    det = f["detection"][...]
+    seg = f["segmentation"][...]
+    assert det.dtype == seg.dtype == np.uint16
+    bw, min_size = 0.5 * 12, 6
+    for s in range(raw.shape[0]):
+        thr = IO.threshold_otsu(emb[s, -1])
+        np.testing.assert_array_equal(f["binary-segmentation"][s, 0], (emb[s, -1] < thr).astype(np.uint16))
+        ref_det = IO.mean_shift_segmentation(emb[s][np.newaxis, :nd].copy(), emb[s, -1], bw, min_size, 0.5, thr, None)
+        np.testing.assert_array_equal(IO.label(det[s, 0]), IO.label(ref_det))
+        ref_seg = IO.size_filter(IO.grow_shrink(det[s, 0].astype(np.int32), 2, 3), min_size)
+        np.testing.assert_array_equal(seg[s, 0], ref_seg.astype(np.uint16))
+        centred = f["centered-embeddings"][s]
+        m = (emb[s, -1] < thr)[None] * emb[s, :nd]
+        for k in range(nd):
+            assert np.allclose(centred[k], emb[s, k] - m[k][m[k] != 0].mean(), atol=0, rtol=0)
