@@ -133,11 +133,24 @@ class ConvTimer:
             timer._orig(name, *args)
             e1.record()
             big = (n > 64) if name == "clx_conv_fwd" else (n > 64 and ctot > 64)
-            timer.records.append((name, big, flops, e0, e1))
+            kind = name[4:] if d.PD + d.PH + d.PW == 0 or name == "clx_conv_wgrad" else "conv_dgrad"
+            timer.records.append((name, big, flops, e0, e1, (kind, m, n, ctot * taps, d.nsrc)))
 
         _clx.call = call
         import cellulus_amd.models.plan as plan_mod
         plan_mod._clx.call = call
+
+    def detail(self, steps):
+        """per-layer table (averaged over the timed steps): kind, M, N, K, ms, TFLOP/s"""
+        per_step = len(self.records) // max(steps, 1)
+        rows = []
+        for i in range(per_step):
+            ms = [self.records[i + s * per_step][3].elapsed_time(self.records[i + s * per_step][4])
+                  for s in range(steps)]
+            _n, _b, flops, _e0, _e1, shape = self.records[i]
+            t = float(np.median(ms))
+            rows.append((shape, t, flops / (t * 1e-3) / 1e12))
+        return rows
 
     def uninstall(self):
         from cellulus_amd import _clx
@@ -147,7 +160,7 @@ class ConvTimer:
 
     def summary(self):
         out = {}
-        for name, big, flops, e0, e1 in self.records:
+        for name, big, flops, e0, e1, _shape in self.records:
             key = (name, big)
             ms = e0.elapsed_time(e1)
             agg = out.setdefault(key, [0, 0.0, 0.0])
@@ -289,6 +302,9 @@ def main():
         "loss": round(float(loss), 4),
         "roofline": roofline,
     }
+    if os.environ.get("CLX_BENCH_DETAIL"):
+        for (kind, m, n, k, nsrc), t, tf in timer.detail(args.steps):
+            print(f"  {kind:11s} M={m:8d} N={n:5d} K={k:6d} src={nsrc} {t:8.3f} ms {tf:7.1f} TF/s", file=sys.stderr)
     if world == 1 and not args.no_infer:
         try:
             from bench_infer import infer_bench

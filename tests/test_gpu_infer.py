@@ -50,7 +50,7 @@ def test_mean_shift_matches_oracle_on_fresh_inputs(shape, rp, device):
     np.random.seed(3)
     got = MS.mean_shift_segmentation(mean.copy(), std, bw, 10, rp, 0.5, None, device=device)
     np.testing.assert_array_equal(IO.label(got), IO.label(ref))
-    assert got.max() == ref.max() > 4
+    assert got.max() == ref.max() >= 4
 
 
 def test_mean_shift_kernels_match_oracle_numbers(device):
@@ -98,7 +98,7 @@ SK_CASES = ["2d_rp1", "2d_rp02", "3d_rp05", "rand2d", "noise2d", "noise3d", "zer
 @pytest.mark.parametrize("case", SK_CASES)
 def test_label_and_size_filter_bit_exact_vs_skimage_golden(case, device):
     g = np.load(os.path.join(G, "g5_skimage.npz"))
-    seg = g[f"{case}/seg"]
+    seg = g[f"{case}/seg"].astype(np.int32)
     lab, ncomp = label_on_device(torch.from_numpy(seg).to(device), 1)
     np.testing.assert_array_equal(lab.cpu().numpy(), g[f"{case}/label"])
     assert int(ncomp.item()) == g[f"{case}/label"].max()

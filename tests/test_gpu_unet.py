@@ -1,10 +1,12 @@
 """GPU parity: HIP U-Net (forward, backward, infer mode) vs the CPU oracle.
 
-Tolerances: embeddings within 1e-4 absolute (BASELINE.json north_star) on
-O(1) inputs.  Gradients: relative L2 error < 2e-4 per parameter tensor and
-max error < 5e-3 of the tensor's max magnitude — both sides are f32 and a
-pre-activation within rounding of 0 can flip one ReLU gate, which moves single
-gradient entries by far more than accumulation-order noise does."""
+Tolerances: embeddings within 1e-4 absolute (BASELINE.json north_star) against
+the f32 CPU oracle.  Gradients are compared with the oracle evaluated in
+FLOAT64: in f32 a pre-activation within rounding of 0 flips a ReLU gate on either
+side, which moves a whole layer's gradient by ~1e-3 (measured: the f32 CPU oracle
+sits 1e-3 from the f64 result on the 3-D case while the HIP path sits 1e-6 from
+it, tools/diag_grad64.py) — so the f64 result is the truth both are judged by:
+relative L2 error < 1e-4 per parameter tensor."""
 
 import numpy as np
 import pytest
@@ -63,21 +65,22 @@ def test_forward_matches_oracle(name, device):
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_backward_matches_oracle(name, device):
     oracle, model, raw = _make(name, device, seed=1)
-    ref = oracle(raw)
+    oracle = oracle.double()
+    ref = oracle(raw.double())
     torch.manual_seed(2)
-    dout = torch.randn_like(ref)
-    ref.backward(dout)
+    dout = torch.randn_like(ref).float()
+    ref.backward(dout.double())
     got = model(raw.to(device))
     assert got.requires_grad
     got.backward(dout.to(device))
     for (n, po), (n2, pm) in zip(oracle.named_parameters(), model.named_parameters()):
         assert n == n2
-        g_ref, g = po.grad, pm.grad.cpu()
+        g_ref, g = po.grad, pm.grad.cpu().double()
         scale = g_ref.abs().max().item() + 1e-12
         err = (g - g_ref).abs().max().item() / scale
         l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-12)).item()
-        assert err < 5e-3, f"{name}: grad of {n}: max rel err {err} (scale {scale})"
-        assert l2 < 2e-4, f"{name}: grad of {n}: rel L2 err {l2}"
+        assert err < 1e-3, f"{name}: grad of {n}: max rel err {err} (scale {scale})"
+        assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
 
 
 def test_forward_is_deterministic_and_repacks_after_weight_change(device):
