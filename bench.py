@@ -242,11 +242,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    timer = ConvTimer()
+    timer.install()          # installed before the warm-up so lazy HIP-event setup is not timed
     for _ in range(args.warmup):
         train_iteration(batch, model, criterion, optimizer, device)
-
-    timer = ConvTimer()
-    timer.install()
+    torch.cuda.synchronize()
+    timer.records.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
