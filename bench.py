@@ -248,12 +248,22 @@ def main():
         train_iteration(batch, model, criterion, optimizer, device)
     torch.cuda.synchronize()
     timer.records.clear()
+    import gc
+
+    gc.collect()
+    gc.disable()     # a cyclic-GC pause inside one step would be charged to the GPU path
     barrier()
     t0 = time.perf_counter()
+    step_times = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         loss, oce, _ = train_iteration(batch, model, criterion, optimizer, device)
+        step_times.append(time.perf_counter() - ts)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("CLX_BENCH_DETAIL") and rank == 0:
+        print("  per-step wall ms:", [round(t * 1e3, 2) for t in step_times], file=sys.stderr)
     timer.uninstall()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)

@@ -17,6 +17,8 @@
 
 namespace {
 
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 constexpr int BK = 32;       // K chunk (floats)
 constexpr int LDS_LD = 36;   // padded LDS row (floats): conflict-free b128 reads
 
@@ -34,6 +36,7 @@ struct ConvP {
   const float* wpack;
   const float* bias;
   const float* mask;
+  const float* zeros;   // 16 zero bytes in global memory (target of out-of-range loads)
   float* out;
   int relu, ld_mask, ld_out;
   int nbm, nbn;
@@ -47,8 +50,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
   constexpr int B_PASSES = BN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
-  __shared__ float As[2][BM * LDS_LD];
-  __shared__ float Bs[2][BN * LDS_LD];
+  // one LDS arena: A/B double buffers during the K loop, the C tile in the epilogue
+  constexpr int LDC = BN + 4;
+  constexpr int SMEM_AB = 2 * (BM + BN) * LDS_LD;
+  constexpr int SMEM_C = BM * LDC;
+  __shared__ float smem[SMEM_AB > SMEM_C ? SMEM_AB : SMEM_C];
+  float (*As)[BM * LDS_LD] = reinterpret_cast<float (*)[BM * LDS_LD]>(smem);
+  float (*Bs)[BN * LDS_LD] = reinterpret_cast<float (*)[BN * LDS_LD]>(smem + 2 * BM * LDS_LD);
 
   const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
   const int tile_n = v % p.nbn;
@@ -111,21 +119,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
   };
 
   f32x4 ra[A_PASSES], rw[B_PASSES];
-  auto load_chunk = [&]() {
+  auto load_a = [&]() {
     const int c = c0 + lcol;
     const bool cv = c < sC;
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[j] = (cv && aoff[j] >= 0) ? *reinterpret_cast<const f32x4*>(sptr + aoff[j] + c) : z;
+      // out-of-range rows/channels read 16 zero bytes: no branch, and no use of the
+      // loaded value before the LDS store (a select here would force vmcnt(0) at once)
+      const bool ok = cv && aoff[j] >= 0;
+      ra[j] = *reinterpret_cast<const f32x4*>(ok ? sptr + aoff[j] + c : p.zeros);
     }
+  };
+  auto load_b = [&]() {
+    const int c = c0 + lcol;
+    const bool cv = c < sC;
     const int kflat = tap * p.Ctot + cbase + c;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      rw[j] = (cv && wrow[j] != nullptr) ? *reinterpret_cast<const f32x4*>(wrow[j] + kflat) : z;
+      const bool ok = cv && wrow[j] != nullptr;
+      rw[j] = *reinterpret_cast<const f32x4*>(ok ? wrow[j] + kflat : p.zeros);
     }
   };
+  auto load_chunk = [&]() { load_a(); load_b(); };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j)
@@ -169,55 +184,118 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
 
   int buf = 0;
   bool more = advance();
-  while (true) {
-    if (more) load_chunk();   // global loads for the next chunk fly during the MFMAs
+  // MFMA operand fragments are double-buffered in registers: the ds_read_b128s of
+  // k-group q+1 are in flight while the 4*TM*TN MFMAs of group q issue.
+  f32x4 af[2][TM], bf[2][TN];
+  auto load_frags = [&](int b, int q, int slot) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 af[TM], bf[TN];
+    for (int a = 0; a < TM; ++a)
+      af[slot][a] = *reinterpret_cast<const f32x4*>(&As[b][a_base + a * 32 * LDS_LD + 8 * q]);
+#pragma unroll
+    for (int c = 0; c < TN; ++c)
+      bf[slot][c] = *reinterpret_cast<const f32x4*>(&Bs[b][b_base + c * 32 * LDS_LD + 8 * q]);
+  };
+  auto mfma_group = [&](int slot) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int a = 0; a < TM; ++a)
-        af[a] = *reinterpret_cast<const f32x4*>(&As[buf][a_base + a * 32 * LDS_LD + 8 * q]);
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
-        bf[b] = *reinterpret_cast<const f32x4*>(&Bs[buf][b_base + b * 32 * LDS_LD + 8 * q]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][e], bf[b][e], acc[a][b], 0, 0, 0);
-    }
+        for (int c = 0; c < TN; ++c)
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a][e], bf[slot][c][e], acc[a][c], 0, 0, 0);
+  };
+  // Per chunk: 4 groups of 4*TM*TN MFMAs.  Everything else is slotted between the
+  // groups so the matrix pipe never waits for a long non-MFMA stretch: global loads of
+  // the next chunk before groups 0/1, their LDS stores (other buffer) before group 3,
+  // operand fragments one group ahead.  Only barrier + first fragment read are exposed.
+  load_frags(buf, 0, 0);
+  while (true) {
+    if (more) load_a();
+    load_frags(buf, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) load_b();
+    load_frags(buf, 2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(buf, 3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store_chunk(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1);
     if (!more) break;
-    store_chunk(buf ^ 1);
     __syncthreads();
     buf ^= 1;
+    load_frags(buf, 0, 0);
     more = advance();
   }
 
-  // ---- epilogue: bias, ReLU, optional (mask > 0) gate, store
+  // ---- epilogue: bias + ReLU in registers, transpose through LDS so that every lane
+  // stores (and reads the ReLU-gate mask as) 16-byte channel runs of one output pixel.
+  __syncthreads();
+  float* Cs = smem;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int n = n0 + (wn * TN + b) * 32 + li;
-      const bool nv = n < p.N;
-      const float bv = (nv && p.bias) ? p.bias[n] : 0.f;
+      const int col = (wn * TN + b) * 32 + li;
+      const int n = n0 + col;
+      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nv && m < p.M) {
-          float val = acc[a][b][r] + bv;
-          if (p.relu) val = fmaxf(val, 0.f);
-          if (p.mask) val = (p.mask[(size_t)m * p.ld_mask + n] > 0.f) ? val : 0.f;
-          p.out[(size_t)m * p.ld_out + n] = val;
-        }
+        const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float val = acc[a][b][r] + bv;
+        if (p.relu) val = fmaxf(val, 0.f);
+        Cs[row * LDC + col] = val;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int F4_PER_ROW = BN / 4;
+  constexpr int ITERS = BM * F4_PER_ROW / 256;
+#pragma unroll 4
+  for (int it = 0; it < ITERS; ++it) {
+    const int idx = tid + 256 * it;
+    const int row = idx / F4_PER_ROW, c4 = (idx % F4_PER_ROW) * 4;
+    const int m = m0 + row, n = n0 + c4;
+    if (m >= p.M || n >= p.N) continue;
+    f32x4 val = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
+    float* dst = p.out + (size_t)m * p.ld_out + n;
+    if (n + 3 < p.N) {
+      if (p.mask) {
+        const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.ld_mask + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = (mk[e] > 0.f) ? val[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dst) = val;
+    } else {
+      for (int e = 0; e < 4 && n + e < p.N; ++e) {
+        float x = val[e];
+        if (p.mask) x = (p.mask[(size_t)m * p.ld_mask + n + e] > 0.f) ? x : 0.f;
+        dst[e] = x;
       }
     }
   }
 }
 
 }  // namespace
+
+// address of g_zero16 on the current device (module data, resolved once per device)
+static const float* zero_buffer() {
+  static const float* cache[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (cache[dev] == nullptr) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_zero16)) != hipSuccess) return nullptr;
+    cache[dev] = (const float*)ptr;
+  }
+  return cache[dev];
+}
 
 static int conv_validate(const clx_conv_desc* d, const char* who) {
   CLX_REQUIRE(d != nullptr, "%s: null descriptor", who);
@@ -276,9 +354,15 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
   CLX_REQUIRE(d->wpack && d->out, "clx_conv_fwd: null wpack/out");
   CLX_REQUIRE(d->N > 0 && d->ld_out >= d->N, "clx_conv_fwd: bad N/ld_out");
   CLX_REQUIRE(((uintptr_t)d->wpack & 15) == 0, "clx_conv_fwd: wpack must be 16-byte aligned");
-  CLX_REQUIRE(d->mask == nullptr || d->ld_mask >= d->N, "clx_conv_fwd: bad ld_mask");
+  CLX_REQUIRE(d->mask == nullptr || (d->ld_mask >= d->N && d->ld_mask % 4 == 0 &&
+                                     ((uintptr_t)d->mask & 15) == 0),
+              "clx_conv_fwd: mask must be 16-byte aligned with ld_mask %% 4 == 0 and >= N");
+  CLX_REQUIRE(d->ld_out % 4 == 0 && ((uintptr_t)d->out & 15) == 0,
+              "clx_conv_fwd: out must be 16-byte aligned with ld_out %% 4 == 0");
   ConvP p;
   fill_params(d, p);
+  p.zeros = zero_buffer();
+  CLX_REQUIRE(p.zeros != nullptr, "clx_conv_fwd: cannot resolve the device zero buffer");
   hipStream_t st = (hipStream_t)stream;
   if (d->N > 64) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);

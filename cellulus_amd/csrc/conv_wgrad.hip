@@ -19,6 +19,8 @@ namespace {
 
 constexpr int BKP = 32;  // pixels per chunk
 
+__device__ __attribute__((aligned(16))) float g_wgrad_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct SrcP {
   const float* ptr;
   int C, ld, D, H, W, oz, oy, ox, fz, fy, fx;
@@ -31,6 +33,7 @@ struct WgradP {
   int N, M, Ctot;
   FastDiv dOW, dOH, dOD;
   const float* dy;
+  const float* zeros;   // 16 zero bytes in global memory (target of out-of-range loads)
   int ld_dy;
   float* dwp;
   float* dbias;
@@ -79,39 +82,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0;
 
-  auto load_chunk = [&](int chunk) {
+  // out-of-range rows read 16 zero bytes instead of branching around the load
+  auto load_dy = [&](int chunk) {
     const int p0 = (chunk0 + chunk) * BKP;
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j) {
       const int pp = p0 + a_row + j * A_RPP;
-      f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      ra[j] = (n_ok && pp < p.M)
-                  ? *reinterpret_cast<const f32x4*>(p.dy + (size_t)pp * p.ld_dy + n_g) : z;
+      const bool ok = n_ok && pp < p.M;
+      ra[j] = *reinterpret_cast<const f32x4*>(ok ? p.dy + (size_t)pp * p.ld_dy + n_g : p.zeros);
     }
+  };
+  auto load_x = [&](int chunk) {
+    // the chunk's first pixel is block-uniform: decode it with scalar arithmetic, then walk
+    const uint32_t p0 = (uint32_t)(chunk0 + chunk) * BKP;
+    const uint32_t q1 = fdiv(p0, p.dOW);
+    const int ox0 = (int)(p0 - q1 * p.OW);
+    const uint32_t q2 = fdiv(q1, p.dOH);
+    const int oy0 = (int)(q1 - q2 * p.OH);
+    const uint32_t q3 = fdiv(q2, p.dOD);
+    const int oz0 = (int)(q2 - q3 * p.OD);
+    const int b0 = (int)q3;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-      const uint32_t pp = (uint32_t)(p0 + b_row + j * B_RPP);
-      f32x4 val = {0.f, 0.f, 0.f, 0.f};
-      if (c_ok && pp < (uint32_t)p.M) {
-        uint32_t q1 = fdiv(pp, p.dOW);
-        const int ox = (int)(pp - q1 * p.OW);
-        uint32_t q2 = fdiv(q1, p.dOH);
-        const int oy = (int)(q1 - q2 * p.OH);
-        uint32_t q3 = fdiv(q2, p.dOD);
-        const int oz = (int)(q2 - q3 * p.OD);
-        const int b = (int)q3;
-        const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
-        if ((unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH &&
-            (unsigned)lx < (unsigned)p.IW) {
-          int sz = lz + S.oz, sy = ly + S.oy, sx = lx + S.ox;
-          if (S.fz > 1) sz /= S.fz;
-          if (S.fy > 1) sy /= S.fy;
-          if (S.fx > 1) sx /= S.fx;
-          const long long pix = (((long long)b * S.D + sz) * S.H + sy) * S.W + sx;
-          val = *reinterpret_cast<const f32x4*>(S.ptr + pix * S.ld + c_l);
-        }
-      }
-      rb[j] = val;
+      const int r = b_row + j * B_RPP;
+      int ox = ox0 + r, oy = oy0, oz = oz0, b = b0;
+      while (ox >= p.OW) { ox -= p.OW; ++oy; }
+      while (oy >= p.OH) { oy -= p.OH; ++oz; }
+      while (oz >= p.OD) { oz -= p.OD; ++b; }
+      const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
+      const bool ok = c_ok && (p0 + (uint32_t)r) < (uint32_t)p.M && (unsigned)lz < (unsigned)p.ID &&
+                      (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW;
+      int sz = lz + S.oz, sy = ly + S.oy, sx = lx + S.ox;
+      if (S.fz > 1) sz /= S.fz;
+      if (S.fy > 1) sy /= S.fy;
+      if (S.fx > 1) sx /= S.fx;
+      const long long pix = (((long long)b * S.D + sz) * S.H + sy) * S.W + sx;
+      rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + pix * S.ld + c_l : p.zeros);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -137,31 +143,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   const int a_base = lh * BMN + wm * TM * 32 + li;
   const int b_base = lh * BNC + wn * TN * 32 + li;
 
+  // fragments of k-pair k2+1 are read from LDS while the MFMAs of k-pair k2 issue; the global
+  // loads of the next chunk and their LDS stores are slotted between MFMA groups.
+  float af[2][TM], bf[2][TN];
+  auto load_frags = [&](int buf, int k2, int slot) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) af[slot][a] = Ys[buf][a_base + 2 * k2 * BMN + a * 32];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) bf[slot][b] = Xs[buf][b_base + 2 * k2 * BNC + b * 32];
+  };
   if (nchunks > 0) {
-    load_chunk(0);
+    load_dy(0);
+    load_x(0);
     store_chunk(0);
     __syncthreads();
     int buf = 0;
+    load_frags(0, 0, 0);
     for (int ch = 0; ch < nchunks; ++ch) {
       const bool more = ch + 1 < nchunks;
-      if (more) load_chunk(ch + 1);
 #pragma unroll
       for (int k2 = 0; k2 < BKP / 2; ++k2) {
-        float af[TM], bf[TN];
-#pragma unroll
-        for (int a = 0; a < TM; ++a) af[a] = Ys[buf][a_base + 2 * k2 * BMN + a * 32];
-#pragma unroll
-        for (int b = 0; b < TN; ++b) bf[b] = Xs[buf][b_base + 2 * k2 * BNC + b * 32];
+        if (k2 == 0 && more) load_dy(ch + 1);
+        if (k2 == 4 && more) load_x(ch + 1);
+        if (k2 == 12 && more) store_chunk(buf ^ 1);
+        if (k2 + 1 < BKP / 2) load_frags(buf, k2 + 1, (k2 + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k2 & 1][a], bf[k2 & 1][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (more) {
-        store_chunk(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+        load_frags(buf, 0, 0);
       }
     }
   }
@@ -201,6 +218,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 
 }  // namespace
 
+// co-resident blocks of a kernel on the current device = CUs x blocks per CU (cached)
+static int resident_blocks(const void* fn) {
+  struct Entry { const void* fn; int dev; int slots; };
+  static Entry cache[16];
+  static int used = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  for (int i = 0; i < used; ++i)
+    if (cache[i].fn == fn && cache[i].dev == dev) return cache[i].slots;
+  int cus = 0, per_cu = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) return 0;
+  if (per_cu < 1) per_cu = 1;
+  const int slots = cus * per_cu;
+  if (used < 16) cache[used++] = Entry{fn, dev, slots};
+  return slots;
+}
+
+static const float* wgrad_zero_buffer() {
+  static const float* cache[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (cache[dev] == nullptr) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_wgrad_zero16)) != hipSuccess) return nullptr;
+    cache[dev] = (const float*)ptr;
+  }
+  return cache[dev];
+}
+
 extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy,
                               float* dwpack, float* dbias, clx_stream stream) {
   CLX_REQUIRE(d && dy && dwpack, "clx_conv_wgrad: null pointer");
@@ -235,6 +282,8 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   p.Ctot = d->src[0].C + (d->nsrc == 2 ? d->src[1].C : 0);
   p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
   p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
+  p.zeros = wgrad_zero_buffer();
+  CLX_REQUIRE(p.zeros != nullptr, "clx_conv_wgrad: cannot resolve the device zero buffer");
   p.taps = d->KD * d->KH * d->KW;
 
   const bool big_n = p.N > 64, big_c = p.Ctot > 64;
@@ -243,7 +292,20 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   p.tiles_c = cdiv(p.Ctot, bnc);
   const int T = p.tiles_n * p.tiles_c * p.taps;
   const int total_chunks = cdiv(p.M, BKP);
-  int nslices = cdiv(2048, T);
+  // Split-K so that the grid is a whole number of "rounds" of co-resident blocks: a grid of
+  // 4 rounds + a few blocks would run 5 rounds (the tail alone costs 20 %).
+  const void* fn = big_n && big_c ? (const void*)conv_wgrad_kernel<128, 128, 2, 2>
+                   : big_n        ? (const void*)conv_wgrad_kernel<128, 64, 4, 1>
+                   : big_c        ? (const void*)conv_wgrad_kernel<64, 128, 1, 4>
+                                  : (const void*)conv_wgrad_kernel<64, 64, 2, 2>;
+  const int slots = resident_blocks(fn);
+  CLX_REQUIRE(slots > 0, "clx_conv_wgrad: occupancy query failed");
+  int nslices = 1;
+  if (T < 4 * slots) {
+    const int rounds = T <= slots ? (T * 4 <= slots ? 1 : 2) : 4;
+    nslices = rounds * slots / T;
+    if (T * 4 <= slots) nslices = 4 * slots / T;   // tiny output: still aim for >= 4 blocks per slot
+  }
   const int max_slices = total_chunks / 8 > 0 ? total_chunks / 8 : 1;
   if (nslices > max_slices) nslices = max_slices;
   if (nslices < 1) nslices = 1;
