@@ -56,3 +56,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 }
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// small-channel (first layer) convolution path, conv_smallc.hip
+bool clx_smallc_applicable(const clx_conv_desc* d);
+int clx_smallc_fwd(const clx_conv_desc* d, hipStream_t st);
+int clx_smallc_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack,
+                     float* dbias, hipStream_t st);

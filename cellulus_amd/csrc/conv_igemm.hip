@@ -359,12 +359,18 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
               "clx_conv_fwd: mask must be 16-byte aligned with ld_mask %% 4 == 0 and >= N");
   CLX_REQUIRE(d->ld_out % 4 == 0 && ((uintptr_t)d->out & 15) == 0,
               "clx_conv_fwd: out must be 16-byte aligned with ld_out %% 4 == 0");
+  if (clx_smallc_applicable(d) && d->mask == nullptr) {
+    clx_smallc_fwd(d, (hipStream_t)stream);
+    CLX_CHECK_LAUNCH("clx_conv_fwd(small-channel)");
+    return CLX_OK;
+  }
   ConvP p;
   fill_params(d, p);
   p.zeros = zero_buffer();
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_fwd: cannot resolve the device zero buffer");
   hipStream_t st = (hipStream_t)stream;
-  if (d->N > 64) {
+  // 128-wide N tiles unless padding N up to a multiple of 128 wastes > 20 % of the MFMAs
+  if (d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
     conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn), dim3(256), 0, st>>>(p);
   } else {

@@ -1,0 +1,261 @@
+// Convolution with <= 4 input channels (the network's first layer: raw image ->
+// num_fmaps): K = taps * 4 is far too short for an MFMA tile, and the layer is bound by
+// writing (forward) / reading (weight gradient) the [M][N] activation once.  Both kernels
+// stage the gathered input patch [pixels][taps*4] and the packed weights in LDS and keep
+// the per-thread work on 16-byte channel runs, so HBM traffic is one pass over [M][N].
+//
+// Selected by clx_conv_fwd / clx_conv_wgrad when nsrc == 1, C == 4, no upsampling.
+// Replaces nn.Conv{2,3}d(in_channels -> num_fmaps, 3) of l_conv.0.conv_pass.0
+// (cellulus/models/unet.py:24-51) and its weight/bias gradient.
+#include "clx_common.h"
+
+namespace {
+
+struct SmallP {
+  const float* x;        // [pixels][ld_x], 4 channels used
+  int ld_x, B, D, H, W;  // stored grid
+  int oz, oy, ox;        // crop offset
+  int ID, IH, IW, KD, KH, KW, PD, PH, PW, OD, OH, OW;
+  int N, M, taps;
+  FastDiv dOW, dOH, dOD;
+  const float* wpack;    // fwd: [N][taps][4]
+  const float* bias;
+  float* out;            // fwd: [M][ld_out]
+  int ld_out, relu;
+  const float* dy;       // wgrad: [M][ld_dy]
+  int ld_dy;
+  float* dwp;            // wgrad: [taps][N][4]
+  float* dbias;
+  int tiles_per_block;
+};
+
+constexpr int PT = 64;          // pixels per tile
+constexpr int MAX_TAPS = 27;
+
+// gathers the input patch of PT output pixels into Xs[PT][taps*4] (zero outside the image)
+template <int PTILE>
+__device__ __forceinline__ void stage_patch(const SmallP& p, int m0, float* Xs) {
+  const int K4 = p.taps;                 // float4s per pixel
+  for (int idx = threadIdx.x; idx < PTILE * K4; idx += blockDim.x) {
+    const int pl = idx % PTILE, tap = idx / PTILE;
+    const uint32_t m = (uint32_t)(m0 + pl);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < (uint32_t)p.M) {
+      const uint32_t q1 = fdiv(m, p.dOW);
+      const int ox = (int)(m - q1 * p.OW);
+      const uint32_t q2 = fdiv(q1, p.dOH);
+      const int oy = (int)(q1 - q2 * p.OH);
+      const uint32_t q3 = fdiv(q2, p.dOD);
+      const int oz = (int)(q2 - q3 * p.OD);
+      const int b = (int)q3;
+      const int tx = tap % p.KW, ty = (tap / p.KW) % p.KH, tz = tap / (p.KW * p.KH);
+      const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
+      if ((unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW) {
+        const long long pix = (((long long)b * p.D + lz + p.oz) * p.H + ly + p.oy) * p.W + lx + p.ox;
+        v = *reinterpret_cast<const f32x4*>(p.x + pix * p.ld_x);
+      }
+    }
+    *reinterpret_cast<f32x4*>(&Xs[(pl * K4 + tap) * 4]) = v;
+  }
+}
+
+// NG = N-tile / 4 channel groups per block (power of two <= 64); each thread owns 4 output
+// channels of PT / (256 / NG) pixels.
+template <int NG>
+__global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(const SmallP p) {
+  constexpr int PL = 256 / NG;          // pixel lanes
+  constexpr int PPT = PT / PL;          // pixels per thread
+  extern __shared__ float smem[];
+  const int K = p.taps * 4;
+  float* Ws = smem;                     // [K][NG*4]
+  float* Xs = smem + K * NG * 4;        // [PT][K]
+  const int n0 = blockIdx.y * NG * 4;
+  const int ng = threadIdx.x % NG, pl = threadIdx.x / NG;
+  for (int idx = threadIdx.x; idx < K * NG * 4; idx += 256) {
+    const int n = idx / K, k = idx % K;
+    Ws[k * NG * 4 + n] = (n0 + n < p.N) ? p.wpack[(size_t)(n0 + n) * K + k] : 0.f;
+  }
+  const int n = n0 + ng * 4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && n < p.N) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[e] = (n + e < p.N) ? p.bias[n + e] : 0.f;
+  }
+  for (int t = 0; t < p.tiles_per_block; ++t) {
+    const int m0 = (blockIdx.x * p.tiles_per_block + t) * PT;
+    if (m0 >= p.M) break;
+    __syncthreads();
+    stage_patch<PT>(p, m0, Xs);
+    __syncthreads();
+    f32x4 acc[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) acc[i] = bv;
+    for (int k = 0; k < K; ++k) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(&Ws[k * NG * 4 + ng * 4]);
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const float xv = Xs[(pl + i * PL) * K + k];
+        acc[i] += xv * w;
+      }
+    }
+    if (n < p.N) {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int m = m0 + pl + i * PL;
+        if (m >= p.M) continue;
+        f32x4 v = acc[i];
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        float* dst = p.out + (size_t)m * p.ld_out + n;
+        if (n + 3 < p.N) *reinterpret_cast<f32x4*>(dst) = v;
+        else
+          for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
+      }
+    }
+  }
+}
+
+// thread = (channel group ng, tap lane tl); owns taps tl, tl+TL, ... x 4 channels x 4 n
+template <int NG>
+__global__ __launch_bounds__(256) void conv_smallc_wgrad_kernel(const SmallP p) {
+  constexpr int TL = 256 / NG;                       // tap lanes
+  constexpr int TPT = (MAX_TAPS + TL - 1) / TL;      // taps per thread (upper bound)
+  constexpr int PTW = NG == 64 ? 32 : 64;            // pixels per tile (keeps LDS <= 64 KB)
+  extern __shared__ float smem[];
+  const int K = p.taps * 4;
+  float* Ys = smem;                     // [PTW][NG*4]
+  float* Xs = smem + PTW * NG * 4;      // [PTW][K]
+  const int n0 = blockIdx.y * NG * 4;
+  const int ng = threadIdx.x % NG, tl = threadIdx.x / NG;
+  f32x4 acc[TPT][4];                    // [tap][c] -> 4 n
+#pragma unroll
+  for (int a = 0; a < TPT; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < p.tiles_per_block; ++t) {
+    const int m0 = (blockIdx.x * p.tiles_per_block + t) * PTW;
+    if (m0 >= p.M) break;
+    __syncthreads();
+    stage_patch<PTW>(p, m0, Xs);
+    for (int idx = threadIdx.x; idx < PTW * NG; idx += 256) {
+      const int pl = idx / NG, g = idx % NG;
+      const int m = m0 + pl, n = n0 + g * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < p.M && n < p.N) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ld_dy + n);
+      *reinterpret_cast<f32x4*>(&Ys[(pl * NG + g) * 4]) = v;
+    }
+    __syncthreads();
+    for (int pl = 0; pl < PTW; ++pl) {
+      const f32x4 dyv = *reinterpret_cast<const f32x4*>(&Ys[(pl * NG + ng) * 4]);
+      if (tl == 0) bsum += dyv;
+#pragma unroll
+      for (int a = 0; a < TPT; ++a) {
+        const int tap = tl + a * TL;
+        if (tap < p.taps) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[(pl * p.taps + tap) * 4]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[a][c] += xv[c] * dyv;
+        }
+      }
+    }
+  }
+  const int n = n0 + ng * 4;
+#pragma unroll
+  for (int a = 0; a < TPT; ++a) {
+    const int tap = tl + a * TL;
+    if (tap >= p.taps) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (n + e >= p.N) continue;
+      float* dst = p.dwp + ((size_t)tap * p.N + n + e) * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) atomicAdd(dst + c, acc[a][c][e]);
+    }
+  }
+  if (tl == 0 && p.dbias) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < p.N) atomicAdd(p.dbias + n + e, bsum[e]);
+  }
+}
+
+bool fill(const clx_conv_desc* d, SmallP& p) {
+  const clx_src& S = d->src[0];
+  p.x = S.ptr; p.ld_x = S.ld; p.B = d->B; p.D = S.D; p.H = S.H; p.W = S.W;
+  p.oz = S.oz; p.oy = S.oy; p.ox = S.ox;
+  p.ID = d->ID; p.IH = d->IH; p.IW = d->IW;
+  p.KD = d->KD; p.KH = d->KH; p.KW = d->KW;
+  p.PD = d->PD; p.PH = d->PH; p.PW = d->PW;
+  p.OD = d->ID + 2 * d->PD - d->KD + 1;
+  p.OH = d->IH + 2 * d->PH - d->KH + 1;
+  p.OW = d->IW + 2 * d->PW - d->KW + 1;
+  p.N = d->N;
+  p.M = d->B * p.OD * p.OH * p.OW;
+  p.taps = d->KD * d->KH * d->KW;
+  p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
+  return true;
+}
+
+int pick_ng(int N) {
+  int ng = 4;
+  while (ng < 64 && ng * 4 < N) ng *= 2;
+  return ng;
+}
+
+}  // namespace
+
+// true if the small-channel path applies to this descriptor
+bool clx_smallc_applicable(const clx_conv_desc* d) {
+  if (d->nsrc != 1) return false;
+  const clx_src& S = d->src[0];
+  if (S.C != 4 || S.fz != 1 || S.fy != 1 || S.fx != 1) return false;
+  const int taps = d->KD * d->KH * d->KW;
+  return taps > 1 && taps <= MAX_TAPS && d->N >= 4;
+}
+
+int clx_smallc_fwd(const clx_conv_desc* d, hipStream_t st) {
+  SmallP p{};
+  fill(d, p);
+  p.wpack = d->wpack; p.bias = d->bias; p.out = d->out; p.ld_out = d->ld_out; p.relu = d->relu;
+  const int ng = pick_ng(p.N);
+  const int K = p.taps * 4;
+  const int tiles = cdiv(p.M, PT);
+  p.tiles_per_block = tiles > 4096 ? 4 : 1;
+  const dim3 grid(cdiv(tiles, p.tiles_per_block), cdiv(p.N, ng * 4));
+  const size_t lds = (size_t)(K * ng * 4 + PT * K) * sizeof(float);
+  switch (ng) {
+    case 4: conv_smallc_fwd_kernel<4><<<grid, 256, lds, st>>>(p); break;
+    case 8: conv_smallc_fwd_kernel<8><<<grid, 256, lds, st>>>(p); break;
+    case 16: conv_smallc_fwd_kernel<16><<<grid, 256, lds, st>>>(p); break;
+    case 32: conv_smallc_fwd_kernel<32><<<grid, 256, lds, st>>>(p); break;
+    default: conv_smallc_fwd_kernel<64><<<grid, 256, lds, st>>>(p); break;
+  }
+  return CLX_OK;
+}
+
+int clx_smallc_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack,
+                     float* dbias, hipStream_t st) {
+  SmallP p{};
+  fill(d, p);
+  p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
+  const int ng = pick_ng(p.N);
+  const int K = p.taps * 4;
+  const int ptw = ng == 64 ? 32 : 64;
+  const int tiles = cdiv(p.M, ptw);
+  int blocks = tiles < 1024 ? tiles : 1024;      // few blocks: one atomic round per block
+  p.tiles_per_block = cdiv(tiles, blocks);
+  blocks = cdiv(tiles, p.tiles_per_block);
+  const dim3 grid(blocks, cdiv(p.N, ng * 4));
+  const size_t lds = (size_t)(ptw * ng * 4 + ptw * K) * sizeof(float);
+  switch (ng) {
+    case 4: conv_smallc_wgrad_kernel<4><<<grid, 256, lds, st>>>(p); break;
+    case 8: conv_smallc_wgrad_kernel<8><<<grid, 256, lds, st>>>(p); break;
+    case 16: conv_smallc_wgrad_kernel<16><<<grid, 256, lds, st>>>(p); break;
+    case 32: conv_smallc_wgrad_kernel<32><<<grid, 256, lds, st>>>(p); break;
+    default: conv_smallc_wgrad_kernel<64><<<grid, 256, lds, st>>>(p); break;
+  }
+  return CLX_OK;
+}

@@ -263,6 +263,11 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
     CLX_REQUIRE(S.fz >= 1 && S.fy >= 1 && S.fx >= 1 && S.oz >= 0 && S.oy >= 0 && S.ox >= 0,
                 "clx_conv_wgrad: bad crop/upsample of source %d", s);
   }
+  if (clx_smallc_applicable(d)) {
+    clx_smallc_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
+    CLX_CHECK_LAUNCH("clx_conv_wgrad(small-channel)");
+    return CLX_OK;
+  }
   WgradP p;
   p.nsrc = d->nsrc;
   for (int s = 0; s < 2; ++s) {
@@ -286,7 +291,9 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_wgrad: cannot resolve the device zero buffer");
   p.taps = d->KD * d->KH * d->KW;
 
-  const bool big_n = p.N > 64, big_c = p.Ctot > 64;
+  // 128-wide tiles unless padding the extent up to a multiple of 128 wastes > 15 % of the MFMAs
+  auto wide = [](int n) { return n > 64 && (double)(cdiv(n, 128) * 128) / n <= 1.15; };
+  const bool big_n = wide(p.N), big_c = wide(p.Ctot);
   const int bmn = big_n ? 128 : 64, bnc = big_c ? 128 : 64;
   p.tiles_n = cdiv(p.N, bmn);
   p.tiles_c = cdiv(p.Ctot, bnc);
