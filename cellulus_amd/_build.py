@@ -51,7 +51,8 @@ def _newest_header_mtime():
 
 def _compile_one(args):
     hipcc, src, obj, flags = args
-    cmd = [hipcc, *COMMON_FLAGS, *flags, "-c", src, "-o", obj]
+    extra = os.environ.get("CLX_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [hipcc, *COMMON_FLAGS, *flags, *extra, "-c", src, "-o", obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{res.stdout}\n{res.stderr}")

@@ -92,32 +92,42 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       ra[j] = *reinterpret_cast<const f32x4*>(ok ? p.dy + (size_t)pp * p.ld_dy + n_g : p.zeros);
     }
   };
-  auto load_x = [&](int chunk) {
-    // the chunk's first pixel is block-uniform: decode it with scalar arithmetic, then walk
-    const uint32_t p0 = (uint32_t)(chunk0 + chunk) * BKP;
-    const uint32_t q1 = fdiv(p0, p.dOW);
-    const int ox0 = (int)(p0 - q1 * p.OW);
-    const uint32_t q2 = fdiv(q1, p.dOH);
-    const int oy0 = (int)(q1 - q2 * p.OH);
-    const uint32_t q3 = fdiv(q2, p.dOD);
-    const int oz0 = (int)(q2 - q3 * p.OD);
-    const int b0 = (int)q3;
+  // Each thread walks its B_PASSES pixel rows incrementally: (ox, oy, oz, b) advance by 32
+  // pixels per chunk with rare wrap-arounds, instead of a full decode per row per chunk.
+  int wx[B_PASSES], wy[B_PASSES], wz[B_PASSES], wb[B_PASSES];
+  {
+    const uint32_t p0 = (uint32_t)chunk0 * BKP;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-      const int r = b_row + j * B_RPP;
-      int ox = ox0 + r, oy = oy0, oz = oz0, b = b0;
-      while (ox >= p.OW) { ox -= p.OW; ++oy; }
-      while (oy >= p.OH) { oy -= p.OH; ++oz; }
-      while (oz >= p.OD) { oz -= p.OD; ++b; }
-      const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
-      const bool ok = c_ok && (p0 + (uint32_t)r) < (uint32_t)p.M && (unsigned)lz < (unsigned)p.ID &&
+      uint32_t m = p0 + (uint32_t)(b_row + j * B_RPP);
+      const uint32_t q1 = fdiv(m, p.dOW);
+      wx[j] = (int)(m - q1 * p.OW);
+      const uint32_t q2 = fdiv(q1, p.dOH);
+      wy[j] = (int)(q1 - q2 * p.OH);
+      const uint32_t q3 = fdiv(q2, p.dOD);
+      wz[j] = (int)(q2 - q3 * p.OD);
+      wb[j] = (int)q3;
+    }
+  }
+  int x_chunk = 0;   // chunk the walk state currently points at
+  auto load_x = [&](int chunk) {
+    const int adv = (chunk - x_chunk) * BKP;
+    x_chunk = chunk;
+#pragma unroll
+    for (int j = 0; j < B_PASSES; ++j) {
+      wx[j] += adv;
+      while (wx[j] >= p.OW) { wx[j] -= p.OW; ++wy[j]; }
+      while (wy[j] >= p.OH) { wy[j] -= p.OH; ++wz[j]; }
+      while (wz[j] >= p.OD) { wz[j] -= p.OD; ++wb[j]; }
+      const int lz = wz[j] + tz - p.PD, ly = wy[j] + ty - p.PH, lx = wx[j] + tx - p.PW;
+      const bool ok = c_ok && wb[j] < p.B && (unsigned)lz < (unsigned)p.ID &&
                       (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW;
       int sz = lz + S.oz, sy = ly + S.oy, sx = lx + S.ox;
       if (S.fz > 1) sz /= S.fz;
       if (S.fy > 1) sy /= S.fy;
       if (S.fx > 1) sx /= S.fx;
-      const long long pix = (((long long)b * S.D + sz) * S.H + sy) * S.W + sx;
-      rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + pix * S.ld + c_l : p.zeros);
+      const int pix = ((wb[j] * S.D + sz) * S.H + sy) * S.W + sx;   // < 2^31 (validated on the host)
+      rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + (size_t)pix * S.ld + c_l : p.zeros);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -262,6 +272,8 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
                 "clx_conv_wgrad: bad source %d", s);
     CLX_REQUIRE(S.fz >= 1 && S.fy >= 1 && S.fx >= 1 && S.oz >= 0 && S.oy >= 0 && S.ox >= 0,
                 "clx_conv_wgrad: bad crop/upsample of source %d", s);
+    CLX_REQUIRE((long long)d->B * S.D * S.H * S.W < (1ll << 31),
+                "clx_conv_wgrad: source %d has too many pixels", s);
   }
   if (clx_smallc_applicable(d)) {
     clx_smallc_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
