@@ -31,8 +31,8 @@ def _create(f, name, shape, dtype, nd):
 def peak_local_max(image):
     """skimage.feature.peak_local_max(image) defaults (min_distance=1, exclude_border=1,
     threshold = image.min()) restated on scipy: coordinates of strict-threshold local maxima
-    of a 3^D neighbourhood, sorted by decreasing intensity.  [unpinned: skimage is not
-    installed under the product interpreter]"""
+    of a 3^D neighbourhood, sorted by decreasing intensity.  Pinned against scikit-image
+    0.18.3 by tests/golden/g5_skimage.npz (tests/test_cpu_host.py)."""
     from scipy.ndimage import maximum_filter
 
     size = 3

@@ -332,3 +332,12 @@ def parallel_shard_cover():
             if got != list(range(n)):
                 return False
     return True
+
+
+def test_peak_local_max_matches_skimage_golden():
+    """detect.py:128-132 seeds: the restated peak_local_max equals scikit-image 0.18.3."""
+    from cellulus_amd.detect import peak_local_max
+
+    g = np.load(os.path.join(G, "g5_skimage.npz"))
+    for k in ("peaks", "peaks3"):
+        np.testing.assert_array_equal(peak_local_max(g[f"{k}/image"]), g[f"{k}/coords"])
