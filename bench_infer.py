@@ -74,6 +74,16 @@ def infer_bench(device, reps=2, with_cpu=True):
     segment_once()
     t_segment, (seg, ncomp) = _sync_time(segment_once, max(reps, 3))
 
+    # mean-shift at full density (reduction_probability 1.0: every foreground pixel is a seed —
+    # the reference's 48.8 s case); reported as pair evaluations per second
+    def detect_full():
+        labels_f, centers_f = mean_shift_on_device(mean_d.clone(), std_d, 15.0, 1.0, 0.5, None)
+        return labels_f, centers_f
+
+    detect_full()
+    t_full, (labels_full, centers_full) = _sync_time(detect_full, 2)
+    nfg = int((std < 0.5).sum())
+
     total = t_embed + t_detect + t_segment
     flops = 2 * n_it * 1.0
     from bench import conv_flops
@@ -86,6 +96,7 @@ def infer_bench(device, reps=2, with_cpu=True):
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
+        "meanshift_rp1": {"ms": round(t_full * 1e3, 2), "seeds": nfg, "clusters": int(len(centers_full))},
         "objects": int(ncomp.item()),
         "clusters": int(len(centers)),
     }

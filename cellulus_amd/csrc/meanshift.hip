@@ -163,6 +163,85 @@ __global__ __launch_bounds__(256) void ms_iterate_kernel(const double* __restric
   }
 }
 
+// Same iteration with the fit points bucketed into cells of edge h >= bandwidth (sorted by
+// cell id, x fastest): the members of a query lie in the 3^ND cells around it, and the 3
+// x-adjacent cells of one (z, y) row are one contiguous run of the sorted array.  Cuts the
+// pair evaluations from nseeds*nfit to nseeds*(points in 3^ND cells) per iteration.
+template <int ND>
+__global__ __launch_bounds__(256) void ms_iterate_grid_kernel(
+    const double* __restrict__ fit, const int* __restrict__ cell_start, double ox, double oy,
+    double oz, double inv_h, int nx, int ny, int nz, const double* __restrict__ seeds, int nseeds,
+    double bw, int max_iter, double* __restrict__ centers, int* __restrict__ counts,
+    int* __restrict__ iters) {
+  const int lane = threadIdx.x & 63;
+  const int seed = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (seed >= nseeds) return;
+  const double bw2 = bw * bw;
+  const double stop = 1e-3 * bw;
+  double mean[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) mean[c] = seeds[(long long)seed * ND + c];
+  int completed = 0, members = 0;
+  while (true) {
+    double sum[ND];
+#pragma unroll
+    for (int c = 0; c < ND; ++c) sum[c] = 0.0;
+    int cnt = 0;
+    const int cx = (int)floor((mean[0] - ox) * inv_h);
+    const int cy = (int)floor((mean[1] - oy) * inv_h);
+    const int cz = (ND == 3) ? (int)floor((mean[2] - oz) * inv_h) : 0;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, nx - 1);
+    if (x0 <= x1) {
+      for (int zz = (ND == 3 ? cz - 1 : 0); zz <= (ND == 3 ? cz + 1 : 0); ++zz) {
+        if (zz < 0 || zz >= nz) continue;
+        for (int yy = cy - 1; yy <= cy + 1; ++yy) {
+          if (yy < 0 || yy >= ny) continue;
+          const long long row = ((long long)zz * ny + yy) * nx;
+          const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];
+          for (int j = lo + lane; j < hi; j += 64) {
+            double x[ND], d2 = 0.0;
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+              x[c] = fit[(long long)j * ND + c];
+              const double df = x[c] - mean[c];
+              d2 += df * df;
+            }
+            if (d2 <= bw2) {
+              ++cnt;
+#pragma unroll
+              for (int c = 0; c < ND; ++c) sum[c] += x[c];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      cnt += __shfl_xor(cnt, o, 64);
+#pragma unroll
+      for (int c = 0; c < ND; ++c) sum[c] += __shfl_xor(sum[c], o, 64);
+    }
+    members = cnt;
+    if (cnt == 0) break;
+    double shift2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+      const double nm = sum[c] / (double)cnt;
+      const double df = nm - mean[c];
+      shift2 += df * df;
+      mean[c] = nm;
+    }
+    if (sqrt(shift2) <= stop || completed == max_iter) break;
+    ++completed;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < ND; ++c) centers[(long long)seed * ND + c] = mean[c];
+    counts[seed] = members;
+    iters[seed] = completed;
+  }
+}
+
 // nearest centre (first minimum) for every foreground pixel; centres staged in LDS
 template <int ND>
 __global__ __launch_bounds__(256) void ms_assign_kernel(const double* __restrict__ X,
@@ -235,6 +314,33 @@ extern "C" int clx_ms_iterate(const double* fit, int nfit, const double* seeds, 
   else
     ms_iterate_kernel<3><<<grid, 256, 0, st>>>(fit, nfit, seeds, nseeds, bandwidth, max_iter, centers, counts, iters);
   CLX_CHECK_LAUNCH("clx_ms_iterate");
+  return CLX_OK;
+}
+
+extern "C" int clx_ms_iterate_grid(const double* fit_sorted, int nfit, const int* cell_start,
+                                   const double* origin, double cell, int nx, int ny, int nz,
+                                   const double* seeds, int nseeds, int ND, double bandwidth,
+                                   int max_iter, double* centers, int* counts, int* iters,
+                                   clx_stream stream) {
+  CLX_REQUIRE(fit_sorted && cell_start && origin && seeds && centers && counts && iters,
+              "clx_ms_iterate_grid: null pointer");
+  CLX_REQUIRE((ND == 2 || ND == 3) && nfit >= 0 && nseeds >= 0 && max_iter >= 0,
+              "clx_ms_iterate_grid: bad extents");
+  CLX_REQUIRE(bandwidth > 0.0 && cell >= bandwidth, "clx_ms_iterate_grid: cell edge must be >= bandwidth > 0");
+  CLX_REQUIRE(nx > 0 && ny > 0 && nz > 0 && (ND == 3 || nz == 1), "clx_ms_iterate_grid: bad grid");
+  if (nseeds == 0) return CLX_OK;
+  const int grid = (nseeds + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  const double inv = 1.0 / cell;
+  if (ND == 2)
+    ms_iterate_grid_kernel<2><<<grid, 256, 0, st>>>(fit_sorted, cell_start, origin[0], origin[1], 0.0, inv,
+                                                     nx, ny, nz, seeds, nseeds, bandwidth, max_iter,
+                                                     centers, counts, iters);
+  else
+    ms_iterate_grid_kernel<3><<<grid, 256, 0, st>>>(fit_sorted, cell_start, origin[0], origin[1], origin[2],
+                                                     inv, nx, ny, nz, seeds, nseeds, bandwidth, max_iter,
+                                                     centers, counts, iters);
+  CLX_CHECK_LAUNCH("clx_ms_iterate_grid");
   return CLX_OK;
 }
 

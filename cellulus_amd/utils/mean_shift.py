@@ -17,6 +17,27 @@ import torch
 from .. import _clx
 
 MAX_ITER = 300   # sklearn.cluster.MeanShift default
+GRID_MIN_POINTS = 2048   # below this a brute-force sweep of the (L2-resident) fit set is cheaper
+
+
+def _bucket(fit, bandwidth):
+    """Sort the fit points by uniform-grid cell (stable, x fastest). Torch ops = plumbing:
+    returns (sorted points, cell_start int32 (ncells+1), origin (host), cell edge, (nx, ny, nz))."""
+    nd = fit.shape[1]
+    cell = float(bandwidth) * (1.0 + 1e-9)        # strictly larger than the query radius
+    origin = fit.min(dim=0).values
+    coords = torch.floor((fit - origin) / cell).to(torch.int64)
+    dims = (coords.max(dim=0).values + 1).cpu().tolist()
+    nx, ny = int(dims[0]), int(dims[1])
+    nz = int(dims[2]) if nd == 3 else 1
+    cid = coords[:, 0] + nx * coords[:, 1]
+    if nd == 3:
+        cid = cid + nx * ny * coords[:, 2]
+    order = torch.sort(cid, stable=True).indices
+    counts = torch.bincount(cid, minlength=nx * ny * nz)
+    cell_start = torch.zeros(nx * ny * nz + 1, dtype=torch.int32, device=fit.device)
+    cell_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return fit[order].contiguous(), cell_start, origin.cpu().numpy().astype(np.float64), cell, (nx, ny, nz)
 
 
 def dedup_centers(centers, counts, bandwidth):
@@ -98,8 +119,19 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     centers = torch.empty((ns, nd), dtype=torch.float64, device=dev)
     counts = torch.empty(ns, dtype=torch.int32, device=dev)
     iters = torch.empty(ns, dtype=torch.int32, device=dev)
-    _clx.call("clx_ms_iterate", _clx.ptr(fit), fit.shape[0], _clx.ptr(seeds_d), ns, nd,
-              float(bandwidth), MAX_ITER, _clx.ptr(centers), _clx.ptr(counts), _clx.ptr(iters), st)
+    if fit.shape[0] >= GRID_MIN_POINTS:
+        import ctypes
+
+        fit_sorted, cell_start, origin, cell, (nx, ny, nz) = _bucket(fit, bandwidth)
+        if seeds is None:
+            seeds_d = fit_sorted          # neighbouring wavefronts then walk neighbouring cells
+        origin_c = (ctypes.c_double * nd)(*origin.tolist())
+        _clx.call("clx_ms_iterate_grid", _clx.ptr(fit_sorted), fit_sorted.shape[0], _clx.ptr(cell_start),
+                  origin_c, cell, nx, ny, nz, _clx.ptr(seeds_d), ns, nd, float(bandwidth), MAX_ITER,
+                  _clx.ptr(centers), _clx.ptr(counts), _clx.ptr(iters), st)
+    else:
+        _clx.call("clx_ms_iterate", _clx.ptr(fit), fit.shape[0], _clx.ptr(seeds_d), ns, nd,
+                  float(bandwidth), MAX_ITER, _clx.ptr(centers), _clx.ptr(counts), _clx.ptr(iters), st)
     cluster_centers = dedup_centers(centers.cpu().numpy(), counts.cpu().numpy(), float(bandwidth))
     cc = torch.from_numpy(np.ascontiguousarray(cluster_centers)).to(dev)
     _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), cc.shape[0], nd,

@@ -212,6 +212,15 @@ int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
 int clx_ms_iterate(const double* fit, int nfit, const double* seeds, int nseeds,
                    int ND, double bandwidth, int max_iter, double* centers,
                    int* counts, int* iters, clx_stream stream);
+/* Same as clx_ms_iterate with the fit points bucketed in a uniform grid (for large
+ * nfit): fit_sorted is sorted by cell id ((z*ny + y)*nx + x, cell coordinate =
+ * floor((p - origin) / cell) per dim, cell >= bandwidth), cell_start (nx*ny*nz + 1)
+ * holds each cell's first row.  `origin` is a HOST pointer to ND doubles. */
+int clx_ms_iterate_grid(const double* fit_sorted, int nfit, const int* cell_start,
+                        const double* origin, double cell, int nx, int ny, int nz,
+                        const double* seeds, int nseeds, int ND, double bandwidth,
+                        int max_iter, double* centers, int* counts, int* iters,
+                        clx_stream stream);
 /* labels[index[i]] = 1 + argmin_k |X[i] - centers[k]|  (first minimum);
  * labels (npix) int32 must be zero-filled by the caller (background = 0). */
 int clx_ms_assign(const double* X, const int* index, int nfg,

@@ -267,3 +267,51 @@ def test_infer_pipeline_matches_oracle(nd, device, tmp_path, monkeypatch):
         m = (emb[s, -1] < thr)[None] * emb[s, :nd]
         for k in range(nd):
             assert np.allclose(centred[k], emb[s, k] - m[k][m[k] != 0].mean(), atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_mean_shift_grid_kernel_equals_bruteforce(nd, device):
+    """The cell-bucketed iteration visits exactly the members the brute-force sweep finds."""
+    import ctypes
+
+    from cellulus_amd import _clx
+
+    shape = (200, 240) if nd == 2 else (24, 64, 72)
+    mean, std = IO.synthetic_embeddings(shape, spacing=40 if nd == 2 else 24, radius=12 if nd == 2 else 8, seed=9)
+    m = mean.copy()
+    for c in range(nd):
+        ax = nd - 1 - c
+        sh = [1] * nd
+        sh[ax] = shape[ax]
+        m[0, c] += np.arange(shape[ax]).reshape(sh)
+    pts = np.ascontiguousarray(np.moveaxis(m[0], 0, -1)[std < 0.5].reshape(-1, nd))
+    assert len(pts) > MS.GRID_MIN_POINTS
+    bw = 13.0 if nd == 2 else 9.0
+    fit = torch.from_numpy(pts).to(device)
+    ns = len(pts)
+    st = _clx.stream_ptr(device)
+
+    def outputs():
+        return (torch.empty((ns, nd), dtype=torch.float64, device=device),
+                torch.empty(ns, dtype=torch.int32, device=device),
+                torch.empty(ns, dtype=torch.int32, device=device))
+
+    c0, n0, i0 = outputs()
+    _clx.call("clx_ms_iterate", _clx.ptr(fit), ns, _clx.ptr(fit), ns, nd, bw, 300,
+              _clx.ptr(c0), _clx.ptr(n0), _clx.ptr(i0), st)
+    fs, cell_start, origin, cell, (nx, ny, nz) = MS._bucket(fit, bw)
+    c1, n1, i1 = outputs()
+    _clx.call("clx_ms_iterate_grid", _clx.ptr(fs), ns, _clx.ptr(cell_start),
+              (ctypes.c_double * nd)(*origin.tolist()), cell, nx, ny, nz, _clx.ptr(fit), ns, nd, bw, 300,
+              _clx.ptr(c1), _clx.ptr(n1), _clx.ptr(i1), st)
+    np.testing.assert_array_equal(n1.cpu().numpy(), n0.cpu().numpy())
+    np.testing.assert_array_equal(i1.cpu().numpy(), i0.cpu().numpy())
+    np.testing.assert_allclose(c1.cpu().numpy(), c0.cpu().numpy(), rtol=0, atol=1e-10)
+    # a seed far outside the grid finds nothing, like the brute-force kernel
+    far = torch.full((1, nd), 1e6, dtype=torch.float64, device=device)
+    c2, n2, i2 = (torch.empty((1, nd), dtype=torch.float64, device=device),
+                  torch.empty(1, dtype=torch.int32, device=device), torch.empty(1, dtype=torch.int32, device=device))
+    _clx.call("clx_ms_iterate_grid", _clx.ptr(fs), ns, _clx.ptr(cell_start),
+              (ctypes.c_double * nd)(*origin.tolist()), cell, nx, ny, nz, _clx.ptr(far), 1, nd, bw, 300,
+              _clx.ptr(c2), _clx.ptr(n2), _clx.ptr(i2), st)
+    assert int(n2.item()) == 0 and int(i2.item()) == 0
