@@ -99,7 +99,7 @@ PROTOTYPES = {
     "clx_cc_workspace": (c_size_t, [_LL]),
     "clx_cc_label_filter": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "clx_edt_workspace": (c_size_t, [_LL]),
-    "clx_edt_sq": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "clx_edt_sq": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "clx_grow_shrink": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "clx_minmax_f64": (_I, [_P, _LL, _P, _P]),
     "clx_histogram_f64": (_I, [_P, _LL, _P, _I, _P, _P]),

@@ -10,8 +10,9 @@
 // Separable min-plus: pass X finds the squared distance to the nearest zero in
 // the same row by an outward search; passes Y and Z take
 // min_{q}( (p-q)^2 + g[q] ) searching outward and stopping as soon as
-// (p-q)^2 >= best (no farther candidate can win), which is exact and cheap
-// because the distances of interest are a few pixels.
+// (p-q)^2 >= best (no farther candidate can win), which is exact.  The callers only
+// compare distances with a small bound, so every search is additionally capped at
+// `cap` steps: results < cap^2 are exact, larger ones are reported as >= cap^2.
 #include "clx_common.h"
 
 namespace {
@@ -26,13 +27,15 @@ inline int grid_for(long long total, int block) {
 }
 
 __global__ void edt_pass_x(const unsigned char* __restrict__ in, int* __restrict__ g, int X,
-                           long long npix) {
+                           long long npix, int cap, int* __restrict__ any_zero) {
+  bool seen = false;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
        i += (long long)gridDim.x * blockDim.x) {
     const int x = (int)(i % X);
     const long long row = i - x;
     int best = EDT_INF;
-    for (int d = 0; d < X; ++d) {
+    seen = seen || (in[i] == 0);
+    for (int d = 0; d < cap; ++d) {
       const int xl = x - d, xr = x + d;
       if (xl < 0 && xr >= X) break;
       if ((xl >= 0 && in[row + xl] == 0) || (xr < X && in[row + xr] == 0)) {
@@ -42,6 +45,7 @@ __global__ void edt_pass_x(const unsigned char* __restrict__ in, int* __restrict
     }
     g[i] = best;
   }
+  if (__any(seen) && (threadIdx.x & 63) == 0) atomicOr(any_zero, 1);
 }
 
 // min over the axis with stride `stride` and extent `n` (axis index = (i / stride) % n).
@@ -49,12 +53,13 @@ __global__ void edt_pass_x(const unsigned char* __restrict__ in, int* __restrict
 // distance; scipy then reports the distance to a phantom zero at index -1 of the
 // FIRST axis (0 on the others) — reproduced here so the result stays bit-exact.
 __global__ void edt_pass_axis(const int* __restrict__ g, int* __restrict__ out, int n,
-                              long long stride, long long npix, int final, int Z, int Y, int X) {
+                              long long stride, long long npix, int final, int Z, int Y, int X,
+                              int cap, const int* __restrict__ any_zero) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
        i += (long long)gridDim.x * blockDim.x) {
     const int p = (int)((i / stride) % n);
     int best = g[i];
-    for (int d = 1; d < n; ++d) {
+    for (int d = 1; d < cap; ++d) {
       const int d2 = d * d;
       if (d2 >= best) break;
       const int lo = p - d, hi = p + d;
@@ -63,7 +68,7 @@ __global__ void edt_pass_axis(const int* __restrict__ g, int* __restrict__ out, 
       if (hi < n) best = min(best, d2 + g[i + (long long)d * stride]);
     }
     best = min(best, EDT_INF);
-    if (final && best >= EDT_INF) {
+    if (final && best >= EDT_INF && *any_zero == 0) {
       const int x = (int)(i % X);
       const long long t = i / X;
       const int y = (int)(t % Y);
@@ -92,14 +97,22 @@ __global__ void zero_where_lt(int* __restrict__ seg, const int* __restrict__ d, 
     if (d[i] < bound) seg[i] = 0;
 }
 
-int edt_run(const unsigned char* in, int* out, int Z, int Y, int X, int* tmp, hipStream_t st) {
+// tmp: npix ints + 1 flag int.  cap <= 0: unlimited search.
+int edt_run(const unsigned char* in, int* out, int Z, int Y, int X, int* tmp, int cap, hipStream_t st) {
   const long long npix = (long long)Z * Y * X;
   const int grid = grid_for(npix, 256);
+  int* any_zero = tmp + npix;
+  const int big = 1 << 20;
+  const int cx = cap > 0 ? (cap < X ? cap : X) : X;
+  const int cy = cap > 0 ? cap : big, cz = cap > 0 ? cap : big;
+  if (hipMemsetAsync(any_zero, 0, sizeof(int), st) != hipSuccess) return CLX_ERR_LAUNCH;
   // X pass -> tmp ; Y pass tmp -> out ; Z pass out -> tmp -> copy (3-D only)
-  edt_pass_x<<<grid, 256, 0, st>>>(in, tmp, X, npix);
-  edt_pass_axis<<<grid, 256, 0, st>>>(tmp, out, Y, (long long)X, npix, Z > 1 ? 0 : 1, Z, Y, X);
+  edt_pass_x<<<grid, 256, 0, st>>>(in, tmp, X, npix, cx, any_zero);
+  edt_pass_axis<<<grid, 256, 0, st>>>(tmp, out, Y, (long long)X, npix, Z > 1 ? 0 : 1, Z, Y, X,
+                                      cy < Y ? cy : Y, any_zero);
   if (Z > 1) {
-    edt_pass_axis<<<grid, 256, 0, st>>>(out, tmp, Z, (long long)X * Y, npix, 1, Z, Y, X);
+    edt_pass_axis<<<grid, 256, 0, st>>>(out, tmp, Z, (long long)X * Y, npix, 1, Z, Y, X,
+                                        cz < Z ? cz : Z, any_zero);
     if (hipMemcpyAsync(out, tmp, (size_t)npix * sizeof(int), hipMemcpyDeviceToDevice, st) != hipSuccess)
       return CLX_ERR_LAUNCH;
   }
@@ -108,15 +121,15 @@ int edt_run(const unsigned char* in, int* out, int Z, int Y, int X, int* tmp, hi
 
 }  // namespace
 
-extern "C" size_t clx_edt_workspace(long long npix) { return (size_t)npix * sizeof(int); }
+extern "C" size_t clx_edt_workspace(long long npix) { return (size_t)(npix + 4) * sizeof(int); }
 
-extern "C" int clx_edt_sq(const unsigned char* in, int* out, int Z, int Y, int X,
+extern "C" int clx_edt_sq(const unsigned char* in, int* out, int Z, int Y, int X, int cap,
                           void* workspace, clx_stream stream) {
   CLX_REQUIRE(in && out && workspace, "clx_edt_sq: null pointer");
   CLX_REQUIRE(Z > 0 && Y > 0 && X > 0, "clx_edt_sq: bad extents");
   CLX_REQUIRE((long long)Z * Y * X < (1ll << 31), "clx_edt_sq: too many pixels");
   CLX_REQUIRE(Z < 16384 && Y < 16384 && X < 16384, "clx_edt_sq: extent too large for int32 distances");
-  const int rc = edt_run(in, out, Z, Y, X, (int*)workspace, (hipStream_t)stream);
+  const int rc = edt_run(in, out, Z, Y, X, (int*)workspace, cap, (hipStream_t)stream);
   if (rc) { clx_set_error("clx_edt_sq: copy failed"); return rc; }
   CLX_CHECK_LAUNCH("clx_edt_sq");
   return CLX_OK;
@@ -130,18 +143,19 @@ extern "C" int clx_grow_shrink(int* seg, int Z, int Y, int X, int grow, int shri
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_grow_shrink: too many pixels");
   int* tmp = (int*)workspace;
-  int* dist = tmp + npix;
+  int* dist = tmp + npix + 4;
   unsigned char* mask = (unsigned char*)(dist + npix);
   const int grid = grid_for(npix, 256);
   hipStream_t st = (hipStream_t)stream;
   // d1 = edt(seg == 0); expanded = d1 < grow
   mask_eq_zero<<<grid, 256, 0, st>>>(seg, mask, npix);
-  int rc = edt_run(mask, dist, Z, Y, X, tmp, st);
+  // only "d < grow" / "d < shrink" are needed: cap the searches at those radii
+  int rc = edt_run(mask, dist, Z, Y, X, tmp, grow > 0 ? grow : 1, st);
   if (rc) { clx_set_error("clx_grow_shrink: copy failed"); return rc; }
   // sqrt(d1) < grow  <=>  d1 < grow^2   (grow <= 0: nothing is expanded)
   mask_lt<<<grid, 256, 0, st>>>(dist, grow > 0 ? grow * grow : 0, mask, npix);
   // d2 = edt(expanded); seg[d2 < shrink] = 0
-  rc = edt_run(mask, dist, Z, Y, X, tmp, st);
+  rc = edt_run(mask, dist, Z, Y, X, tmp, shrink > 0 ? shrink : 1, st);
   if (rc) { clx_set_error("clx_grow_shrink: copy failed"); return rc; }
   zero_where_lt<<<grid, 256, 0, st>>>(seg, dist, shrink > 0 ? shrink * shrink : 0, npix);
   CLX_CHECK_LAUNCH("clx_grow_shrink");

@@ -157,6 +157,34 @@ __global__ void noise_stats_kernel(const float* __restrict__ preds, float* __res
   }
 }
 
+// same arithmetic, the T samples of a pixel are read ONCE and kept in registers
+template <int TCAP>
+__global__ void noise_stats_reg_kernel(const float* __restrict__ preds, float* __restrict__ out,
+                                       int T, int C, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float std_sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float v[TCAP];
+#pragma unroll
+      for (int t = 0; t < TCAP; ++t) v[t] = (t < T) ? preds[((long long)t * C + c) * n + i] : 0.f;
+      float s = 0.f;
+#pragma unroll
+      for (int t = 0; t < TCAP; ++t) s += (t < T) ? v[t] : 0.f;
+      const float mean = s / (float)T;
+      float var = 0.f;
+#pragma unroll
+      for (int t = 0; t < TCAP; ++t) {
+        const float d = v[t] - mean;
+        var += (t < T) ? d * d : 0.f;
+      }
+      out[(long long)c * n + i] = mean;
+      std_sum += sqrtf(var / (float)T);
+    }
+    out[(long long)C * n + i] = std_sum;
+  }
+}
+
 }  // namespace
 
 extern "C" int clx_maxpool_fwd(const float* x, float* y, int B, int D, int H, int W, int C,
@@ -206,7 +234,12 @@ extern "C" int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD,
 extern "C" int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
                                clx_stream stream) {
   CLX_REQUIRE(preds && out && T > 0 && C > 0 && n > 0, "clx_noise_stats: bad arguments");
-  noise_stats_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
+  if (T <= 32)
+    noise_stats_reg_kernel<32><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
+  else if (T <= 64)
+    noise_stats_reg_kernel<64><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
+  else
+    noise_stats_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
   CLX_CHECK_LAUNCH("clx_noise_stats");
   return CLX_OK;
 }

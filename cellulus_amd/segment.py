@@ -27,7 +27,7 @@ def grow_shrink_on_device(seg, grow_distance, shrink_distance):
     assert seg.dtype == torch.int32 and seg.is_contiguous() and seg.ndim in (2, 3)
     Z, Y, X = (1,) * (3 - seg.ndim) + tuple(seg.shape)
     npix = Z * Y * X
-    ws = torch.empty(9 * npix + 64, dtype=torch.uint8, device=seg.device)
+    ws = torch.empty(9 * npix + 128, dtype=torch.uint8, device=seg.device)
     _clx.call("clx_grow_shrink", _clx.ptr(seg), Z, Y, X, int(grow_distance), int(shrink_distance),
               _clx.ptr(ws), _clx.stream_ptr(seg.device))
     return seg

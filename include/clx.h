@@ -246,14 +246,17 @@ int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X,
 /* as used by cellulus/segment.py:41-51)                                    */
 /* ------------------------------------------------------------------------ */
 size_t clx_edt_workspace(long long npix);
-/* out[p] = min over q with in[q]==0 of |p-q|^2 (int32; "infinite" when the
- * image has no zero pixel is reported as INT32_MAX/2). */
-int clx_edt_sq(const unsigned char* in, int* out, int Z, int Y, int X,
+/* out[p] = min over q with in[q]==0 of |p-q|^2 (int32).  cap > 0 limits every
+ * axis search to `cap` steps: values < cap^2 are exact, larger ones are only
+ * guaranteed to be >= cap^2 (enough for "distance < cap" tests); cap <= 0 is the
+ * full transform.  An image without any zero reproduces scipy's phantom zero at
+ * index -1 of the first axis. */
+int clx_edt_sq(const unsigned char* in, int* out, int Z, int Y, int X, int cap,
                void* workspace, clx_stream stream);
 /* segment "cell" post-processing in one call (segment.py:41-51):
  *   d1 = edt(seg==0); grown = d1 < grow; d2 = edt(grown); seg[d2 < shrink] = 0 */
 int clx_grow_shrink(int* seg, int Z, int Y, int X, int grow, int shrink,
-                    void* workspace /* 2*clx_edt_workspace + npix */,
+                    void* workspace /* 2*clx_edt_workspace(npix) + npix bytes */,
                     clx_stream stream);
 
 /* ------------------------------------------------------------------------ */

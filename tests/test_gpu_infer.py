@@ -158,9 +158,18 @@ def test_edt_sq_bit_exact(shape, device):
         Z, Y, X = (1,) * (3 - len(shape)) + tuple(shape)
         md = torch.from_numpy(m.astype(np.uint8)).to(device)
         out = torch.empty(shape, dtype=torch.int32, device=device)
-        ws = torch.empty(m.size * 4 + 16, dtype=torch.uint8, device=device)
-        _clx.call("clx_edt_sq", _clx.ptr(md), _clx.ptr(out), Z, Y, X, _clx.ptr(ws), _clx.stream_ptr(device))
+        ws = torch.empty(m.size * 4 + 64, dtype=torch.uint8, device=device)
+        _clx.call("clx_edt_sq", _clx.ptr(md), _clx.ptr(out), Z, Y, X, 0, _clx.ptr(ws), _clx.stream_ptr(device))
         np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        # capped search: exact below cap^2, >= cap^2 elsewhere
+        cap = 4
+        _clx.call("clx_edt_sq", _clx.ptr(md), _clx.ptr(out), Z, Y, X, cap, _clx.ptr(ws), _clx.stream_ptr(device))
+        got = out.cpu().numpy()
+        if density < 1.0:
+            np.testing.assert_array_equal(got[ref < cap * cap], ref[ref < cap * cap])
+            assert (got[ref >= cap * cap] >= cap * cap).all()
+        else:
+            np.testing.assert_array_equal(got, ref)     # no zero at all: phantom distances
 
 
 @pytest.mark.parametrize("shape", [(96, 96), (24, 40, 40)])
