@@ -11,25 +11,57 @@ namespace {
 
 constexpr int PREP_BLOCK = 1024;   // pixels per compaction block
 
-// pass 1: add coordinates in place, count foreground per block
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// pass 1: add coordinates in place, count foreground per block.  Each thread owns two
+// adjacent pixels so every access is a 16-byte load/store (npix even; odd sizes take the
+// scalar tail below).
 __global__ __launch_bounds__(256) void ms_prepare_count(double* __restrict__ emb,
                                                         const double* __restrict__ sd,
                                                         double thr, int ND, int Y, int X,
-                                                        long long npix, int* __restrict__ counts) {
+                                                        long long npix, int vec,
+                                                        int* __restrict__ counts) {
   __shared__ int wsum[4];
   const long long base = (long long)blockIdx.x * PREP_BLOCK;
   int local = 0;
-  for (int k = 0; k < PREP_BLOCK / 256; ++k) {
-    const long long i = base + k * 256 + threadIdx.x;
-    if (i < npix) {
-      const int x = (int)(i % X);
-      const long long t = i / X;
-      const int y = (int)(t % Y);
-      const int z = (int)(t / Y);
-      emb[i] += (double)x;
-      emb[npix + i] += (double)y;
-      if (ND == 3) emb[2 * npix + i] += (double)z;
-      local += (sd[i] < thr) ? 1 : 0;
+  if (vec) {
+    for (int k = 0; k < PREP_BLOCK / 512; ++k) {
+      const long long i = base + (long long)(k * 256 + threadIdx.x) * 2;
+      if (i < npix) {      // npix is even here, so i + 1 < npix too
+        const int x0 = (int)(i % X);
+        const long long t = i / X;
+        const int y0 = (int)(t % Y);
+        const int z0 = (int)(t / Y);
+        int x1 = x0 + 1, y1 = y0, z1 = z0;
+        if (x1 == X) { x1 = 0; if (++y1 == Y) { y1 = 0; ++z1; } }
+        f64x2 v = *reinterpret_cast<f64x2*>(emb + i);
+        v[0] += (double)x0; v[1] += (double)x1;
+        *reinterpret_cast<f64x2*>(emb + i) = v;
+        v = *reinterpret_cast<f64x2*>(emb + npix + i);
+        v[0] += (double)y0; v[1] += (double)y1;
+        *reinterpret_cast<f64x2*>(emb + npix + i) = v;
+        if (ND == 3) {
+          v = *reinterpret_cast<f64x2*>(emb + 2 * npix + i);
+          v[0] += (double)z0; v[1] += (double)z1;
+          *reinterpret_cast<f64x2*>(emb + 2 * npix + i) = v;
+        }
+        const f64x2 s2 = *reinterpret_cast<const f64x2*>(sd + i);
+        local += (s2[0] < thr ? 1 : 0) + (s2[1] < thr ? 1 : 0);
+      }
+    }
+  } else {
+    for (int k = 0; k < PREP_BLOCK / 256; ++k) {
+      const long long i = base + k * 256 + threadIdx.x;
+      if (i < npix) {
+        const int x = (int)(i % X);
+        const long long t = i / X;
+        const int y = (int)(t % Y);
+        const int z = (int)(t / Y);
+        emb[i] += (double)x;
+        emb[npix + i] += (double)y;
+        if (ND == 3) emb[2 * npix + i] += (double)z;
+        local += (sd[i] < thr) ? 1 : 0;
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
@@ -65,10 +97,11 @@ __global__ __launch_bounds__(1024) void scan_counts(int* __restrict__ counts, in
   if (tid == 1023 && total_out) *total_out = part[1023];
 }
 
-// pass 3: stable (raster-order) compaction of the foreground pixels
+// pass 3: stable (raster-order) compaction of the foreground pixels (two adjacent pixels per
+// thread when `vec`, so the std read is a 16-byte load)
 __global__ __launch_bounds__(256) void ms_prepare_scatter(const double* __restrict__ emb,
                                                           const double* __restrict__ sd,
-                                                          double thr, int ND, long long npix,
+                                                          double thr, int ND, long long npix, int vec,
                                                           const int* __restrict__ offsets,
                                                           double* __restrict__ Xout,
                                                           int* __restrict__ index) {
@@ -78,19 +111,35 @@ __global__ __launch_bounds__(256) void ms_prepare_scatter(const double* __restri
   __syncthreads();
   const long long base = (long long)blockIdx.x * PREP_BLOCK;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int k = 0; k < PREP_BLOCK / 256; ++k) {
-    const long long i = base + k * 256 + threadIdx.x;
-    const bool fg = (i < npix) && (sd[i] < thr);
-    const unsigned long long ball = __ballot(fg);
-    const int before = __popcll(ball & ((1ull << lane) - 1ull));
-    if (lane == 0) wcount[wid] = __popcll(ball);
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  const int per = vec ? 2 : 1;
+  for (int k = 0; k < PREP_BLOCK / (256 * per); ++k) {
+    const long long i = base + (long long)(k * 256 + threadIdx.x) * per;
+    bool fg0 = false, fg1 = false;
+    if (vec) {
+      if (i < npix) {
+        const f64x2 s2 = *reinterpret_cast<const f64x2*>(sd + i);
+        fg0 = s2[0] < thr;
+        fg1 = s2[1] < thr;
+      }
+    } else {
+      fg0 = (i < npix) && (sd[i] < thr);
+    }
+    const unsigned long long b0 = __ballot(fg0), b1 = __ballot(fg1);
+    const int before = __popcll(b0 & lower) + __popcll(b1 & lower);
+    if (lane == 0) wcount[wid] = __popcll(b0) + __popcll(b1);
     __syncthreads();
     int woff = running;
     for (int w = 0; w < wid; ++w) woff += wcount[w];
-    if (fg) {
-      const int pos = woff + before;
+    int pos = woff + before;
+    if (fg0) {
       for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = emb[(long long)c * npix + i];
       index[pos] = (int)i;
+      ++pos;
+    }
+    if (fg1) {
+      for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = emb[(long long)c * npix + i + 1];
+      index[pos] = (int)(i + 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) running += wcount[0] + wcount[1] + wcount[2] + wcount[3];
@@ -292,9 +341,10 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   const int nblocks = (int)((npix + PREP_BLOCK - 1) / PREP_BLOCK);
   int* counts = (int*)workspace;
   hipStream_t st = (hipStream_t)stream;
-  ms_prepare_count<<<nblocks, 256, 0, st>>>(emb, std, threshold, ND, Y, X, npix, counts);
+  const int vec = (npix % 2 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
+  ms_prepare_count<<<nblocks, 256, 0, st>>>(emb, std, threshold, ND, Y, X, npix, vec, counts);
   scan_counts<<<1, 1024, 0, st>>>(counts, nblocks, nfg_out);
-  ms_prepare_scatter<<<nblocks, 256, 0, st>>>(emb, std, threshold, ND, npix, counts, Xout, index);
+  ms_prepare_scatter<<<nblocks, 256, 0, st>>>(emb, std, threshold, ND, npix, vec, counts, Xout, index);
   CLX_CHECK_LAUNCH("clx_ms_prepare");
   return CLX_OK;
 }

@@ -39,14 +39,29 @@ __global__ void minmax_init(double* mm) {
   mm[1] = __longlong_as_double(0xfff0000000000000ll);   // -inf
 }
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+// 16-byte loads (two doubles per lane): 8-byte accesses run at 0.54-0.70x the 16-byte rate
 __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ x, long long n, double* mm) {
   __shared__ double smin[4], smax[4];
   double lo = __longlong_as_double(0x7ff0000000000000ll), hi = -lo;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
-    const double v = x[i];
-    lo = fmin(lo, v);
-    hi = fmax(hi, v);
+  const long long n2 = n >> 1;
+  const f64x2* x2 = reinterpret_cast<const f64x2*>(x);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n2; i += 4 * stride) {      // 4 independent 16-byte loads in flight
+    const f64x2 a = x2[i], b = x2[i + stride], c = x2[i + 2 * stride], d = x2[i + 3 * stride];
+    lo = fmin(fmin(fmin(lo, a[0]), fmin(a[1], b[0])), fmin(fmin(b[1], c[0]), fmin(fmin(c[1], d[0]), d[1])));
+    hi = fmax(fmax(fmax(hi, a[0]), fmax(a[1], b[0])), fmax(fmax(b[1], c[0]), fmax(fmax(c[1], d[0]), d[1])));
+  }
+  for (; i < n2; i += stride) {
+    const f64x2 a = x2[i];
+    lo = fmin(lo, fmin(a[0], a[1]));
+    hi = fmax(hi, fmax(a[0], a[1]));
+  }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    lo = fmin(lo, x[n - 1]);
+    hi = fmax(hi, x[n - 1]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     lo = fmin(lo, __shfl_down(lo, o, 64));
@@ -62,37 +77,55 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
   }
 }
 
+__device__ __forceinline__ void hist_one(double v, double first, double last, double denom, int nbins,
+                                         const double* __restrict__ edges, unsigned int* local) {
+  if (!(v >= first) || !(v <= last)) return;
+  const double f = ((v - first) / denom) * (double)nbins;
+  int idx = (int)f;
+  if (idx == nbins) idx -= 1;
+  if (v < edges[idx]) idx -= 1;
+  if (v >= edges[idx + 1] && idx != nbins - 1) idx += 1;
+  atomicAdd(&local[idx], 1u);
+}
+
+// per-WAVE private histograms in LDS (4 copies) cut the LDS-atomic contention; the bin
+// edges are staged in LDS too (the +-1 corrections read them for every element)
 __global__ __launch_bounds__(256) void histogram_kernel(const double* __restrict__ x, long long n,
                                                         const double* __restrict__ edges, int nbins,
                                                         unsigned long long* __restrict__ counts) {
-  extern __shared__ unsigned int local[];
-  for (int k = threadIdx.x; k < nbins; k += blockDim.x) local[k] = 0u;
+  extern __shared__ unsigned char hist_smem[];
+  double* eds = reinterpret_cast<double*>(hist_smem);                       // [nbins + 1]
+  unsigned int* local = reinterpret_cast<unsigned int*>(eds + nbins + 1);   // [4][nbins]
+  for (int k = threadIdx.x; k <= nbins; k += blockDim.x) eds[k] = edges[k];
+  for (int k = threadIdx.x; k < 4 * nbins; k += blockDim.x) local[k] = 0u;
   __syncthreads();
-  const double first = edges[0], last = edges[nbins];
+  unsigned int* mine = local + (threadIdx.x >> 6) * nbins;
+  const double first = eds[0], last = eds[nbins];
   const double denom = last - first;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+  const long long n2 = n >> 1;
+  const f64x2* x2 = reinterpret_cast<const f64x2*>(x);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
        i += (long long)gridDim.x * blockDim.x) {
-    const double v = x[i];
-    if (!(v >= first) || !(v <= last)) continue;
-    const double f = ((v - first) / denom) * (double)nbins;
-    int idx = (int)f;
-    if (idx == nbins) idx -= 1;
-    if (v < edges[idx]) idx -= 1;
-    if (v >= edges[idx + 1] && idx != nbins - 1) idx += 1;
-    atomicAdd(&local[idx], 1u);
+    const f64x2 v = x2[i];
+    hist_one(v[0], first, last, denom, nbins, eds, mine);
+    hist_one(v[1], first, last, denom, nbins, eds, mine);
   }
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) hist_one(x[n - 1], first, last, denom, nbins, eds, mine);
   __syncthreads();
-  for (int k = threadIdx.x; k < nbins; k += blockDim.x)
-    if (local[k]) atomicAdd(&counts[k], (unsigned long long)local[k]);
+  for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+    const unsigned int c = local[k] + local[nbins + k] + local[2 * nbins + k] + local[3 * nbins + k];
+    if (c) atomicAdd(&counts[k], (unsigned long long)c);
+  }
 }
 
 }  // namespace
 
 extern "C" int clx_minmax_f64(const double* x, long long n, double* minmax, clx_stream stream) {
   CLX_REQUIRE(x && minmax && n > 0, "clx_minmax_f64: bad arguments");
+  CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_minmax_f64: x must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   minmax_init<<<1, 1, 0, st>>>(minmax);
-  minmax_kernel<<<grid_for(n, 256), 256, 0, st>>>(x, n, minmax);
+  minmax_kernel<<<grid_for(n / 8 + 1, 256), 256, 0, st>>>(x, n, minmax);
   CLX_CHECK_LAUNCH("clx_minmax_f64");
   return CLX_OK;
 }
@@ -100,8 +133,10 @@ extern "C" int clx_minmax_f64(const double* x, long long n, double* minmax, clx_
 extern "C" int clx_histogram_f64(const double* x, long long n, const double* edges, int nbins,
                                  long long* counts, clx_stream stream) {
   CLX_REQUIRE(x && edges && counts && n > 0, "clx_histogram_f64: bad arguments");
-  CLX_REQUIRE(nbins > 0 && nbins <= 8192, "clx_histogram_f64: nbins must be in 1..8192");
-  histogram_kernel<<<grid_for(n, 256), 256, (size_t)nbins * sizeof(unsigned int), (hipStream_t)stream>>>(
+  CLX_REQUIRE(nbins > 0 && nbins <= 2048, "clx_histogram_f64: nbins must be in 1..2048");
+  CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_histogram_f64: x must be 16-byte aligned");
+  const size_t lds = (size_t)(nbins + 1) * sizeof(double) + (size_t)4 * nbins * sizeof(unsigned int);
+  histogram_kernel<<<grid_for(n / 2 + 1, 256), 256, lds, (hipStream_t)stream>>>(
       x, n, edges, nbins, (unsigned long long*)counts);
   CLX_CHECK_LAUNCH("clx_histogram_f64");
   return CLX_OK;
