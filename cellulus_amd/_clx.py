@@ -62,6 +62,9 @@ class ClxConvDesc(Structure):
         ("ld_mask", c_int),
         ("out", c_void_p),
         ("ld_out", c_int),
+        ("algo", c_int),
+        ("workspace", c_void_p),
+        ("workspace_bytes", c_size_t),
     ]
 
 
@@ -79,6 +82,8 @@ PROTOTYPES = {
     "clx_conv_wgrad": (_I, [POINTER(ClxConvDesc), _P, _I, _P, _P, _P]),
     "clx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
     "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_pixel_to_planar": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -40,6 +40,7 @@ struct ConvP {
   float* out;
   int relu, ld_mask, ld_out;
   int nbm, nbn;
+  long long bs_in, bs_w, bs_out;   // per-batch strides in floats (gridDim.y batches; 0 = none)
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -90,18 +91,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
     int n = n0 + lrow + 32 * j;
-    wrow[j] = (n < p.N) ? p.wpack + (size_t)n * p.Ktot : nullptr;
+    wrow[j] = (n < p.N) ? p.wpack + blockIdx.y * p.bs_w + (size_t)n * p.Ktot : nullptr;
   }
 
   // ---- K-loop state: (tap, source, channel chunk)
   int tz = 0, ty = 0, tx = 0, tap = 0, s = 0, c0 = 0;
   long long aoff[A_PASSES];   // float offset of the row in the current source, -1 = zero row
-  const float* sptr = p.src[0].ptr;
+  const float* sptr = p.src[0].ptr + blockIdx.y * p.bs_in;
   int sC = p.src[0].C, cbase = 0;
 
   auto set_source = [&]() {
     const SrcP& S = p.src[s];
-    sptr = S.ptr;
+    sptr = S.ptr + blockIdx.y * p.bs_in;
     sC = S.C;
     cbase = (s == 0) ? 0 : p.src[0].C;
 #pragma unroll
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     const int m = m0 + row, n = n0 + c4;
     if (m >= p.M || n >= p.N) continue;
     f32x4 val = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
-    float* dst = p.out + (size_t)m * p.ld_out + n;
+    float* dst = p.out + blockIdx.y * p.bs_out + (size_t)m * p.ld_out + n;
     if (n + 3 < p.N) {
       if (p.mask) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.ld_mask + n);
@@ -346,6 +347,7 @@ static void fill_params(const clx_conv_desc* d, ConvP& p) {
   p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
   p.wpack = d->wpack; p.bias = d->bias; p.mask = d->mask; p.out = d->out;
   p.relu = d->relu; p.ld_mask = d->ld_mask; p.ld_out = d->ld_out;
+  p.bs_in = p.bs_w = p.bs_out = 0;
 }
 
 extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
@@ -364,19 +366,29 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
     CLX_CHECK_LAUNCH("clx_conv_fwd(small-channel)");
     return CLX_OK;
   }
+  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_fwd(d, (hipStream_t)stream);
+  rc = clx_igemm_launch(d, 1, 0, 0, 0, (hipStream_t)stream);
+  if (rc) return rc;
+  CLX_CHECK_LAUNCH("clx_conv_fwd");
+  return CLX_OK;
+}
+
+// `batch` independent problems of identical geometry: batch b reads src[0].ptr + b*bs_in,
+// wpack + b*bs_w and writes out + b*bs_out (mask is not batched).  Used by the Winograd path.
+int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long long bs_w,
+                     long long bs_out, hipStream_t st) {
   ConvP p;
   fill_params(d, p);
   p.zeros = zero_buffer();
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_fwd: cannot resolve the device zero buffer");
-  hipStream_t st = (hipStream_t)stream;
+  p.bs_in = bs_in; p.bs_w = bs_w; p.bs_out = bs_out;
   // 128-wide N tiles unless padding N up to a multiple of 128 wastes > 20 % of the MFMAs
   if (d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
-    conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn), dim3(256), 0, st>>>(p);
+    conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
   } else {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
-    conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn), dim3(256), 0, st>>>(p);
+    conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
   }
-  CLX_CHECK_LAUNCH("clx_conv_fwd");
   return CLX_OK;
 }

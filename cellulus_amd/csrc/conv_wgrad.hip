@@ -38,6 +38,7 @@ struct WgradP {
   float* dwp;
   float* dbias;
   int tiles_n, tiles_c, taps, nslices, chunks_per_slice;
+  long long bs_x, bs_dy, bs_out;   // per-batch strides in floats (gridDim.y batches)
 };
 
 template <int BMN, int BNC, int WAVES_M, int WAVES_N>
@@ -71,7 +72,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   const int c_g = tile_c * BNC + b_col;       // first of this thread's 4 input channels
   const bool c_ok = c_g < p.Ctot;
   const int s = (p.nsrc == 2 && c_g >= p.src[0].C) ? 1 : 0;
-  const SrcP S = p.src[s];
+  SrcP S = p.src[s];
+  S.ptr += blockIdx.y * p.bs_x;
+  const float* dyp = p.dy + blockIdx.y * p.bs_dy;
   const int c_l = c_g - (s ? p.src[0].C : 0);
 
   const int chunk0 = slice * p.chunks_per_slice;
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
 
   f32x4 ra[A_PASSES], rb[B_PASSES];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0;
+  const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0 && blockIdx.y == 0;
 
   // out-of-range rows read 16 zero bytes instead of branching around the load
   auto load_dy = [&](int chunk) {
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     for (int j = 0; j < A_PASSES; ++j) {
       const int pp = p0 + a_row + j * A_RPP;
       const bool ok = n_ok && pp < p.M;
-      ra[j] = *reinterpret_cast<const f32x4*>(ok ? p.dy + (size_t)pp * p.ld_dy + n_g : p.zeros);
+      ra[j] = *reinterpret_cast<const f32x4*>(ok ? dyp + (size_t)pp * p.ld_dy + n_g : p.zeros);
     }
   };
   // Each thread walks its B_PASSES pixel rows incrementally: (ox, oy, oz, b) advance by 32
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
   }
 
   // ---- combine: float atomics into dwpack[tap][n][c]
-  float* dst = p.dwp + (size_t)tap * p.N * p.Ctot;
+  float* dst = p.dwp + blockIdx.y * p.bs_out + (size_t)tap * p.N * p.Ctot;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -258,6 +261,72 @@ static const float* wgrad_zero_buffer() {
   return cache[dev];
 }
 
+int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
+                     int batch, long long bs_x, long long bs_dy, long long bs_out, hipStream_t st) {
+  WgradP p;
+  p.nsrc = d->nsrc;
+  for (int s = 0; s < 2; ++s) {
+    const clx_src& S = d->src[s < d->nsrc ? s : 0];
+    p.src[s] = SrcP{S.ptr, S.C, S.ld, S.D, S.H, S.W, S.oz, S.oy, S.ox, S.fz, S.fy, S.fx};
+  }
+  p.B = d->B; p.ID = d->ID; p.IH = d->IH; p.IW = d->IW;
+  p.KD = d->KD; p.KH = d->KH; p.KW = d->KW;
+  p.PD = d->PD; p.PH = d->PH; p.PW = d->PW;
+  p.OD = d->ID + 2 * d->PD - d->KD + 1;
+  p.OH = d->IH + 2 * d->PH - d->KH + 1;
+  p.OW = d->IW + 2 * d->PW - d->KW + 1;
+  CLX_REQUIRE(p.OD > 0 && p.OH > 0 && p.OW > 0, "clx_conv_wgrad: empty output");
+  const long long M = (long long)d->B * p.OD * p.OH * p.OW;
+  CLX_REQUIRE(M < (1ll << 31), "clx_conv_wgrad: too many pixels");
+  p.N = d->N; p.M = (int)M;
+  p.Ctot = d->src[0].C + (d->nsrc == 2 ? d->src[1].C : 0);
+  p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
+  p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
+  p.bs_x = bs_x; p.bs_dy = bs_dy; p.bs_out = bs_out;
+  p.zeros = wgrad_zero_buffer();
+  CLX_REQUIRE(p.zeros != nullptr, "clx_conv_wgrad: cannot resolve the device zero buffer");
+  p.taps = d->KD * d->KH * d->KW;
+
+  // 128-wide tiles unless padding the extent up to a multiple of 128 wastes > 15 % of the MFMAs
+  auto wide = [](int n) { return n > 64 && (double)(cdiv(n, 128) * 128) / n <= 1.15; };
+  const bool big_n = wide(p.N), big_c = wide(p.Ctot);
+  const int bmn = big_n ? 128 : 64, bnc = big_c ? 128 : 64;
+  p.tiles_n = cdiv(p.N, bmn);
+  p.tiles_c = cdiv(p.Ctot, bnc);
+  const int T = p.tiles_n * p.tiles_c * p.taps;
+  const int Tall = T * batch;
+  const int total_chunks = cdiv(p.M, BKP);
+  // Split-K so that the grid is a whole number of "rounds" of co-resident blocks: a grid of
+  // 4 rounds + a few blocks would run 5 rounds (the tail alone costs 20 %).
+  const void* fn = big_n && big_c ? (const void*)conv_wgrad_kernel<128, 128, 2, 2>
+                   : big_n        ? (const void*)conv_wgrad_kernel<128, 64, 4, 1>
+                   : big_c        ? (const void*)conv_wgrad_kernel<64, 128, 1, 4>
+                                  : (const void*)conv_wgrad_kernel<64, 64, 2, 2>;
+  const int slots = resident_blocks(fn);
+  CLX_REQUIRE(slots > 0, "clx_conv_wgrad: occupancy query failed");
+  int nslices = 1;
+  if (Tall < 4 * slots) {
+    const int rounds = Tall <= slots ? (Tall * 4 <= slots ? 1 : 2) : 4;
+    nslices = rounds * slots / Tall;
+    if (Tall * 4 <= slots) nslices = 4 * slots / Tall;   // tiny output: still aim for >= 4 blocks per slot
+  }
+  const int max_slices = total_chunks / 8 > 0 ? total_chunks / 8 : 1;
+  if (nslices > max_slices) nslices = max_slices;
+  if (nslices < 1) nslices = 1;
+  p.chunks_per_slice = cdiv(total_chunks, nslices);
+  p.nslices = cdiv(total_chunks, p.chunks_per_slice);
+  const dim3 grid(T * p.nslices, batch), block(256);
+  if (big_n && big_c)
+    conv_wgrad_kernel<128, 128, 2, 2><<<grid, block, 0, st>>>(p);
+  else if (big_n)
+    conv_wgrad_kernel<128, 64, 4, 1><<<grid, block, 0, st>>>(p);
+  else if (big_c)
+    conv_wgrad_kernel<64, 128, 1, 4><<<grid, block, 0, st>>>(p);
+  else
+    conv_wgrad_kernel<64, 64, 2, 2><<<grid, block, 0, st>>>(p);
+  return CLX_OK;
+}
+
 extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy,
                               float* dwpack, float* dbias, clx_stream stream) {
   CLX_REQUIRE(d && dy && dwpack, "clx_conv_wgrad: null pointer");
@@ -280,66 +349,9 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
     CLX_CHECK_LAUNCH("clx_conv_wgrad(small-channel)");
     return CLX_OK;
   }
-  WgradP p;
-  p.nsrc = d->nsrc;
-  for (int s = 0; s < 2; ++s) {
-    const clx_src& S = d->src[s < d->nsrc ? s : 0];
-    p.src[s] = SrcP{S.ptr, S.C, S.ld, S.D, S.H, S.W, S.oz, S.oy, S.ox, S.fz, S.fy, S.fx};
-  }
-  p.B = d->B; p.ID = d->ID; p.IH = d->IH; p.IW = d->IW;
-  p.KD = d->KD; p.KH = d->KH; p.KW = d->KW;
-  p.PD = d->PD; p.PH = d->PH; p.PW = d->PW;
-  p.OD = d->ID + 2 * d->PD - d->KD + 1;
-  p.OH = d->IH + 2 * d->PH - d->KH + 1;
-  p.OW = d->IW + 2 * d->PW - d->KW + 1;
-  CLX_REQUIRE(p.OD > 0 && p.OH > 0 && p.OW > 0, "clx_conv_wgrad: empty output");
-  const long long M = (long long)d->B * p.OD * p.OH * p.OW;
-  CLX_REQUIRE(M < (1ll << 31), "clx_conv_wgrad: too many pixels");
-  p.N = d->N; p.M = (int)M;
-  p.Ctot = d->src[0].C + (d->nsrc == 2 ? d->src[1].C : 0);
-  p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
-  p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
-  p.zeros = wgrad_zero_buffer();
-  CLX_REQUIRE(p.zeros != nullptr, "clx_conv_wgrad: cannot resolve the device zero buffer");
-  p.taps = d->KD * d->KH * d->KW;
-
-  // 128-wide tiles unless padding the extent up to a multiple of 128 wastes > 15 % of the MFMAs
-  auto wide = [](int n) { return n > 64 && (double)(cdiv(n, 128) * 128) / n <= 1.15; };
-  const bool big_n = wide(p.N), big_c = wide(p.Ctot);
-  const int bmn = big_n ? 128 : 64, bnc = big_c ? 128 : 64;
-  p.tiles_n = cdiv(p.N, bmn);
-  p.tiles_c = cdiv(p.Ctot, bnc);
-  const int T = p.tiles_n * p.tiles_c * p.taps;
-  const int total_chunks = cdiv(p.M, BKP);
-  // Split-K so that the grid is a whole number of "rounds" of co-resident blocks: a grid of
-  // 4 rounds + a few blocks would run 5 rounds (the tail alone costs 20 %).
-  const void* fn = big_n && big_c ? (const void*)conv_wgrad_kernel<128, 128, 2, 2>
-                   : big_n        ? (const void*)conv_wgrad_kernel<128, 64, 4, 1>
-                   : big_c        ? (const void*)conv_wgrad_kernel<64, 128, 1, 4>
-                                  : (const void*)conv_wgrad_kernel<64, 64, 2, 2>;
-  const int slots = resident_blocks(fn);
-  CLX_REQUIRE(slots > 0, "clx_conv_wgrad: occupancy query failed");
-  int nslices = 1;
-  if (T < 4 * slots) {
-    const int rounds = T <= slots ? (T * 4 <= slots ? 1 : 2) : 4;
-    nslices = rounds * slots / T;
-    if (T * 4 <= slots) nslices = 4 * slots / T;   // tiny output: still aim for >= 4 blocks per slot
-  }
-  const int max_slices = total_chunks / 8 > 0 ? total_chunks / 8 : 1;
-  if (nslices > max_slices) nslices = max_slices;
-  if (nslices < 1) nslices = 1;
-  p.chunks_per_slice = cdiv(total_chunks, nslices);
-  p.nslices = cdiv(total_chunks, p.chunks_per_slice);
-  const dim3 grid(T * p.nslices), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (big_n && big_c)
-    conv_wgrad_kernel<128, 128, 2, 2><<<grid, block, 0, st>>>(p);
-  else if (big_n)
-    conv_wgrad_kernel<128, 64, 4, 1><<<grid, block, 0, st>>>(p);
-  else if (big_c)
-    conv_wgrad_kernel<64, 128, 1, 4><<<grid, block, 0, st>>>(p);
-  else
-    conv_wgrad_kernel<64, 64, 2, 2><<<grid, block, 0, st>>>(p);
+  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
+  const int rc = clx_wgrad_launch(d, dy, ld_dy, dwpack, dbias, 1, 0, 0, 0, (hipStream_t)stream);
+  if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_conv_wgrad");
   return CLX_OK;
 }

@@ -13,6 +13,7 @@ multiple of 4; the padded channels stay zero for the life of a buffer.
 
 import ctypes
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
@@ -24,6 +25,16 @@ from .._clx import ClxConvDesc, ClxSrc
 
 def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
+
+
+# Winograd F(2x2, 3x3) is used for 2-D 3x3 layers whose channel counts (both sides) reach this
+# value: below it the extra HBM traffic of the transformed tensors outweighs the 2.25x fewer
+# MFMA FLOPs.  CLX_WINOGRAD=0 forces the direct implicit-GEMM kernels everywhere.
+WINO_MIN_CHANNELS = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS", "128"))
+
+
+def winograd_enabled() -> bool:
+    return os.environ.get("CLX_WINOGRAD", "1") != "0"
 
 
 def _tri(v):
@@ -229,12 +240,37 @@ class UNetPlan:
         for name, (shape, c) in t.shapes.items():
             n = self.B * shape[0] * shape[1] * shape[2]
             self.buf[name] = torch.zeros((n, pad4(c)), dtype=torch.float32, device=self.device)
+        # per-layer algorithm (direct implicit GEMM / Winograd) for forward, dgrad and wgrad
+        self.algo = {}
+        self.workspace = None
+        ws_bytes = 0
+        for layer in t.convs:
+            a = dict(fwd=0, dgrad=0, wgrad=0)
+            if winograd_enabled() and min(layer.cin_pad, layer.cout) >= WINO_MIN_CHANNELS:
+                lib = _clx.load()
+                d = self._desc(layer)
+                d.N = layer.cout
+                nf = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 0))
+                if nf:
+                    a["fwd"], ws_bytes = 1, max(ws_bytes, nf)
+                d.N = pad4(layer.cout)
+                nw = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 1))
+                if nw and self.keep:
+                    a["wgrad"], ws_bytes = 1, max(ws_bytes, nw)
+                if self.keep and layer.param_index > 0:
+                    nd_ = int(lib.clx_conv_workspace_bytes(ctypes.byref(self._dgrad_desc(layer, None)), 0))
+                    if nd_:
+                        a["dgrad"], ws_bytes = 1, max(ws_bytes, nd_)
+            self.algo[layer.name] = a
+        if ws_bytes:
+            self.workspace = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=self.device)
         # packed weights
         self.wpack_fwd = {}
         self.wpack_dgrad = {}
         for layer in t.convs:
+            taps = 16 if self.algo[layer.name]["fwd"] else layer.taps
             self.wpack_fwd[layer.name] = torch.empty(
-                layer.cout * layer.taps * layer.cin_pad, dtype=torch.float32, device=self.device)
+                pad4(layer.cout) * taps * layer.cin_pad, dtype=torch.float32, device=self.device)
         self._packed_version = None
         self._bwd_ready = False
 
@@ -255,10 +291,11 @@ class UNetPlan:
         self.dw_off = {}
         for layer in t.convs:
             self.dw_off[layer.name] = total
-            total += layer.taps * pad4(layer.cout) * layer.cin_pad
+            total += (16 if self.algo[layer.name]["wgrad"] else layer.taps) * pad4(layer.cout) * layer.cin_pad
             if layer.param_index > 0:  # first layer needs no data gradient
+                taps = 16 if self.algo[layer.name]["dgrad"] else layer.taps
                 self.wpack_dgrad[layer.name] = torch.empty(
-                    layer.cin_pad * layer.taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
+                    layer.cin_pad * taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
         self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
         self._bwd_ready = True
 
@@ -281,7 +318,39 @@ class UNetPlan:
         d.ID, d.IH, d.IW = layer.in_shape
         d.KD, d.KH, d.KW = layer.kernel
         d.PD = d.PH = d.PW = 0
+        d.algo = 0
+        d.workspace = None
+        d.workspace_bytes = 0
         return d
+
+    def _use_workspace(self, d):
+        d.algo = 1
+        d.workspace = self.workspace.data_ptr()
+        d.workspace_bytes = self.workspace.numel() * 4
+
+    def _dgrad_desc(self, layer: ConvLayer, dy):
+        """Data gradient as a convolution of dy (zero padding k-1, flipped transposed weights)."""
+        dd = ClxConvDesc()
+        dd.nsrc = 1
+        src = ClxSrc()
+        src.ptr = dy.data_ptr() if dy is not None else 16      # geometry-only queries never dereference
+        src.C = pad4(layer.cout)
+        src.ld = pad4(layer.cout)
+        src.D, src.H, src.W = layer.out_shape
+        src.oz = src.oy = src.ox = 0
+        src.fz = src.fy = src.fx = 1
+        dd.src[0] = src
+        dd.B = self.B
+        dd.ID, dd.IH, dd.IW = layer.out_shape
+        dd.KD, dd.KH, dd.KW = layer.kernel
+        dd.PD, dd.PH, dd.PW = (k - 1 for k in layer.kernel)
+        dd.N = layer.cin_pad
+        dd.bias = None
+        dd.relu = 0
+        dd.algo = 0
+        dd.workspace = None
+        dd.workspace_bytes = 0
+        return dd
 
     def _expand_cin(self, layer, w):
         """torch weight (cout, cin, taps) -> (cout, cin_gapped, taps) when a concat source is padded."""
@@ -321,11 +390,14 @@ class UNetPlan:
             if not wv.is_contiguous():
                 wv = wv.contiguous()
             wv, cin_eff = self._expand_cin(layer, wv)
+            algo = self.algo[layer.name]
             _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_fwd[layer.name]),
-                      layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout), 0, st)
+                      layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
+                      2 if algo["fwd"] else 0, st)
             if need_dgrad and layer.name in self.wpack_dgrad:
                 _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_dgrad[layer.name]),
-                          layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout), 1, st)
+                          layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
+                          3 if algo["dgrad"] else 1, st)
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward
@@ -349,6 +421,8 @@ class UNetPlan:
                 d.ld_mask = 0
                 d.out = self.buf[op.out].data_ptr()
                 d.ld_out = pad4(op.cout)
+                if self.algo[op.name]["fwd"]:
+                    self._use_workspace(d)
                 _clx.call("clx_conv_fwd", ctypes.byref(d), st)
             else:
                 D, H, W = op.in_shape
@@ -393,11 +467,18 @@ class UNetPlan:
             d.N = pad4(layer.cout)
             gb = grads[2 * layer.param_index + 1]
             off = self.dw_off[layer.name]
-            dwp = self.dwpack[off:off + layer.taps * pad4(layer.cout) * layer.cin_pad]
+            wino_w = bool(self.algo[layer.name]["wgrad"])
+            wtaps = 16 if wino_w else layer.taps
+            dwp = self.dwpack[off:off + wtaps * pad4(layer.cout) * layer.cin_pad]
+            if wino_w:
+                self._use_workspace(d)
             _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), pad4(layer.cout), _clx.ptr(dwp),
                       _clx.ptr(gb) if gb is not None else None, st)
             gw = grads[2 * layer.param_index]
-            if len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
+            if wino_w:
+                _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
+                          pad4(layer.cout), layer.cin_pad, st)
+            elif len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
                 _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
                           layer.taps, pad4(layer.cout), layer.cin_pad, st)
             else:
@@ -409,24 +490,10 @@ class UNetPlan:
             # ---- data gradient
             if layer.param_index == 0:
                 continue
-            dd = ClxConvDesc()
-            dd.nsrc = 1
-            src = ClxSrc()
-            src.ptr = dy.data_ptr()
-            src.C = pad4(layer.cout)
-            src.ld = pad4(layer.cout)
-            src.D, src.H, src.W = layer.out_shape
-            src.oz = src.oy = src.ox = 0
-            src.fz = src.fy = src.fx = 1
-            dd.src[0] = src
-            dd.B = self.B
-            dd.ID, dd.IH, dd.IW = layer.out_shape
-            dd.KD, dd.KH, dd.KW = layer.kernel
-            dd.PD, dd.PH, dd.PW = (k - 1 for k in layer.kernel)
-            dd.N = layer.cin_pad
+            dd = self._dgrad_desc(layer, dy)
             dd.wpack = self.wpack_dgrad[layer.name].data_ptr()
-            dd.bias = None
-            dd.relu = 0
+            if self.algo[layer.name]["dgrad"]:
+                self._use_workspace(dd)
             if len(layer.sources) == 2:
                 info = r_by_conv0[layer.name]
                 cat = self.gbuf["cat%d" % info["level"]]

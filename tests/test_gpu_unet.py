@@ -131,3 +131,53 @@ def test_bad_shapes_raise(device):
         model(torch.zeros(1, 1, 45, 52, device=device))
     with pytest.raises(ValueError):
         model(torch.zeros(1, 2, 44, 52, device=device))
+
+
+# ------------------------------------------------------------------ Winograd F(2x2, 3x3)
+WINO_CASES = ["2d_small", "2d_wide", "2d_odd_channels", "2d_two_levels"]
+
+
+@pytest.mark.parametrize("name", WINO_CASES)
+def test_winograd_forward_backward_match_oracle(name, device, monkeypatch):
+    """Same parity bars with the Winograd path forced onto every eligible 3x3 layer
+    (forward, data gradient and weight gradient), including odd extents and padded channels."""
+    import cellulus_amd.models.plan as plan_mod
+
+    monkeypatch.setattr(plan_mod, "WINO_MIN_CHANNELS", 4)
+    monkeypatch.setenv("CLX_WINOGRAD", "1")
+    oracle, model, raw = _make(name, device, seed=4)
+    with torch.no_grad():
+        ref = oracle(raw)
+        got = model(raw.to(device)).cpu()
+    plan = next(iter(model._plans.values()))
+    assert any(a["fwd"] for a in plan.algo.values()), "Winograd was not selected"
+    assert (got - ref).abs().max().item() < 1e-4
+    oracle = oracle.double()
+    ref = oracle(raw.double())
+    torch.manual_seed(5)
+    dout = torch.randn_like(ref).float()
+    ref.backward(dout.double())
+    out = model(raw.to(device))
+    out.backward(dout.to(device))
+    plan = [p for k, p in model._plans.items() if k[2]][0]
+    assert any(a["wgrad"] for a in plan.algo.values()) and any(a["dgrad"] for a in plan.algo.values())
+    for (n, po), (_, pm) in zip(oracle.named_parameters(), model.named_parameters()):
+        g_ref, g = po.grad, pm.grad.cpu().double()
+        l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-12)).item()
+        assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
+
+
+def test_winograd_equals_direct_path(device, monkeypatch):
+    import cellulus_amd.models.plan as plan_mod
+
+    oracle, model, raw = _make("2d_wide", device, seed=6)
+    x = raw.to(device)
+    monkeypatch.setenv("CLX_WINOGRAD", "0")
+    with torch.no_grad():
+        direct = model(x).clone()
+    model._plans = {}
+    monkeypatch.setenv("CLX_WINOGRAD", "1")
+    monkeypatch.setattr(plan_mod, "WINO_MIN_CHANNELS", 4)
+    with torch.no_grad():
+        wino = model(x).clone()
+    assert (wino - direct).abs().max().item() < 2e-5
