@@ -252,6 +252,8 @@ def main():
 
     gc.collect()
     gc.disable()     # a cyclic-GC pause inside one step would be charged to the GPU path
+    from cellulus_amd import _clx as _clx_mod
+    _clx_mod.call("clx_profile_enable", 2)      # HIP events around every MFMA kernel launch
     barrier()
     t0 = time.perf_counter()
     step_times = []
@@ -276,23 +278,39 @@ def main():
     plan = next(iter(model._plans.values()))
     fwd_flops, train_flops, _ = conv_flops(plan.topo, 1)
 
-    # ---- roofline of the dominant kernel
+    # ---- roofline of the dominant kernel: executed MFMA FLOPs of its launches / their
+    # HIP-event durations (events recorded inside libclx around the kernel launch itself)
+    import ctypes
+
+    lib = _clx_mod.load()
+    kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel"}
+    prof = {}
+    for kind, kname in kinds.items():
+        n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        lib.clx_profile_read(kind, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+        prof[kname] = (n_l.value, ms_l.value, fl_l.value)
+    _clx_mod.call("clx_profile_enable", 0)
+    dom_name, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    mfma_ms = sum(v[1] for v in prof.values())
+    mfma_fl = sum(v[2] for v in prof.values())
     summ = timer.summary()
-    dom_key, dom = max(summ.items(), key=lambda kv: kv[1][2])
-    launches, flops, ms = dom
-    achieved = flops / (ms * 1e-3) / 1e12
     conv_ms = sum(v[2] for v in summ.values())
-    conv_fl = sum(v[1] for v in summ.values())
+    plan_algo = getattr(plan, "algo", {})
+    n_wino = sum(1 for a in plan_algo.values() if a.get("fwd"))
     roofline = dict(
-        bound="mfma", kernel=("conv_igemm_kernel" if dom_key[0] == "clx_conv_fwd" else "conv_wgrad_kernel")
-        + ("<128,128>" if dom_key[1] else "<narrow tile>"),
+        bound="mfma", kernel=dom_name,
         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
         frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-        launches_per_step=launches // args.steps,
-        avg_launch_ms=round(ms / launches, 4),
-        all_conv_kernels=dict(tflops=round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                              ms_per_step=round(conv_ms / args.steps, 3)),
-        step_model_tflops=round(crops_per_s / world * train_flops / 1e12, 2),
+        launches_per_step=int(launches // args.steps),
+        avg_launch_ms=round(ms / max(launches, 1), 4),
+        note="achieved = FLOPs the kernel executes (2*M*N*K per GEMM, real extents) / HIP-event time of "
+             "its launches; Winograd layers execute 4/9 of the direct-convolution FLOPs",
+        all_mfma_kernels=dict(tflops=round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else 0.0,
+                              ms_per_step=round(mfma_ms / args.steps, 3)),
+        conv_calls_ms_per_step=round(conv_ms / args.steps, 3),
+        winograd_layers=n_wino,
+        direct_equivalent_tflops=round(crops_per_s / world * train_flops / 1e12, 2),
     )
 
     out = {

@@ -78,6 +78,8 @@ PROTOTYPES = {
     "clx_last_error": (c_char_p, []),
     "clx_abi_version": (_I, []),
     "clx_device_count": (_I, []),
+    "clx_profile_enable": (_I, [_I]),
+    "clx_profile_read": (_I, [_I, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "clx_conv_fwd": (_I, [POINTER(ClxConvDesc), _P]),
     "clx_conv_wgrad": (_I, [POINTER(ClxConvDesc), _P, _I, _P, _P, _P]),
     "clx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

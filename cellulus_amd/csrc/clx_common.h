@@ -74,3 +74,8 @@ int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dw
                    hipStream_t st);
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad,
                   hipStream_t st);
+
+// in-library kernel timing (clx_core.hip); kinds match enum clx_profile_kind in clx.h
+bool clx_prof_enabled();
+void clx_prof_begin(int kind, double flops, hipStream_t st);
+void clx_prof_end(hipStream_t st);

@@ -20,3 +20,52 @@ extern "C" int clx_device_count(void) {
   }
   return n;
 }
+
+// ---------------------------------------------------------------------------
+// Optional in-library kernel timing (bench.py roofline): when enabled, the MFMA kernel
+// launchers bracket their launch with HIP events on the launch stream and record the
+// FLOPs the launch executes.  Off by default; no cost when off.
+// ---------------------------------------------------------------------------
+#include <vector>
+
+namespace {
+struct ProfRec { int kind; double flops; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+bool clx_prof_enabled() { return g_prof_on; }
+
+void clx_prof_begin(int kind, double flops, hipStream_t st) {
+  ProfRec r;
+  r.kind = kind; r.flops = flops;
+  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+  (void)hipEventRecord(r.e0, st);
+  g_prof.push_back(r);
+}
+
+void clx_prof_end(hipStream_t st) {
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
+}
+
+extern "C" int clx_profile_enable(int on) {
+  g_prof_on = on != 0;
+  if (!g_prof_on || on == 2) {   // 2 = enable and clear
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+  }
+  return CLX_OK;
+}
+
+extern "C" int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops) {
+  CLX_REQUIRE(launches && total_ms && total_flops, "clx_profile_read: null pointer");
+  *launches = *total_ms = *total_flops = 0.0;
+  for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) { clx_set_error("clx_profile_read: event sync failed"); return CLX_ERR_LAUNCH; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+    *launches += 1.0; *total_ms += ms; *total_flops += r.flops;
+  }
+  return CLX_OK;
+}

@@ -361,12 +361,13 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
               "clx_conv_fwd: mask must be 16-byte aligned with ld_mask %% 4 == 0 and >= N");
   CLX_REQUIRE(d->ld_out % 4 == 0 && ((uintptr_t)d->out & 15) == 0,
               "clx_conv_fwd: out must be 16-byte aligned with ld_out %% 4 == 0");
+  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD, "clx_conv_fwd: bad algo");
+  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_fwd(d, (hipStream_t)stream);
   if (clx_smallc_applicable(d) && d->mask == nullptr) {
     clx_smallc_fwd(d, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_fwd(small-channel)");
     return CLX_OK;
   }
-  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_fwd(d, (hipStream_t)stream);
   rc = clx_igemm_launch(d, 1, 0, 0, 0, (hipStream_t)stream);
   if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_conv_fwd");
@@ -383,12 +384,17 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_fwd: cannot resolve the device zero buffer");
   p.bs_in = bs_in; p.bs_w = bs_w; p.bs_out = bs_out;
   // 128-wide N tiles unless padding N up to a multiple of 128 wastes > 20 % of the MFMAs
-  if (d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2) {
+  const bool wide = d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2;
+  const bool prof = clx_prof_enabled();
+  if (prof) clx_prof_begin(wide ? CLX_PROF_IGEMM_WIDE : CLX_PROF_IGEMM_NARROW,
+                           2.0 * p.M * p.N * p.Ktot * batch, st);
+  if (wide) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
     conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
   } else {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
     conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
   }
+  if (prof) clx_prof_end(st);
   return CLX_OK;
 }

@@ -316,6 +316,8 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   p.chunks_per_slice = cdiv(total_chunks, nslices);
   p.nslices = cdiv(total_chunks, p.chunks_per_slice);
   const dim3 grid(T * p.nslices, batch), block(256);
+  const bool prof = clx_prof_enabled();
+  if (prof) clx_prof_begin(CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, st);
   if (big_n && big_c)
     conv_wgrad_kernel<128, 128, 2, 2><<<grid, block, 0, st>>>(p);
   else if (big_n)
@@ -324,6 +326,7 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
     conv_wgrad_kernel<64, 128, 1, 4><<<grid, block, 0, st>>>(p);
   else
     conv_wgrad_kernel<64, 64, 2, 2><<<grid, block, 0, st>>>(p);
+  if (prof) clx_prof_end(st);
   return CLX_OK;
 }
 
@@ -344,12 +347,13 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
     CLX_REQUIRE((long long)d->B * S.D * S.H * S.W < (1ll << 31),
                 "clx_conv_wgrad: source %d has too many pixels", s);
   }
+  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD, "clx_conv_wgrad: bad algo");
+  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
   if (clx_smallc_applicable(d)) {
     clx_smallc_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_wgrad(small-channel)");
     return CLX_OK;
   }
-  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
   const int rc = clx_wgrad_launch(d, dy, ld_dy, dwpack, dbias, 1, 0, 0, 0, (hipStream_t)stream);
   if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_conv_wgrad");

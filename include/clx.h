@@ -42,6 +42,18 @@ int clx_abi_version(void);
 /* Number of HIP devices visible to the library (0 = none; not an error). */
 int clx_device_count(void);
 
+/* Kernel timing for roofline reports: while enabled (on = 1; on = 2 also clears the
+ * records, 0 disables and clears) every launch of an MFMA kernel is bracketed by HIP
+ * events on its stream.  clx_profile_read sums launches / milliseconds / executed FLOPs
+ * (2*M*N*K per GEMM of the launch, real extents) of one kernel kind; it synchronises. */
+enum clx_profile_kind {
+  CLX_PROF_IGEMM_WIDE = 0,   /* conv_igemm_kernel<128,128> */
+  CLX_PROF_IGEMM_NARROW = 1, /* conv_igemm_kernel<128,64>  */
+  CLX_PROF_WGRAD = 2         /* conv_wgrad_kernel<...>     */
+};
+int clx_profile_enable(int on);
+int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);
+
 /* ------------------------------------------------------------------------ */
 /* Convolution (valid, stride 1, kernel extent 1 or 3 per dim)              */
 /* replaces: nn.Conv{2,3}d + nn.ReLU inside funlib ConvPass and the 1x1     */
