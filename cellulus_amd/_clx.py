@@ -62,6 +62,7 @@ class ClxConvDesc(Structure):
         ("ld_mask", c_int),
         ("out", c_void_p),
         ("ld_out", c_int),
+        ("accumulate", c_int),
         ("algo", c_int),
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),
@@ -88,6 +89,8 @@ PROTOTYPES = {
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
     "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_pixel_to_planar": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
+    "clx_depth_to_space": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_space_to_depth": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_maxpool_bwd": (_I, [_P, _P, _P, _P] + [_I] * 7 + [_P] + [_I] * 8 + [_P]),
     "clx_upsample_bwd": (_I, [_P] + [_I] * 8 + [_P, _P] + [_I] * 8 + [_P]),

@@ -38,7 +38,7 @@ struct ConvP {
   const float* mask;
   const float* zeros;   // 16 zero bytes in global memory (target of out-of-range loads)
   float* out;
-  int relu, ld_mask, ld_out;
+  int relu, ld_mask, ld_out, accumulate;
   int nbm, nbn;
   long long bs_in, bs_w, bs_out;   // per-batch strides in floats (gridDim.y batches; 0 = none)
 };
@@ -249,9 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float val = acc[a][b][r] + bv;
-        if (p.relu) val = fmaxf(val, 0.f);
-        Cs[row * LDC + col] = val;
+        Cs[row * LDC + col] = acc[a][b][r] + bv;
       }
     }
   }
@@ -266,6 +264,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     if (m >= p.M || n >= p.N) continue;
     f32x4 val = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
     float* dst = p.out + blockIdx.y * p.bs_out + (size_t)m * p.ld_out + n;
+    if (p.accumulate) {       // out = act(conv + bias + out): n + 3 < ld_out always (ld_out % 4 == 0)
+      const f32x4 prev = *reinterpret_cast<const f32x4*>(dst);
+      val += prev;
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+    }
     if (n + 3 < p.N) {
       if (p.mask) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.ld_mask + n);
@@ -306,7 +312,7 @@ static int conv_validate(const clx_conv_desc* d, const char* who) {
   const int P[3] = {d->PD, d->PH, d->PW};
   const int I[3] = {d->ID, d->IH, d->IW};
   for (int i = 0; i < 3; ++i) {
-    CLX_REQUIRE(K[i] == 1 || K[i] == 3, "%s: kernel extent must be 1 or 3", who);
+    CLX_REQUIRE(K[i] >= 1 && K[i] <= 3, "%s: kernel extent must be 1, 2 or 3", who);
     CLX_REQUIRE(P[i] >= 0 && P[i] < K[i], "%s: padding must be < kernel extent", who);
     CLX_REQUIRE(I[i] + 2 * P[i] - K[i] + 1 > 0, "%s: input smaller than kernel", who);
   }
@@ -347,6 +353,7 @@ static void fill_params(const clx_conv_desc* d, ConvP& p) {
   p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
   p.wpack = d->wpack; p.bias = d->bias; p.mask = d->mask; p.out = d->out;
   p.relu = d->relu; p.ld_mask = d->ld_mask; p.ld_out = d->ld_out;
+  p.accumulate = d->accumulate;
   p.bs_in = p.bs_w = p.bs_out = 0;
 }
 

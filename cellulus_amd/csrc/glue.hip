@@ -134,6 +134,31 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dcat, int ld_cat, 
   }
 }
 
+// lo[(b,z,y,x)][phase*N + n] <-> hi[(b, z*fz+a, y*fy+bb, x*fx+c)][n], phase = (a*fy+bb)*fx+c
+template <bool TO_SPACE>
+__global__ void subpixel_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld_lo,
+                                int ld_hi, int D, int H, int W, int N4, int fz, int fy, int fx,
+                                long long total) {
+  const int P = fz * fy * fx;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N4) * 4;
+    long long q = i / N4;
+    const int ph = (int)(q % P); q /= P;
+    const int x = (int)(q % W); q /= W;
+    const int y = (int)(q % H); q /= H;
+    const int z = (int)(q % D);
+    const long long b = q / D;
+    const int c = ph % fx, bb = (ph / fx) % fy, a = ph / (fx * fy);
+    const long long lo_pix = ((b * D + z) * H + y) * W + x;
+    const long long hi_pix = ((b * D * fz + z * fz + a) * (H * fy) + y * fy + bb) * (long long)(W * fx) + x * fx + c;
+    const long long lo_off = lo_pix * ld_lo + (long long)ph * N4 * 4 + n;
+    const long long hi_off = hi_pix * ld_hi + n;
+    if (TO_SPACE) st4(dst + hi_off, ld4(src + lo_off));
+    else st4(dst + lo_off, ld4(src + hi_off));
+  }
+}
+
 // torch.std_mean(stack(preds), dim=0, unbiased=False); std summed over channels
 // [cellulus/models/unet.py:90-98]
 __global__ void noise_stats_kernel(const float* __restrict__ preds, float* __restrict__ out,
@@ -242,4 +267,32 @@ extern "C" int clx_noise_stats(const float* preds, float* out, int T, int C, lon
     noise_stats_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
   CLX_CHECK_LAUNCH("clx_noise_stats");
   return CLX_OK;
+}
+
+static int subpixel_launch(bool to_space, const float* src, float* dst, int ld_lo, int ld_hi, int B,
+                           int D, int H, int W, int N, int fz, int fy, int fx, hipStream_t st,
+                           const char* who) {
+  CLX_REQUIRE(src && dst, "%s: null pointer", who);
+  CLX_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && N > 0 && N % 4 == 0, "%s: bad extents", who);
+  CLX_REQUIRE(fz >= 1 && fy >= 1 && fx >= 1, "%s: bad factors", who);
+  CLX_REQUIRE(ld_lo % 4 == 0 && ld_lo >= fz * fy * fx * N && ld_hi % 4 == 0 && ld_hi >= N, "%s: bad strides", who);
+  const long long total = (long long)B * D * H * W * fz * fy * fx * (N / 4);
+  if (to_space)
+    subpixel_kernel<true><<<grid_for(total, 256), 256, 0, st>>>(src, dst, ld_lo, ld_hi, D, H, W, N / 4, fz, fy, fx, total);
+  else
+    subpixel_kernel<false><<<grid_for(total, 256), 256, 0, st>>>(src, dst, ld_lo, ld_hi, D, H, W, N / 4, fz, fy, fx, total);
+  CLX_CHECK_LAUNCH(who);
+  return CLX_OK;
+}
+
+extern "C" int clx_depth_to_space(const float* lo, int ld_lo, float* hi, int ld_hi, int B, int D, int H,
+                                  int W, int N, int fz, int fy, int fx, clx_stream stream) {
+  return subpixel_launch(true, lo, hi, ld_lo, ld_hi, B, D, H, W, N, fz, fy, fx, (hipStream_t)stream,
+                         "clx_depth_to_space");
+}
+
+extern "C" int clx_space_to_depth(const float* hi, int ld_hi, float* lo, int ld_lo, int B, int D, int H,
+                                  int W, int N, int fz, int fy, int fx, clx_stream stream) {
+  return subpixel_launch(false, hi, lo, ld_lo, ld_hi, B, D, H, W, N, fz, fy, fx, (hipStream_t)stream,
+                         "clx_space_to_depth");
 }

@@ -264,6 +264,18 @@ class UNetPlan:
             self.algo[layer.name] = a
         if ws_bytes:
             self.workspace = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=self.device)
+        # sub-pixel form of the convolutions that read a nearest-upsampled tensor
+        self.subpixel = {}
+        for info in t.r_info:
+            sp = self._subpixel_geometry(info["conv0"])
+            if sp is not None:
+                self.subpixel[info["conv0"].name] = sp
+                n = self.B * sp["zshape"][0] * sp["zshape"][1] * sp["zshape"][2]
+                self.buf[sp["zname"]] = torch.zeros((n, sp["P"] * sp["N"]), dtype=torch.float32, device=self.device)
+                sp["wp_skip_fwd"] = torch.empty(sp["N"] * info["conv0"].taps * sp["C0p"],
+                                                dtype=torch.float32, device=self.device)
+                sp["wp_z_fwd"] = torch.empty(sp["P"] * sp["N"] * sp["ztaps"] * sp["C1p"],
+                                             dtype=torch.float32, device=self.device)
         # packed weights
         self.wpack_fwd = {}
         self.wpack_dgrad = {}
@@ -285,8 +297,22 @@ class UNetPlan:
         for info in t.r_info:
             layer = info["conv0"]
             n = self.B * layer.in_shape[0] * layer.in_shape[1] * layer.in_shape[2]
-            self.gbuf["cat%d" % info["level"]] = torch.zeros(
-                (n, layer.cin_pad), dtype=torch.float32, device=self.device)
+            sp = self.subpixel.get(layer.name)
+            if sp is None:
+                self.gbuf["cat%d" % info["level"]] = torch.zeros(
+                    (n, layer.cin_pad), dtype=torch.float32, device=self.device)
+            else:
+                self.gbuf["dskip%d" % info["level"]] = torch.zeros(
+                    (n, sp["C0p"]), dtype=torch.float32, device=self.device)
+                self.gbuf[sp["zname"]] = torch.zeros_like(self.buf[sp["zname"]])
+                sp["wp_skip_dgrad"] = torch.empty(sp["C0p"] * layer.taps * sp["N"], dtype=torch.float32,
+                                                  device=self.device)
+                sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * sp["ztaps"] * sp["P"] * sp["N"],
+                                               dtype=torch.float32, device=self.device)
+                sp["dw_skip"] = torch.zeros(layer.taps * sp["N"] * sp["C0p"], dtype=torch.float32,
+                                            device=self.device)
+                sp["dw_z"] = torch.zeros(sp["ztaps"] * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
+                                         device=self.device)
         total = 0
         self.dw_off = {}
         for layer in t.convs:
@@ -298,6 +324,231 @@ class UNetPlan:
                     layer.cin_pad * taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
         self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
         self._bwd_ready = True
+
+    # --------------------------------------------------------------- sub-pixel
+    def _subpixel_geometry(self, layer: ConvLayer):
+        """A convolution over cat(skip, nearest-upsample(low)) equals, exactly,
+             conv(skip) + depth_to_space( conv_{2^d taps}(low, phase-summed weights) )
+        because the k=3 taps of an output pixel with parity a fall on only two low-res rows.
+        Returns the geometry of that rewrite or None when it does not apply (odd crop, odd
+        output extent, cropped low-res grid, CLX_SUBPIXEL=0)."""
+        if os.environ.get("CLX_SUBPIXEL", "1") == "0" or len(layer.sources) != 2:
+            return None
+        skip_s, up_s = layer.sources
+        f, k, o = up_s.factor, layer.kernel, up_s.crop
+        if max(f) != 2 or min(f) < 1 or skip_s.factor != (1, 1, 1):
+            return None
+        low_shape, low_c = self.topo.shapes[up_s.tensor]
+        zshape, zk, zcrop = [], [], []
+        for d in range(3):
+            if f[d] == 2:
+                if k[d] != 3 or o[d] % 2 != 0 or layer.out_shape[d] % 2 != 0:
+                    return None
+                zshape.append(layer.out_shape[d] // 2)
+                zk.append(2)
+                zcrop.append(o[d] // 2)
+            else:
+                zshape.append(layer.out_shape[d])
+                zk.append(k[d])
+                zcrop.append(o[d])
+            # the Z convolution must read the WHOLE low-res grid (its dgrad writes all of it)
+            if zcrop[d] != 0 or zshape[d] + zk[d] - 1 != low_shape[d]:
+                return None
+        level = [i["level"] for i in self.topo.r_info if i["conv0"] is layer][0]
+        return dict(fac=f, P=f[0] * f[1] * f[2], N=pad4(layer.cout), C0=skip_s.channels, C0p=pad4(skip_s.channels),
+                    C1=up_s.channels, C1p=pad4(up_s.channels), zshape=tuple(zshape), zk=tuple(zk),
+                    ztaps=zk[0] * zk[1] * zk[2], zname="Z%d" % level, level=level)
+
+    @staticmethod
+    def _phase_matrix(a, device):
+        """(2 x 3): which of the 3 taps of an output pixel with parity `a` land on low-res row r."""
+        rows = [[1., 1., 0.], [0., 0., 1.]] if a == 0 else [[1., 0., 0.], [0., 1., 1.]]
+        return torch.tensor(rows, dtype=torch.float32, device=device)
+
+    def _phase_weights(self, layer, sp, w_up):
+        """w_up (cout, C1, kd, kh, kw) -> phase-summed (P*N, C1, zkd, zkh, zkw); rows of padded
+        output channels are zero.  Tiny tensors: plain torch ops."""
+        f, N, cout = sp["fac"], sp["N"], layer.cout
+        dev = w_up.device
+        out = w_up.new_zeros((sp["P"], N, sp["C1"]) + sp["zk"])
+        eye = [torch.eye(layer.kernel[d], dtype=torch.float32, device=dev) for d in range(3)]
+        for a in range(f[0]):
+            for b in range(f[1]):
+                for c in range(f[2]):
+                    Tz = self._phase_matrix(a, dev) if f[0] == 2 else eye[0]
+                    Ty = self._phase_matrix(b, dev) if f[1] == 2 else eye[1]
+                    Tx = self._phase_matrix(c, dev) if f[2] == 2 else eye[2]
+                    ph = (a * f[1] + b) * f[2] + c
+                    out[ph, :cout] = torch.einsum("rz,sy,tx,nczyx->ncrst", Tz, Ty, Tx, w_up)
+        return out.reshape((sp["P"] * N, sp["C1"]) + sp["zk"])
+
+    def _fold_phase_grads(self, layer, sp, dweff):
+        """adjoint of _phase_weights: (P*N, C1, zk...) -> (cout, C1, kd, kh, kw)."""
+        f, N, cout = sp["fac"], sp["N"], layer.cout
+        dev = dweff.device
+        g = dweff.reshape((sp["P"], N, sp["C1"]) + sp["zk"])
+        eye = [torch.eye(layer.kernel[d], dtype=torch.float32, device=dev) for d in range(3)]
+        out = dweff.new_zeros((cout, sp["C1"]) + tuple(layer.kernel))
+        for a in range(f[0]):
+            for b in range(f[1]):
+                for c in range(f[2]):
+                    Tz = self._phase_matrix(a, dev) if f[0] == 2 else eye[0]
+                    Ty = self._phase_matrix(b, dev) if f[1] == 2 else eye[1]
+                    Tx = self._phase_matrix(c, dev) if f[2] == 2 else eye[2]
+                    ph = (a * f[1] + b) * f[2] + c
+                    out += torch.einsum("rz,sy,tx,ncrst->nczyx", Tz, Ty, Tx, g[ph, :cout])
+        return out
+
+    def _sp_descs(self, layer, sp):
+        """(Z-convolution descriptor over the low-res tensor, skip-convolution descriptor)."""
+        t = self.topo
+        skip_s, up_s = layer.sources
+        dz = ClxConvDesc()
+        dz.nsrc = 1
+        low_shape, low_c = t.shapes[up_s.tensor]
+        src = ClxSrc()
+        src.ptr = self.buf[up_s.tensor].data_ptr()
+        src.C = sp["C1p"]
+        src.ld = pad4(low_c)
+        src.D, src.H, src.W = low_shape
+        src.oz = src.oy = src.ox = 0
+        src.fz = src.fy = src.fx = 1
+        dz.src[0] = src
+        dz.B = self.B
+        dz.ID, dz.IH, dz.IW = low_shape
+        dz.KD, dz.KH, dz.KW = sp["zk"]
+        dz.PD = dz.PH = dz.PW = 0
+        dz.N = sp["P"] * sp["N"]
+        ds = ClxConvDesc()
+        ds.nsrc = 1
+        sshape, sc = t.shapes[skip_s.tensor]
+        src2 = ClxSrc()
+        src2.ptr = self.buf[skip_s.tensor].data_ptr()
+        src2.C = sp["C0p"]
+        src2.ld = pad4(sc)
+        src2.D, src2.H, src2.W = sshape
+        src2.oz, src2.oy, src2.ox = skip_s.crop
+        src2.fz = src2.fy = src2.fx = 1
+        ds.src[0] = src2
+        ds.B = self.B
+        ds.ID, ds.IH, ds.IW = layer.in_shape
+        ds.KD, ds.KH, ds.KW = layer.kernel
+        ds.PD = ds.PH = ds.PW = 0
+        for d in (dz, ds):
+            d.algo = 0
+            d.accumulate = 0
+            d.workspace = None
+            d.workspace_bytes = 0
+            d.mask = None
+            d.ld_mask = 0
+            d.bias = None
+            d.relu = 0
+        return dz, ds
+
+    def _sp_pack(self, layer, sp, w, need_dgrad, st):
+        wv = w.detach().reshape((layer.cout, layer.cin) + tuple(layer.kernel))
+        w_skip = wv[:, :sp["C0"]].reshape(layer.cout, sp["C0"], layer.taps).contiguous()
+        weff = self._phase_weights(layer, sp, wv[:, sp["C0"]:]).reshape(sp["P"] * sp["N"], sp["C1"], sp["ztaps"])
+        weff = weff.contiguous()
+        _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_fwd"]), layer.cout, sp["C0"],
+                  layer.taps, sp["C0p"], sp["N"], 0, st)
+        _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_fwd"]), sp["P"] * sp["N"], sp["C1"],
+                  sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 0, st)
+        if need_dgrad:
+            _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_dgrad"]), layer.cout, sp["C0"],
+                      layer.taps, sp["C0p"], sp["N"], 1, st)
+            _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_dgrad"]), sp["P"] * sp["N"],
+                      sp["C1"], sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 1, st)
+        sp["_keepalive"] = (w_skip, weff)
+
+    def _sp_forward(self, layer, sp, bias, st):
+        dz, ds = self._sp_descs(layer, sp)
+        zbuf = self.buf[sp["zname"]]
+        dz.wpack = sp["wp_z_fwd"].data_ptr()
+        dz.out = zbuf.data_ptr()
+        dz.ld_out = sp["P"] * sp["N"]
+        _clx.call("clx_conv_fwd", ctypes.byref(dz), st)
+        out = self.buf[layer.out]
+        zs = sp["zshape"]
+        _clx.call("clx_depth_to_space", _clx.ptr(zbuf), sp["P"] * sp["N"], _clx.ptr(out), sp["N"], self.B,
+                  zs[0], zs[1], zs[2], sp["N"], *sp["fac"], st)
+        ds.N = layer.cout
+        ds.wpack = sp["wp_skip_fwd"].data_ptr()
+        ds.bias = bias.data_ptr() if bias is not None else None
+        ds.relu = 1 if layer.relu else 0
+        ds.accumulate = 1
+        ds.out = out.data_ptr()
+        ds.ld_out = sp["N"]
+        _clx.call("clx_conv_fwd", ctypes.byref(ds), st)
+
+    def _sp_backward(self, layer, sp, dy, gw, gb, st):
+        """weight/bias gradient and both data gradients of a sub-pixel layer; returns the skip
+        gradient buffer (pre-gate, full skip-crop grid)."""
+        t = self.topo
+        dz, ds = self._sp_descs(layer, sp)
+        zs, PN = sp["zshape"], sp["P"] * sp["N"]
+        # dZ = space_to_depth(dY)
+        dzbuf = self.gbuf[sp["zname"]]
+        _clx.call("clx_space_to_depth", _clx.ptr(dy), sp["N"], _clx.ptr(dzbuf), PN, self.B,
+                  zs[0], zs[1], zs[2], sp["N"], *sp["fac"], st)
+        # weight gradients
+        sp["dw_skip"].zero_()
+        sp["dw_z"].zero_()
+        ds.N = sp["N"]
+        _clx.call("clx_conv_wgrad", ctypes.byref(ds), _clx.ptr(dy), sp["N"], _clx.ptr(sp["dw_skip"]),
+                  _clx.ptr(gb) if gb is not None else None, st)
+        _clx.call("clx_conv_wgrad", ctypes.byref(dz), _clx.ptr(dzbuf), PN, _clx.ptr(sp["dw_z"]), None, st)
+        g_skip = torch.empty((layer.cout, sp["C0"], layer.taps), dtype=torch.float32, device=self.device)
+        _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
+                  layer.taps, sp["N"], sp["C0p"], st)
+        g_z = torch.empty((PN, sp["C1"], sp["ztaps"]), dtype=torch.float32, device=self.device)
+        _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
+                  sp["C1p"], st)
+        gwv = gw.view(layer.cout, layer.cin, layer.taps)
+        gwv[:, :sp["C0"]] = g_skip
+        gwv[:, sp["C0"]:] = self._fold_phase_grads(layer, sp, g_z.reshape((PN, sp["C1"]) + sp["zk"])).reshape(
+            layer.cout, sp["C1"], layer.taps)
+        # data gradient of the skip branch (gated later, together with the max-pool gradient)
+        dskip = self.gbuf["dskip%d" % sp["level"]]
+        dd = self._dgrad_desc(layer, dy)
+        dd.N = sp["C0p"]
+        dd.wpack = sp["wp_skip_dgrad"].data_ptr()
+        dd.mask = None
+        dd.ld_mask = 0
+        dd.out = dskip.data_ptr()
+        dd.ld_out = sp["C0p"]
+        _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+        # data gradient of the low-res tensor straight from dZ (replaces upsample backward)
+        up_s = layer.sources[1]
+        low_shape, low_c = t.shapes[up_s.tensor]
+        dl = ClxConvDesc()
+        dl.nsrc = 1
+        src = ClxSrc()
+        src.ptr = dzbuf.data_ptr()
+        src.C = PN
+        src.ld = PN
+        src.D, src.H, src.W = zs
+        src.oz = src.oy = src.ox = 0
+        src.fz = src.fy = src.fx = 1
+        dl.src[0] = src
+        dl.B = self.B
+        dl.ID, dl.IH, dl.IW = zs
+        dl.KD, dl.KH, dl.KW = sp["zk"]
+        dl.PD, dl.PH, dl.PW = (k - 1 for k in sp["zk"])
+        dl.N = sp["C1p"]
+        dl.wpack = sp["wp_z_dgrad"].data_ptr()
+        dl.bias = None
+        dl.relu = 0
+        dl.accumulate = 0
+        dl.algo = 0
+        dl.workspace = None
+        dl.workspace_bytes = 0
+        dl.mask = self.buf[up_s.tensor].data_ptr()        # ReLU gate of the low-res tensor
+        dl.ld_mask = pad4(low_c)
+        dl.out = self.gbuf[up_s.tensor].data_ptr()
+        dl.ld_out = pad4(low_c)
+        _clx.call("clx_conv_fwd", ctypes.byref(dl), st)
+        return dskip
 
     # ------------------------------------------------------------- descriptors
     def _desc(self, layer: ConvLayer, dgrad=False):
@@ -318,6 +569,7 @@ class UNetPlan:
         d.ID, d.IH, d.IW = layer.in_shape
         d.KD, d.KH, d.KW = layer.kernel
         d.PD = d.PH = d.PW = 0
+        d.accumulate = 0
         d.algo = 0
         d.workspace = None
         d.workspace_bytes = 0
@@ -347,6 +599,7 @@ class UNetPlan:
         dd.N = layer.cin_pad
         dd.bias = None
         dd.relu = 0
+        dd.accumulate = 0
         dd.algo = 0
         dd.workspace = None
         dd.workspace_bytes = 0
@@ -386,6 +639,9 @@ class UNetPlan:
         st = _clx.stream_ptr(self.device)
         for layer in self.topo.convs:
             w = params[2 * layer.param_index]
+            if layer.name in self.subpixel:
+                self._sp_pack(layer, self.subpixel[layer.name], w, need_dgrad, st)
+                continue
             wv = w.detach().reshape(layer.cout, layer.cin, layer.taps)
             if not wv.is_contiguous():
                 wv = wv.contiguous()
@@ -410,7 +666,9 @@ class UNetPlan:
         _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
                   t.in_channels, npix_in, pad4(t.in_channels), st)
         for op in t.fwd_order:
-            if isinstance(op, ConvLayer):
+            if isinstance(op, ConvLayer) and op.name in self.subpixel:
+                self._sp_forward(op, self.subpixel[op.name], params[2 * op.param_index + 1], st)
+            elif isinstance(op, ConvLayer):
                 d = self._desc(op)
                 d.N = op.cout
                 d.wpack = self.wpack_fwd[op.name].data_ptr()
@@ -462,6 +720,12 @@ class UNetPlan:
                 continue  # handled when its consumer's data gradient is produced
             layer = op
             dy = self.gbuf[layer.out]
+            if layer.name in self.subpixel:
+                sp = self.subpixel[layer.name]
+                dskip = self._sp_backward(layer, sp, dy, grads[2 * layer.param_index],
+                                          grads[2 * layer.param_index + 1], st)
+                pending_skip[layer.sources[0].tensor] = (dskip, sp["C0p"], layer)
+                continue
             # ---- weight + bias gradient
             d = self._desc(layer)
             d.N = pad4(layer.cout)
@@ -510,7 +774,7 @@ class UNetPlan:
                           LD, LH, LW, *up_s.crop, _clx.ptr(self.buf[up_s.tensor]),
                           _clx.ptr(self.gbuf[up_s.tensor]), self.B, ushape[0], ushape[1], ushape[2],
                           pad4(uc), *up_s.factor, st)
-                pending_skip[skip_s.tensor] = (cat, layer)
+                pending_skip[skip_s.tensor] = (cat, layer.cin_pad, layer)
             else:
                 s = layer.sources[0]
                 if s.tensor in pool_by_out:
@@ -522,12 +786,12 @@ class UNetPlan:
                     dd.out = self.gbuf[pool.out].data_ptr()
                     dd.ld_out = pad4(pool.channels)
                     _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
-                    cat, rl = pending_skip.pop(pool.src)
+                    cat, ld_cat, rl = pending_skip.pop(pool.src)
                     skip_s = rl.sources[0]
                     D, H, W = pool.in_shape
                     SD, SH, SW = rl.in_shape
                     _clx.call("clx_maxpool_bwd", _clx.ptr(self.buf[pool.src]), _clx.ptr(self.buf[pool.out]),
-                              _clx.ptr(self.gbuf[pool.out]), _clx.ptr(cat), rl.cin_pad, SD, SH, SW,
+                              _clx.ptr(self.gbuf[pool.out]), _clx.ptr(cat), ld_cat, SD, SH, SW,
                               *skip_s.crop, _clx.ptr(self.gbuf[pool.src]), self.B, D, H, W,
                               pad4(pool.channels), *pool.factor, st)
                 else:

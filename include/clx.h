@@ -80,7 +80,7 @@ typedef struct clx_conv_desc {
   clx_src src[2];
   int B;
   int ID, IH, IW; /* logical input extent */
-  int KD, KH, KW; /* kernel extent, each 1 or 3 */
+  int KD, KH, KW; /* kernel extent, each 1, 2 or 3 */
   int PD, PH, PW; /* zero padding per side (0 for the valid forward conv) */
   int N;          /* output channels actually computed (<= ld_out) */
   const float* wpack; /* [N][KD*KH*KW][Ctot] packed weights (clx_pack_weights) */
@@ -90,6 +90,7 @@ typedef struct clx_conv_desc {
   int ld_mask;
   float* out;         /* [M][ld_out], M = B*OD*OH*OW, O = I + 2P - K + 1 */
   int ld_out;
+  int accumulate;     /* epilogue: out = act(conv + bias + out) (residual already in `out`) */
   int algo;           /* clx_conv_algo: 0 = direct implicit GEMM */
   void* workspace;    /* CLX_ALGO_WINOGRAD: clx_conv_workspace_bytes() bytes of scratch */
   size_t workspace_bytes;
@@ -148,6 +149,17 @@ int clx_planar_to_pixel(const float* planar, float* pixel, int B, int C,
                         long long n, int ld, clx_stream stream);
 int clx_pixel_to_planar(const float* pixel, float* planar, int B, int C,
                         long long n, int ld, clx_stream stream);
+
+/* Sub-pixel re-indexing used to run the convolution over a nearest-upsampled tensor on
+ * the LOW-resolution grid: with P = fz*fy*fx phases,
+ *   depth_to_space: hi[(b, z*fz+a, y*fy+bb, x*fx+c)][n] = lo[(b,z,y,x)][((a*fy+bb)*fx+c)*N + n]
+ *   space_to_depth: the inverse gather.
+ * lo: (B, D, H, W) grid, P*N channels (pixel stride ld_lo); hi: (B, D*fz, H*fy, W*fx) grid,
+ * N channels (pixel stride ld_hi). N % 4 == 0. */
+int clx_depth_to_space(const float* lo, int ld_lo, float* hi, int ld_hi, int B, int D, int H,
+                       int W, int N, int fz, int fy, int fx, clx_stream stream);
+int clx_space_to_depth(const float* hi, int ld_hi, float* lo, int ld_lo, int B, int D, int H,
+                       int W, int N, int fz, int fy, int fx, clx_stream stream);
 
 /* ------------------------------------------------------------------------ */
 /* Max pooling / upsample backward (funlib Downsample / Upsample,           */
