@@ -341,3 +341,34 @@ def test_peak_local_max_matches_skimage_golden():
     g = np.load(os.path.join(G, "g5_skimage.npz"))
     for k in ("peaks", "peaks3"):
         np.testing.assert_array_equal(peak_local_max(g[f"{k}/image"]), g[f"{k}/coords"])
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_subpixel_phase_weights_equal_upsample_then_conv(nd):
+    """Algebra behind the sub-pixel rewrite (plan._phase_weights / _fold_phase_grads), on the CPU:
+    conv3(nearest_upsample2(x), w) == depth_to_space(conv2(x, phase_weights(w))) and the fold is
+    the adjoint of the phase summation."""
+    from cellulus_amd.models.plan import UNetPlan
+
+    class L:
+        pass
+
+    torch.manual_seed(0)
+    f = (1, 2, 2) if nd == 2 else (2, 2, 2)
+    layer = L()
+    layer.cout = 5
+    layer.kernel = (1, 3, 3) if nd == 2 else (3, 3, 3)
+    C1, N = 3, 8
+    sp = dict(fac=f, P=f[0] * f[1] * f[2], N=N, C1=C1, zk=tuple(2 if ff == 2 else k for ff, k in zip(f, layer.kernel)))
+    plan = UNetPlan.__new__(UNetPlan)
+    w = torch.randn((5, C1) + layer.kernel)
+    weff = plan._phase_weights(layer, sp, w)
+    low = torch.randn(2, C1, *((1, 7, 8) if nd == 2 else (5, 6, 7)))
+    ref = torch.nn.functional.conv3d(torch.nn.functional.interpolate(low, scale_factor=f, mode="nearest"), w)
+    z = torch.nn.functional.conv3d(low, weff)
+    zs = z.shape[2:]
+    z = z.reshape(2, f[0], f[1], f[2], N, *zs)[:, :, :, :, :5]
+    out = z.permute(0, 4, 5, 1, 6, 2, 7, 3).reshape(2, 5, zs[0] * f[0], zs[1] * f[1], zs[2] * f[2])
+    assert (out - ref).abs().max().item() < 1e-4
+    g = torch.randn_like(weff)
+    assert abs((weff * g).sum().item() - (w * plan._fold_phase_grads(layer, sp, g)).sum().item()) < 1e-3

@@ -181,3 +181,41 @@ def test_winograd_equals_direct_path(device, monkeypatch):
     with torch.no_grad():
         wino = model(x).clone()
     assert (wino - direct).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["2d_small", "3d_small"])
+def test_plain_paths_without_subpixel_and_winograd(name, device, monkeypatch):
+    """The two-source gather convolution (upsample + crop + concat fused into the A gather),
+    upsample backward and the direct kernels stay covered when the rewrites are disabled."""
+    monkeypatch.setenv("CLX_SUBPIXEL", "0")
+    monkeypatch.setenv("CLX_WINOGRAD", "0")
+    oracle, model, raw = _make(name, device, seed=7)
+    with torch.no_grad():
+        ref = oracle(raw)
+        got = model(raw.to(device)).cpu()
+    plan = next(iter(model._plans.values()))
+    assert not plan.subpixel and not any(a["fwd"] for a in plan.algo.values())
+    assert (got - ref).abs().max().item() < 1e-4
+    oracle = oracle.double()
+    ref = oracle(raw.double())
+    torch.manual_seed(8)
+    dout = torch.randn_like(ref).float()
+    ref.backward(dout.double())
+    out = model(raw.to(device))
+    out.backward(dout.to(device))
+    for (n, po), (_, pm) in zip(oracle.named_parameters(), model.named_parameters()):
+        l2 = ((pm.grad.cpu().double() - po.grad).norm() / (po.grad.norm() + 1e-12)).item()
+        assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
+
+
+def test_subpixel_rewrite_is_selected_and_exact(device):
+    """Default plan: the conv over cat(skip, upsample(low)) runs on the low-res grid."""
+    oracle, model, raw = _make("3d_small", device, seed=9)
+    with torch.no_grad():
+        ref = oracle(raw)
+        got = model(raw.to(device)).cpu()
+    plan = next(iter(model._plans.values()))
+    assert len(plan.subpixel) == 1
+    sp = next(iter(plan.subpixel.values()))
+    assert sp["P"] == 8 and sp["zk"] == (2, 2, 2)
+    assert (got - ref).abs().max().item() < 1e-4
