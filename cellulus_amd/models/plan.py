@@ -360,43 +360,48 @@ class UNetPlan:
                     ztaps=zk[0] * zk[1] * zk[2], zname="Z%d" % level, level=level)
 
     @staticmethod
-    def _phase_matrix(a, device):
-        """(2 x 3): which of the 3 taps of an output pixel with parity `a` land on low-res row r."""
-        rows = [[1., 1., 0.], [0., 0., 1.]] if a == 0 else [[1., 0., 0.], [0., 1., 1.]]
-        return torch.tensor(rows, dtype=torch.float32, device=device)
+    def _phase_sum(w, axis, a):
+        """3 taps -> 2 taps along `axis` for output parity `a`: the taps that land on the same
+        low-res row are summed (a = 0: {0,1},{2};  a = 1: {0},{1,2}).  Elementwise torch ops."""
+        t0, t1, t2 = w.select(axis, 0), w.select(axis, 1), w.select(axis, 2)
+        pair = (t0 + t1, t2) if a == 0 else (t0, t1 + t2)
+        return torch.stack(pair, dim=axis)
+
+    @staticmethod
+    def _phase_spread(g, axis, a):
+        """adjoint of _phase_sum: 2 taps -> 3 taps."""
+        g0, g1 = g.select(axis, 0), g.select(axis, 1)
+        trip = (g0, g0, g1) if a == 0 else (g0, g1, g1)
+        return torch.stack(trip, dim=axis)
 
     def _phase_weights(self, layer, sp, w_up):
         """w_up (cout, C1, kd, kh, kw) -> phase-summed (P*N, C1, zkd, zkh, zkw); rows of padded
-        output channels are zero.  Tiny tensors: plain torch ops."""
+        output channels are zero.  Tiny tensors: plain elementwise torch ops."""
         f, N, cout = sp["fac"], sp["N"], layer.cout
-        dev = w_up.device
         out = w_up.new_zeros((sp["P"], N, sp["C1"]) + sp["zk"])
-        eye = [torch.eye(layer.kernel[d], dtype=torch.float32, device=dev) for d in range(3)]
         for a in range(f[0]):
             for b in range(f[1]):
                 for c in range(f[2]):
-                    Tz = self._phase_matrix(a, dev) if f[0] == 2 else eye[0]
-                    Ty = self._phase_matrix(b, dev) if f[1] == 2 else eye[1]
-                    Tx = self._phase_matrix(c, dev) if f[2] == 2 else eye[2]
-                    ph = (a * f[1] + b) * f[2] + c
-                    out[ph, :cout] = torch.einsum("rz,sy,tx,nczyx->ncrst", Tz, Ty, Tx, w_up)
+                    v = w_up
+                    for axis, (ff, par) in enumerate(zip(f, (a, b, c))):
+                        if ff == 2:
+                            v = self._phase_sum(v, 2 + axis, par)
+                    out[(a * f[1] + b) * f[2] + c, :cout] = v
         return out.reshape((sp["P"] * N, sp["C1"]) + sp["zk"])
 
     def _fold_phase_grads(self, layer, sp, dweff):
         """adjoint of _phase_weights: (P*N, C1, zk...) -> (cout, C1, kd, kh, kw)."""
         f, N, cout = sp["fac"], sp["N"], layer.cout
-        dev = dweff.device
         g = dweff.reshape((sp["P"], N, sp["C1"]) + sp["zk"])
-        eye = [torch.eye(layer.kernel[d], dtype=torch.float32, device=dev) for d in range(3)]
         out = dweff.new_zeros((cout, sp["C1"]) + tuple(layer.kernel))
         for a in range(f[0]):
             for b in range(f[1]):
                 for c in range(f[2]):
-                    Tz = self._phase_matrix(a, dev) if f[0] == 2 else eye[0]
-                    Ty = self._phase_matrix(b, dev) if f[1] == 2 else eye[1]
-                    Tx = self._phase_matrix(c, dev) if f[2] == 2 else eye[2]
-                    ph = (a * f[1] + b) * f[2] + c
-                    out += torch.einsum("rz,sy,tx,ncrst->nczyx", Tz, Ty, Tx, g[ph, :cout])
+                    v = g[(a * f[1] + b) * f[2] + c, :cout]
+                    for axis, (ff, par) in enumerate(zip(f, (a, b, c))):
+                        if ff == 2:
+                            v = self._phase_spread(v, 2 + axis, par)
+                    out += v
         return out
 
     def _sp_descs(self, layer, sp):
