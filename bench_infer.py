@@ -85,9 +85,8 @@ def infer_bench(device, reps=2, with_cpu=True):
     nfg = int((std < 0.5).sum())
 
     total = t_embed + t_detect + t_segment
-    flops = 2 * n_it * 1.0
     from bench import conv_flops
-    plan = next(iter(p for k, p in model._plans.items()))
+    plan = next(iter(model._plans.values()))
     fwd_flops, _, _ = conv_flops(plan.topo, 1)
     out = {
         "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 512x512, 1 GPU",

@@ -15,7 +15,7 @@ import ctypes
 import math
 import os
 from dataclasses import dataclass, field
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import torch
 
@@ -35,12 +35,6 @@ WINO_MIN_CHANNELS = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS", "128"))
 
 def winograd_enabled() -> bool:
     return os.environ.get("CLX_WINOGRAD", "1") != "0"
-
-
-def _tri(v):
-    """(z, y, x) triple from a 2- or 3-tuple (2-D data gets z = 1 / 0)."""
-    v = tuple(int(a) for a in v)
-    return v if len(v) == 3 else (None,) + v
 
 
 @dataclass
@@ -556,7 +550,7 @@ class UNetPlan:
         return dskip
 
     # ------------------------------------------------------------- descriptors
-    def _desc(self, layer: ConvLayer, dgrad=False):
+    def _desc(self, layer: ConvLayer):
         d = ClxConvDesc()
         d.nsrc = len(layer.sources)
         t = self.topo

@@ -48,10 +48,8 @@ def size_filter(segmentation, min_size, filter_non_connected=True, device=None):
     seg_d = torch.from_numpy(seg.astype(np.int32)).to(device)
     out, _ = label_on_device(seg_d, device_min)
     out = out.cpu().numpy().astype(np.int64)
-    if filter_non_connected and (0 in np.unique(np.ascontiguousarray(segmentation)) or True):
-        # the reference labels 0-valued pixels as background but counts the background region
-        # among `ids`: a background smaller than min_size is "removed" too — a no-op
-        pass
+    # (the reference also counts the background region among `ids`; zeroing a background smaller
+    #  than min_size is a no-op, so nothing to reproduce there)
     try:
         segmentation[out == 0] = 0
     except (ValueError, TypeError):
