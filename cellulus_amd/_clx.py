@@ -106,6 +106,7 @@ PROTOTYPES = {
     "clx_ms_iterate_grid": (_I, [_P, _I, _P, POINTER(c_double), _D, _I, _I, _I, _P, _I, _I, _D, _I,
                                  _P, _P, _P, _P]),
     "clx_ms_assign": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "clx_greedy_cluster": (_I, [_P, _P, _I, _I, _I, _D, _I, _D, _I, _P, _P, _P, _P]),
     "clx_cc_workspace": (c_size_t, [_LL]),
     "clx_cc_label_filter": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),
     "clx_edt_workspace": (c_size_t, [_LL]),

@@ -71,11 +71,6 @@ def detect(inference_config: InferenceConfig) -> None:
     ds_binary_segmentation = f["binary-segmentation"]
     ds_object_centered_embeddings = f["centered-embeddings"]
 
-    if inference_config.clustering == "greedy":
-        raise NotImplementedError(
-            "clustering='greedy' (cellulus/utils/greedy_cluster.py) is not part of the MI355X hot "
-            "path yet (SURVEY.md §8f-3); use clustering='meanshift'")
-
     lo, hi = parallel.shard_range(meta.num_samples)
     for sample in tqdm(range(lo, hi), disable=parallel.rank() != 0):
         embeddings = ds[sample]                                  # (D+1, *spatial) float64
@@ -96,6 +91,22 @@ def detect(inference_config: InferenceConfig) -> None:
             ck = masked[k]
             embeddings_centered[k] -= ck[ck != 0].mean()
         ds_object_centered_embeddings[sample] = embeddings_centered
+
+        if inference_config.clustering == "greedy":        # detect.py:162-192
+            from .utils.greedy_cluster import Cluster2d, Cluster3d
+
+            if nd == 3:
+                cluster = Cluster3d(width=embeddings.shape[-1], height=embeddings.shape[-2],
+                                    depth=embeddings.shape[-3], fg_mask=binary_mask, device=device)
+            else:
+                cluster = Cluster2d(width=embeddings.shape[-1], height=embeddings.shape[-2],
+                                    fg_mask=binary_mask, device=device)
+            for bandwidth_factor in range(inference_config.num_bandwidths):
+                segmentation = cluster.cluster(
+                    prediction=embeddings, bandwidth=inference_config.bandwidth / (2 ** bandwidth_factor),
+                    min_object_size=inference_config.min_size)
+                ds_detection[sample, bandwidth_factor, ...] = segmentation.numpy()
+            continue
 
         for bandwidth_factor in range(inference_config.num_bandwidths):
             bandwidth = inference_config.bandwidth / (2 ** bandwidth_factor)

@@ -274,6 +274,23 @@ int clx_ms_assign(const double* X, const int* index, int nfg,
                   clx_stream stream);
 
 /* ------------------------------------------------------------------------ */
+/* Greedy clustering (cellulus/utils/greedy_cluster.py:46-120,176-253)      */
+/* ------------------------------------------------------------------------ */
+/* emb: (ND, n) embeddings + coordinates of the n foreground pixels (raster order);
+ * seedmap: (n) normalised seediness; both float32 (is_f64 = 0, the reference's 2-D
+ * class) or float64 (is_f64 = 1, its 3-D class).  Runs the reference's whole
+ * seed loop on the device: pick the unclustered pixel of highest seediness (stop
+ * below seed_thresh), propose exp(-|e - c|^2 / (2 bw^2)) > 0.5, accept the
+ * proposal as instance `count` if it has more than min_object_size pixels of
+ * which more than half were unclustered, clear it, repeat while more than
+ * min_unclustered_sum pixels remain.  instance: (n) int32 ids (0 = none);
+ * result[0] = instances, result[1] = seeds tried.  workspace: 2*(n+16) bytes. */
+int clx_greedy_cluster(const void* emb, const void* seedmap, int n, int ND, int is_f64,
+                       double bandwidth, int min_object_size, double seed_thresh,
+                       int min_unclustered_sum, void* workspace, int* instance, int* result,
+                       clx_stream stream);
+
+/* ------------------------------------------------------------------------ */
 /* Connected components + size filter (cellulus/utils/misc.py:11-25 ->      */
 /* skimage.measure.label, full connectivity, background 0)                  */
 /* ------------------------------------------------------------------------ */

@@ -186,10 +186,39 @@ secondary_dataset_name = "detection"
                         infer_toml=np.frombuffer(infer_toml, dtype=np.uint8), reprs=np.array(reprs))
 
 
+
+
+def g6_greedy():
+    """Real reference Cluster2d / Cluster3d (device="cpu") on synthetic disc/ball embeddings."""
+    from cellulus.utils.greedy_cluster import Cluster2d, Cluster3d
+
+    out = {}
+    for name, shape, kw, bw in (("2d", (96, 128), dict(spacing=32, radius=9), 6.0),
+                                ("3d", (24, 40, 40), dict(spacing=20, radius=6), 4.0)):
+        nd = len(shape)
+        mean, std = IO.synthetic_embeddings(shape, seed=5, **kw)
+        rng = np.random.RandomState(2)
+        std = std + rng.uniform(0, 0.05, size=std.shape)        # distinct seed scores
+        pred = np.concatenate([mean[0], std[None]], 0)           # float64, like the zarr data
+        fg = std < 0.5
+        if nd == 2:
+            seg = Cluster2d(width=shape[1], height=shape[0], fg_mask=fg, device="cpu").cluster(
+                prediction=pred, bandwidth=bw, min_object_size=20)
+        else:
+            seg = Cluster3d(width=shape[2], height=shape[1], depth=shape[0], fg_mask=fg, device="cpu").cluster(
+                prediction=pred, bandwidth=bw, min_object_size=20)
+        out[f"{name}/pred"] = pred
+        out[f"{name}/fg"] = fg
+        out[f"{name}/seg"] = seg.numpy()
+        out[f"{name}/params"] = np.array([bw, 20])
+    np.savez_compressed(os.path.join(HERE, "g6_greedy.npz"), **out)
+
+
 if __name__ == "__main__":
     g1_oce()
     g2_gather()
     g3_unet()
     g4_mean_shift()
+    g6_greedy()
     g7_configs()
     print("golden vectors written to", HERE)

@@ -109,3 +109,13 @@ def test_edt_sq_matches_scipy_semantics():
     ones3 = np.ones((3, 4, 5), dtype=bool)
     zz, yy, xx = np.mgrid[0:3, 0:4, 0:5]
     np.testing.assert_array_equal(IO.edt_sq(ones3), (zz + 1) ** 2 + yy ** 2 + xx ** 2)
+
+
+@pytest.mark.parametrize("case", ["2d", "3d"])
+def test_greedy_cluster_oracle_matches_reference(case):
+    """numpy restatement == the real Cluster2d / Cluster3d of cellulus/utils/greedy_cluster.py."""
+    g = _load("g6_greedy.npz")
+    bw, ms = g[f"{case}/params"]
+    out = IO.greedy_cluster(g[f"{case}/pred"], g[f"{case}/fg"], float(bw), int(ms))
+    assert out.dtype == np.int16 and out.max() >= 4
+    np.testing.assert_array_equal(out, g[f"{case}/seg"])

@@ -324,3 +324,40 @@ def test_mean_shift_grid_kernel_equals_bruteforce(nd, device):
               (ctypes.c_double * nd)(*origin.tolist()), cell, nx, ny, nz, _clx.ptr(far), 1, nd, bw, 300,
               _clx.ptr(c2), _clx.ptr(n2), _clx.ptr(i2), st)
     assert int(n2.item()) == 0 and int(i2.item()) == 0
+
+
+# ------------------------------------------------------------------ greedy clustering
+@pytest.mark.parametrize("case", ["2d", "3d"])
+def test_greedy_cluster_matches_reference_golden(case, device):
+    from cellulus_amd.utils.greedy_cluster import Cluster2d, Cluster3d
+
+    g = np.load(os.path.join(G, "g6_greedy.npz"))
+    pred, fg = g[f"{case}/pred"], g[f"{case}/fg"]
+    bw, ms = g[f"{case}/params"]
+    if case == "2d":
+        c = Cluster2d(width=pred.shape[2], height=pred.shape[1], fg_mask=fg, device=device)
+    else:
+        c = Cluster3d(width=pred.shape[3], height=pred.shape[2], depth=pred.shape[1], fg_mask=fg, device=device)
+    seg = c.cluster(prediction=pred, bandwidth=float(bw), min_object_size=int(ms))
+    assert seg.dtype == torch.int16 and not seg.is_cuda
+    np.testing.assert_array_equal(seg.numpy(), g[f"{case}/seg"])
+
+
+def test_greedy_cluster_matches_oracle_fresh_and_degenerate(device):
+    from cellulus_amd.utils.greedy_cluster import Cluster2d
+
+    mean, std = IO.synthetic_embeddings((160, 144), spacing=40, radius=11, seed=12)
+    rng = np.random.RandomState(3)
+    std = std + rng.uniform(0, 0.05, size=std.shape)
+    pred = np.concatenate([mean[0], std[None]], 0)
+    fg = std < 0.5
+    for bw, ms in ((7.0, 30), (3.0, 5), (20.0, 30)):
+        ref = IO.greedy_cluster(pred, fg, bw, ms)
+        got = Cluster2d(width=144, height=160, fg_mask=fg, device=device).cluster(pred, bw, ms).numpy()
+        np.testing.assert_array_equal(got, ref)
+    # empty foreground -> all zeros, no launch
+    got = Cluster2d(width=144, height=160, fg_mask=np.zeros_like(fg), device=device).cluster(pred, 7.0, 30)
+    assert got.shape == (160, 144) and int(got.max()) == 0
+    # seed threshold above every score -> nothing clustered
+    got = Cluster2d(width=144, height=160, fg_mask=fg, device=device).cluster(pred, 7.0, 30, seed_thresh=2.0)
+    assert int(got.max()) == 0
