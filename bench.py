@@ -272,7 +272,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
 
+    if world > 1:
+        torch.distributed.barrier()
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
     crops_per_s = world * B * args.steps / dt
     plan = next(iter(model._plans.values()))
@@ -343,7 +347,9 @@ def main():
             out["infer"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample, seed=0)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -19,12 +19,17 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: CLX_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that),
+    # CLX_LOCAL_DEVICE pins every rank to one device index
+    backend = backend or os.environ.get("CLX_DIST_BACKEND")
+    if "CLX_LOCAL_DEVICE" in os.environ:
+        local_rank = int(os.environ["CLX_LOCAL_DEVICE"])
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
-        if backend == "nccl":
+        if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank

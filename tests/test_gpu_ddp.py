@@ -1,0 +1,113 @@
+"""GPU: data-parallel training = single process at the same global batch.
+Two ranks share the one GPU of the test box over gloo (RCCL refuses two ranks on one
+device; the collective semantics under test — SUM all-reduce of the flat gradient, no
+averaging, identical Adam step — are backend-independent), and bench.py's multi-rank
+control flow is exercised the same way."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RANK_SCRIPT = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from cellulus_amd import parallel
+from cellulus_amd.criterions import get_loss
+from cellulus_amd.models import get_model
+from cellulus_amd.optim import Adam
+from cellulus_amd.train import train_iteration
+rank, world, local = parallel.init_from_env()
+dev = torch.device("cuda", local)
+cfg = dict(in_channels=1, out_channels=2, num_fmaps=8, fmap_inc_factor=3, features_in_last_layer=16,
+           downsampling_factors=[[2, 2]], num_spatial_dims=2)
+torch.manual_seed(100 + rank)                       # different initial weights per rank ...
+model = get_model(**cfg).to(dev)
+flat, _ = model.flatten_parameters()
+parallel.broadcast_(flat, src=0)                    # ... made identical by the broadcast
+crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=2, device=dev)
+opt = Adam(model.parameters(), lr=1e-3, weight_decay=0.01)
+data = np.load(sys.argv[2])
+losses = []
+for step in range(2):
+    raw = torch.from_numpy(data[f"raw{step}"][rank * 2:(rank + 1) * 2])
+    a = torch.from_numpy(data[f"a{step}"][rank * 2:(rank + 1) * 2])
+    r = torch.from_numpy(data[f"r{step}"][rank * 2:(rank + 1) * 2])
+    loss, _, _ = train_iteration((raw, a, r), model, crit, opt, dev)
+    losses.append(loss)
+if rank == 0:
+    np.savez(sys.argv[3], flat=model._flat.cpu().numpy(), losses=np.array(losses))
+torch.distributed.barrier()
+"""
+
+
+def _launch(script, args, env_extra, nproc=2, port=29631):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nproc),
+               CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0", **env_extra)
+    procs = [subprocess.Popen([sys.executable, script, *args], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(nproc)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return outs
+
+
+def test_two_ranks_equal_one_process_at_global_batch(tmp_path, device):
+    from cellulus_amd.criterions import get_loss
+    from cellulus_amd.models import get_model
+    from cellulus_amd.optim import Adam
+    from cellulus_amd.train import train_iteration
+
+    rng = np.random.default_rng(0)
+    data = {}
+    for step in range(2):
+        data[f"raw{step}"] = rng.random((4, 1, 44, 52)).astype(np.float32)
+        a = np.repeat(rng.integers(3, 25, size=(4, 40, 2)), 5, axis=1)
+        data[f"a{step}"] = a.astype(np.int64)
+        data[f"r{step}"] = (a + rng.integers(1, 3, size=a.shape)).astype(np.int64)
+    np.savez(tmp_path / "data.npz", **data)
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    _launch(str(script), [ROOT, str(tmp_path / "data.npz"), str(tmp_path / "out.npz")], {})
+    got = np.load(tmp_path / "out.npz")
+
+    # single process, global batch 4, same initial weights (rank 0's seed)
+    cfg = dict(in_channels=1, out_channels=2, num_fmaps=8, fmap_inc_factor=3, features_in_last_layer=16,
+               downsampling_factors=[[2, 2]], num_spatial_dims=2)
+    torch.manual_seed(100)
+    model = get_model(**cfg).to(device)
+    crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=2, device=device)
+    opt = Adam(model.parameters(), lr=1e-3, weight_decay=0.01)
+    losses = []
+    for step in range(2):
+        batch = tuple(torch.from_numpy(data[f"{k}{step}"]) for k in ("raw", "a", "r"))
+        loss, _, _ = train_iteration(batch, model, crit, opt, device)
+        losses.append(loss)
+    # the loss is a SUM over pairs: the all-reduced loss equals the global-batch loss
+    np.testing.assert_allclose(got["losses"], losses, rtol=1e-5)
+    np.testing.assert_allclose(got["flat"], model._flat.cpu().numpy(), atol=2e-5)
+
+
+def test_bench_multi_rank_control_flow(tmp_path):
+    cmd_env = {}
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2",
+               CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0", **cmd_env)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                               "--warmup", "1", "--workload", "tiny"],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = [l for l in outs[0][0].strip().split("\n") if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 4
+    assert rec["value"] > 0 and "roofline" in rec and "cpu_baseline" not in rec
+    assert outs[1][0].strip() == ""          # only rank 0 prints
