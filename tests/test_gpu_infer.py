@@ -361,3 +361,49 @@ def test_greedy_cluster_matches_oracle_fresh_and_degenerate(device):
     # seed threshold above every score -> nothing clustered
     got = Cluster2d(width=144, height=160, fg_mask=fg, device=device).cluster(pred, 7.0, 30, seed_thresh=2.0)
     assert int(got.max()) == 0
+
+
+def test_detect_use_seeds_and_two_bandwidths_match_oracle(device, tmp_path, monkeypatch):
+    """detect() with use_seeds=True (gaussian-smoothed offset magnitude -> peak_local_max seeds,
+    centred embeddings, detect.py:126-144) and num_bandwidths=2, vs the oracle restatement."""
+    from scipy.ndimage import gaussian_filter
+
+    from cellulus_amd.configs import InferenceConfig
+    from cellulus_amd.detect import detect, peak_local_max
+    from cellulus_amd.utils import zarr_io
+
+    monkeypatch.chdir(tmp_path)
+    container = str(tmp_path / "d.zarr")
+    f = zarr_io.open(container)
+    shape = (96, 112)
+    embs = []
+    for s in range(2):
+        mean, std = IO.synthetic_embeddings(shape, spacing=32, radius=9, noise=0.2, seed=20 + s)
+        embs.append(np.concatenate([mean[0], std[None] + 0.001 * np.random.default_rng(s).random(shape)], 0))
+    f["raw"] = np.zeros((2, 1) + shape, dtype=np.float32)
+    f["raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    f["embeddings"] = np.stack(embs)
+    cfg = InferenceConfig(
+        dataset_config=dict(container_path=container, dataset_name="raw"),
+        detection_dataset_config=dict(container_path=container, dataset_name="detection",
+                                      secondary_dataset_name="embeddings"),
+        use_seeds=True, num_bandwidths=2, bandwidth=10.0, min_size=10, reduction_probability=0.5,
+        device="cuda:0")
+    np.random.seed(7)
+    detect(cfg)
+    det = zarr_io.open(container, "r")["detection"][...]
+    assert det.shape == (2, 2) + shape and det.dtype == np.uint16
+    np.random.seed(7)
+    for s in range(2):
+        e = embs[s]
+        thr = IO.threshold_otsu(e[-1])
+        mask = e[-1] < thr
+        centred = e.copy()
+        for k in range(2):
+            ck = (mask * e[k])
+            centred[k] -= ck[ck != 0].mean()
+        for b in range(2):
+            seeds = np.flip(peak_local_max(-gaussian_filter(np.linalg.norm(centred[:-1], axis=0), sigma=2)), 1)
+            ref = IO.mean_shift_segmentation(centred[np.newaxis, :2].copy(), centred[-1], 10.0 / 2 ** b, 10, 0.5,
+                                             thr, seeds)
+            np.testing.assert_array_equal(IO.label(det[s, b]), IO.label(ref))
