@@ -119,3 +119,40 @@ def test_greedy_cluster_oracle_matches_reference(case):
     out = IO.greedy_cluster(g[f"{case}/pred"], g[f"{case}/fg"], float(bw), int(ms))
     assert out.dtype == np.int16 and out.max() >= 4
     np.testing.assert_array_equal(out, g[f"{case}/seg"])
+
+
+STAGE_CASES = ["2d_f32", "2d_u8_seeds", "2d_f64", "3d_u16"]
+
+
+@pytest.mark.parametrize("case", STAGE_CASES)
+def test_stage_oracle_matches_reference_detect_and_segment(case):
+    """g8: the REAL cellulus.detect.detect / cellulus.segment.segment (cell + nucleus), run end to
+    end over an in-memory zarr stand-in (tests/golden/make_golden_stages.py), vs the oracle."""
+    g = _load("g8_stages.npz")
+    bw, ms, rp, seed, nb, use_seeds = g[f"{case}/params"]
+    emb, raw = g[f"{case}/embeddings"], g[f"{case}/raw"]
+    np.random.seed(int(seed))
+    for s in range(emb.shape[0]):
+        mask, centred, labels = IO.detect_sample(emb[s], bw, int(nb), int(ms), rp, None, bool(use_seeds))
+        np.testing.assert_array_equal(mask.astype(np.uint16), g[f"{case}/binary-segmentation"][s, 0])
+        np.testing.assert_array_equal(centred[..., ::4, ::4], g[f"{case}/centered-embeddings_s4"][s])
+        for b in range(int(nb)):
+            det = g[f"{case}/detection"][s, b]
+            np.testing.assert_array_equal(labels[b].astype(np.uint16), det)
+            for pp in ("cell", "nucleus"):
+                seg = IO.segment_sample(det.astype(np.int32), raw[s, 0], pp, 3, 6, int(ms))
+                np.testing.assert_array_equal(seg, g[f"{case}/segmentation_{pp}"][s, b])
+    # the nucleus refinement really changes something (holes filled, dim rim dropped)
+    assert not np.array_equal(g[f"{case}/segmentation_nucleus"], g[f"{case}/segmentation_cell"])
+
+
+def test_stage_oracle_reproduces_reference_error_with_seeds_and_two_bandwidths():
+    """use_seeds + num_bandwidths=2: the reference's in-place coordinate add leaks into the second
+    bandwidth (detect.py:116-118,142-144) and sklearn raises; the oracle keeps that behaviour."""
+    g = _load("g8_stages.npz")
+    case = "2d_seeds_bw2"
+    bw, ms, rp, seed, nb, use_seeds = g[f"{case}/params"]
+    assert str(g[f"{case}/detect_error"]).startswith("ValueError: No point was within bandwidth=5.0")
+    np.random.seed(int(seed))
+    with pytest.raises(ValueError, match="No point was within bandwidth=5.0"):
+        IO.detect_sample(g[f"{case}/embeddings"][0], bw, int(nb), int(ms), rp, None, bool(use_seeds))
