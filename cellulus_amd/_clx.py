@@ -114,6 +114,9 @@ PROTOTYPES = {
     "clx_grow_shrink": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "clx_minmax_f64": (_I, [_P, _LL, _P, _P]),
     "clx_histogram_f64": (_I, [_P, _LL, _P, _I, _P, _P]),
+    "clx_inst_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "clx_inst_histogram": (_I, [_P, _P, _I, _LL, _P, _I, _P, _I, _P, _P]),
+    "clx_inst_refine": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
 }
 
 _lib = None

@@ -108,6 +108,12 @@ def detect(inference_config: InferenceConfig) -> None:
                 ds_detection[sample, bandwidth_factor, ...] = segmentation.numpy()
             continue
 
+        # use_seeds keeps the reference's aliasing (detect.py:116-118,142-144): the first
+        # mean_shift_segmentation call adds the pixel coordinates to `embeddings_centered` IN PLACE
+        # (its input is a view), later bandwidths re-read that mutated array — magnitudes, seeds
+        # and inputs then carry offsets + coordinates, exactly as in the reference (where sklearn
+        # then usually raises "No point was within bandwidth ... of any seed").
+        centered_aliased = True
         for bandwidth_factor in range(inference_config.num_bandwidths):
             bandwidth = inference_config.bandwidth / (2 ** bandwidth_factor)
             if inference_config.use_seeds:
@@ -123,4 +129,7 @@ def detect(inference_config: InferenceConfig) -> None:
                 mean_d, sd_d = emb_d[:nd].contiguous().clone(), std_d
             labels, _ = mean_shift_on_device(
                 mean_d, sd_d, bandwidth, inference_config.reduction_probability, threshold, seeds)
+            if inference_config.use_seeds and centered_aliased:
+                embeddings_centered[:nd] = mean_d.cpu().numpy()      # offsets + coordinates
+                centered_aliased = False
             ds_detection[sample, bandwidth_factor, ...] = labels.cpu().numpy()

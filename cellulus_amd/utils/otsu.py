@@ -30,8 +30,12 @@ def histogram_on_device(x, nbins=256):
 
 
 def otsu_from_histogram(counts, bin_edges):
+    return otsu_from_centers(counts, (bin_edges[:-1] + bin_edges[1:]) / 2.0)
+
+
+def otsu_from_centers(counts, bin_centers):
+    """skimage filters/thresholding.py:333-350 on a (counts, bin_centers) histogram."""
     counts = counts.astype(float)
-    bin_centers = (bin_edges[:-1] + bin_edges[1:]) / 2.0
     weight1 = np.cumsum(counts)
     weight2 = np.cumsum(counts[::-1])[::-1]
     with np.errstate(divide="ignore", invalid="ignore"):

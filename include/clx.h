@@ -332,6 +332,39 @@ int clx_minmax_f64(const double* x, long long n, double* minmax, clx_stream stre
 int clx_histogram_f64(const double* x, long long n, const double* edges,
                       int nbins, long long* counts, clx_stream stream);
 
+/* ------------------------------------------------------------------------ */
+/* "nucleus" post-processing (cellulus/segment.py:52-101): per-instance Otsu */
+/* of the raw intensities + scipy.ndimage.binary_fill_holes in the bbox      */
+/* ------------------------------------------------------------------------ */
+typedef enum { CLX_RAW_F32 = 0, CLX_RAW_F64 = 1, CLX_RAW_I32 = 2 } clx_raw_type;
+/* For every id in [1, nid): bbox[id] = {zmin,ymin,xmin,zmax,ymax,xmax} (max < 0:
+ * id absent) and vkey[id] = {min,max} of raw over seg==id as order-preserving
+ * keys (f32: u32 bits, sign-flipped, in the low word; f64: same on 64 bits;
+ * i32: v ^ 0x80000000).  Replaces np.unique/np.where/min/max, segment.py:58-79. */
+int clx_inst_stats(const int32_t* seg, const void* raw, int raw_type, int Z, int Y,
+                   int X, int nid, int32_t* bbox, unsigned long long* vkey,
+                   clx_stream stream);
+/* All instance histograms of skimage.filters.threshold_otsu(raw[seg==id])
+ * (segment.py:80-81) in one pass.  slot[id] = row of `counts` (or -1: skip).
+ * Float raw: edges_or_min = [rows][nbins+1] np.linspace edges in the raw dtype,
+ * numpy.histogram's index arithmetic is followed in that dtype.  Integer raw:
+ * edges_or_min = int32[rows] minimum per row, one bin per value.
+ * counts: u32 [rows][nbins], zeroed by the caller. */
+int clx_inst_histogram(const int32_t* seg, const void* raw, int raw_type,
+                       long long npix, const int32_t* slot, int nid,
+                       const void* edges_or_min, int nbins, uint32_t* counts,
+                       clx_stream stream);
+/* For instance k (id ids[k], ascending): mask = (seg==id) & (raw > thr[k]);
+ * binary_fill_holes inside bbox[id] (face connectivity, background connected to
+ * the box border stays background; ndim 2 or 3 says whether the z faces of the
+ * box are borders); out[p] = max(out[p], id) on the filled mask — `out` zeroed
+ * by the caller (segment.py:82-101).  scratch: one byte per bounding-box voxel,
+ * instance k at scratch_off[k]. */
+int clx_inst_refine(const int32_t* seg, const void* raw, int raw_type, int ndim,
+                    int Z, int Y, int X, const int32_t* ids, const int32_t* bbox,
+                    const double* thr, const long long* scratch_off,
+                    unsigned char* scratch, int n, int32_t* out, clx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -363,47 +363,108 @@ def test_greedy_cluster_matches_oracle_fresh_and_degenerate(device):
     assert int(got.max()) == 0
 
 
-def test_detect_use_seeds_and_two_bandwidths_match_oracle(device, tmp_path, monkeypatch):
-    """detect() with use_seeds=True (gaussian-smoothed offset magnitude -> peak_local_max seeds,
-    centred embeddings, detect.py:126-144) and num_bandwidths=2, vs the oracle restatement."""
-    from scipy.ndimage import gaussian_filter
+STAGE_CASES = ["2d_f32", "2d_u8_seeds", "2d_f64", "3d_u16"]
 
-    from cellulus_amd.configs import InferenceConfig
-    from cellulus_amd.detect import detect, peak_local_max
+
+def _stage_container(tmp_path, g, case):
     from cellulus_amd.utils import zarr_io
 
-    monkeypatch.chdir(tmp_path)
-    container = str(tmp_path / "d.zarr")
+    container = str(tmp_path / f"{case}.zarr")
     f = zarr_io.open(container)
-    shape = (96, 112)
-    embs = []
-    for s in range(2):
-        mean, std = IO.synthetic_embeddings(shape, spacing=32, radius=9, noise=0.2, seed=20 + s)
-        embs.append(np.concatenate([mean[0], std[None] + 0.001 * np.random.default_rng(s).random(shape)], 0))
-    f["raw"] = np.zeros((2, 1) + shape, dtype=np.float32)
-    f["raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
-    f["embeddings"] = np.stack(embs)
-    cfg = InferenceConfig(
+    raw = g[f"{case}/raw"]
+    f["raw"] = raw
+    f["raw"].attrs["axis_names"] = ["s", "c"] + ["z", "y", "x"][-(raw.ndim - 2):]
+    f["embeddings"] = g[f"{case}/embeddings"]
+    return container
+
+
+def _stage_config(container, g, case, **kw):
+    from cellulus_amd.configs import InferenceConfig
+
+    bw, ms, rp, _seed, nb, use_seeds = g[f"{case}/params"]
+    return InferenceConfig(
         dataset_config=dict(container_path=container, dataset_name="raw"),
         detection_dataset_config=dict(container_path=container, dataset_name="detection",
                                       secondary_dataset_name="embeddings"),
-        use_seeds=True, num_bandwidths=2, bandwidth=10.0, min_size=10, reduction_probability=0.5,
-        device="cuda:0")
-    np.random.seed(7)
-    detect(cfg)
-    det = zarr_io.open(container, "r")["detection"][...]
-    assert det.shape == (2, 2) + shape and det.dtype == np.uint16
-    np.random.seed(7)
-    for s in range(2):
-        e = embs[s]
-        thr = IO.threshold_otsu(e[-1])
-        mask = e[-1] < thr
-        centred = e.copy()
-        for k in range(2):
-            ck = (mask * e[k])
-            centred[k] -= ck[ck != 0].mean()
-        for b in range(2):
-            seeds = np.flip(peak_local_max(-gaussian_filter(np.linalg.norm(centred[:-1], axis=0), sigma=2)), 1)
-            ref = IO.mean_shift_segmentation(centred[np.newaxis, :2].copy(), centred[-1], 10.0 / 2 ** b, 10, 0.5,
-                                             thr, seeds)
-            np.testing.assert_array_equal(IO.label(det[s, b]), IO.label(ref))
+        segmentation_dataset_config=dict(container_path=container, dataset_name="segmentation",
+                                         secondary_dataset_name=kw.pop("segment_from", "detection")),
+        use_seeds=bool(use_seeds), num_bandwidths=int(nb), bandwidth=float(bw), min_size=int(ms),
+        reduction_probability=float(rp), grow_distance=3, shrink_distance=6, device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("case", STAGE_CASES)
+def test_detect_and_segment_stages_match_real_reference(device, tmp_path, monkeypatch, case):
+    """g8: outputs of the REAL cellulus detect() / segment() (tests/golden/make_golden_stages.py)
+    vs the HIP stages on the same zarr inputs: Otsu mask, centred embeddings, mean-shift
+    detection (2-D/3-D, with seeds, two bandwidths), then cell and nucleus post-processing
+    (raw f32 / f64 / u8 / u16) + size filter.  Integer outputs bit-exact."""
+    from cellulus_amd.detect import detect
+    from cellulus_amd.segment import segment
+    from cellulus_amd.utils import zarr_io
+
+    g = np.load(os.path.join(G, "g8_stages.npz"))
+    monkeypatch.chdir(tmp_path)
+    container = _stage_container(tmp_path, g, case)
+    np.random.seed(int(g[f"{case}/params"][3]))
+    detect(_stage_config(container, g, case))
+    f = zarr_io.open(container, "r")
+    np.testing.assert_array_equal(f["binary-segmentation"][...], g[f"{case}/binary-segmentation"])
+    np.testing.assert_array_equal(f["centered-embeddings"][...][..., ::4, ::4], g[f"{case}/centered-embeddings_s4"])
+    det, ref = f["detection"][...], g[f"{case}/detection"]
+    assert det.dtype == np.uint16 and det.shape == ref.shape
+    for s in range(det.shape[0]):
+        for b in range(det.shape[1]):          # cluster numbering = sort of near-tied centres
+            np.testing.assert_array_equal(det[s, b] > 0, ref[s, b] > 0)
+            np.testing.assert_array_equal(IO.label(det[s, b].astype(np.int32)), IO.label(ref[s, b].astype(np.int32)))
+    np.testing.assert_array_equal(det, ref)    # ... and on these inputs the numbering agrees too
+    for pp in ("cell", "nucleus"):
+        # post-process the REFERENCE's detection so that this half does not depend on the first
+        w = zarr_io.open(container)
+        w["detection_ref"] = ref
+        segment(_stage_config(container, g, case, post_processing=pp, segment_from="detection_ref"))
+        seg = zarr_io.open(container, "r")["segmentation"][...]
+        assert seg.dtype == np.uint16
+        np.testing.assert_array_equal(seg, g[f"{case}/segmentation_{pp}"])
+
+
+def test_detect_seeds_with_two_bandwidths_raises_like_reference(device, tmp_path, monkeypatch):
+    """The reference re-reads the centred embeddings after the first bandwidth added pixel
+    coordinates to them in place (detect.py:116-118,142-144); the second bandwidth then finds no
+    point near any seed and sklearn raises ValueError.  Same inputs, same error here."""
+    from cellulus_amd.detect import detect
+
+    g = np.load(os.path.join(G, "g8_stages.npz"))
+    case = "2d_seeds_bw2"
+    assert str(g[f"{case}/detect_error"]).startswith("ValueError: No point was within bandwidth=5.0")
+    monkeypatch.chdir(tmp_path)
+    container = _stage_container(tmp_path, g, case)
+    np.random.seed(int(g[f"{case}/params"][3]))
+    with pytest.raises(ValueError, match="No point was within bandwidth=5.0"):
+        detect(_stage_config(container, g, case))
+    from cellulus_amd.utils import zarr_io
+    np.testing.assert_array_equal(zarr_io.open(container, "r")["detection"][...], g[f"{case}/detection_partial"])
+
+
+def test_nucleus_refine_on_device_matches_oracle_random(device):
+    """Denser parity sweep for csrc/nucleus.hip: random label images with nested / touching
+    instances, holes, constant instances; raw in every supported dtype, 2-D and 3-D."""
+    from cellulus_amd.segment import _raw_to_device, nucleus_refine_on_device
+
+    rng = np.random.default_rng(5)
+    for shape in ((70, 90), (12, 40, 36)):
+        for dtype in (np.float32, np.float64, np.uint8, np.uint16, np.int16):
+            blocks = rng.integers(0, 9, size=tuple(-(-s // 10) for s in shape))
+            seg = np.kron(blocks, np.ones((10,) * len(shape), dtype=np.int64))[tuple(slice(0, s) for s in shape)]
+            seg[rng.random(shape) < 0.05] = 0
+            seg = seg.astype(np.int32)
+            raw = rng.random(shape)
+            raw[rng.random(shape) < 0.3] *= 0.2                    # dark specks -> holes
+            raw[seg == 3] = 0.5                                    # a constant instance
+            if np.issubdtype(dtype, np.integer):
+                raw = (raw * 200).astype(dtype) - (50 if dtype == np.int16 else 0)
+            else:
+                raw = raw.astype(dtype)
+            ref = IO.nucleus_refine(seg, raw)
+            raw_d, rt = _raw_to_device(raw, device)
+            out = nucleus_refine_on_device(torch.from_numpy(seg).to(device), raw_d, rt)
+            np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"{shape} {dtype}")
