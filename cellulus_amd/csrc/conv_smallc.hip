@@ -4,7 +4,8 @@
 // stage the gathered input patch [pixels][taps*4] and the packed weights in LDS and keep
 // the per-thread work on 16-byte channel runs, so HBM traffic is one pass over [M][N].
 //
-// Selected by clx_conv_fwd / clx_conv_wgrad when nsrc == 1, C == 4, no upsampling.
+// Selected by clx_conv_fwd / clx_conv_wgrad when nsrc == 1, C == 4, no upsampling, no
+// accumulate / mask epilogue (those go to the implicit-GEMM kernel whatever the width).
 // Replaces nn.Conv{2,3}d(in_channels -> num_fmaps, 3) of l_conv.0.conv_pass.0
 // (cellulus/models/unet.py:24-51) and its weight/bias gradient.
 #include "clx_common.h"
@@ -209,7 +210,7 @@ int pick_ng(int N) {
 
 // true if the small-channel path applies to this descriptor
 bool clx_smallc_applicable(const clx_conv_desc* d) {
-  if (d->nsrc != 1) return false;
+  if (d->nsrc != 1 || d->accumulate) return false;   // the kernels overwrite their output
   const clx_src& S = d->src[0];
   if (S.C != 4 || S.fz != 1 || S.fy != 1 || S.fx != 1) return false;
   const int taps = d->KD * d->KH * d->KW;

@@ -214,7 +214,60 @@ def g6_greedy():
     np.savez_compressed(os.path.join(HERE, "g6_greedy.npz"), **out)
 
 
+def g9_train_iteration():
+    """REAL cellulus.train.train_iteration (train.py:160-180) with the real get_model / get_loss
+    and the optimizer exactly as train.py:80-82 builds it, four iterations on fresh batches.
+    `zarr` and `gunpowder` (imported at module level by cellulus.train / cellulus.datasets,
+    never touched by train_iteration) are empty stub modules; the backbone is the stub above."""
+    for name in ("zarr", "gunpowder"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from cellulus.models import get_model
+    from cellulus.train import train_iteration
+
+    out = {}
+    lr = 1e-3
+    for nd, spatial, npairs in ((2, (36, 40), 60), (3, (20, 20, 24), 40)):
+        torch.manual_seed(200 + nd)
+        model = get_model(in_channels=1, out_channels=nd, num_fmaps=4, fmap_inc_factor=2,
+                          features_in_last_layer=8, downsampling_factors=[(2,) * nd], num_spatial_dims=nd)
+        for _n, layer in model.named_modules():                       # train.py:65-68
+            if isinstance(layer, torch.nn.modules.conv._ConvNd):
+                torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+        criterion = get_loss(regularizer_weight=1e-5, temperature=10.0, density=0.1,
+                             num_spatial_dims=nd, device=torch.device("cpu"))
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.01)   # train.py:80-82
+        for k, v in model.state_dict().items():
+            out[f"w{nd}/init/{k}"] = v.numpy().copy()
+        out_shape = tuple(s - 16 for s in spatial)
+        rng = np.random.RandomState(300 + nd)
+        losses = []
+        for it in range(4):
+            raw = torch.from_numpy(rng.rand(2, 1, *spatial).astype(np.float32))
+            # coordinates (x, y[, z]) order, column 0 indexes the last axis (unet.py:113-118)
+            hi = np.array(out_shape[::-1])
+            anchor = torch.from_numpy(rng.randint(0, hi, size=(2, npairs, nd)).astype(np.int64))
+            reference = torch.from_numpy(rng.randint(0, hi, size=(2, npairs, nd)).astype(np.int64))
+            loss, oce, offsets = train_iteration((raw, anchor, reference), model, criterion, optimizer,
+                                                 torch.device("cpu"))
+            losses.append([loss, oce])
+            out[f"b{nd}/{it}/raw"] = raw.numpy()
+            out[f"b{nd}/{it}/anchor"] = anchor.numpy()
+            out[f"b{nd}/{it}/reference"] = reference.numpy()
+            out[f"b{nd}/{it}/offsets"] = offsets.detach().numpy().copy()
+        out[f"losses{nd}"] = np.array(losses, dtype=np.float64)
+        for k, v in model.state_dict().items():
+            out[f"w{nd}/final/{k}"] = v.numpy().copy()
+    out["lr"] = np.array(lr)
+    np.savez_compressed(os.path.join(HERE, "g9_train_iteration.npz"), **out)
+
+
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        for fn in only:
+            globals()[fn]()
+        sys.exit(0)
+    g9_train_iteration()
     g1_oce()
     g2_gather()
     g3_unet()

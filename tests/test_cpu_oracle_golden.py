@@ -156,3 +156,23 @@ def test_stage_oracle_reproduces_reference_error_with_seeds_and_two_bandwidths()
     np.random.seed(int(seed))
     with pytest.raises(ValueError, match="No point was within bandwidth=5.0"):
         IO.detect_sample(g[f"{case}/embeddings"][0], bw, int(nb), int(ms), rp, None, bool(use_seeds))
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_train_step_oracle_matches_reference_train_iteration(nd):
+    """g9: the REAL cellulus.train.train_iteration + get_model + get_loss + Adam(weight_decay=0.01)
+    (train.py:80-82,160-180), four iterations, vs the oracle's train_step."""
+    g = _load("g9_train_iteration.npz")
+    model = UO.OracleUNetModel(in_channels=1, out_channels=nd, num_fmaps=4, fmap_inc_factor=2,
+                               features_in_last_layer=8, downsampling_factors=[(2,) * nd], num_spatial_dims=nd)
+    pre = f"w{nd}/init/"
+    model.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}, strict=True)
+    opt = torch.optim.Adam(model.parameters(), lr=float(g["lr"]), weight_decay=0.01)
+    for it in range(4):
+        b = [torch.from_numpy(g[f"b{nd}/{it}/{k}"]) for k in ("raw", "anchor", "reference")]
+        loss, oce, offsets = UO.train_step(model, opt, *b, 10.0, 1e-5)
+        np.testing.assert_allclose([loss, oce], g[f"losses{nd}"][it], rtol=1e-6)
+        np.testing.assert_allclose(offsets.detach().numpy(), g[f"b{nd}/{it}/offsets"], atol=1e-6)
+    post = f"w{nd}/final/"
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g[post + k], atol=1e-6, err_msg=k)

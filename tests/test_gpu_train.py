@@ -184,3 +184,34 @@ def test_autograd_path_equals_fused_path(device):
     assert abs(loss.item() - l1) < 1e-4 * max(1.0, abs(l1))
     for p1, p2 in zip(m1.parameters(), m2.parameters()):
         assert torch.allclose(p1, p2, atol=1e-5)
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_train_iteration_matches_real_reference_golden(nd, device):
+    """g9: four iterations of the REAL cellulus.train.train_iteration (tests/golden/make_golden.py)
+    vs the fused HIP step: losses, offsets and the parameters after four Adam updates."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_train_iteration.npz"))
+    model = get_model(in_channels=1, out_channels=nd, num_fmaps=4, fmap_inc_factor=2, features_in_last_layer=8,
+                      downsampling_factors=[[2] * nd], num_spatial_dims=nd)
+    pre = f"w{nd}/init/"
+    model.load_state_dict({k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}, strict=True)
+    model = model.to(device)
+    crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=nd, device=device)
+    opt = Adam(model.parameters(), lr=float(g["lr"]), weight_decay=0.01)
+    for it in range(4):
+        b = tuple(torch.from_numpy(g[f"b{nd}/{it}/{k}"]) for k in ("raw", "anchor", "reference"))
+        loss, oce, offsets = train_iteration(b, model, crit, opt, device)
+        ref_loss, ref_oce = g[f"losses{nd}"][it]
+        assert abs(loss - ref_loss) < 1e-4 * max(1.0, abs(ref_loss)), (it, loss, ref_loss)
+        assert abs(oce - ref_oce) < 1e-4 * max(1.0, abs(ref_oce))
+        assert np.abs(offsets.cpu().numpy() - g[f"b{nd}/{it}/offsets"]).max() < 1e-4     # north_star tolerance
+    post = f"w{nd}/final/"
+    moved = 0.0
+    for k, v in model.state_dict().items():
+        ref = g[post + k]
+        moved = max(moved, float(np.abs(ref - g[pre + k]).max()))
+        # parameters travel ~4 * lr = 4e-3; agree to 1 % of that
+        assert np.abs(v.cpu().numpy() - ref).max() < 4e-5, k
+    assert moved > 1e-3

@@ -30,6 +30,13 @@ CONFIGS = {
     "2d_two_levels": dict(cfg=dict(in_channels=1, out_channels=2, num_fmaps=8, fmap_inc_factor=2,
                                    features_in_last_layer=12, downsampling_factors=[[2, 2], [3, 3]],
                                    num_spatial_dims=2), spatial=(108, 108), batch=1),
+    # num_fmaps=4: the skip half of the sub-pixel right-path convolution is a 4-channel source
+    "2d_four_fmaps": dict(cfg=dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=2,
+                                   features_in_last_layer=8, downsampling_factors=[[2, 2]],
+                                   num_spatial_dims=2), spatial=(36, 40), batch=2),
+    "3d_four_fmaps": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=4, fmap_inc_factor=2,
+                                   features_in_last_layer=8, downsampling_factors=[[2, 2, 2]],
+                                   num_spatial_dims=3), spatial=(20, 20, 24), batch=2),
     "3d_small": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=8, fmap_inc_factor=2,
                               features_in_last_layer=16, downsampling_factors=[[2, 2, 2]],
                               num_spatial_dims=3), spatial=(28, 24, 32), batch=2),
