@@ -1,0 +1,824 @@
+// Experiment: f32 GEMM C[M][N] = A[M][K] * B[N][K]^T on the bf16 matrix cores by splitting every
+// f32 operand exactly into three bf16 pieces (8+8+8 mantissa bits, truncation split) and keeping
+// the six products a_i*b_j with i+j <= 2 (dropped terms <= 2^-24 relative — the size of one f32
+// rounding).  Products are exact in the f32 accumulator.  Standalone microbenchmark.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/exp/gemm_split.hip -o tools/exp/gemm_split
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int RS = 40;                    // LDS row stride in bf16 (80 B): 16 consecutive rows hit 64 distinct banks
+constexpr int PIECE = BM * RS;            // bf16 elements per piece plane
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+// x = h0 + h1 + h2 exactly, each h_i with <= 8 significant bits (top half of an f32 word)
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  unsigned int u[4], a1[4], a2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u[e] = __float_as_uint(v[e]);
+    const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
+    a1[e] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(a1[e] & 0xffff0000u);
+    a2[e] = __float_as_uint(r2);
+  }
+  p0[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+  p0[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+  p1[0] = __builtin_amdgcn_perm(a1[1], a1[0], 0x07060302u);
+  p1[1] = __builtin_amdgcn_perm(a1[3], a1[2], 0x07060302u);
+  p2[0] = __builtin_amdgcn_perm(a2[1], a2[0], 0x07060302u);
+  p2[1] = __builtin_amdgcn_perm(a2[3], a2[2], 0x07060302u);
+}
+
+// B (weights) split once into three bf16 planes [3][N][K]
+__global__ void presplit_kernel(const float* __restrict__ B, unsigned short* __restrict__ Bp, long long n) {
+  for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+    u32x2 p0, p1, p2;
+    split4(*reinterpret_cast<const f32x4*>(B + i), p0, p1, p2);
+    *reinterpret_cast<u32x2*>(Bp + i) = p0;
+    *reinterpret_cast<u32x2*>(Bp + n + i) = p1;
+    *reinterpret_cast<u32x2*>(Bp + 2 * n + i) = p2;
+  }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_v1_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Bp,
+                                                         float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * PIECE];
+  unsigned short* As = lds;
+  unsigned short* Bs = lds + 3 * PIECE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int lr = t >> 3, lk = (t & 7) * 4;
+  const float* ap = A + (size_t)(m0 + lr) * K + lk;
+  // B pieces: thread loads 16 B (8 k) of rows br, br + 64 for each piece
+  const int br = t >> 2, bk = (t & 3) * 8;
+  const size_t plane = (size_t)N * K;
+  const unsigned short* bp = Bp + (size_t)(n0 + br) * K + bk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ga[2][4];
+  u32x4 gb[2][6];
+  const int nk = K / BK;
+  auto issue = [&](int slot, int kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ga[slot][i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + kc * BK);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      gb[slot][2 * p] = *reinterpret_cast<const u32x4*>(bp + p * plane + (size_t)kc * BK);
+      gb[slot][2 * p + 1] = *reinterpret_cast<const u32x4*>(bp + p * plane + (size_t)64 * K + (size_t)kc * BK);
+    }
+  };
+  issue(0, 0);
+  if (nk > 1) issue(1, 1);
+  const int fr = lane & 31, fh = lane >> 5;
+  auto body = [&](int slot, int kc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 p0, p1, p2;
+      split4(ga[slot][i], p0, p1, p2);
+      const int off = (lr + 32 * i) * RS + lk;
+      *reinterpret_cast<u32x2*>(As + off) = p0;
+      *reinterpret_cast<u32x2*>(As + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(As + 2 * PIECE + off) = p2;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      *reinterpret_cast<u32x4*>(Bs + p * PIECE + br * RS + bk) = gb[slot][2 * p];
+      *reinterpret_cast<u32x4*>(Bs + p * PIECE + (br + 64) * RS + bk) = gb[slot][2 * p + 1];
+    }
+    __syncthreads();
+    if (kc + 2 < nk) issue(slot, kc + 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PIECE + (wm * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+          b[i][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PIECE + (wn * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (NPROD >= 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  };
+  for (int kc = 0; kc < nk; kc += 2) {
+    body(0, kc);
+    if (kc + 1 < nk) body(1, kc + 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+// ---- v2: 256x128 block tile, one wave per SIMD (wave tile 128x64), LDS double-buffered with an XOR
+// swizzle instead of padding (2 x 72 KB), one barrier per K chunk; the next chunk's split + LDS
+// writes and the global loads of the chunk after it sit in the same instruction stream as the MFMAs.
+constexpr int V2_BM = 256, V2_BN = 128;
+constexpr int V2_APIECE = V2_BM * 32, V2_BPIECE = V2_BN * 32;     // bf16 elements per piece plane (64-B rows)
+constexpr int V2_STAGE = 3 * (V2_APIECE + V2_BPIECE);             // bf16 elements per stage (72 KB)
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 32 + ((slot ^ ((row >> 2) & 3)) << 3); }
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 1) void gemm_v2_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Bp,
+                                                         float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds2[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / V2_BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;      // same-XCD blocks share A rows
+  const int m0 = (bid / nbn) * V2_BM, n0 = (bid % nbn) * V2_BN;
+  const int lr = t >> 3, lq = t & 7;                 // A: rows lr + 32 i, k = 4 lq .. 4 lq + 3
+  const float* ap = A + (size_t)(m0 + lr) * K + lq * 4;
+  const int br = t >> 2, bs = t & 3;                 // B pieces: rows br, br + 64, 16-B slot bs
+  const size_t plane = (size_t)N * K;
+  const unsigned short* bp = Bp + (size_t)(n0 + br) * K + bs * 8;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ga[8];
+  u32x4 gb[6];
+  const int nk = K / BK;
+  auto issue = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + kc * BK);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      gb[2 * p] = *reinterpret_cast<const u32x4*>(bp + p * plane + (size_t)kc * BK);
+      gb[2 * p + 1] = *reinterpret_cast<const u32x4*>(bp + p * plane + (size_t)64 * K + (size_t)kc * BK);
+    }
+  };
+  auto stage_write = [&](int st) {
+    unsigned short* As = lds2 + st * V2_STAGE;
+    unsigned short* Bs = As + 3 * V2_APIECE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u32x2 p0, p1, p2;
+      split4(ga[i], p0, p1, p2);
+      const int off = swz(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+      *reinterpret_cast<u32x2*>(As + off) = p0;
+      *reinterpret_cast<u32x2*>(As + V2_APIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(As + 2 * V2_APIECE + off) = p2;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      *reinterpret_cast<u32x4*>(Bs + p * V2_BPIECE + swz(br, bs)) = gb[2 * p];
+      *reinterpret_cast<u32x4*>(Bs + p * V2_BPIECE + swz(br + 64, bs)) = gb[2 * p + 1];
+    }
+  };
+  const int fr = lane & 31, fh = lane >> 5;
+  auto mfma_step = [&](int st, int ks) {
+    const unsigned short* As = lds2 + st * V2_STAGE;
+    const unsigned short* Bs = As + 3 * V2_APIECE;
+    bf16x8 a[4][3], b[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * V2_APIECE + swz(wm * 128 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * V2_BPIECE + swz(wn * 64 + j * 32 + fr, ks * 2 + fh));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        if (NPROD >= 6) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+        }
+        if (NPROD >= 3) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  issue(0);
+  stage_write(0);
+  if (nk > 1) issue(1);
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const int st = kc & 1;
+    mfma_step(st, 0);
+    if (kc + 1 < nk) stage_write(st ^ 1);
+    if (kc + 2 < nk) issue(kc + 2);
+    mfma_step(st, 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 1) void gemm_v3_kernel(const float* __restrict__ A, const unsigned short* __restrict__ Bp,
+                                                         float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds2[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / V2_BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;      // same-XCD blocks share A rows
+  const int m0 = (bid / nbn) * V2_BM, n0 = (bid % nbn) * V2_BN;
+  const int lr = t >> 3, lq = t & 7;                 // A: rows lr + 32 i, k = 4 lq .. 4 lq + 3
+  const float* ap = A + (size_t)(m0 + lr) * K + lq * 4;
+  const int br = t >> 2, bs = t & 3;                 // B pieces: rows br, br + 64, 16-B slot bs
+  const size_t plane = (size_t)N * K;
+  const unsigned short* bp = Bp + (size_t)(n0 + br) * K + bs * 8;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ga[8];
+  u32x4 gb[6];
+  const int nk = K / BK;
+  auto issue = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + kc * BK);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      gb[2 * p] = *reinterpret_cast<const u32x4*>(bp + p * plane + (size_t)kc * BK);
+      gb[2 * p + 1] = *reinterpret_cast<const u32x4*>(bp + p * plane + (size_t)64 * K + (size_t)kc * BK);
+    }
+  };
+  const int fr = lane & 31, fh = lane >> 5;
+  // one slice of the next chunk's staging: A row group i (split + 3 LDS writes) and B vector i
+  auto write_slice = [&](int st, int i) {
+    unsigned short* As = lds2 + st * V2_STAGE;
+    unsigned short* Bs = As + 3 * V2_APIECE;
+    u32x2 p0, p1, p2;
+    split4(ga[i], p0, p1, p2);
+    const int off = swz(lr + 32 * i, lq >> 1) + (lq & 1) * 4;
+    *reinterpret_cast<u32x2*>(As + off) = p0;
+    *reinterpret_cast<u32x2*>(As + V2_APIECE + off) = p1;
+    *reinterpret_cast<u32x2*>(As + 2 * V2_APIECE + off) = p2;
+    if (i < 6) *reinterpret_cast<u32x4*>(Bs + (i >> 1) * V2_BPIECE + swz(br + 64 * (i & 1), bs)) = gb[i];
+  };
+  auto load_slice = [&](int kc, int i) {
+    ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + kc * BK);
+    if (i < 6) gb[i] = *reinterpret_cast<const u32x4*>(bp + (i >> 1) * plane + (size_t)(64 * (i & 1)) * K + (size_t)kc * BK);
+  };
+  bf16x8 fa[2][4][3], fb[2][2][3];
+  auto read_frags = [&](int st, int ks, int buf) {
+    const unsigned short* As = lds2 + st * V2_STAGE;
+    const unsigned short* Bs = As + 3 * V2_APIECE;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        fa[buf][i][p] = *reinterpret_cast<const bf16x8*>(As + p * V2_APIECE + swz(wm * 128 + i * 32 + fr, ks * 2 + fh));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[buf][j][p] = *reinterpret_cast<const bf16x8*>(Bs + p * V2_BPIECE + swz(wn * 64 + j * 32 + fr, ks * 2 + fh));
+    }
+  };
+  auto mfma_pair = [&](int buf, int i, int j) {
+    f32x16 c = acc[i][j];
+    if (NPROD >= 6) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][2], fb[buf][j][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][0], fb[buf][j][2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][1], fb[buf][j][1], c, 0, 0, 0);
+    }
+    if (NPROD >= 3) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][1], fb[buf][j][0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][0], fb[buf][j][1], c, 0, 0, 0);
+    }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[buf][i][0], fb[buf][j][0], c, 0, 0, 0);
+    acc[i][j] = c;
+  };
+#pragma unroll
+  for (int i = 0; i < 8; ++i) load_slice(0, i);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) write_slice(0, i);
+  if (nk > 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) load_slice(1, i);
+  }
+  __syncthreads();
+  read_frags(0, 0, 0);
+  for (int kc = 0; kc < nk; ++kc) {
+    const int st = kc & 1;
+    const bool more1 = kc + 1 < nk, more2 = kc + 2 < nk;
+    read_frags(st, 1, 1);                 // k-step 1 fragments arrive under k-step 0's MFMAs
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mfma_pair(0, q >> 1, q & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more1) write_slice(st ^ 1, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mfma_pair(1, q >> 1, q & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more2) load_slice(kc + 2, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (more1) read_frags(st ^ 1, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+// ---- v4: producer / consumer waves.  512 threads: waves 0-3 only issue LDS fragment reads + MFMAs
+// (2x2 arrangement of 64x64 wave tiles over a 128x128 block tile), waves 4-7 only stage: global
+// loads two chunks ahead, the exact three-way split, LDS writes into the other stage.  Each SIMD
+// hosts one consumer and one producer, so the split's VALU work issues in the shadow of the MFMAs.
+constexpr int V4_STAGE = 2 * 3 * PIECE;     // bf16 elements per stage (A + B pieces, padded rows)
+
+template <int NPROD, int SKIP = 0>
+__global__ __launch_bounds__(512, 1) void gemm_v4_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                         float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds4[];
+  const int t = threadIdx.x;
+  const int nbn = N / BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int nk = K / BK;
+  if (t >= 256) {
+    // ------------------------------------------------------------------ producers
+    const int pt = t - 256;
+    const int lr = pt >> 3, lk = (pt & 7) * 4;
+    const float* ap = A + (size_t)(m0 + lr) * K + lk;
+    const float* bp = B + (size_t)(n0 + lr) * K + lk;
+    f32x4 ga[2][4], gb[2][4];
+    auto issue = [&](int set, int kc) {
+      if ((SKIP & 4) && kc > 1) return;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ga[set][i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + kc * BK);
+        gb[set][i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K + kc * BK);
+      }
+    };
+    auto stage_write = [&](int set, int st) {
+      unsigned short* As = lds4 + st * V4_STAGE;
+      unsigned short* Bs = As + 3 * PIECE;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x2 p0, p1, p2;
+        const int off = (lr + 32 * i) * RS + lk;
+        if (SKIP & 2) continue;
+        if (SKIP & 1) { p0[0] = __float_as_uint(ga[set][i][0]); p0[1] = __float_as_uint(ga[set][i][1]); p1[0] = __float_as_uint(ga[set][i][2]); p1[1] = __float_as_uint(ga[set][i][3]); p2 = p1; }
+        else split4(ga[set][i], p0, p1, p2);
+        *reinterpret_cast<u32x2*>(As + off) = p0;
+        *reinterpret_cast<u32x2*>(As + PIECE + off) = p1;
+        *reinterpret_cast<u32x2*>(As + 2 * PIECE + off) = p2;
+        if (SKIP & 1) { p0[0] = __float_as_uint(gb[set][i][0]); p0[1] = __float_as_uint(gb[set][i][1]); p1[0] = __float_as_uint(gb[set][i][2]); p1[1] = __float_as_uint(gb[set][i][3]); p2 = p1; }
+        else split4(gb[set][i], p0, p1, p2);
+        *reinterpret_cast<u32x2*>(Bs + off) = p0;
+        *reinterpret_cast<u32x2*>(Bs + PIECE + off) = p1;
+        *reinterpret_cast<u32x2*>(Bs + 2 * PIECE + off) = p2;
+      }
+    };
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    stage_write(0, 0);
+    if (nk > 2) issue(0, 2);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+      if (kc + 1 < nk) { stage_write(1, 1); if (kc + 3 < nk) issue(1, kc + 3); }
+      __syncthreads();
+      if (kc + 1 < nk) {
+        if (kc + 2 < nk) { stage_write(0, 0); if (kc + 4 < nk) issue(0, kc + 4); }
+        __syncthreads();
+      }
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- consumers
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    const unsigned short* As = lds4 + (kc & 1) * V4_STAGE;
+    const unsigned short* Bs = As + 3 * PIECE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PIECE + (wm * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+          b[i][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PIECE + (wn * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (NPROD >= 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+template <int NPROD, int SKIP>
+__global__ __launch_bounds__(256, 2) void gemm_ablate_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                            float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * PIECE];
+  unsigned short* As = lds;
+  unsigned short* Bs = lds + 3 * PIECE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int lr = t >> 3, lk = (t & 7) * 4;
+  const float* ap = A + (size_t)(m0 + lr) * K + lk;
+  const float* bp = B + (size_t)(n0 + lr) * K + lk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ga[4], gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K);
+    gb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K);
+  }
+  const int nk = K / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 p0, p1, p2;
+      if (SKIP & 1) { p0[0] = __float_as_uint(ga[i][0]); p0[1] = __float_as_uint(ga[i][1]); p1[0] = __float_as_uint(ga[i][2]); p1[1] = __float_as_uint(ga[i][3]); p2 = p0; }
+      else split4(ga[i], p0, p1, p2);
+      const int off = (lr + 32 * i) * RS + lk;
+      if ((SKIP & 2) && kc > 0) continue;
+      *reinterpret_cast<u32x2*>(As + off) = p0;
+      *reinterpret_cast<u32x2*>(As + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(As + 2 * PIECE + off) = p2;
+      if (SKIP & 1) { p0[0] = __float_as_uint(gb[i][0]); p0[1] = __float_as_uint(gb[i][1]); p1[0] = __float_as_uint(gb[i][2]); p1[1] = __float_as_uint(gb[i][3]); p2 = p0; }
+      else split4(gb[i], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(Bs + off) = p0;
+      *reinterpret_cast<u32x2*>(Bs + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(Bs + 2 * PIECE + off) = p2;
+    }
+    __syncthreads();
+    if (kc + 1 < nk && !(SKIP & 4)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + (kc + 1) * BK);
+        gb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K + (kc + 1) * BK);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PIECE + (wm * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+          b[i][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PIECE + (wn * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (NPROD >= 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  }
+  // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+
+template <int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                            float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * PIECE];
+  unsigned short* As = lds;
+  unsigned short* Bs = lds + 3 * PIECE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int lr = t >> 3, lk = (t & 7) * 4;
+  const float* ap = A + (size_t)(m0 + lr) * K + lk;
+  const float* bp = B + (size_t)(n0 + lr) * K + lk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ga[4], gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K);
+    gb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K);
+  }
+  const int nk = K / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kc = 0; kc < nk; ++kc) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 p0, p1, p2;
+      split4(ga[i], p0, p1, p2);
+      const int off = (lr + 32 * i) * RS + lk;
+      *reinterpret_cast<u32x2*>(As + off) = p0;
+      *reinterpret_cast<u32x2*>(As + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(As + 2 * PIECE + off) = p2;
+      split4(gb[i], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(Bs + off) = p0;
+      *reinterpret_cast<u32x2*>(Bs + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(Bs + 2 * PIECE + off) = p2;
+    }
+    __syncthreads();
+    if (kc + 1 < nk) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + (kc + 1) * BK);
+        gb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K + (kc + 1) * BK);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PIECE + (wm * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+          b[i][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PIECE + (wn * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (NPROD >= 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  }
+  // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+static unsigned short* g_Bp = nullptr;
+static int g_version = 0;
+static double run(int nprod, const float* A, const float* B, float* C, int M, int N, int K, int reps) {
+  dim3 grid((N / BN) * (M / BM));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+  auto launch = [&]() {
+    if (g_version >= 40 && g_version < 48) {
+      const size_t sh = 2 * V4_STAGE * sizeof(unsigned short);
+#define AB4(S) case S: if (nprod == 6) gemm_v4_kernel<6, S><<<grid, 512, sh>>>(A, B, C, M, N, K); else gemm_v4_kernel<1, S><<<grid, 512, sh>>>(A, B, C, M, N, K); break;
+      switch (g_version - 40) { AB4(0) AB4(1) AB4(2) AB4(3) AB4(4) AB4(5) AB4(6) AB4(7) }
+      return;
+    }
+    if (g_version == 4) {
+      const size_t sh = 2 * V4_STAGE * sizeof(unsigned short);
+      if (nprod == 6) gemm_v4_kernel<6><<<grid, 512, sh>>>(A, B, C, M, N, K);
+      else if (nprod == 3) gemm_v4_kernel<3><<<grid, 512, sh>>>(A, B, C, M, N, K);
+      else gemm_v4_kernel<1><<<grid, 512, sh>>>(A, B, C, M, N, K);
+      return;
+    }
+    if (g_version == 3) {
+      dim3 g2((N / V2_BN) * (M / V2_BM));
+      const size_t sh = 2 * V2_STAGE * sizeof(unsigned short);
+      if (nprod == 6) gemm_v3_kernel<6><<<g2, 256, sh>>>(A, g_Bp, C, M, N, K);
+      else if (nprod == 3) gemm_v3_kernel<3><<<g2, 256, sh>>>(A, g_Bp, C, M, N, K);
+      else gemm_v3_kernel<1><<<g2, 256, sh>>>(A, g_Bp, C, M, N, K);
+      return;
+    }
+    if (g_version == 2) {
+      dim3 g2((N / V2_BN) * (M / V2_BM));
+      const size_t sh = 2 * V2_STAGE * sizeof(unsigned short);
+      if (nprod == 6) gemm_v2_kernel<6><<<g2, 256, sh>>>(A, g_Bp, C, M, N, K);
+      else if (nprod == 3) gemm_v2_kernel<3><<<g2, 256, sh>>>(A, g_Bp, C, M, N, K);
+      else gemm_v2_kernel<1><<<g2, 256, sh>>>(A, g_Bp, C, M, N, K);
+      return;
+    }
+    if (g_version >= 10) {
+      const int sk = g_version - 10;
+#define AB(S) case S: gemm_ablate_kernel<6, S><<<grid, 256>>>(A, B, C, M, N, K); break;
+      switch (sk) { AB(0) AB(1) AB(2) AB(3) AB(4) AB(5) AB(6) AB(7) }
+      return;
+    }
+    if (g_version == 1) {
+      if (nprod == 6) gemm_v1_kernel<6><<<grid, 256>>>(A, g_Bp, C, M, N, K);
+      else if (nprod == 3) gemm_v1_kernel<3><<<grid, 256>>>(A, g_Bp, C, M, N, K);
+      else gemm_v1_kernel<1><<<grid, 256>>>(A, g_Bp, C, M, N, K);
+      return;
+    }
+    if (nprod == 6) gemm_split_kernel<6><<<grid, 256>>>(A, B, C, M, N, K);
+    else if (nprod == 3) gemm_split_kernel<3><<<grid, 256>>>(A, B, C, M, N, K);
+    else gemm_split_kernel<1><<<grid, 256>>>(A, B, C, M, N, K);
+  };
+  launch();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  for (int r = 0; r < reps; ++r) launch();
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  return ms / reps;
+}
+
+int main(int argc, char** argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 122880, N = argc > 2 ? atoi(argv[2]) : 768, K = argc > 3 ? atoi(argv[3]) : 6912;
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+  srand(1);
+  for (auto& v : hA) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+  for (auto& v : hB) v = ((float)rand() / RAND_MAX * 2.f - 1.f) * 0.05f;
+  float *A, *B, *C;
+  CHECK(hipMalloc(&A, hA.size() * 4)); CHECK(hipMalloc(&B, hB.size() * 4)); CHECK(hipMalloc(&C, (size_t)M * N * 4));
+  CHECK(hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(B, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> hC((size_t)M * N);
+  g_version = argc > 4 ? atoi(argv[4]) : 0;
+  CHECK(hipMalloc(&g_Bp, hB.size() * 6));
+#define ATTR4(S) CHECK(hipFuncSetAttribute((const void*)gemm_v4_kernel<6, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V4_STAGE * 2)); CHECK(hipFuncSetAttribute((const void*)gemm_v4_kernel<1, S>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V4_STAGE * 2));
+  ATTR4(1) ATTR4(2) ATTR4(3) ATTR4(4) ATTR4(5) ATTR4(6) ATTR4(7)
+  CHECK(hipFuncSetAttribute((const void*)gemm_v4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V4_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V4_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V4_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V2_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V2_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V2_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v2_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V2_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V2_STAGE * 2));
+  CHECK(hipFuncSetAttribute((const void*)gemm_v2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * V2_STAGE * 2));
+  presplit_kernel<<<1024, 256>>>(B, g_Bp, (long long)hB.size());
+  CHECK(hipDeviceSynchronize());
+  for (int nprod : {6, 3, 1}) {
+    if (g_version >= 40 && nprod == 3) continue;
+    const double ms = run(nprod, A, B, C, M, N, K, 5);
+    CHECK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0, maxref = 0, f32err = 0;
+    for (int s = 0; s < 400; ++s) {
+      const int i = (int)((size_t)rand() % M), j = rand() % N;
+      double ref = 0; float f = 0.f;
+      for (int k = 0; k < K; ++k) { ref += (double)hA[(size_t)i * K + k] * hB[(size_t)j * K + k]; f = fmaf(hA[(size_t)i * K + k], hB[(size_t)j * K + k], f); }
+      maxerr = fmax(maxerr, fabs(hC[(size_t)i * N + j] - ref));
+      f32err = fmax(f32err, fabs((double)f - ref));
+      maxref = fmax(maxref, fabs(ref));
+    }
+    printf("v%d M=%d N=%d K=%d products=%d: %.3f ms  %.1f TF/s (f32-equivalent)  max|err| %.3e (f32 fma chain %.3e, max|ref| %.3f)\n",
+           g_version, M, N, K, nprod, ms, 2.0 * M * N * K / ms / 1e9, maxerr, f32err, maxref);
+  }
+  return 0;
+}
