@@ -226,3 +226,43 @@ def test_subpixel_rewrite_is_selected_and_exact(device):
     sp = next(iter(plan.subpixel.values()))
     assert sp["P"] == 8 and sp["zk"] == (2, 2, 2)
     assert (got - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("N,cin,shape", [(256, 1, (2, 40, 64)), (160, 3, (2, 32, 50)), (64, 3, (3, 33, 47)),
+                                         (12, 2, (2, 32, 50)), (8, 4, (1, 21, 19))])
+def test_first_layer_weight_gradient_kernel(N, cin, shape, device):
+    """clx_conv_wgrad on <= 4 input channels (streaming small-channel kernel, every lane grouping)
+    vs an f64 einsum: all taps, all four channel slots, bias gradient."""
+    import ctypes
+
+    from cellulus_amd import _clx
+    from cellulus_amd._clx import ClxConvDesc, ClxSrc
+
+    B, H, W = shape
+    torch.manual_seed(N + cin)
+    x = torch.zeros(B * H * W, 4, device=device)
+    x[:, :cin] = torch.rand(B * H * W, cin, device=device)
+    M = B * (H - 2) * (W - 2)
+    dy = torch.randn(M, N, device=device)
+    dw = torch.zeros(9 * N * 4, device=device)
+    db = torch.zeros(N, device=device)
+    d = ClxConvDesc()
+    d.nsrc = 1
+    s = ClxSrc()
+    s.ptr, s.C, s.ld = x.data_ptr(), 4, 4
+    s.D, s.H, s.W = 1, H, W
+    s.oz = s.oy = s.ox = 0
+    s.fz = s.fy = s.fx = 1
+    d.src[0] = s
+    d.B = B
+    d.ID, d.IH, d.IW = 1, H, W
+    d.KD, d.KH, d.KW = 1, 3, 3
+    d.PD = d.PH = d.PW = 0
+    d.N = N
+    _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), N, _clx.ptr(dw), _clx.ptr(db), _clx.stream_ptr(device))
+    xi, dyi = x.view(B, H, W, 4).double(), dy.view(B, H - 2, W - 2, N).double()
+    ref = torch.stack([torch.einsum("bhwc,bhwn->nc", xi[:, ty:ty + H - 2, tx:tx + W - 2], dyi)
+                       for ty in range(3) for tx in range(3)])
+    got = dw.view(9, N, 4).double()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-5
+    assert (db.double() - dyi.sum((0, 1, 2))).abs().max().item() < 1e-3 * max(1.0, dyi.abs().sum((0, 1, 2)).max().item())
