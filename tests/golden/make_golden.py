@@ -261,6 +261,30 @@ def g9_train_iteration():
     np.savez_compressed(os.path.join(HERE, "g9_train_iteration.npz"), **out)
 
 
+def g10_evaluate():
+    """REAL cellulus.evaluate.compute_pairwise_IoU / compute_F1 (evaluate.py:72-105) on seeded label
+    images (zarr / gunpowder, imported at module level only, are empty stubs)."""
+    for name in ("zarr", "gunpowder"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from cellulus.evaluate import compute_F1, compute_pairwise_IoU
+
+    out = {}
+    rng = np.random.RandomState(5)
+    for i, shape in enumerate([(48, 56), (40, 40), (16, 16, 24)]):
+        gt = np.kron(rng.randint(0, 6, size=tuple(s // 8 for s in shape)), np.ones((8,) * len(shape), dtype=np.int64))
+        pred = np.roll(gt, 2, axis=-1) * (rng.rand(*shape) < 0.9)
+        pred[pred == 3] = 9                        # relabelled instance
+        pred[tuple(slice(0, 6) for _ in shape)] = 11     # a false positive
+        gt, pred = gt.astype(np.uint16), pred.astype(np.uint16)
+        iou, seg, n = compute_pairwise_IoU(pred, gt)
+        f1, tp, fp, fn = compute_F1(iou)
+        out[f"{i}/gt"], out[f"{i}/pred"] = gt, pred
+        out[f"{i}/iou"] = iou
+        out[f"{i}/scalars"] = np.array([seg, n, f1, tp, fp, fn], dtype=np.float64)
+    out["none_for_empty_gt"] = np.array(compute_pairwise_IoU(pred, np.zeros_like(gt)) is None)
+    np.savez_compressed(os.path.join(HERE, "g10_evaluate.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -268,6 +292,7 @@ if __name__ == "__main__":
             globals()[fn]()
         sys.exit(0)
     g9_train_iteration()
+    g10_evaluate()
     g1_oce()
     g2_gather()
     g3_unet()

@@ -372,3 +372,17 @@ def test_subpixel_phase_weights_equal_upsample_then_conv(nd):
     assert (out - ref).abs().max().item() < 1e-4
     g = torch.randn_like(weff)
     assert abs((weff * g).sum().item() - (w * plan._fold_phase_grads(layer, sp, g)).sum().item()) < 1e-3
+
+
+def test_evaluate_matches_real_reference_golden():
+    """g10: the REAL cellulus.evaluate.compute_pairwise_IoU / compute_F1 (O(#pred x #gt) mask loops)
+    vs the joint-histogram implementation: identical IoU tables, SEG, F1, TP, FP, FN."""
+    from cellulus_amd.evaluate import compute_F1, compute_pairwise_IoU
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_evaluate.npz"))
+    for i in range(3):
+        iou, seg, n = compute_pairwise_IoU(g[f"{i}/pred"], g[f"{i}/gt"])
+        np.testing.assert_array_equal(iou, g[f"{i}/iou"])
+        f1, tp, fp, fn = compute_F1(iou)
+        np.testing.assert_allclose([seg, n, f1, tp, fp, fn], g[f"{i}/scalars"], rtol=1e-15)
+    assert bool(g["none_for_empty_gt"]) and compute_pairwise_IoU(g["0/pred"], np.zeros_like(g["0/gt"])) is None
