@@ -285,6 +285,29 @@ def g10_evaluate():
     np.savez_compressed(os.path.join(HERE, "g10_evaluate.npz"), **out)
 
 
+def g11_pair_sampler():
+    """REAL ZarrDataset.sample_coordinates / sample_offsets_within_radius (zarr_dataset.py:163-248)
+    called on an instance built without __init__ (which would need gunpowder), np.random seeded."""
+    for name in ("zarr", "gunpowder"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    from cellulus.datasets.zarr_dataset import ZarrDataset
+
+    out = {}
+    for tag, nd, output_shape, kappa, density, seed in (("2d", 2, (60, 72), 10.0, 0.1, 3), ("3d", 3, (24, 28, 32), 6.0, 0.2, 4),
+                                                         ("2d_small", 2, (30, 30), 3.0, 0.3, 5)):
+        ds = object.__new__(ZarrDataset)
+        ds.num_spatial_dims, ds.kappa, ds.density = nd, kappa, density
+        ds.output_shape = output_shape
+        ds.unbiased_shape = tuple(int(s - 2 * kappa) for s in output_shape)
+        np.random.seed(seed)
+        anchors, references = ds.sample_coordinates()
+        out[f"{tag}/params"] = np.array([nd, kappa, density, seed], dtype=np.float64)
+        out[f"{tag}/output_shape"] = np.array(output_shape)
+        out[f"{tag}/anchors"], out[f"{tag}/references"] = anchors, references
+        out[f"{tag}/counts"] = np.array([ds.get_num_anchors(), ds.get_num_references(), ds.get_num_samples()])
+    np.savez_compressed(os.path.join(HERE, "g11_pair_sampler.npz"), **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -293,6 +316,7 @@ if __name__ == "__main__":
         sys.exit(0)
     g9_train_iteration()
     g10_evaluate()
+    g11_pair_sampler()
     g1_oce()
     g2_gather()
     g3_unet()

@@ -386,3 +386,23 @@ def test_evaluate_matches_real_reference_golden():
         f1, tp, fp, fn = compute_F1(iou)
         np.testing.assert_allclose([seg, n, f1, tp, fp, fn], g[f"{i}/scalars"], rtol=1e-15)
     assert bool(g["none_for_empty_gt"]) and compute_pairwise_IoU(g["0/pred"], np.zeros_like(g["0/gt"])) is None
+
+
+@pytest.mark.parametrize("tag", ["2d", "3d", "2d_small"])
+def test_pair_sampler_matches_real_reference_golden(tag):
+    """g11: the REAL ZarrDataset.sample_coordinates (zarr_dataset.py:163-248) under np.random.seed
+    vs this package's sampler: identical anchor / reference coordinates, identical counts."""
+    from cellulus_amd.datasets.zarr_dataset import ZarrDataset
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g11_pair_sampler.npz"))
+    nd, kappa, density, seed = g[f"{tag}/params"]
+    ds = object.__new__(ZarrDataset)
+    ds.num_spatial_dims, ds.kappa, ds.density = int(nd), float(kappa), float(density)
+    ds.output_shape = tuple(int(v) for v in g[f"{tag}/output_shape"])
+    ds.unbiased_shape = tuple(int(s - 2 * ds.kappa) for s in ds.output_shape)
+    np.random.seed(int(seed))
+    anchors, references = ds.sample_coordinates()
+    np.testing.assert_array_equal(anchors, g[f"{tag}/anchors"])
+    np.testing.assert_array_equal(references, g[f"{tag}/references"])
+    np.testing.assert_array_equal([ds.get_num_anchors(), ds.get_num_references(), ds.get_num_samples()],
+                                  g[f"{tag}/counts"])
