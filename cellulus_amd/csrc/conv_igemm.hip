@@ -209,14 +209,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
   // groups so the matrix pipe never waits for a long non-MFMA stretch: global loads of
   // the next chunk before groups 0/1, their LDS stores (other buffer) before group 3,
   // operand fragments one group ahead.  Only barrier + first fragment read are exposed.
+  // The steady-state loop has NO conditional around the loads and stores: with `if (more)`
+  // around each of them the compiler's wait-count pass sees paths on which a load was issued
+  // and never consumed, and guards every later write of those registers with s_waitcnt
+  // vmcnt(<=3) — the B loads then waited for the A loads issued one MFMA group earlier, every
+  // chunk.  The last chunk (nothing left to prefetch) runs after the loop.
   load_frags(buf, 0, 0);
-  while (true) {
-    if (more) load_a();
+  while (more) {
+    load_a();
     load_frags(buf, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) load_b();
+    load_b();
     load_frags(buf, 2, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(1);
@@ -225,15 +230,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (more) store_chunk(buf ^ 1);
+    store_chunk(buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(1);
-    if (!more) break;
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);     // keep the barrier BEHIND the last group: the MFMAs
+    __syncthreads();                       // already issued absorb the skew between the waves
     buf ^= 1;
     load_frags(buf, 0, 0);
     more = advance();
   }
+  load_frags(buf, 1, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group(0);
+  __builtin_amdgcn_sched_barrier(0);
+  load_frags(buf, 2, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group(1);
+  __builtin_amdgcn_sched_barrier(0);
+  load_frags(buf, 3, 1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group(0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_group(1);
 
   // ---- epilogue: bias + ReLU in registers, transpose through LDS so that every lane
   // stores (and reads the ReLU-gate mask as) 16-byte channel runs of one output pixel.

@@ -15,6 +15,8 @@
 // reference train step (cellulus/train.py:178).
 #include "clx_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int BKP = 32;  // pixels per chunk
@@ -24,6 +26,7 @@ __device__ __attribute__((aligned(16))) float g_wgrad_zero16[4] = {0.f, 0.f, 0.f
 struct SrcP {
   const float* ptr;
   int C, ld, D, H, W, oz, oy, ox, fz, fy, fx;
+  FastDiv dfz, dfy, dfx;   // nearest-upsampling factors as fast divisions (factor 1 = identity)
 };
 
 struct WgradP {
@@ -95,41 +98,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       ra[j] = *reinterpret_cast<const f32x4*>(ok ? dyp + (size_t)pp * p.ld_dy + n_g : p.zeros);
     }
   };
-  // Each thread walks its B_PASSES pixel rows incrementally: (ox, oy, oz, b) advance by 32
-  // pixels per chunk with rare wrap-arounds, instead of a full decode per row per chunk.
-  int wx[B_PASSES], wy[B_PASSES], wz[B_PASSES], wb[B_PASSES];
-  {
-    const uint32_t p0 = (uint32_t)chunk0 * BKP;
+  // Every chunk decodes its B_PASSES pixel rows from the linear pixel index with fast divisions:
+  // straight-line code.  (An incremental walk with `while` wrap-arounds is fewer instructions, but
+  // its divergent loops made the compiler put s_waitcnt vmcnt(<=3) in front of every row — the
+  // x loads then waited for the dy loads issued four MFMA groups earlier, every chunk.)
+  uint32_t wlin[B_PASSES];
 #pragma unroll
-    for (int j = 0; j < B_PASSES; ++j) {
-      uint32_t m = p0 + (uint32_t)(b_row + j * B_RPP);
-      const uint32_t q1 = fdiv(m, p.dOW);
-      wx[j] = (int)(m - q1 * p.OW);
-      const uint32_t q2 = fdiv(q1, p.dOH);
-      wy[j] = (int)(q1 - q2 * p.OH);
-      const uint32_t q3 = fdiv(q2, p.dOD);
-      wz[j] = (int)(q2 - q3 * p.OD);
-      wb[j] = (int)q3;
-    }
-  }
-  int x_chunk = 0;   // chunk the walk state currently points at
+  for (int j = 0; j < B_PASSES; ++j) wlin[j] = (uint32_t)chunk0 * BKP + (uint32_t)(b_row + j * B_RPP);
   auto load_x = [&](int chunk) {
-    const int adv = (chunk - x_chunk) * BKP;
-    x_chunk = chunk;
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
-      wx[j] += adv;
-      while (wx[j] >= p.OW) { wx[j] -= p.OW; ++wy[j]; }
-      while (wy[j] >= p.OH) { wy[j] -= p.OH; ++wz[j]; }
-      while (wz[j] >= p.OD) { wz[j] -= p.OD; ++wb[j]; }
-      const int lz = wz[j] + tz - p.PD, ly = wy[j] + ty - p.PH, lx = wx[j] + tx - p.PW;
-      const bool ok = c_ok && wb[j] < p.B && (unsigned)lz < (unsigned)p.ID &&
+      const uint32_t m = wlin[j] + (uint32_t)chunk * BKP;
+      const uint32_t q1 = fdiv(m, p.dOW);
+      const int ox = (int)(m - q1 * p.OW);
+      const uint32_t q2 = fdiv(q1, p.dOH);
+      const int oy = (int)(q1 - q2 * p.OH);
+      const uint32_t q3 = fdiv(q2, p.dOD);
+      const int oz = (int)(q2 - q3 * p.OD);
+      const int ob = (int)q3;
+      const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
+      const bool ok = c_ok && m < (uint32_t)p.M && (unsigned)lz < (unsigned)p.ID &&
                       (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW;
-      int sz = lz + S.oz, sy = ly + S.oy, sx = lx + S.ox;
-      if (S.fz > 1) sz /= S.fz;
-      if (S.fy > 1) sy /= S.fy;
-      if (S.fx > 1) sx /= S.fx;
-      const int pix = ((wb[j] * S.D + sz) * S.H + sy) * S.W + sx;   // < 2^31 (validated on the host)
+      // (garbage for out-of-range rows: their pointer is replaced by the zero buffer below)
+      const int sz = (int)fdiv((uint32_t)(lz + S.oz), S.dfz);
+      const int sy = (int)fdiv((uint32_t)(ly + S.oy), S.dfy);
+      const int sx = (int)fdiv((uint32_t)(lx + S.ox), S.dfx);
+      const int pix = ((ob * S.D + sz) * S.H + sy) * S.W + sx;   // < 2^31 (validated on the host)
       rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + (size_t)pix * S.ld + c_l : p.zeros);
     }
   };
@@ -172,13 +166,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
     __syncthreads();
     int buf = 0;
     load_frags(0, 0, 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const bool more = ch + 1 < nchunks;
+    // `MORE` is a compile-time flag, the last chunk runs after the loop: with a run-time
+    // `if (more)` around the loads and the LDS stores the compiler's wait-count pass sees paths
+    // on which a load is issued and never consumed, and guards later writes of those registers
+    // with s_waitcnt vmcnt(<=3) — the x loads then waited for the dy loads issued four MFMA
+    // groups earlier, in every chunk.
+    auto chunk_body = [&](int ch, auto more_tag) {
+      constexpr bool MORE = decltype(more_tag)::value;
 #pragma unroll
       for (int k2 = 0; k2 < BKP / 2; ++k2) {
-        if (k2 == 0 && more) load_dy(ch + 1);
-        if (k2 == 4 && more) load_x(ch + 1);
-        if (k2 == 12 && more) store_chunk(buf ^ 1);
+        if constexpr (MORE) {
+          if (k2 == 0) load_dy(ch + 1);
+          if (k2 == 4) load_x(ch + 1);
+          if (k2 == 12) store_chunk(buf ^ 1);
+        }
         if (k2 + 1 < BKP / 2) load_frags(buf, k2 + 1, (k2 + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -188,12 +189,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k2 & 1][a], bf[k2 & 1][b], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (more) {
+      if constexpr (MORE) {
         __syncthreads();
         buf ^= 1;
         load_frags(buf, 0, 0);
       }
-    }
+    };
+    for (int ch = 0; ch + 1 < nchunks; ++ch) chunk_body(ch, std::true_type{});
+    chunk_body(nchunks - 1, std::false_type{});
   }
 
   // ---- combine: float atomics into dwpack[tap][n][c]
@@ -267,7 +270,9 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   p.nsrc = d->nsrc;
   for (int s = 0; s < 2; ++s) {
     const clx_src& S = d->src[s < d->nsrc ? s : 0];
-    p.src[s] = SrcP{S.ptr, S.C, S.ld, S.D, S.H, S.W, S.oz, S.oy, S.ox, S.fz, S.fy, S.fx};
+    p.src[s] = SrcP{S.ptr, S.C, S.ld, S.D, S.H, S.W, S.oz, S.oy, S.ox, S.fz, S.fy, S.fx,
+                    make_fastdiv((uint32_t)(S.fz > 0 ? S.fz : 1)), make_fastdiv((uint32_t)(S.fy > 0 ? S.fy : 1)),
+                    make_fastdiv((uint32_t)(S.fx > 0 ? S.fx : 1))};
   }
   p.B = d->B; p.ID = d->ID; p.IH = d->IH; p.IW = d->IW;
   p.KD = d->KD; p.KH = d->KH; p.KW = d->KW;
