@@ -447,12 +447,21 @@ __global__ __launch_bounds__(512, 1) void gemm_v4_kernel(const float* __restrict
         *reinterpret_cast<u32x2*>(Bs + 2 * PIECE + off) = p2;
       }
     };
+    // requires nk even and >= 4 (microbenchmark sizes); steady state has no conditionals
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    issue(1, 1);
     stage_write(0, 0);
-    if (nk > 2) issue(0, 2);
+    issue(0, 2);
     __syncthreads();
-    for (int kc = 0; kc < nk; kc += 2) {
+    int kc = 0;
+    for (; kc + 4 < nk; kc += 2) {
+      stage_write(1, 1); issue(1, kc + 3);
+      __syncthreads();
+      stage_write(0, 0); issue(0, kc + 4);
+      __syncthreads();
+    }
+    // kc == nk - 4 or nk - 2 ... finish remaining chunks with guarded code
+    for (; kc < nk; kc += 2) {
       if (kc + 1 < nk) { stage_write(1, 1); if (kc + 3 < nk) issue(1, kc + 3); }
       __syncthreads();
       if (kc + 1 < nk) {
@@ -715,6 +724,110 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const float* __restr
       }
 }
 
+template <int NPROD>
+__global__ __launch_bounds__(256, 2) void gemm_v5_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                            float* __restrict__ C, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * 3 * PIECE];
+  unsigned short* As = lds;
+  unsigned short* Bs = lds + 3 * PIECE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nbn = N / BN, nblk = gridDim.x;
+  const int bid = (blockIdx.x % 8) * (nblk / 8) + blockIdx.x / 8;
+  const int m0 = (bid / nbn) * BM, n0 = (bid % nbn) * BN;
+  const int lr = t >> 3, lk = (t & 7) * 4;
+  const float* ap = A + (size_t)(m0 + lr) * K + lk;
+  const float* bp = B + (size_t)(n0 + lr) * K + lk;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  f32x4 ga[4], gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K);
+    gb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K);
+  }
+  const int nk = K / BK;
+  const int fr = lane & 31, fh = lane >> 5;
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x2 p0, p1, p2;
+      split4(ga[i], p0, p1, p2);
+      const int off = (lr + 32 * i) * RS + lk;
+      *reinterpret_cast<u32x2*>(As + off) = p0;
+      *reinterpret_cast<u32x2*>(As + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(As + 2 * PIECE + off) = p2;
+      split4(gb[i], p0, p1, p2);
+      *reinterpret_cast<u32x2*>(Bs + off) = p0;
+      *reinterpret_cast<u32x2*>(Bs + PIECE + off) = p1;
+      *reinterpret_cast<u32x2*>(Bs + 2 * PIECE + off) = p2;
+    }
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[i][p] = *reinterpret_cast<const bf16x8*>(As + p * PIECE + (wm * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+          b[i][p] = *reinterpret_cast<const bf16x8*>(Bs + p * PIECE + (wn * 64 + i * 32 + fr) * RS + ks * 16 + fh * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          if (NPROD >= 6) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+          }
+          if (NPROD >= 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+          }
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    }
+  };
+  for (int kc = 0; kc + 1 < nk; ++kc) {      // steady state: always a next chunk, no conditionals
+    __syncthreads();
+    stage();
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ga[i] = *reinterpret_cast<const f32x4*>(ap + (size_t)(32 * i) * K + (kc + 1) * BK);
+      gb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(32 * i) * K + (kc + 1) * BK);
+    }
+    compute();
+  }
+  __syncthreads();
+  stage();
+  __syncthreads();
+  compute();
+  // C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int col = n0 + wn * 64 + j * 32 + fr;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 static unsigned short* g_Bp = nullptr;
 static int g_version = 0;
 static double run(int nprod, const float* A, const float* B, float* C, int M, int N, int K, int reps) {
@@ -726,6 +839,12 @@ static double run(int nprod, const float* A, const float* B, float* C, int M, in
       const size_t sh = 2 * V4_STAGE * sizeof(unsigned short);
 #define AB4(S) case S: if (nprod == 6) gemm_v4_kernel<6, S><<<grid, 512, sh>>>(A, B, C, M, N, K); else gemm_v4_kernel<1, S><<<grid, 512, sh>>>(A, B, C, M, N, K); break;
       switch (g_version - 40) { AB4(0) AB4(1) AB4(2) AB4(3) AB4(4) AB4(5) AB4(6) AB4(7) }
+      return;
+    }
+    if (g_version == 5) {
+      if (nprod == 6) gemm_v5_kernel<6><<<grid, 256>>>(A, B, C, M, N, K);
+      else if (nprod == 3) gemm_v5_kernel<3><<<grid, 256>>>(A, B, C, M, N, K);
+      else gemm_v5_kernel<1><<<grid, 256>>>(A, B, C, M, N, K);
       return;
     }
     if (g_version == 4) {
