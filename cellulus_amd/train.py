@@ -131,7 +131,7 @@ def train(experiment_config):
 
     # call `train_iteration`
     for iteration, batch in tqdm(
-        zip(range(start_iteration, train_config.max_iterations), train_dataloader),
+        zip(range(start_iteration, train_config.max_iterations), _DevicePrefetcher(train_dataloader, device)),
         disable=not is_main,
     ):
         loss, oce_loss, prediction = train_iteration(
@@ -165,6 +165,43 @@ def train(experiment_config):
             save_snapshot(batch, prediction, iteration)
     if is_main:
         logger.plot(force=True)
+
+
+class _DevicePrefetcher:
+    """Stages batch i+1 (pinned host memory -> HBM, 40 MB at the 2-D configuration: raw plus two
+    int64 coordinate arrays) on a copy stream while step i computes, so that the transfer is off
+    the step's critical path; the batches come out as device tensors, which
+    ``train_iteration``'s ``.to(device)`` passes through."""
+
+    def __init__(self, loader, device):
+        self.it = iter(loader)
+        self.device = device
+        self.stream = torch.cuda.Stream(device)
+        self.next = None
+        self._stage()
+
+    def _stage(self):
+        try:
+            batch = next(self.it)
+        except StopIteration:
+            self.next = None
+            return
+        with torch.cuda.stream(self.stream):
+            self.next = tuple(t.to(self.device, non_blocking=True) for t in batch)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.next is None:
+            raise StopIteration
+        current = torch.cuda.current_stream(self.device)
+        current.wait_stream(self.stream)
+        batch = self.next
+        for t in batch:
+            t.record_stream(current)
+        self._stage()
+        return batch
 
 
 def _state(iteration, lowest_loss, model, optimizer, logger):
