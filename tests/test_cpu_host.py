@@ -276,6 +276,13 @@ def test_logger_csv_layout(tmp_path, monkeypatch):
 
 
 # ------------------------------------------------------------- DDP (gloo)
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 _DDP_SCRIPT = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -307,7 +314,7 @@ print("rank", rank, "ok")
 def test_data_parallel_wiring_gloo_world2(tmp_path):
     script = tmp_path / "ddp.py"
     script.write_text(_DDP_SCRIPT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = []
     for r in range(2):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))

@@ -48,7 +48,16 @@ torch.distributed.barrier()
 """
 
 
-def _launch(script, args, env_extra, nproc=2, port=29631):
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(script, args, env_extra, nproc=2, port=None):
+    port = port or _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nproc),
                CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0", **env_extra)
     procs = [subprocess.Popen([sys.executable, script, *args], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
@@ -97,7 +106,7 @@ def test_two_ranks_equal_one_process_at_global_batch(tmp_path, device):
 
 def test_bench_multi_rank_control_flow(tmp_path):
     cmd_env = {}
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2",
                CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0", **cmd_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
                                "--warmup", "1", "--workload", "tiny"],
