@@ -74,62 +74,92 @@ def detect(inference_config: InferenceConfig) -> None:
     lo, hi = parallel.shard_range(meta.num_samples)
     for sample in tqdm(range(lo, hi), disable=parallel.rank() != 0):
         embeddings = ds[sample]                                  # (D+1, *spatial) float64
+
+        def emit(kind, index, value, sample=sample):      # written as soon as it exists, as the
+            if kind == "binary":                           # reference does (a later bandwidth may raise)
+                ds_binary_segmentation[sample, 0, ...] = value
+            elif kind == "centered":
+                ds_object_centered_embeddings[sample] = value
+            else:
+                ds_detection[sample, index, ...] = _labels_to_host(value)
+
+        detect_sample(embeddings, inference_config, nd, device, sample, emit=emit)
+
+
+def _labels_to_host(labels):
+    return labels.numpy() if labels.device.type == "cpu" else labels.cpu().numpy()
+
+
+def detect_sample(embeddings, inference_config, nd, device, sample=0, emb_d=None, emit=None):
+    """detect.py:82-192 for ONE sample.  embeddings: (D+1, *spatial) float64 host array (what the
+    ``embeddings`` dataset holds); emb_d: the same values already on the device, if the caller has
+    them (the fused driver does).  ``emit(kind, index, value)`` receives every output the moment
+    it exists — "binary" mask, "centered" embeddings, "detection" label tensor of bandwidth
+    ``index`` — in the order the reference writes them.  Returns the list of label tensors."""
+    if emit is None:
+        def emit(kind, index, value):
+            return None
+    if emb_d is None:
         emb_d = torch.from_numpy(np.ascontiguousarray(embeddings)).to(device)
-        std_d = emb_d[-1].contiguous()
-        if inference_config.threshold is None:
-            threshold = threshold_otsu(std_d)
+    std_d = emb_d[-1].contiguous()
+    if inference_config.threshold is None:
+        threshold = threshold_otsu(std_d)
+    else:
+        threshold = inference_config.threshold
+    print(f"For sample {sample}, binary threshold {threshold} was used.")
+    binary_mask = embeddings[-1] < threshold
+
+    # centred embeddings: subtract the mean of the non-zero masked offsets per channel
+    embeddings_centered = embeddings.copy()
+    masked = binary_mask[np.newaxis, ...] * embeddings[:nd]
+    for k in range(nd):
+        ck = masked[k]
+        embeddings_centered[k] -= ck[ck != 0].mean()
+    emit("binary", 0, binary_mask)
+    emit("centered", 0, embeddings_centered.copy())     # (the seeds path below mutates the array)
+    detections = []
+
+    if inference_config.clustering == "greedy":        # detect.py:162-192
+        from .utils.greedy_cluster import Cluster2d, Cluster3d
+
+        if nd == 3:
+            cluster = Cluster3d(width=embeddings.shape[-1], height=embeddings.shape[-2],
+                                depth=embeddings.shape[-3], fg_mask=binary_mask, device=device)
         else:
-            threshold = inference_config.threshold
-        print(f"For sample {sample}, binary threshold {threshold} was used.")
-        binary_mask = embeddings[-1] < threshold
-        ds_binary_segmentation[sample, 0, ...] = binary_mask
-
-        # centred embeddings: subtract the mean of the non-zero masked offsets per channel
-        embeddings_centered = embeddings.copy()
-        masked = binary_mask[np.newaxis, ...] * embeddings[:nd]
-        for k in range(nd):
-            ck = masked[k]
-            embeddings_centered[k] -= ck[ck != 0].mean()
-        ds_object_centered_embeddings[sample] = embeddings_centered
-
-        if inference_config.clustering == "greedy":        # detect.py:162-192
-            from .utils.greedy_cluster import Cluster2d, Cluster3d
-
-            if nd == 3:
-                cluster = Cluster3d(width=embeddings.shape[-1], height=embeddings.shape[-2],
-                                    depth=embeddings.shape[-3], fg_mask=binary_mask, device=device)
-            else:
-                cluster = Cluster2d(width=embeddings.shape[-1], height=embeddings.shape[-2],
-                                    fg_mask=binary_mask, device=device)
-            for bandwidth_factor in range(inference_config.num_bandwidths):
-                segmentation = cluster.cluster(
-                    prediction=embeddings, bandwidth=inference_config.bandwidth / (2 ** bandwidth_factor),
-                    min_object_size=inference_config.min_size)
-                ds_detection[sample, bandwidth_factor, ...] = segmentation.numpy()
-            continue
-
-        # use_seeds keeps the reference's aliasing (detect.py:116-118,142-144): the first
-        # mean_shift_segmentation call adds the pixel coordinates to `embeddings_centered` IN PLACE
-        # (its input is a view), later bandwidths re-read that mutated array — magnitudes, seeds
-        # and inputs then carry offsets + coordinates, exactly as in the reference (where sklearn
-        # then usually raises "No point was within bandwidth ... of any seed").
-        centered_aliased = True
+            cluster = Cluster2d(width=embeddings.shape[-1], height=embeddings.shape[-2],
+                                fg_mask=binary_mask, device=device)
         for bandwidth_factor in range(inference_config.num_bandwidths):
-            bandwidth = inference_config.bandwidth / (2 ** bandwidth_factor)
-            if inference_config.use_seeds:
-                from scipy.ndimage import gaussian_filter
+            segmentation = cluster.cluster(
+                prediction=embeddings, bandwidth=inference_config.bandwidth / (2 ** bandwidth_factor),
+                min_object_size=inference_config.min_size)
+            emit("detection", bandwidth_factor, segmentation)
+            detections.append(segmentation)
+        return detections
 
-                offset_magnitude = np.linalg.norm(embeddings_centered[:-1], axis=0)
-                smooth = gaussian_filter(offset_magnitude, sigma=2)
-                seeds = np.flip(peak_local_max(-smooth), 1)
-                src = torch.from_numpy(np.ascontiguousarray(embeddings_centered)).to(device)
-                mean_d, sd_d = src[:nd].contiguous().clone(), src[-1].contiguous()
-            else:
-                seeds = None
-                mean_d, sd_d = emb_d[:nd].contiguous().clone(), std_d
-            labels, _ = mean_shift_on_device(
-                mean_d, sd_d, bandwidth, inference_config.reduction_probability, threshold, seeds)
-            if inference_config.use_seeds and centered_aliased:
-                embeddings_centered[:nd] = mean_d.cpu().numpy()      # offsets + coordinates
-                centered_aliased = False
-            ds_detection[sample, bandwidth_factor, ...] = labels.cpu().numpy()
+    # use_seeds keeps the reference's aliasing (detect.py:116-118,142-144): the first
+    # mean_shift_segmentation call adds the pixel coordinates to `embeddings_centered` IN PLACE
+    # (its input is a view), later bandwidths re-read that mutated array — magnitudes, seeds
+    # and inputs then carry offsets + coordinates, exactly as in the reference (where sklearn
+    # then usually raises "No point was within bandwidth ... of any seed").
+    centered_aliased = True
+    for bandwidth_factor in range(inference_config.num_bandwidths):
+        bandwidth = inference_config.bandwidth / (2 ** bandwidth_factor)
+        if inference_config.use_seeds:
+            from scipy.ndimage import gaussian_filter
+
+            offset_magnitude = np.linalg.norm(embeddings_centered[:-1], axis=0)
+            smooth = gaussian_filter(offset_magnitude, sigma=2)
+            seeds = np.flip(peak_local_max(-smooth), 1)
+            src = torch.from_numpy(np.ascontiguousarray(embeddings_centered)).to(device)
+            mean_d, sd_d = src[:nd].contiguous().clone(), src[-1].contiguous()
+        else:
+            seeds = None
+            mean_d, sd_d = emb_d[:nd].contiguous().clone(), std_d
+        labels, _ = mean_shift_on_device(
+            mean_d, sd_d, bandwidth, inference_config.reduction_probability, threshold, seeds)
+        if inference_config.use_seeds and centered_aliased:
+            embeddings_centered[:nd] = mean_d.cpu().numpy()      # offsets + coordinates
+            centered_aliased = False
+        emit("detection", bandwidth_factor, labels)
+        detections.append(labels)
+    return detections

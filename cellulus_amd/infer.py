@@ -16,6 +16,80 @@ from .segment import segment
 from .train import _require_hip_device
 
 
+def _stages_chain(cfg):
+    """True if detect reads what predict writes and segment reads what detect writes."""
+    p, d, s = cfg.prediction_dataset_config, cfg.detection_dataset_config, cfg.segmentation_dataset_config
+    return (p is not None and d is not None and s is not None
+            and d.container_path == p.container_path and d.secondary_dataset_name == p.dataset_name
+            and s.container_path == d.container_path and s.secondary_dataset_name == d.dataset_name)
+
+
+def fused_stages(model, inference_config, normalization_factor, device):
+    """The three stages of ``infer.py:69-77`` sample by sample instead of dataset by dataset: the
+    embeddings go from the U-Net to the mean-shift and on to the post-processing in HBM, the
+    zarr datasets — the same ones, with the same contents — are written by a background thread
+    while the next stage computes.  What the staged path reads back from disk is reproduced
+    exactly: float32 embeddings widened to float64, label maps through their uint16 storage type.
+    Every stage draws from its own generator in the staged order too (torch for the noise,
+    numpy for the mean-shift sub-sampling), so interleaving them changes no random number."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from .detect import _create, _labels_to_host, detect_sample
+    from .predict import PredictScan
+    from .segment import segment_sample
+    from .utils import zarr_io
+
+    dataset_config = inference_config.dataset_config
+    meta = DatasetMetaData.from_dataset_config(dataset_config)
+    nd = meta.num_spatial_dims
+    spatial = tuple(meta.spatial_array)
+    model.set_infer(p_salt_pepper=inference_config.p_salt_pepper,
+                    num_infer_iterations=inference_config.num_infer_iterations, device=device)
+    raw_ds = zarr_io.open(dataset_config.container_path, "r")[dataset_config.dataset_name]
+    f = zarr_io.open(inference_config.prediction_dataset_config.container_path)
+    ds_emb = _create(f, inference_config.prediction_dataset_config.dataset_name,
+                     (meta.num_samples, nd + 1, *spatial), float, nd)
+    ds_det = _create(f, inference_config.detection_dataset_config.dataset_name,
+                     (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
+    ds_bin = _create(f, "binary-segmentation", (meta.num_samples, 1, *spatial), np.uint16, nd)
+    ds_cen = _create(f, "centered-embeddings", (meta.num_samples, nd + 1, *spatial), float, nd)
+    ds_seg = _create(f, inference_config.segmentation_dataset_config.dataset_name,
+                     (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
+
+    scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)
+    pending = []
+    with ThreadPoolExecutor(max_workers=1) as writer:
+        def write(ds, key, value):
+            def job():
+                ds[key] = value
+            pending.append(writer.submit(job))
+
+        for sample in range(meta.num_samples):
+            raw = raw_ds[sample]
+            emb_d = scan.predict_sample(raw).double()            # == astype(float64) of the f32 result
+            embeddings = emb_d.cpu().numpy()
+            write(ds_emb, sample, embeddings)
+
+            def emit(kind, index, value, sample=sample):
+                if kind == "binary":
+                    write(ds_bin, (sample, 0, Ellipsis), value)
+                elif kind == "centered":
+                    write(ds_cen, sample, value)
+                else:
+                    write(ds_det, (sample, index, Ellipsis), _labels_to_host(value))
+
+            detections = detect_sample(embeddings, inference_config, nd, device, sample, emb_d=emb_d, emit=emit)
+            for bandwidth_factor, labels in enumerate(detections):
+                # through the uint16 storage type, as segment() reads it back
+                seg_d = (labels.to(device=device, dtype=torch.int32) & 0xFFFF).contiguous()
+                out = segment_sample(seg_d, raw[0], inference_config, device)
+                write(ds_seg, (sample, bandwidth_factor, Ellipsis), out.cpu().numpy())
+            while len(pending) > 16:                              # bound the host copies in flight
+                pending.pop(0).result()
+        for job in pending:
+            job.result()
+
+
 def infer(experiment_config):
     print(experiment_config)
     rank, world, local_rank = parallel.init_from_env()
@@ -63,15 +137,19 @@ def infer(experiment_config):
     # set in eval mode
     model.eval()
 
-    # get predicted embeddings...
-    if inference_config.prediction_dataset_config is not None:
-        predict(model, inference_config, normalization_factor)
-    # ...turn them into a detection ...
-    if inference_config.detection_dataset_config is not None:
-        detect(inference_config)
-    # ...and post-process the detection to obtain an instance segmentation
-    if inference_config.segmentation_dataset_config is not None:
-        segment(inference_config)
+    if world == 1 and _stages_chain(inference_config) and os.environ.get("CLX_FUSED_INFER", "1") != "0":
+        # predict -> detect -> segment per sample with the hand-off in device memory
+        fused_stages(model, inference_config, normalization_factor, device)
+    else:
+        # get predicted embeddings...
+        if inference_config.prediction_dataset_config is not None:
+            predict(model, inference_config, normalization_factor)
+        # ...turn them into a detection ...
+        if inference_config.detection_dataset_config is not None:
+            detect(inference_config)
+        # ...and post-process the detection to obtain an instance segmentation
+        if inference_config.segmentation_dataset_config is not None:
+            segment(inference_config)
     # ...and evaluate if ground-truth exists
     if inference_config.evaluation_dataset_config is not None and rank == 0:
         if world > 1:

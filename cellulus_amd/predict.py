@@ -38,6 +38,43 @@ def tile_offsets(size, tile):
     return offs
 
 
+class PredictScan:
+    """The tile scan of one sample (predict.py:28-135 restated): reflect-pad by the network
+    context, visit tiles of ``crop_size`` with the stride of the output tile, (mean, std) of the
+    noisy forwards per tile.  ``predict_sample`` returns the (D+1, *spatial) float32 result on the
+    device; the float64 cast happens where it is written."""
+
+    def __init__(self, model, inference_config, meta, normalization_factor, raw_dtype, device):
+        nd = meta.num_spatial_dims
+        self.model, self.device, self.nd = model, device, nd
+        self.crop = tuple(int(c) for c in inference_config.crop_size)
+        if len(self.crop) != nd:
+            raise ValueError(f"crop_size must have {nd} entries, got {self.crop}")
+        topo = build_topology(model.in_channels, model.out_channels, model.num_fmaps, model.fmap_inc_factor,
+                              model.features_in_last_layer, model.downsampling_factors, nd, self.crop)
+        self.out_tile = tuple(topo.out_shape[3 - nd:])
+        self.context = tuple((c - o) // 2 for c, o in zip(self.crop, self.out_tile))
+        self.factor = normalization_factor
+        if self.factor is None:
+            self.factor = default_normalization_factor(raw_dtype)
+        self.spatial = tuple(meta.spatial_array)
+        self.offsets = [tile_offsets(s, t) for s, t in zip(self.spatial, self.out_tile)]
+        self.pad = [(0, 0)] + [(c, c) for c in self.context]
+
+    def predict_sample(self, raw):
+        raw = raw.astype(np.float32) * np.float32(self.factor)             # gp.Normalize
+        raw = np.pad(raw, self.pad, mode="reflect")                        # gp.Pad(mode="reflect")
+        raw_d = torch.from_numpy(raw).to(self.device)
+        result = torch.empty((self.nd + 1,) + self.spatial, dtype=torch.float32, device=self.device)
+        for off in itertools.product(*self.offsets):
+            in_sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, self.crop))
+            tile = raw_d[in_sl].unsqueeze(0).contiguous()
+            emb = self.model.infer_on_device(tile)[0]
+            out_sl = (slice(None),) + tuple(slice(o, o + t) for o, t in zip(off, self.out_tile))
+            result[out_sl] = emb
+        return result
+
+
 def predict(model: torch.nn.Module, inference_config: InferenceConfig, normalization_factor: float) -> None:
     dataset_config = inference_config.dataset_config
     meta = DatasetMetaData.from_dataset_config(dataset_config)
@@ -48,19 +85,7 @@ def predict(model: torch.nn.Module, inference_config: InferenceConfig, normaliza
     model.set_infer(p_salt_pepper=inference_config.p_salt_pepper,
                     num_infer_iterations=inference_config.num_infer_iterations, device=device)
 
-    crop = tuple(int(c) for c in inference_config.crop_size)
-    if len(crop) != nd:
-        raise ValueError(f"crop_size must have {nd} entries, got {crop}")
-    topo = build_topology(model.in_channels, model.out_channels, model.num_fmaps, model.fmap_inc_factor,
-                          model.features_in_last_layer, model.downsampling_factors, nd, crop)
-    out_tile = tuple(topo.out_shape[3 - nd:])
-    context = tuple((c - o) // 2 for c, o in zip(crop, out_tile))
-
     raw_ds = zarr_io.open(dataset_config.container_path, "r")[dataset_config.dataset_name]
-    factor = normalization_factor
-    if factor is None:
-        factor = default_normalization_factor(raw_ds.dtype)
-
     f = zarr_io.open(inference_config.prediction_dataset_config.container_path)
     ds = f.create_dataset(
         inference_config.prediction_dataset_config.dataset_name,
@@ -68,22 +93,10 @@ def predict(model: torch.nn.Module, inference_config: InferenceConfig, normaliza
         dtype=float,
     )
 
-    spatial = tuple(meta.spatial_array)
-    offsets = [tile_offsets(s, t) for s, t in zip(spatial, out_tile)]
+    scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)
     lo, hi = parallel.shard_range(meta.num_samples)
-    pad = [(0, 0)] + [(c, c) for c in context]
     for sample in range(lo, hi):
-        raw = raw_ds[sample].astype(np.float32) * np.float32(factor)      # gp.Normalize
-        raw = np.pad(raw, pad, mode="reflect")                             # gp.Pad(mode="reflect")
-        raw_d = torch.from_numpy(raw).to(device)
-        result = torch.empty((nd + 1,) + spatial, dtype=torch.float32, device=device)
-        for off in itertools.product(*offsets):
-            in_sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, crop))
-            tile = raw_d[in_sl].unsqueeze(0).contiguous()
-            emb = model.infer_on_device(tile)[0]
-            out_sl = (slice(None),) + tuple(slice(o, o + t) for o, t in zip(off, out_tile))
-            result[out_sl] = emb
-        ds[sample] = result.cpu().numpy().astype(np.float64)
+        ds[sample] = scan.predict_sample(raw_ds[sample]).cpu().numpy().astype(np.float64)
 
     if parallel.world_size() > 1:
         torch.distributed.barrier()

@@ -159,22 +159,28 @@ def segment(inference_config: InferenceConfig) -> None:
     if parallel.world_size() > 1:
         torch.distributed.barrier()
     ds_segmented = f[inference_config.segmentation_dataset_config.dataset_name]
-    min_size = inference_config.min_size
 
     lo, hi = parallel.shard_range(meta.num_samples)
     for sample in tqdm(range(lo, hi), disable=parallel.rank() != 0):
+        raw_image = None
+        if inference_config.post_processing != "cell":
+            raw_image = f[dataset_config.dataset_name][sample, 0]
         for bandwidth_factor in range(inference_config.num_bandwidths):
-            segmentation = ds[sample, bandwidth_factor]
-            if inference_config.post_processing == "cell":
-                seg_d = torch.from_numpy(segmentation.astype(np.int32)).to(device)
-                grow_shrink_on_device(seg_d, inference_config.grow_distance,
-                                      inference_config.shrink_distance)
-            else:  # "nucleus"
-                seg_in = torch.from_numpy(segmentation.astype(np.int32)).to(device)
-                raw_d, raw_type = _raw_to_device(f[dataset_config.dataset_name][sample, 0], device)
-                seg_d = nucleus_refine_on_device(seg_in, raw_d, raw_type)
-            if min_size == 0:          # size_filter returns its input unchanged (misc.py:12-13)
-                out = seg_d
-            else:
-                out, _ = label_on_device(seg_d, min_size)
+            seg_d = torch.from_numpy(ds[sample, bandwidth_factor].astype(np.int32)).to(device)
+            out = segment_sample(seg_d, raw_image, inference_config, device)
             ds_segmented[sample, bandwidth_factor, ...] = out.cpu().numpy()
+
+
+def segment_sample(seg_d, raw_image, inference_config, device):
+    """segment.py:41-108 for one (sample, bandwidth).  seg_d: int32 device tensor holding the
+    detection labels (consumed); raw_image: host array of the sample's first raw channel (only the
+    "nucleus" post-processing reads it).  Returns the int32 device tensor to store as uint16."""
+    if inference_config.post_processing == "cell":
+        grow_shrink_on_device(seg_d, inference_config.grow_distance, inference_config.shrink_distance)
+    else:  # "nucleus"
+        raw_d, raw_type = _raw_to_device(raw_image, device)
+        seg_d = nucleus_refine_on_device(seg_d, raw_d, raw_type)
+    if inference_config.min_size == 0:          # size_filter returns its input unchanged (misc.py:12-13)
+        return seg_d
+    out, _ = label_on_device(seg_d, inference_config.min_size)
+    return out

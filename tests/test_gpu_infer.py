@@ -468,3 +468,53 @@ def test_nucleus_refine_on_device_matches_oracle_random(device):
             raw_d, rt = _raw_to_device(raw, device)
             out = nucleus_refine_on_device(torch.from_numpy(seg).to(device), raw_d, rt)
             np.testing.assert_array_equal(out.cpu().numpy(), ref, err_msg=f"{shape} {dtype}")
+
+
+def test_fused_infer_writes_the_same_datasets_as_the_staged_path(device, tmp_path, monkeypatch):
+    """infer() hands embeddings and label maps from stage to stage in device memory (default) or
+    goes through the zarr datasets stage by stage (CLX_FUSED_INFER=0, the reference's order): every
+    dataset and attribute on disk is identical, for both post-processing modes."""
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.infer import infer
+    from cellulus_amd.utils import zarr_io
+    from oracle.unet_oracle import OracleUNetModel
+
+    monkeypatch.chdir(tmp_path)
+    mcfg = dict(num_fmaps=8, fmap_inc_factor=2, features_in_last_layer=16, downsampling_factors=[[2, 2]])
+    torch.manual_seed(0)
+    oracle = OracleUNetModel(in_channels=1, out_channels=2, num_spatial_dims=2, **mcfg)
+    os.makedirs("models", exist_ok=True)
+    torch.save({"model_state_dict": oracle.state_dict()}, "models/best_loss.pth")
+    results = {}
+    for post in ("cell", "nucleus"):
+        for fused in ("1", "0"):
+            container = str(tmp_path / f"data_{post}_{fused}.zarr")
+            _write_raw(container, 2)
+            cfg = ExperimentConfig(
+                model_config=dict(checkpoint="models/best_loss.pth", **mcfg),
+                object_size=12, normalization_factor=1.0,
+                inference_config=dict(
+                    dataset_config=dict(container_path=container, dataset_name="test/raw"),
+                    prediction_dataset_config=dict(container_path=container, dataset_name="embeddings"),
+                    detection_dataset_config=dict(container_path=container, dataset_name="detection",
+                                                  secondary_dataset_name="embeddings"),
+                    segmentation_dataset_config=dict(container_path=container, dataset_name="segmentation",
+                                                     secondary_dataset_name="detection"),
+                    crop_size=[56, 56], num_infer_iterations=2, p_salt_pepper=0.05, num_bandwidths=2,
+                    reduction_probability=0.5, min_size=6, grow_distance=2, shrink_distance=3,
+                    post_processing=post, device="cuda:0"))
+            monkeypatch.setenv("CLX_FUSED_INFER", fused)
+            torch.manual_seed(42)
+            np.random.seed(42)
+            infer(cfg)
+            f = zarr_io.open(container, "r")
+            results[post, fused] = {name: (f[name][...], dict(f[name].attrs)) for name in
+                                    ("embeddings", "detection", "binary-segmentation", "centered-embeddings",
+                                     "segmentation")}
+        for name, (data, attrs) in results[post, "1"].items():
+            ref_data, ref_attrs = results[post, "0"][name]
+            assert data.dtype == ref_data.dtype and data.shape == ref_data.shape, name
+            np.testing.assert_array_equal(data, ref_data, err_msg=f"{post}/{name}")
+            assert {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in attrs.items()} == \
+                   {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in ref_attrs.items()}, name
+        assert results[post, "1"]["segmentation"][0].max() > 0
