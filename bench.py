@@ -302,6 +302,7 @@ def main():
     conv_ms = sum(v[2] for v in summ.values())
     plan_algo = getattr(plan, "algo", {})
     n_wino = sum(1 for a in plan_algo.values() if a.get("fwd"))
+    wino_tile = max([{1: 2, 2: 4}.get(a.get("fwd"), 0) for a in plan_algo.values()] or [0])
     roofline = dict(
         bound="mfma", kernel=dom_name,
         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
@@ -309,11 +310,11 @@ def main():
         launches_per_step=int(launches // args.steps),
         avg_launch_ms=round(ms / max(launches, 1), 4),
         note="achieved = FLOPs the kernel executes (2*M*N*K per GEMM, real extents) / HIP-event time of "
-             "its launches; Winograd layers execute 4/9 of the direct-convolution FLOPs",
+             "its launches; Winograd F(2x2) / F(4x4) layers execute 4/9 / 1/4 of the direct-convolution FLOPs",
         all_mfma_kernels=dict(tflops=round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else 0.0,
                               ms_per_step=round(mfma_ms / args.steps, 3)),
         conv_calls_ms_per_step=round(conv_ms / args.steps, 3),
-        winograd_layers=n_wino,
+        winograd_layers=n_wino, winograd_tile=wino_tile,
         direct_equivalent_tflops=round(crops_per_s / world * train_flops / 1e12, 2),
     )
 

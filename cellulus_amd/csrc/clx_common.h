@@ -68,11 +68,11 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
                      long long bs_out, hipStream_t st);
 int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
                      int batch, long long bs_x, long long bs_dy, long long bs_out, hipStream_t st);
-// Winograd F(2x2, 3x3) path (wino.hip)
+// Winograd F(2x2, 3x3) / F(4x4, 3x3) path (wino.hip)
 int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st);
 int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
                    hipStream_t st);
-int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad,
+int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad, int tile,
                   hipStream_t st);
 
 // in-library kernel timing (clx_core.hip); kinds match enum clx_profile_kind in clx.h

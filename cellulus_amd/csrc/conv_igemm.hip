@@ -386,8 +386,9 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
               "clx_conv_fwd: mask must be 16-byte aligned with ld_mask %% 4 == 0 and >= N");
   CLX_REQUIRE(d->ld_out % 4 == 0 && ((uintptr_t)d->out & 15) == 0,
               "clx_conv_fwd: out must be 16-byte aligned with ld_out %% 4 == 0");
-  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD, "clx_conv_fwd: bad algo");
-  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_fwd(d, (hipStream_t)stream);
+  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
+              "clx_conv_fwd: bad algo");
+  if (d->algo != CLX_ALGO_DIRECT) return clx_wino_fwd(d, (hipStream_t)stream);
   if (clx_smallc_applicable(d) && d->mask == nullptr) {
     clx_smallc_fwd(d, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_fwd(small-channel)");

@@ -352,8 +352,9 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
     CLX_REQUIRE((long long)d->B * S.D * S.H * S.W < (1ll << 31),
                 "clx_conv_wgrad: source %d has too many pixels", s);
   }
-  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD, "clx_conv_wgrad: bad algo");
-  if (d->algo == CLX_ALGO_WINOGRAD) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
+  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
+              "clx_conv_wgrad: bad algo");
+  if (d->algo != CLX_ALGO_DIRECT) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
   if (clx_smallc_applicable(d)) {
     clx_smallc_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_wgrad(small-channel)");

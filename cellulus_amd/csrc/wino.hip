@@ -1,16 +1,16 @@
-// Winograd F(2x2, 3x3) convolution for 2-D 3x3 layers (forward, data gradient, weight
-// gradient) on top of the f32-MFMA GEMM kernels:
+// Winograd F(m x m, 3x3), m = 2 or 4, for 2-D 3x3 layers (forward, data gradient, weight
+// gradient) on top of the f32-MFMA GEMM kernels; a = m + 2:
 //
-//   forward / dgrad:  V = B^T d B  (4x4 input patches, stride 2)      [HBM streaming]
-//                     M[xi] = V[xi] . U[xi]^T, xi = 0..15             [16 batched MFMA GEMMs]
+//   forward / dgrad:  V = B^T d B  (a x a input patches, stride m)    [HBM streaming]
+//                     M[xi] = V[xi] . U[xi]^T, xi = 0..a^2-1          [a^2 batched MFMA GEMMs]
 //                     Y = A^T M A (+ bias, ReLU, ReLU gate)           [HBM streaming]
-//   wgrad:            dU[xi] = (A dY A^T)[xi]^T . V[xi]  over tiles   [16 batched MFMA GEMMs]
+//   wgrad:            dU[xi] = (A dY A^T)[xi]^T . V[xi]  over tiles   [a^2 batched MFMA GEMMs]
 //                     dW = G^T dU G   (clx_unpack_wgrad_wino)
 //
-// 16 multiplications per 2x2 outputs instead of 36: 2.25x fewer MFMA FLOPs, all in f32
-// (measured error 3e-6 vs 1e-6 for the direct form on a 768-channel layer).  The price is
-// HBM traffic for V and M (4x the activation each), so the plan selects it only for layers
-// with enough channels on both sides.
+// a^2 multiplications per m^2 outputs instead of 9 m^2: 2.25x (m = 2) / 4x (m = 4) fewer MFMA
+// FLOPs, all in f32.  The price is HBM traffic for V and M (a^2/m^2 = 4x / 2.25x the activation
+// each) and rounding error (see WT below), so the plan selects it only for layers with enough
+// channels on both sides.
 //
 // Replaces the same reference calls as conv_igemm.hip / conv_wgrad.hip (nn.Conv2d 3x3 and
 // its autograd backward, cellulus/models/unet.py:24-51, cellulus/train.py:178).
@@ -35,9 +35,48 @@ struct Geom {
   long long T;             // B * th * tw
 };
 
-// V[xi][t][c] = (B^T d B)[xi],  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-__global__ void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4, Geom g,
-                                  float* __restrict__ V, long long total) {
+// Transform matrices of F(MT x MT, 3 x 3) (Cook-Toom, y = A^T [(G g) o (B^T d)]), A = MT + 2.
+//   MT = 2: points {0, 1, -1, inf}
+//   MT = 4: points {0, 1, -1, 1/2, -2, inf} — measured on a 768-channel layer in f32 (max abs
+//           error / max|y|): 4.7e-6, against 1.1e-5 for the textbook {0, +-1, +-2}, 7e-7 for
+//           MT = 2 and 3.5e-7 for the direct convolution (tools/wino_numerics.py).
+// All entries of A^T and B^T are dyadic, i.e. exact in f32; G is applied in double.
+template <int MT> struct WT;
+template <> struct WT<2> {
+  static constexpr int A = 4;
+  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+  static constexpr double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+};
+template <> struct WT<4> {
+  static constexpr int A = 6;
+  static constexpr float BT[6][6] = {{1, -1.5f, -2, 1.5f, 1, 0},  {0, -1, 0.5f, 2.5f, 1, 0}, {0, 1, -2.5f, 0.5f, 1, 0},
+                                     {0, -2, -1, 2, 1, 0},        {0, 0.5f, -1, -0.5f, 1, 0}, {0, 1, -1.5f, -2, 1.5f, 1}};
+  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, -2, 0}, {0, 1, 1, 0.25f, 4, 0}, {0, 1, -1, 0.125f, -8, 1}};
+  static constexpr double G[6][3] = {{1, 0, 0},
+                                     {1.0 / 3, 1.0 / 3, 1.0 / 3},
+                                     {-1.0 / 3, 1.0 / 3, -1.0 / 3},
+                                     {-16.0 / 15, -8.0 / 15, -4.0 / 15},
+                                     {1.0 / 15, -2.0 / 15, 4.0 / 15},
+                                     {0, 0, 1}};
+};
+
+// acc (+)= coef * v with the coefficient known at compile time: zeros vanish, +-1 become add/sub
+template <typename V>
+__device__ __forceinline__ void axpy(V& acc, bool& first, float coef, const V& v) {
+  if (coef == 0.f) return;
+  if (first) { acc = (coef == 1.f) ? v : (coef == -1.f) ? -v : coef * v; first = false; }
+  else if (coef == 1.f) acc += v;
+  else if (coef == -1.f) acc -= v;
+  else acc += coef * v;
+}
+
+// V[xi][t][c] = (B^T d B)[xi] for the A x A input patch of tile t (stride MT)
+template <int MT>
+__global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4, Geom g,
+                                                         float* __restrict__ V, long long total) {
+  using W = WT<MT>;
+  constexpr int A = W::A;
   const int C = C4 * 4;
   const long long plane = g.T * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -48,13 +87,13 @@ __global__ void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4,
     const long long q = t / g.tw;
     const int ty = (int)(q % g.th);
     const int b = (int)(q / g.th);
-    f32x4 d[4][4];
+    f32x4 d[A][A];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ly = 2 * ty - g.P + r;
+    for (int r = 0; r < A; ++r) {
+      const int ly = MT * ty - g.P + r;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int lx = 2 * tx - g.P + s;
+      for (int s = 0; s < A; ++s) {
+        const int lx = MT * tx - g.P + s;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)ly < (unsigned)g.IH && (unsigned)lx < (unsigned)g.IW) {
           const long long pix = ((long long)b * g.SH + ly + g.oy) * g.SW + lx + g.ox;
@@ -63,30 +102,42 @@ __global__ void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4,
         d[r][s] = v;
       }
     }
-    f32x4 w[4][4];
+    // columns: w[:, s] = B^T d[:, s]
+    f32x4 w[A][A];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {      // rows: B^T d
-      w[0][s] = d[0][s] - d[2][s];
-      w[1][s] = d[1][s] + d[2][s];
-      w[2][s] = d[2][s] - d[1][s];
-      w[3][s] = d[1][s] - d[3][s];
-    }
+    for (int s = 0; s < A; ++s)
+#pragma unroll
+      for (int r = 0; r < A; ++r) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy(acc, first, W::BT[r][k], d[k][s]);
+        w[r][s] = acc;
+      }
+    // rows: V[r][q] = sum_k w[r][k] * B^T[q][k]
     float* dst = V + t * C + c;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {      // columns: (.) B
-      st4(dst + (r * 4 + 0) * plane, w[r][0] - w[r][2]);
-      st4(dst + (r * 4 + 1) * plane, w[r][1] + w[r][2]);
-      st4(dst + (r * 4 + 2) * plane, w[r][2] - w[r][1]);
-      st4(dst + (r * 4 + 3) * plane, w[r][1] - w[r][3]);
-    }
+    for (int r = 0; r < A; ++r)
+#pragma unroll
+      for (int qq = 0; qq < A; ++qq) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy(acc, first, W::BT[qq][k], w[r][k]);
+        st4(dst + (r * A + qq) * plane, acc);
+      }
   }
 }
 
-// Y = A^T m A,  A^T = [1 1 1 0; 0 1 -1 -1]; bias, ReLU, ReLU gate fused
-__global__ void wino_output_kernel(const float* __restrict__ M, int N4, Geom g,
-                                   const float* __restrict__ bias, int relu,
-                                   const float* __restrict__ mask, int ld_mask,
-                                   float* __restrict__ out, int ld_out, int Nreal, long long total) {
+// Y = A^T m A (MT x MT outputs per tile); bias, ReLU, ReLU gate fused
+template <int MT>
+__global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, int N4, Geom g,
+                                                          const float* __restrict__ bias, int relu,
+                                                          const float* __restrict__ mask, int ld_mask,
+                                                          float* __restrict__ out, int ld_out, int Nreal,
+                                                          long long total) {
+  using W = WT<MT>;
+  constexpr int A = W::A;
   const int N = N4 * 4;
   const long long plane = g.T * N;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -98,34 +149,41 @@ __global__ void wino_output_kernel(const float* __restrict__ M, int N4, Geom g,
     const int ty = (int)(q % g.th);
     const int b = (int)(q / g.th);
     const float* src = M + t * N + n;
-    f32x4 r0[4], r1[4];
+    // rows first, one column of m at a time: r[a][s] = sum_k A^T[a][k] m[k][s]
+    f32x4 rr[MT][A];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {      // rows: A^T m
-      const f32x4 m0 = ld4(src + (0 * 4 + s) * plane), m1 = ld4(src + (1 * 4 + s) * plane);
-      const f32x4 m2 = ld4(src + (2 * 4 + s) * plane), m3 = ld4(src + (3 * 4 + s) * plane);
-      r0[s] = m0 + m1 + m2;
-      r1[s] = m1 - m2 - m3;
+    for (int s = 0; s < A; ++s) {
+      f32x4 m[A];
+#pragma unroll
+      for (int k = 0; k < A; ++k) m[k] = ld4(src + (k * A + s) * plane);
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy(acc, first, W::AT[a][k], m[k]);
+        rr[a][s] = acc;
+      }
     }
-    f32x4 y[2][2];
-    y[0][0] = r0[0] + r0[1] + r0[2];
-    y[0][1] = r0[1] - r0[2] - r0[3];
-    y[1][0] = r1[0] + r1[1] + r1[2];
-    y[1][1] = r1[1] - r1[2] - r1[3];
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (bias) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[e] = (n + e < Nreal) ? bias[n + e] : 0.f;
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int oy = 2 * ty + a;
+    for (int a = 0; a < MT; ++a) {
+      const int oy = MT * ty + a;
       if (oy >= g.OH) continue;
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int ox = 2 * tx + c;
+      for (int cc = 0; cc < MT; ++cc) {
+        const int ox = MT * tx + cc;
         if (ox >= g.OW) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy(v, first, W::AT[cc][k], rr[a][k]);
+        v += bv;
         const long long m = ((long long)b * g.OH + oy) * g.OW + ox;
-        f32x4 v = y[a][c] + bv;
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -149,12 +207,15 @@ __global__ void wino_output_kernel(const float* __restrict__ M, int N4, Geom g,
   }
 }
 
-// Mdy[xi][t][n] = (A dy A^T)[xi],  A = [1 0; 1 1; 1 -1; 0 -1]; dbias[n] += sum of dy
+// Mdy[xi][t][n] = (A dy A^T)[xi] with A = (A^T)^T (A x MT); dbias[n] += sum of dy
 // (block-private LDS accumulator, then one global atomic per channel per block)
+template <int MT>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int ld_dy, int N4,
                                                       Geom g, float* __restrict__ Md,
                                                       float* __restrict__ dbias, int Nreal,
                                                       long long total) {
+  using W = WT<MT>;
+  constexpr int A = W::A;
   extern __shared__ float bacc[];
   const int N = N4 * 4;
   const long long plane = g.T * N;
@@ -170,37 +231,45 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
     const long long q = t / g.tw;
     const int ty = (int)(q % g.th);
     const int b = (int)(q / g.th);
-    f32x4 d[2][2];
+    f32x4 d[MT][MT];
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int oy = 2 * ty + a, ox = 2 * tx + c;
+      for (int c = 0; c < MT; ++c) {
+        const int oy = MT * ty + a, ox = MT * tx + c;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (oy < g.OH && ox < g.OW) v = ld4(dy + (((long long)b * g.OH + oy) * g.OW + ox) * ld_dy + n);
         d[a][c] = v;
+        sum += v;
       }
     if (dbias) {
-      const f32x4 sum = d[0][0] + d[0][1] + d[1][0] + d[1][1];
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(&bacc[n + e], sum[e]);
     }
-    f32x4 w[4][2];
+    // w[r][c] = sum_a A^T[a][r] d[a][c]
+    f32x4 w[A][MT];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {      // rows: A dy
-      w[0][c] = d[0][c];
-      w[1][c] = d[0][c] + d[1][c];
-      w[2][c] = d[0][c] - d[1][c];
-      w[3][c] = -d[1][c];
-    }
+    for (int c = 0; c < MT; ++c)
+#pragma unroll
+      for (int r = 0; r < A; ++r) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) axpy(acc, first, W::AT[a][r], d[a][c]);
+        w[r][c] = acc;
+      }
     float* dst = Md + t * N + n;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {      // columns: (.) A^T
-      st4(dst + (r * 4 + 0) * plane, w[r][0]);
-      st4(dst + (r * 4 + 1) * plane, w[r][0] + w[r][1]);
-      st4(dst + (r * 4 + 2) * plane, w[r][0] - w[r][1]);
-      st4(dst + (r * 4 + 3) * plane, -w[r][1]);
-    }
+    for (int r = 0; r < A; ++r)
+#pragma unroll
+      for (int qq = 0; qq < A; ++qq) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int c = 0; c < MT; ++c) axpy(acc, first, W::AT[c][qq], w[r][c]);
+        st4(dst + (r * A + qq) * plane, acc);
+      }
   }
   if (dbias) {
     __syncthreads();
@@ -209,73 +278,80 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
 }
 
-// U[xi][n][c] = (G g G^T)[xi],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+// U[xi][n][c] = (G g G^T)[xi], computed in double
 // mode FWD:   g = w[n][c][:, :]            rows n < rows_pad (cout_pad), cols c < cin_pad
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
+template <int MT>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
                                    int cin, int rows, int cols, int dgrad, long long total) {
+  using W = WT<MT>;
+  constexpr int A = W::A;
   const long long plane = (long long)rows * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int col = (int)(i % cols), row = (int)(i / cols);
     const int n = dgrad ? col : row, c = dgrad ? row : col;
-    float g[3][3];
+    double g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        float v = 0.f;
+        double v = 0.0;
         if (n < cout && c < cin) {
           const int rr = dgrad ? 2 - r : r, ss = dgrad ? 2 - s : s;
-          v = w[((long long)n * cin + c) * 9 + rr * 3 + ss];
+          v = (double)w[((long long)n * cin + c) * 9 + rr * 3 + ss];
         }
         g[r][s] = v;
       }
-    float t[4][3];
+    double tt[A][3];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      t[0][s] = g[0][s];
-      t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-      t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-      t[3][s] = g[2][s];
-    }
+    for (int r = 0; r < A; ++r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      U[(r * 4 + 0) * plane + i] = t[r][0];
-      U[(r * 4 + 1) * plane + i] = 0.5f * (t[r][0] + t[r][1] + t[r][2]);
-      U[(r * 4 + 2) * plane + i] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
-      U[(r * 4 + 3) * plane + i] = t[r][2];
-    }
+      for (int s = 0; s < 3; ++s) tt[r][s] = W::G[r][0] * g[0][s] + W::G[r][1] * g[1][s] + W::G[r][2] * g[2][s];
+#pragma unroll
+    for (int r = 0; r < A; ++r)
+#pragma unroll
+      for (int qq = 0; qq < A; ++qq)
+        U[(r * A + qq) * plane + i] =
+            (float)(tt[r][0] * W::G[qq][0] + tt[r][1] * W::G[qq][1] + tt[r][2] * W::G[qq][2]);
   }
 }
 
-// dw[n][c][3x3] = G^T dU G,  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+// dw[n][c][3x3] = G^T dU G
+template <int MT>
 __global__ void wino_unpack_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout,
                                    int cin, int rows, int cin_pad, long long total) {
+  using W = WT<MT>;
+  constexpr int A = W::A;
   const long long plane = (long long)rows * cin_pad;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cin), n = (int)(i / cin);
     const float* src = dU + (long long)n * cin_pad + c;
-    float u[4][4];
+    double t[3][A];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int s = 0; s < A; ++s) {
+      double u[A];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) u[r][s] = src[(r * 4 + s) * plane];
-    float t[3][4];
+      for (int r = 0; r < A; ++r) u[r] = (double)src[(r * A + s) * plane];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      t[0][s] = u[0][s] + 0.5f * (u[1][s] + u[2][s]);
-      t[1][s] = 0.5f * (u[1][s] - u[2][s]);
-      t[2][s] = 0.5f * (u[1][s] + u[2][s]) + u[3][s];
+      for (int k = 0; k < 3; ++k) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < A; ++r) acc += W::G[r][k] * u[r];
+        t[k][s] = acc;
+      }
     }
     float* dst = dw + i * 9;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      dst[r * 3 + 0] = t[r][0] + 0.5f * (t[r][1] + t[r][2]);
-      dst[r * 3 + 1] = 0.5f * (t[r][1] - t[r][2]);
-      dst[r * 3 + 2] = 0.5f * (t[r][1] + t[r][2]) + t[r][3];
-    }
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        double acc = 0.0;
+#pragma unroll
+        for (int s = 0; s < A; ++s) acc += t[k][s] * W::G[s][l];
+        dst[k * 3 + l] = (float)acc;
+      }
   }
 }
 
@@ -288,109 +364,131 @@ bool applicable(const clx_conv_desc* d) {
   return true;
 }
 
-Geom geom(const clx_conv_desc* d) {
+// output tile size selected by the descriptor: CLX_ALGO_WINOGRAD = F(2x2), CLX_ALGO_WINOGRAD4 = F(4x4)
+inline int tile_of(const clx_conv_desc* d) { return d->algo == CLX_ALGO_WINOGRAD4 ? 4 : 2; }
+
+Geom geom(const clx_conv_desc* d, int mt) {
   Geom g;
   const clx_src& S = d->src[0];
   g.B = d->B; g.SH = S.H; g.SW = S.W; g.oy = S.oy; g.ox = S.ox;
   g.IH = d->IH; g.IW = d->IW; g.P = d->PH;
   g.OH = d->IH + 2 * d->PH - 2; g.OW = d->IW + 2 * d->PW - 2;
-  g.th = (g.OH + 1) / 2; g.tw = (g.OW + 1) / 2;
+  g.th = (g.OH + mt - 1) / mt; g.tw = (g.OW + mt - 1) / mt;
   g.T = (long long)g.B * g.th * g.tw;
   return g;
 }
 
 inline int pad4(int n) { return (n + 3) / 4 * 4; }
 
-}  // namespace
-
-extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
-  if (d == nullptr || !applicable(d)) return 0;
-  if (pass == CLX_PASS_WGRAD && d->PH != 0) return 0;
-  const Geom g = geom(d);
-  if (g.OH <= 0 || g.OW <= 0 || g.T >= (1ll << 31)) return 0;
-  const long long C = d->src[0].C, N = pad4(d->N);
-  return (size_t)(16 * g.T * (C + N)) * sizeof(float);
-}
-
-int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st) {
-  CLX_REQUIRE(applicable(d), "clx_conv_fwd: CLX_ALGO_WINOGRAD does not apply to this geometry");
-  const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_FWD);
-  CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,
-              "clx_conv_fwd: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
-  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0, "clx_conv_fwd: workspace must be 16-byte aligned");
-  const Geom g = geom(d);
-  const clx_src& S = d->src[0];
-  const int C = S.C, Np = pad4(d->N);
-  float* V = (float*)d->workspace;
-  float* M = V + 16 * g.T * C;
-  const long long tot_in = g.T * (C / 4);
-  wino_input_kernel<<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
-  // 16 GEMMs [T x C] . [C x N] as a batched 1x1 "convolution" over T pixels
+// the batched GEMM descriptor: A^2 problems [T x C] . [C x N] as 1x1 "convolutions" over T pixels
+clx_conv_desc gemm_desc(float* V, int C, long long T) {
   clx_conv_desc gd = {};
   gd.nsrc = 1;
   gd.src[0].ptr = V; gd.src[0].C = C; gd.src[0].ld = C;
-  gd.src[0].D = 1; gd.src[0].H = 1; gd.src[0].W = (int)g.T;
+  gd.src[0].D = 1; gd.src[0].H = 1; gd.src[0].W = (int)T;
   gd.src[0].fz = gd.src[0].fy = gd.src[0].fx = 1;
-  gd.B = 1; gd.ID = 1; gd.IH = 1; gd.IW = (int)g.T;
+  gd.B = 1; gd.ID = 1; gd.IH = 1; gd.IW = (int)T;
   gd.KD = gd.KH = gd.KW = 1;
+  return gd;
+}
+
+template <int MT>
+int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
+  constexpr int AA = WT<MT>::A * WT<MT>::A;
+  const Geom g = geom(d, MT);
+  const clx_src& S = d->src[0];
+  const int C = S.C, Np = pad4(d->N);
+  float* V = (float*)d->workspace;
+  float* M = V + AA * g.T * C;
+  const long long tot_in = g.T * (C / 4);
+  wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+  clx_conv_desc gd = gemm_desc(V, C, g.T);
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
-  const int rc = clx_igemm_launch(&gd, 16, g.T * C, (long long)Np * C, g.T * Np, st);
+  const int rc = clx_igemm_launch(&gd, AA, g.T * C, (long long)Np * C, g.T * Np, st);
   if (rc) return rc;
   const long long tot_out = g.T * (Np / 4);
-  wino_output_kernel<<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, g, d->bias, d->relu, d->mask,
-                                                               d->ld_mask, d->out, d->ld_out, d->N, tot_out);
+  wino_output_kernel<MT><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, g, d->bias, d->relu, d->mask,
+                                                                   d->ld_mask, d->out, d->ld_out, d->N, tot_out);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }
 
-int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
-                   hipStream_t st) {
-  CLX_REQUIRE(applicable(d) && d->PH == 0, "clx_conv_wgrad: CLX_ALGO_WINOGRAD does not apply to this geometry");
-  const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_WGRAD);
-  CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,
-              "clx_conv_wgrad: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
-  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0, "clx_conv_wgrad: workspace must be 16-byte aligned");
-  const Geom g = geom(d);
+template <int MT>
+int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias, hipStream_t st) {
+  constexpr int AA = WT<MT>::A * WT<MT>::A;
+  const Geom g = geom(d, MT);
   const clx_src& S = d->src[0];
   const int C = S.C, N = d->N;     // N is a multiple of 4 (validated by clx_conv_wgrad)
   float* V = (float*)d->workspace;
-  float* Md = V + 16 * g.T * C;
+  float* Md = V + AA * g.T * C;
   const long long tot_in = g.T * (C / 4);
-  wino_input_kernel<<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+  wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
   const long long tot_dy = g.T * (N / 4);
-  CLX_REQUIRE(N <= 8192, "clx_conv_wgrad: too many output channels for the Winograd bias accumulator");
   int blocks = grid_for(tot_dy, 256);
   if (blocks > 2048) blocks = 2048;
-  wino_dy_kernel<<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, g, Md, dbias, N, tot_dy);
-  clx_conv_desc gd = {};
-  gd.nsrc = 1;
-  gd.src[0].ptr = V; gd.src[0].C = C; gd.src[0].ld = C;
-  gd.src[0].D = 1; gd.src[0].H = 1; gd.src[0].W = (int)g.T;
-  gd.src[0].fz = gd.src[0].fy = gd.src[0].fx = 1;
-  gd.B = 1; gd.ID = 1; gd.IH = 1; gd.IW = (int)g.T;
-  gd.KD = gd.KH = gd.KW = 1;
+  wino_dy_kernel<MT><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, g, Md, dbias, N, tot_dy);
+  clx_conv_desc gd = gemm_desc(V, C, g.T);
   gd.N = N;
-  const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, 16, g.T * C, g.T * N, (long long)N * C, st);
+  const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, g.T * C, g.T * N, (long long)N * C, st);
   if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_conv_wgrad(winograd)");
   return CLX_OK;
 }
 
+}  // namespace
+
+extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
+  if (d == nullptr || !applicable(d)) return 0;
+  if (pass == CLX_PASS_WGRAD && d->PH != 0) return 0;
+  const int mt = tile_of(d), a = mt + 2;
+  const Geom g = geom(d, mt);
+  if (g.OH <= 0 || g.OW <= 0 || g.T >= (1ll << 31)) return 0;
+  const long long C = d->src[0].C, N = pad4(d->N);
+  return (size_t)(a * a * g.T * (C + N)) * sizeof(float);
+}
+
+int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st) {
+  CLX_REQUIRE(applicable(d), "clx_conv_fwd: Winograd does not apply to this geometry");
+  const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_FWD);
+  CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,
+              "clx_conv_fwd: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
+  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0, "clx_conv_fwd: workspace must be 16-byte aligned");
+  return tile_of(d) == 4 ? wino_fwd_t<4>(d, st) : wino_fwd_t<2>(d, st);
+}
+
+int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
+                   hipStream_t st) {
+  CLX_REQUIRE(applicable(d) && d->PH == 0, "clx_conv_wgrad: Winograd does not apply to this geometry");
+  const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_WGRAD);
+  CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,
+              "clx_conv_wgrad: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
+  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0, "clx_conv_wgrad: workspace must be 16-byte aligned");
+  CLX_REQUIRE(d->N <= 8192, "clx_conv_wgrad: too many output channels for the Winograd bias accumulator");
+  return tile_of(d) == 4 ? wino_wgrad_t<4>(d, dy, ld_dy, dwpack, dbias, st)
+                         : wino_wgrad_t<2>(d, dy, ld_dy, dwpack, dbias, st);
+}
+
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad,
-                  hipStream_t st) {
+                  int tile, hipStream_t st) {
   const int rows = dgrad ? cin_pad : cout_pad, cols = dgrad ? cout_pad : cin_pad;
   const long long total = (long long)rows * cols;
-  wino_filter_kernel<<<grid_for(total, 256), 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
+  if (tile == 4)
+    wino_filter_kernel<4><<<grid_for(total, 256), 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
+  else
+    wino_filter_kernel<2><<<grid_for(total, 256), 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
   return CLX_OK;
 }
 
 extern "C" int clx_unpack_wgrad_wino(const float* du, float* dw, int cout, int cin, int rows,
-                                     int cin_pad, clx_stream stream) {
+                                     int cin_pad, int tile, clx_stream stream) {
   CLX_REQUIRE(du && dw, "clx_unpack_wgrad_wino: null pointer");
   CLX_REQUIRE(cout > 0 && cin > 0 && rows >= cout && cin_pad >= cin, "clx_unpack_wgrad_wino: bad extents");
+  CLX_REQUIRE(tile == 2 || tile == 4, "clx_unpack_wgrad_wino: tile must be 2 or 4");
   const long long total = (long long)cout * cin;
-  wino_unpack_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(du, dw, cout, cin, rows,
-                                                                           cin_pad, total);
+  if (tile == 4)
+    wino_unpack_kernel<4><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(du, dw, cout, cin, rows, cin_pad, total);
+  else
+    wino_unpack_kernel<2><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(du, dw, cout, cin, rows, cin_pad, total);
   CLX_CHECK_LAUNCH("clx_unpack_wgrad_wino");
   return CLX_OK;
 }

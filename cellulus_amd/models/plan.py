@@ -27,10 +27,21 @@ def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
-# Winograd F(2x2, 3x3) is used for 2-D 3x3 layers whose channel counts (both sides) reach this
-# value: below it the extra HBM traffic of the transformed tensors outweighs the 2.25x fewer
-# MFMA FLOPs.  CLX_WINOGRAD=0 forces the direct implicit-GEMM kernels everywhere.
+# Winograd is used for 2-D 3x3 layers whose channel counts (both sides) reach this value: below it
+# the extra HBM traffic of the transformed tensors outweighs the fewer MFMA FLOPs.
+# CLX_WINOGRAD=0 forces the direct implicit-GEMM kernels everywhere; CLX_WINOGRAD_TILE selects
+# F(2x2, 3x3) (2.25x fewer multiplications, error ~7e-7 of the output range on a 768-channel
+# layer) or F(4x4, 3x3) (4x fewer, ~5e-6; the direct kernel: ~4e-7).
 WINO_MIN_CHANNELS = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS", "128"))
+# per-layer algorithm code = clx_conv_algo: 0 direct, 1 Winograd F(2x2), 2 Winograd F(4x4)
+WINO_TAPS = {1: 16, 2: 36}
+WINO_PACK_FWD = {1: 2, 2: 4}        # clx_pack_mode
+WINO_PACK_DGRAD = {1: 3, 2: 5}
+WINO_TILE = {1: 2, 2: 4}
+
+
+def winograd_code() -> int:
+    return 2 if os.environ.get("CLX_WINOGRAD_TILE", "4") == "4" else 1
 
 
 def winograd_enabled() -> bool:
@@ -242,19 +253,23 @@ class UNetPlan:
             a = dict(fwd=0, dgrad=0, wgrad=0)
             if winograd_enabled() and min(layer.cin_pad, layer.cout) >= WINO_MIN_CHANNELS:
                 lib = _clx.load()
+                code = winograd_code()
                 d = self._desc(layer)
+                d.algo = code
                 d.N = layer.cout
                 nf = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 0))
                 if nf:
-                    a["fwd"], ws_bytes = 1, max(ws_bytes, nf)
+                    a["fwd"], ws_bytes = code, max(ws_bytes, nf)
                 d.N = pad4(layer.cout)
                 nw = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 1))
                 if nw and self.keep:
-                    a["wgrad"], ws_bytes = 1, max(ws_bytes, nw)
+                    a["wgrad"], ws_bytes = code, max(ws_bytes, nw)
                 if self.keep and layer.param_index > 0:
-                    nd_ = int(lib.clx_conv_workspace_bytes(ctypes.byref(self._dgrad_desc(layer, None)), 0))
+                    dd = self._dgrad_desc(layer, None)
+                    dd.algo = code
+                    nd_ = int(lib.clx_conv_workspace_bytes(ctypes.byref(dd), 0))
                     if nd_:
-                        a["dgrad"], ws_bytes = 1, max(ws_bytes, nd_)
+                        a["dgrad"], ws_bytes = code, max(ws_bytes, nd_)
             self.algo[layer.name] = a
         if ws_bytes:
             self.workspace = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=self.device)
@@ -274,7 +289,7 @@ class UNetPlan:
         self.wpack_fwd = {}
         self.wpack_dgrad = {}
         for layer in t.convs:
-            taps = 16 if self.algo[layer.name]["fwd"] else layer.taps
+            taps = WINO_TAPS.get(self.algo[layer.name]["fwd"], layer.taps)
             self.wpack_fwd[layer.name] = torch.empty(
                 pad4(layer.cout) * taps * layer.cin_pad, dtype=torch.float32, device=self.device)
         self._packed_version = None
@@ -311,9 +326,9 @@ class UNetPlan:
         self.dw_off = {}
         for layer in t.convs:
             self.dw_off[layer.name] = total
-            total += (16 if self.algo[layer.name]["wgrad"] else layer.taps) * pad4(layer.cout) * layer.cin_pad
+            total += WINO_TAPS.get(self.algo[layer.name]["wgrad"], layer.taps) * pad4(layer.cout) * layer.cin_pad
             if layer.param_index > 0:  # first layer needs no data gradient
-                taps = 16 if self.algo[layer.name]["dgrad"] else layer.taps
+                taps = WINO_TAPS.get(self.algo[layer.name]["dgrad"], layer.taps)
                 self.wpack_dgrad[layer.name] = torch.empty(
                     layer.cin_pad * taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
         self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
@@ -574,8 +589,8 @@ class UNetPlan:
         d.workspace_bytes = 0
         return d
 
-    def _use_workspace(self, d):
-        d.algo = 1
+    def _use_workspace(self, d, code):
+        d.algo = code
         d.workspace = self.workspace.data_ptr()
         d.workspace_bytes = self.workspace.numel() * 4
 
@@ -648,11 +663,11 @@ class UNetPlan:
             algo = self.algo[layer.name]
             _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_fwd[layer.name]),
                       layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
-                      2 if algo["fwd"] else 0, st)
+                      WINO_PACK_FWD.get(algo["fwd"], 0), st)
             if need_dgrad and layer.name in self.wpack_dgrad:
                 _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_dgrad[layer.name]),
                           layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
-                          3 if algo["dgrad"] else 1, st)
+                          WINO_PACK_DGRAD.get(algo["dgrad"], 1), st)
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward
@@ -679,7 +694,7 @@ class UNetPlan:
                 d.out = self.buf[op.out].data_ptr()
                 d.ld_out = pad4(op.cout)
                 if self.algo[op.name]["fwd"]:
-                    self._use_workspace(d)
+                    self._use_workspace(d, self.algo[op.name]["fwd"])
                 _clx.call("clx_conv_fwd", ctypes.byref(d), st)
             else:
                 D, H, W = op.in_shape
@@ -730,17 +745,17 @@ class UNetPlan:
             d.N = pad4(layer.cout)
             gb = grads[2 * layer.param_index + 1]
             off = self.dw_off[layer.name]
-            wino_w = bool(self.algo[layer.name]["wgrad"])
-            wtaps = 16 if wino_w else layer.taps
+            wino_w = self.algo[layer.name]["wgrad"]
+            wtaps = WINO_TAPS.get(wino_w, layer.taps)
             dwp = self.dwpack[off:off + wtaps * pad4(layer.cout) * layer.cin_pad]
             if wino_w:
-                self._use_workspace(d)
+                self._use_workspace(d, wino_w)
             _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), pad4(layer.cout), _clx.ptr(dwp),
                       _clx.ptr(gb) if gb is not None else None, st)
             gw = grads[2 * layer.param_index]
             if wino_w:
                 _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
-                          pad4(layer.cout), layer.cin_pad, st)
+                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], st)
             elif len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
                 _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
                           layer.taps, pad4(layer.cout), layer.cin_pad, st)
@@ -756,7 +771,7 @@ class UNetPlan:
             dd = self._dgrad_desc(layer, dy)
             dd.wpack = self.wpack_dgrad[layer.name].data_ptr()
             if self.algo[layer.name]["dgrad"]:
-                self._use_workspace(dd)
+                self._use_workspace(dd, self.algo[layer.name]["dgrad"])
             if len(layer.sources) == 2:
                 info = r_by_conv0[layer.name]
                 cat = self.gbuf["cat%d" % info["level"]]

@@ -102,11 +102,16 @@ enum clx_conv_algo {
    * input transform -> 16 batched f32-MFMA GEMMs over C -> output transform; 2.25x fewer
    * multiplications than the direct form, f32 throughout (error ~3e-6 vs ~1e-6 relative).
    * wpack must come from clx_pack_weights(CLX_PACK_WINO_FWD / _WINO_DGRAD). */
-  CLX_ALGO_WINOGRAD = 1
+  CLX_ALGO_WINOGRAD = 1,
+  /* Winograd F(4x4, 3x3), interpolation points {0, 1, -1, 1/2, -2}: 36 batched GEMMs per 4x4
+   * outputs, 4x fewer multiplications than the direct form; f32 throughout, error ~5e-6 of the
+   * output range on a 768-channel layer (F(2x2): ~7e-7, direct: ~4e-7).
+   * wpack must come from clx_pack_weights(CLX_PACK_WINO4_FWD / _WINO4_DGRAD). */
+  CLX_ALGO_WINOGRAD4 = 2
 };
 enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
 /* Scratch bytes clx_conv_fwd (pass FWD; also the dgrad form) / clx_conv_wgrad (pass WGRAD)
- * need for descriptor `d` with algo = CLX_ALGO_WINOGRAD; 0 if Winograd does not apply to
+ * need for descriptor `d` with algo = CLX_ALGO_WINOGRAD / _WINOGRAD4; 0 if Winograd does not apply to
  * the geometry (the caller must then use CLX_ALGO_DIRECT). */
 size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass);
 
@@ -127,7 +132,9 @@ enum clx_pack_mode {
   CLX_PACK_FWD = 0,        /* w[n][c][tap] -> wp[n][tap][cpad]               */
   CLX_PACK_DGRAD = 1,      /* w[n][c][tap] -> wp[c][flip(tap)][npad] (rows c < cpad) */
   CLX_PACK_WINO_FWD = 2,   /* 3x3 only: U[16][cout_pad][cin_pad] = G g G^T             */
-  CLX_PACK_WINO_DGRAD = 3  /* 3x3 only: U[16][cin_pad][cout_pad] of the flipped filter */
+  CLX_PACK_WINO_DGRAD = 3, /* 3x3 only: U[16][cin_pad][cout_pad] of the flipped filter */
+  CLX_PACK_WINO4_FWD = 4,  /* F(4x4, 3x3): U[36][cout_pad][cin_pad]                    */
+  CLX_PACK_WINO4_DGRAD = 5 /* F(4x4, 3x3): U[36][cin_pad][cout_pad] of the flipped filter */
 };
 /* Repack torch-layout conv weights w (Cout, Cin, taps) for clx_conv_fwd.
  * cin_pad/cout_pad >= real extents (multiples of 4), padding is zero-filled.
@@ -139,9 +146,10 @@ int clx_pack_weights(const float* w, float* wp, int cout, int cin, int taps,
  * torch layout). dwpack is [taps][rows][cin_pad], rows >= cout. */
 int clx_unpack_wgrad(const float* dwpack, float* dw, int cout, int cin, int taps,
                      int rows, int cin_pad, clx_stream stream);
-/* Winograd wgrad output dU[16][rows][cin_pad] -> dw[n][c][3x3] = G^T dU G (torch layout). */
+/* Winograd wgrad output dU[a*a][rows][cin_pad] (a = tile + 2, tile = 2 or 4) ->
+ * dw[n][c][3x3] = G^T dU G (torch layout). */
 int clx_unpack_wgrad_wino(const float* du, float* dw, int cout, int cin, int rows,
-                          int cin_pad, clx_stream stream);
+                          int cin_pad, int tile, clx_stream stream);
 
 /* (B, C, n) planar <-> (B, n, ld) pixel-major; channels c >= C of the
  * pixel-major side are written as zero / ignored. */
