@@ -66,6 +66,8 @@ class ClxConvDesc(Structure):
         ("algo", c_int),
         ("workspace", c_void_p),
         ("workspace_bytes", c_size_t),
+        ("vcache", c_void_p),
+        ("vcache_valid", c_int),
     ]
 
 

@@ -398,8 +398,8 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   const Geom g = geom(d, MT);
   const clx_src& S = d->src[0];
   const int C = S.C, Np = pad4(d->N);
-  float* V = (float*)d->workspace;
-  float* M = V + AA * g.T * C;
+  float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
+  float* M = (float*)d->workspace + AA * g.T * C;
   const long long tot_in = g.T * (C / 4);
   wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
   clx_conv_desc gd = gemm_desc(V, C, g.T);
@@ -419,10 +419,12 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
   const Geom g = geom(d, MT);
   const clx_src& S = d->src[0];
   const int C = S.C, N = d->N;     // N is a multiple of 4 (validated by clx_conv_wgrad)
-  float* V = (float*)d->workspace;
-  float* Md = V + AA * g.T * C;
-  const long long tot_in = g.T * (C / 4);
-  wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+  float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
+  float* Md = (float*)d->workspace + AA * g.T * C;
+  if (!(d->vcache && d->vcache_valid)) {
+    const long long tot_in = g.T * (C / 4);
+    wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+  }
   const long long tot_dy = g.T * (N / 4);
   int blocks = grid_for(tot_dy, 256);
   if (blocks > 2048) blocks = 2048;
@@ -452,7 +454,8 @@ int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st) {
   const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_FWD);
   CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,
               "clx_conv_fwd: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
-  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0, "clx_conv_fwd: workspace must be 16-byte aligned");
+  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0 && ((uintptr_t)d->vcache & 15) == 0,
+              "clx_conv_fwd: workspace / vcache must be 16-byte aligned");
   return tile_of(d) == 4 ? wino_fwd_t<4>(d, st) : wino_fwd_t<2>(d, st);
 }
 

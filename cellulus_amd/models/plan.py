@@ -294,6 +294,8 @@ class UNetPlan:
                 pad4(layer.cout) * taps * layer.cin_pad, dtype=torch.float32, device=self.device)
         self._packed_version = None
         self._bwd_ready = False
+        self.vcache = {}
+        self._vcache_fresh = set()
 
     def _alloc_backward(self):
         t = self.topo
@@ -322,6 +324,15 @@ class UNetPlan:
                                             device=self.device)
                 sp["dw_z"] = torch.zeros(sp["ztaps"] * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
                                          device=self.device)
+        # forward and weight gradient of a Winograd layer transform the same input: keep V
+        self.vcache = {}
+        for layer in t.convs:
+            a = self.algo[layer.name]
+            if a["fwd"] and a["fwd"] == a["wgrad"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
+                m = WINO_TILE[a["fwd"]]
+                tiles = self.B * -(-layer.out_shape[1] // m) * -(-layer.out_shape[2] // m)
+                self.vcache[layer.name] = torch.empty(WINO_TAPS[a["fwd"]] * tiles * layer.cin_pad,
+                                                      dtype=torch.float32, device=self.device)
         total = 0
         self.dw_off = {}
         for layer in t.convs:
@@ -675,6 +686,7 @@ class UNetPlan:
         """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial)."""
         t = self.topo
         st = _clx.stream_ptr(self.device)
+        self._vcache_fresh = set()      # Winograd layers whose V this forward left in self.vcache
         npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
         raw = raw.contiguous()
         _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
@@ -695,6 +707,9 @@ class UNetPlan:
                 d.ld_out = pad4(op.cout)
                 if self.algo[op.name]["fwd"]:
                     self._use_workspace(d, self.algo[op.name]["fwd"])
+                    if self.keep and self._bwd_ready and op.name in self.vcache:
+                        d.vcache = self.vcache[op.name].data_ptr()
+                        self._vcache_fresh.add(op.name)
                 _clx.call("clx_conv_fwd", ctypes.byref(d), st)
             else:
                 D, H, W = op.in_shape
@@ -750,6 +765,9 @@ class UNetPlan:
             dwp = self.dwpack[off:off + wtaps * pad4(layer.cout) * layer.cin_pad]
             if wino_w:
                 self._use_workspace(d, wino_w)
+                if layer.name in self.vcache and layer.name in self._vcache_fresh:
+                    d.vcache = self.vcache[layer.name].data_ptr()
+                    d.vcache_valid = 1
             _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), pad4(layer.cout), _clx.ptr(dwp),
                       _clx.ptr(gb) if gb is not None else None, st)
             gw = grads[2 * layer.param_index]

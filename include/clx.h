@@ -92,8 +92,14 @@ typedef struct clx_conv_desc {
   int ld_out;
   int accumulate;     /* epilogue: out = act(conv + bias + out) (residual already in `out`) */
   int algo;           /* clx_conv_algo: 0 = direct implicit GEMM */
-  void* workspace;    /* CLX_ALGO_WINOGRAD: clx_conv_workspace_bytes() bytes of scratch */
+  void* workspace;    /* CLX_ALGO_WINOGRAD*: clx_conv_workspace_bytes() bytes of scratch */
   size_t workspace_bytes;
+  /* Winograd only, optional: a^2 * T * C floats (the head of the workspace layout) that hold the
+   * transformed input V = B^T d B instead of the workspace.  clx_conv_fwd writes it; a later
+   * clx_conv_wgrad of the same layer with vcache_valid = 1 reads it and skips its own input
+   * transform (the forward and the weight gradient transform the same tensor). */
+  void* vcache;
+  int vcache_valid;
 } clx_conv_desc;
 
 enum clx_conv_algo {
