@@ -84,10 +84,11 @@ extern "C" int clx_pack_weights(const float* w, float* wp, int cout, int cin, in
               "clx_pack_weights: padded extents must be >= real and multiples of 4");
   if (mode == CLX_PACK_WINO_FWD || mode == CLX_PACK_WINO_DGRAD || mode == CLX_PACK_WINO4_FWD ||
       mode == CLX_PACK_WINO4_DGRAD) {
-    CLX_REQUIRE(taps == 9, "clx_pack_weights: Winograd packing needs a 3x3 kernel");
     const bool four = mode == CLX_PACK_WINO4_FWD || mode == CLX_PACK_WINO4_DGRAD;
+    CLX_REQUIRE(taps == 9 || (taps == 4 && four),
+                "clx_pack_weights: Winograd packing needs a 3x3 kernel (or 2x2 with the F(4x4) modes)");
     clx_wino_pack(w, wp, cout, cin, cin_pad, cout_pad, mode == CLX_PACK_WINO_DGRAD || mode == CLX_PACK_WINO4_DGRAD,
-                  four ? 4 : 2, (hipStream_t)stream);
+                  four ? 4 : 2, taps == 4 ? 2 : 3, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_pack_weights(winograd)");
     return CLX_OK;
   }

@@ -41,14 +41,14 @@ struct Geom {
 //           error / max|y|): 4.7e-6, against 1.1e-5 for the textbook {0, +-1, +-2}, 7e-7 for
 //           MT = 2 and 3.5e-7 for the direct convolution (tools/wino_numerics.py).
 // All entries of A^T and B^T are dyadic, i.e. exact in f32; G is applied in double.
-template <int MT> struct WT;
-template <> struct WT<2> {
+template <int MT, int R> struct WT;
+template <> struct WT<2, 3> {
   static constexpr int A = 4;
   static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
   static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
   static constexpr double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
 };
-template <> struct WT<4> {
+template <> struct WT<4, 3> {
   static constexpr int A = 6;
   static constexpr float BT[6][6] = {{1, -1.5f, -2, 1.5f, 1, 0},  {0, -1, 0.5f, 2.5f, 1, 0}, {0, 1, -2.5f, 0.5f, 1, 0},
                                      {0, -2, -1, 2, 1, 0},        {0, 0.5f, -1, -0.5f, 1, 0}, {0, 1, -1.5f, -2, 1.5f, 1}};
@@ -59,6 +59,17 @@ template <> struct WT<4> {
                                      {-16.0 / 15, -8.0 / 15, -4.0 / 15},
                                      {1.0 / 15, -2.0 / 15, 4.0 / 15},
                                      {0, 0, 1}};
+};
+
+// F(4x4, 2x2) — the 2x2 convolution over the low-resolution tensor in the sub-pixel form of the
+// upsample convolution (plan.py): points {0, 1, -1, 1/2, inf}, 25 multiplications per 4x4 outputs
+// instead of 64; every |A^T| entry <= 1.
+template <> struct WT<4, 2> {
+  static constexpr int A = 5;
+  static constexpr float BT[5][5] = {{0.5f, -1, -0.5f, 1, 0}, {0, -0.5f, 0.5f, 1, 0}, {0, 0.5f, -1.5f, 1, 0},
+                                     {0, -1, 0, 1, 0},        {0, 0.5f, -1, -0.5f, 1}};
+  static constexpr float AT[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, 0}, {0, 1, 1, 0.25f, 0}, {0, 1, -1, 0.125f, 1}};
+  static constexpr double G[5][2] = {{2, 0}, {1, 1}, {-1.0 / 3, 1.0 / 3}, {-8.0 / 3, -4.0 / 3}, {0, 1}};
 };
 
 // acc (+)= coef * v with the coefficient known at compile time: zeros vanish, +-1 become add/sub
@@ -72,10 +83,10 @@ __device__ __forceinline__ void axpy(V& acc, bool& first, float coef, const V& v
 }
 
 // V[xi][t][c] = (B^T d B)[xi] for the A x A input patch of tile t (stride MT)
-template <int MT>
+template <int MT, int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4, Geom g,
                                                          float* __restrict__ V, long long total) {
-  using W = WT<MT>;
+  using W = WT<MT, R>;
   constexpr int A = W::A;
   const int C = C4 * 4;
   const long long plane = g.T * C;
@@ -130,13 +141,13 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 }
 
 // Y = A^T m A (MT x MT outputs per tile); bias, ReLU, ReLU gate fused
-template <int MT>
+template <int MT, int R>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ M, int N4, Geom g,
                                                           const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ mask, int ld_mask,
                                                           float* __restrict__ out, int ld_out, int Nreal,
                                                           long long total) {
-  using W = WT<MT>;
+  using W = WT<MT, R>;
   constexpr int A = W::A;
   const int N = N4 * 4;
   const long long plane = g.T * N;
@@ -209,12 +220,12 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 
 // Mdy[xi][t][n] = (A dy A^T)[xi] with A = (A^T)^T (A x MT); dbias[n] += sum of dy
 // (block-private LDS accumulator, then one global atomic per channel per block)
-template <int MT>
+template <int MT, int R>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int ld_dy, int N4,
                                                       Geom g, float* __restrict__ Md,
                                                       float* __restrict__ dbias, int Nreal,
                                                       long long total) {
-  using W = WT<MT>;
+  using W = WT<MT, R>;
   constexpr int A = W::A;
   extern __shared__ float bacc[];
   const int N = N4 * 4;
@@ -281,83 +292,92 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 // U[xi][n][c] = (G g G^T)[xi], computed in double
 // mode FWD:   g = w[n][c][:, :]            rows n < rows_pad (cout_pad), cols c < cin_pad
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
-template <int MT>
+template <int MT, int R>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
                                    int cin, int rows, int cols, int dgrad, long long total) {
-  using W = WT<MT>;
+  using W = WT<MT, R>;
   constexpr int A = W::A;
   const long long plane = (long long)rows * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int col = (int)(i % cols), row = (int)(i / cols);
     const int n = dgrad ? col : row, c = dgrad ? row : col;
-    double g[3][3];
+    double g[R][R];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
+      for (int s2 = 0; s2 < R; ++s2) {
         double v = 0.0;
         if (n < cout && c < cin) {
-          const int rr = dgrad ? 2 - r : r, ss = dgrad ? 2 - s : s;
-          v = (double)w[((long long)n * cin + c) * 9 + rr * 3 + ss];
+          const int rr = dgrad ? R - 1 - r : r, ss = dgrad ? R - 1 - s2 : s2;
+          v = (double)w[((long long)n * cin + c) * (R * R) + rr * R + ss];
         }
-        g[r][s] = v;
+        g[r][s2] = v;
       }
-    double tt[A][3];
+    double tt[A][R];
 #pragma unroll
     for (int r = 0; r < A; ++r)
 #pragma unroll
-      for (int s = 0; s < 3; ++s) tt[r][s] = W::G[r][0] * g[0][s] + W::G[r][1] * g[1][s] + W::G[r][2] * g[2][s];
+      for (int s2 = 0; s2 < R; ++s2) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc += W::G[r][k] * g[k][s2];
+        tt[r][s2] = acc;
+      }
 #pragma unroll
     for (int r = 0; r < A; ++r)
 #pragma unroll
-      for (int qq = 0; qq < A; ++qq)
-        U[(r * A + qq) * plane + i] =
-            (float)(tt[r][0] * W::G[qq][0] + tt[r][1] * W::G[qq][1] + tt[r][2] * W::G[qq][2]);
+      for (int qq = 0; qq < A; ++qq) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) acc += tt[r][k] * W::G[qq][k];
+        U[(r * A + qq) * plane + i] = (float)acc;
+      }
   }
 }
 
-// dw[n][c][3x3] = G^T dU G
-template <int MT>
+// dw[n][c][R x R] = G^T dU G
+template <int MT, int R>
 __global__ void wino_unpack_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout,
                                    int cin, int rows, int cin_pad, long long total) {
-  using W = WT<MT>;
+  using W = WT<MT, R>;
   constexpr int A = W::A;
   const long long plane = (long long)rows * cin_pad;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cin), n = (int)(i / cin);
     const float* src = dU + (long long)n * cin_pad + c;
-    double t[3][A];
+    double t[R][A];
 #pragma unroll
-    for (int s = 0; s < A; ++s) {
+    for (int s2 = 0; s2 < A; ++s2) {
       double u[A];
 #pragma unroll
-      for (int r = 0; r < A; ++r) u[r] = (double)src[(r * A + s) * plane];
+      for (int r = 0; r < A; ++r) u[r] = (double)src[(r * A + s2) * plane];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < R; ++k) {
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < A; ++r) acc += W::G[r][k] * u[r];
-        t[k][s] = acc;
+        t[k][s2] = acc;
       }
     }
-    float* dst = dw + i * 9;
+    float* dst = dw + i * (R * R);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < R; ++k)
 #pragma unroll
-      for (int l = 0; l < 3; ++l) {
+      for (int l = 0; l < R; ++l) {
         double acc = 0.0;
 #pragma unroll
-        for (int s = 0; s < A; ++s) acc += t[k][s] * W::G[s][l];
-        dst[k * 3 + l] = (float)acc;
+        for (int s2 = 0; s2 < A; ++s2) acc += t[k][s2] * W::G[s2][l];
+        dst[k * R + l] = (float)acc;
       }
   }
 }
 
 bool applicable(const clx_conv_desc* d) {
-  if (d->nsrc != 1 || d->KD != 1 || d->KH != 3 || d->KW != 3 || d->ID != 1 || d->PD != 0) return false;
-  if (d->PH != d->PW || (d->PH != 0 && d->PH != 2)) return false;
+  if (d->nsrc != 1 || d->KD != 1 || d->KH != d->KW || d->ID != 1 || d->PD != 0) return false;
+  if (d->KH != 3 && !(d->KH == 2 && d->algo == CLX_ALGO_WINOGRAD4)) return false;
+  if (d->PH != d->PW || (d->PH != 0 && d->PH != d->KH - 1)) return false;
   const clx_src& S = d->src[0];
   if (S.fz != 1 || S.fy != 1 || S.fx != 1 || S.D != 1 || S.oz != 0) return false;
   if (S.C % 4 != 0 || d->N <= 0) return false;
@@ -372,7 +392,7 @@ Geom geom(const clx_conv_desc* d, int mt) {
   const clx_src& S = d->src[0];
   g.B = d->B; g.SH = S.H; g.SW = S.W; g.oy = S.oy; g.ox = S.ox;
   g.IH = d->IH; g.IW = d->IW; g.P = d->PH;
-  g.OH = d->IH + 2 * d->PH - 2; g.OW = d->IW + 2 * d->PW - 2;
+  g.OH = d->IH + 2 * d->PH - (d->KH - 1); g.OW = d->IW + 2 * d->PW - (d->KW - 1);
   g.th = (g.OH + mt - 1) / mt; g.tw = (g.OW + mt - 1) / mt;
   g.T = (long long)g.B * g.th * g.tw;
   return g;
@@ -392,30 +412,30 @@ clx_conv_desc gemm_desc(float* V, int C, long long T) {
   return gd;
 }
 
-template <int MT>
+template <int MT, int R>
 int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
-  constexpr int AA = WT<MT>::A * WT<MT>::A;
+  constexpr int AA = WT<MT, R>::A * WT<MT, R>::A;
   const Geom g = geom(d, MT);
   const clx_src& S = d->src[0];
   const int C = S.C, Np = pad4(d->N);
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
   float* M = (float*)d->workspace + AA * g.T * C;
   const long long tot_in = g.T * (C / 4);
-  wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+  wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
   clx_conv_desc gd = gemm_desc(V, C, g.T);
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
   const int rc = clx_igemm_launch(&gd, AA, g.T * C, (long long)Np * C, g.T * Np, st);
   if (rc) return rc;
   const long long tot_out = g.T * (Np / 4);
-  wino_output_kernel<MT><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, g, d->bias, d->relu, d->mask,
-                                                                   d->ld_mask, d->out, d->ld_out, d->N, tot_out);
+  wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, g, d->bias, d->relu, d->mask,
+                                                                      d->ld_mask, d->out, d->ld_out, d->N, tot_out);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }
 
-template <int MT>
+template <int MT, int R>
 int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias, hipStream_t st) {
-  constexpr int AA = WT<MT>::A * WT<MT>::A;
+  constexpr int AA = WT<MT, R>::A * WT<MT, R>::A;
   const Geom g = geom(d, MT);
   const clx_src& S = d->src[0];
   const int C = S.C, N = d->N;     // N is a multiple of 4 (validated by clx_conv_wgrad)
@@ -423,12 +443,12 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
   float* Md = (float*)d->workspace + AA * g.T * C;
   if (!(d->vcache && d->vcache_valid)) {
     const long long tot_in = g.T * (C / 4);
-    wino_input_kernel<MT><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
   }
   const long long tot_dy = g.T * (N / 4);
   int blocks = grid_for(tot_dy, 256);
   if (blocks > 2048) blocks = 2048;
-  wino_dy_kernel<MT><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, g, Md, dbias, N, tot_dy);
+  wino_dy_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, g, Md, dbias, N, tot_dy);
   clx_conv_desc gd = gemm_desc(V, C, g.T);
   gd.N = N;
   const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, g.T * C, g.T * N, (long long)N * C, st);
@@ -442,7 +462,7 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
 extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
   if (d == nullptr || !applicable(d)) return 0;
   if (pass == CLX_PASS_WGRAD && d->PH != 0) return 0;
-  const int mt = tile_of(d), a = mt + 2;
+  const int mt = tile_of(d), a = mt + d->KH - 1;
   const Geom g = geom(d, mt);
   if (g.OH <= 0 || g.OW <= 0 || g.T >= (1ll << 31)) return 0;
   const long long C = d->src[0].C, N = pad4(d->N);
@@ -456,7 +476,8 @@ int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st) {
               "clx_conv_fwd: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
   CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0 && ((uintptr_t)d->vcache & 15) == 0,
               "clx_conv_fwd: workspace / vcache must be 16-byte aligned");
-  return tile_of(d) == 4 ? wino_fwd_t<4>(d, st) : wino_fwd_t<2>(d, st);
+  if (d->KH == 2) return wino_fwd_t<4, 2>(d, st);
+  return tile_of(d) == 4 ? wino_fwd_t<4, 3>(d, st) : wino_fwd_t<2, 3>(d, st);
 }
 
 int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
@@ -465,33 +486,37 @@ int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dw
   const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_WGRAD);
   CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,
               "clx_conv_wgrad: Winograd needs %zu workspace bytes (%zu given)", need, d->workspace_bytes);
-  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0, "clx_conv_wgrad: workspace must be 16-byte aligned");
+  CLX_REQUIRE(((uintptr_t)d->workspace & 15) == 0 && ((uintptr_t)d->vcache & 15) == 0,
+              "clx_conv_wgrad: workspace / vcache must be 16-byte aligned");
   CLX_REQUIRE(d->N <= 8192, "clx_conv_wgrad: too many output channels for the Winograd bias accumulator");
-  return tile_of(d) == 4 ? wino_wgrad_t<4>(d, dy, ld_dy, dwpack, dbias, st)
-                         : wino_wgrad_t<2>(d, dy, ld_dy, dwpack, dbias, st);
+  if (d->KH == 2) return wino_wgrad_t<4, 2>(d, dy, ld_dy, dwpack, dbias, st);
+  return tile_of(d) == 4 ? wino_wgrad_t<4, 3>(d, dy, ld_dy, dwpack, dbias, st)
+                         : wino_wgrad_t<2, 3>(d, dy, ld_dy, dwpack, dbias, st);
 }
 
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad,
-                  int tile, hipStream_t st) {
+                  int tile, int ksize, hipStream_t st) {
   const int rows = dgrad ? cin_pad : cout_pad, cols = dgrad ? cout_pad : cin_pad;
   const long long total = (long long)rows * cols;
-  if (tile == 4)
-    wino_filter_kernel<4><<<grid_for(total, 256), 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
-  else
-    wino_filter_kernel<2><<<grid_for(total, 256), 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
+  const int grid = grid_for(total, 256);
+  if (ksize == 2) wino_filter_kernel<4, 2><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
+  else if (tile == 4) wino_filter_kernel<4, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
+  else wino_filter_kernel<2, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
   return CLX_OK;
 }
 
 extern "C" int clx_unpack_wgrad_wino(const float* du, float* dw, int cout, int cin, int rows,
-                                     int cin_pad, int tile, clx_stream stream) {
+                                     int cin_pad, int tile, int ksize, clx_stream stream) {
   CLX_REQUIRE(du && dw, "clx_unpack_wgrad_wino: null pointer");
   CLX_REQUIRE(cout > 0 && cin > 0 && rows >= cout && cin_pad >= cin, "clx_unpack_wgrad_wino: bad extents");
-  CLX_REQUIRE(tile == 2 || tile == 4, "clx_unpack_wgrad_wino: tile must be 2 or 4");
+  CLX_REQUIRE((ksize == 3 && (tile == 2 || tile == 4)) || (ksize == 2 && tile == 4),
+              "clx_unpack_wgrad_wino: (tile, ksize) must be (2, 3), (4, 3) or (4, 2)");
   const long long total = (long long)cout * cin;
-  if (tile == 4)
-    wino_unpack_kernel<4><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(du, dw, cout, cin, rows, cin_pad, total);
-  else
-    wino_unpack_kernel<2><<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(du, dw, cout, cin, rows, cin_pad, total);
+  const int grid = grid_for(total, 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 2) wino_unpack_kernel<4, 2><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, total);
+  else if (tile == 4) wino_unpack_kernel<4, 3><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, total);
+  else wino_unpack_kernel<2, 3><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, total);
   CLX_CHECK_LAUNCH("clx_unpack_wgrad_wino");
   return CLX_OK;
 }

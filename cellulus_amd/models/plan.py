@@ -271,8 +271,6 @@ class UNetPlan:
                     if nd_:
                         a["dgrad"], ws_bytes = code, max(ws_bytes, nd_)
             self.algo[layer.name] = a
-        if ws_bytes:
-            self.workspace = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=self.device)
         # sub-pixel form of the convolutions that read a nearest-upsampled tensor
         self.subpixel = {}
         for info in t.r_info:
@@ -281,10 +279,29 @@ class UNetPlan:
                 self.subpixel[info["conv0"].name] = sp
                 n = self.B * sp["zshape"][0] * sp["zshape"][1] * sp["zshape"][2]
                 self.buf[sp["zname"]] = torch.zeros((n, sp["P"] * sp["N"]), dtype=torch.float32, device=self.device)
+                # the 2x2 convolution over the low-res tensor as Winograd F(4x4, 2x2)
+                sp["wino"] = 0
+                if (winograd_enabled() and winograd_code() == 2 and sp["zk"] == (1, 2, 2)
+                        and min(sp["C1p"], sp["P"] * sp["N"]) >= WINO_MIN_CHANNELS):
+                    lib = _clx.load()
+                    dz, _ds = self._sp_descs(info["conv0"], sp)
+                    dz.algo = 2
+                    need = [int(lib.clx_conv_workspace_bytes(ctypes.byref(dz), 0))]
+                    if self.keep:
+                        need.append(int(lib.clx_conv_workspace_bytes(ctypes.byref(dz), 1)))
+                        dl = self._sp_low_dgrad_desc(info["conv0"], sp, None)
+                        dl.algo = 2
+                        need.append(int(lib.clx_conv_workspace_bytes(ctypes.byref(dl), 0)))
+                    if all(need):
+                        sp["wino"] = 2
+                        ws_bytes = max([ws_bytes] + need)
+                ztaps = 25 if sp["wino"] else sp["ztaps"]
                 sp["wp_skip_fwd"] = torch.empty(sp["N"] * info["conv0"].taps * sp["C0p"],
                                                 dtype=torch.float32, device=self.device)
-                sp["wp_z_fwd"] = torch.empty(sp["P"] * sp["N"] * sp["ztaps"] * sp["C1p"],
+                sp["wp_z_fwd"] = torch.empty(sp["P"] * sp["N"] * ztaps * sp["C1p"],
                                              dtype=torch.float32, device=self.device)
+        if ws_bytes:
+            self.workspace = torch.empty(ws_bytes // 4 + 4, dtype=torch.float32, device=self.device)
         # packed weights
         self.wpack_fwd = {}
         self.wpack_dgrad = {}
@@ -318,12 +335,17 @@ class UNetPlan:
                 self.gbuf[sp["zname"]] = torch.zeros_like(self.buf[sp["zname"]])
                 sp["wp_skip_dgrad"] = torch.empty(sp["C0p"] * layer.taps * sp["N"], dtype=torch.float32,
                                                   device=self.device)
-                sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * sp["ztaps"] * sp["P"] * sp["N"],
+                ztaps = 25 if sp["wino"] else sp["ztaps"]
+                sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * ztaps * sp["P"] * sp["N"],
                                                dtype=torch.float32, device=self.device)
                 sp["dw_skip"] = torch.zeros(layer.taps * sp["N"] * sp["C0p"], dtype=torch.float32,
                                             device=self.device)
-                sp["dw_z"] = torch.zeros(sp["ztaps"] * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
+                sp["dw_z"] = torch.zeros(ztaps * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
                                          device=self.device)
+                if sp["wino"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
+                    zs = sp["zshape"]
+                    tiles = self.B * -(-zs[1] // 4) * -(-zs[2] // 4)
+                    sp["vcache"] = torch.empty(25 * tiles * sp["C1p"], dtype=torch.float32, device=self.device)
         # forward and weight gradient of a Winograd layer transform the same input: keep V
         self.vcache = {}
         for layer in t.convs:
@@ -478,12 +500,12 @@ class UNetPlan:
         _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_fwd"]), layer.cout, sp["C0"],
                   layer.taps, sp["C0p"], sp["N"], 0, st)
         _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_fwd"]), sp["P"] * sp["N"], sp["C1"],
-                  sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 0, st)
+                  sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 4 if sp["wino"] else 0, st)
         if need_dgrad:
             _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_dgrad"]), layer.cout, sp["C0"],
                       layer.taps, sp["C0p"], sp["N"], 1, st)
             _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_dgrad"]), sp["P"] * sp["N"],
-                      sp["C1"], sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 1, st)
+                      sp["C1"], sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 5 if sp["wino"] else 1, st)
         sp["_keepalive"] = (w_skip, weff)
 
     def _sp_forward(self, layer, sp, bias, st):
@@ -492,6 +514,12 @@ class UNetPlan:
         dz.wpack = sp["wp_z_fwd"].data_ptr()
         dz.out = zbuf.data_ptr()
         dz.ld_out = sp["P"] * sp["N"]
+        sp["_v_fresh"] = False
+        if sp["wino"]:
+            self._use_workspace(dz, sp["wino"])
+            if self.keep and "vcache" in sp:
+                dz.vcache = sp["vcache"].data_ptr()
+                sp["_v_fresh"] = True
         _clx.call("clx_conv_fwd", ctypes.byref(dz), st)
         out = self.buf[layer.out]
         zs = sp["zshape"]
@@ -522,13 +550,22 @@ class UNetPlan:
         ds.N = sp["N"]
         _clx.call("clx_conv_wgrad", ctypes.byref(ds), _clx.ptr(dy), sp["N"], _clx.ptr(sp["dw_skip"]),
                   _clx.ptr(gb) if gb is not None else None, st)
+        if sp["wino"]:
+            self._use_workspace(dz, sp["wino"])
+            if sp.get("_v_fresh"):
+                dz.vcache = sp["vcache"].data_ptr()
+                dz.vcache_valid = 1
         _clx.call("clx_conv_wgrad", ctypes.byref(dz), _clx.ptr(dzbuf), PN, _clx.ptr(sp["dw_z"]), None, st)
         g_skip = torch.empty((layer.cout, sp["C0"], layer.taps), dtype=torch.float32, device=self.device)
         _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
                   layer.taps, sp["N"], sp["C0p"], st)
         g_z = torch.empty((PN, sp["C1"], sp["ztaps"]), dtype=torch.float32, device=self.device)
-        _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
-                  sp["C1p"], st)
+        if sp["wino"]:
+            _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], PN, sp["C1p"],
+                      4, 2, st)
+        else:
+            _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
+                      sp["C1p"], st)
         gwv = gw.view(layer.cout, layer.cin, layer.taps)
         gwv[:, :sp["C0"]] = g_skip
         gwv[:, sp["C0"]:] = self._fold_phase_grads(layer, sp, g_z.reshape((PN, sp["C1"]) + sp["zk"])).reshape(
@@ -544,12 +581,23 @@ class UNetPlan:
         dd.ld_out = sp["C0p"]
         _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
         # data gradient of the low-res tensor straight from dZ (replaces upsample backward)
+        dl = self._sp_low_dgrad_desc(layer, sp, dzbuf)
+        dl.wpack = sp["wp_z_dgrad"].data_ptr()
+        if sp["wino"]:
+            self._use_workspace(dl, sp["wino"])
+        _clx.call("clx_conv_fwd", ctypes.byref(dl), st)
+        return dskip
+
+    def _sp_low_dgrad_desc(self, layer, sp, dzbuf):
+        """dL/d(low-res tensor) as the transposed 2x2(x2) convolution of dZ, ReLU gate fused."""
+        t = self.topo
+        zs, PN = sp["zshape"], sp["P"] * sp["N"]
         up_s = layer.sources[1]
         low_shape, low_c = t.shapes[up_s.tensor]
         dl = ClxConvDesc()
         dl.nsrc = 1
         src = ClxSrc()
-        src.ptr = dzbuf.data_ptr()
+        src.ptr = dzbuf.data_ptr() if dzbuf is not None else 16      # geometry-only queries never dereference
         src.C = PN
         src.ld = PN
         src.D, src.H, src.W = zs
@@ -561,7 +609,6 @@ class UNetPlan:
         dl.KD, dl.KH, dl.KW = sp["zk"]
         dl.PD, dl.PH, dl.PW = (k - 1 for k in sp["zk"])
         dl.N = sp["C1p"]
-        dl.wpack = sp["wp_z_dgrad"].data_ptr()
         dl.bias = None
         dl.relu = 0
         dl.accumulate = 0
@@ -570,10 +617,9 @@ class UNetPlan:
         dl.workspace_bytes = 0
         dl.mask = self.buf[up_s.tensor].data_ptr()        # ReLU gate of the low-res tensor
         dl.ld_mask = pad4(low_c)
-        dl.out = self.gbuf[up_s.tensor].data_ptr()
+        dl.out = self.gbuf[up_s.tensor].data_ptr() if dzbuf is not None else None
         dl.ld_out = pad4(low_c)
-        _clx.call("clx_conv_fwd", ctypes.byref(dl), st)
-        return dskip
+        return dl
 
     # ------------------------------------------------------------- descriptors
     def _desc(self, layer: ConvLayer):
@@ -773,7 +819,7 @@ class UNetPlan:
             gw = grads[2 * layer.param_index]
             if wino_w:
                 _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
-                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], st)
+                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], 3, st)
             elif len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
                 _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
                           layer.taps, pad4(layer.cout), layer.cin_pad, st)

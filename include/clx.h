@@ -112,7 +112,9 @@ enum clx_conv_algo {
   /* Winograd F(4x4, 3x3), interpolation points {0, 1, -1, 1/2, -2}: 36 batched GEMMs per 4x4
    * outputs, 4x fewer multiplications than the direct form; f32 throughout, error ~5e-6 of the
    * output range on a 768-channel layer (F(2x2): ~7e-7, direct: ~4e-7).
-   * wpack must come from clx_pack_weights(CLX_PACK_WINO4_FWD / _WINO4_DGRAD). */
+   * wpack must come from clx_pack_weights(CLX_PACK_WINO4_FWD / _WINO4_DGRAD).
+   * Also accepts 2x2 kernels (F(4x4, 2x2), points {0, 1, -1, 1/2}: 25 GEMMs per 4x4 outputs
+   * instead of 64 multiplications) — the low-resolution half of the sub-pixel upsample conv. */
   CLX_ALGO_WINOGRAD4 = 2
 };
 enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
@@ -139,8 +141,8 @@ enum clx_pack_mode {
   CLX_PACK_DGRAD = 1,      /* w[n][c][tap] -> wp[c][flip(tap)][npad] (rows c < cpad) */
   CLX_PACK_WINO_FWD = 2,   /* 3x3 only: U[16][cout_pad][cin_pad] = G g G^T             */
   CLX_PACK_WINO_DGRAD = 3, /* 3x3 only: U[16][cin_pad][cout_pad] of the flipped filter */
-  CLX_PACK_WINO4_FWD = 4,  /* F(4x4, 3x3): U[36][cout_pad][cin_pad]                    */
-  CLX_PACK_WINO4_DGRAD = 5 /* F(4x4, 3x3): U[36][cin_pad][cout_pad] of the flipped filter */
+  CLX_PACK_WINO4_FWD = 4,  /* F(4x4, 3x3): U[36][cout_pad][cin_pad]; taps = 4: F(4x4, 2x2), U[25][..] */
+  CLX_PACK_WINO4_DGRAD = 5 /* the same for the flipped filter: U[a*a][cin_pad][cout_pad]          */
 };
 /* Repack torch-layout conv weights w (Cout, Cin, taps) for clx_conv_fwd.
  * cin_pad/cout_pad >= real extents (multiples of 4), padding is zero-filled.
@@ -152,10 +154,10 @@ int clx_pack_weights(const float* w, float* wp, int cout, int cin, int taps,
  * torch layout). dwpack is [taps][rows][cin_pad], rows >= cout. */
 int clx_unpack_wgrad(const float* dwpack, float* dw, int cout, int cin, int taps,
                      int rows, int cin_pad, clx_stream stream);
-/* Winograd wgrad output dU[a*a][rows][cin_pad] (a = tile + 2, tile = 2 or 4) ->
- * dw[n][c][3x3] = G^T dU G (torch layout). */
+/* Winograd wgrad output dU[a*a][rows][cin_pad] (a = tile + ksize - 1; (tile, ksize) = (2, 3),
+ * (4, 3) or (4, 2)) -> dw[n][c][ksize x ksize] = G^T dU G (torch layout). */
 int clx_unpack_wgrad_wino(const float* du, float* dw, int cout, int cin, int rows,
-                          int cin_pad, int tile, clx_stream stream);
+                          int cin_pad, int tile, int ksize, clx_stream stream);
 
 /* (B, C, n) planar <-> (B, n, ld) pixel-major; channels c >= C of the
  * pixel-major side are written as zero / ignored. */
