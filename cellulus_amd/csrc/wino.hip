@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ mask, int ld_mask,
                                                           float* __restrict__ out, int ld_out, int Nreal,
-                                                          long long total) {
+                                                          int accumulate, long long total) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   const int N = N4 * 4;
@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         for (int k = 0; k < A; ++k) axpy(v, first, W::AT[cc][k], rr[a][k]);
         v += bv;
         const long long m = ((long long)b * g.OH + oy) * g.OW + ox;
+        if (accumulate) {       // out = act(conv + bias + out); ld_out % 4 == 0, so the 16 bytes exist
+          v += ld4(out + m * ld_out + n);
+        }
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -428,7 +431,7 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   if (rc) return rc;
   const long long tot_out = g.T * (Np / 4);
   wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, g, d->bias, d->relu, d->mask,
-                                                                      d->ld_mask, d->out, d->ld_out, d->N, tot_out);
+                                                                      d->ld_mask, d->out, d->ld_out, d->N, d->accumulate, tot_out);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }

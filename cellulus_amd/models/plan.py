@@ -295,8 +295,27 @@ class UNetPlan:
                     if all(need):
                         sp["wino"] = 2
                         ws_bytes = max([ws_bytes] + need)
+                # ... and the 3x3 convolution over the skip tensor as F(4x4, 3x3), forward and weight
+                # gradient only: its data gradient has K = N (64 at the benchmark config), too short
+                # a contraction for the batched GEMMs to pay
+                sp["wino_skip"] = 0
+                conv0 = info["conv0"]
+                if (winograd_enabled() and winograd_code() == 2 and tuple(conv0.kernel) == (1, 3, 3)
+                        and sp["C0p"] >= WINO_MIN_CHANNELS and sp["N"] >= WINO_MIN_CHANNELS // 2):
+                    lib = _clx.load()
+                    _dz, ds = self._sp_descs(conv0, sp)
+                    ds.algo = 2
+                    ds.N = conv0.cout
+                    need = [int(lib.clx_conv_workspace_bytes(ctypes.byref(ds), 0))]
+                    if self.keep:
+                        ds.N = sp["N"]
+                        need.append(int(lib.clx_conv_workspace_bytes(ctypes.byref(ds), 1)))
+                    if all(need):
+                        sp["wino_skip"] = 2
+                        ws_bytes = max([ws_bytes] + need)
                 ztaps = 25 if sp["wino"] else sp["ztaps"]
-                sp["wp_skip_fwd"] = torch.empty(sp["N"] * info["conv0"].taps * sp["C0p"],
+                staps = 36 if sp["wino_skip"] else info["conv0"].taps
+                sp["wp_skip_fwd"] = torch.empty(sp["N"] * staps * sp["C0p"],
                                                 dtype=torch.float32, device=self.device)
                 sp["wp_z_fwd"] = torch.empty(sp["P"] * sp["N"] * ztaps * sp["C1p"],
                                              dtype=torch.float32, device=self.device)
@@ -338,8 +357,11 @@ class UNetPlan:
                 ztaps = 25 if sp["wino"] else sp["ztaps"]
                 sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * ztaps * sp["P"] * sp["N"],
                                                dtype=torch.float32, device=self.device)
-                sp["dw_skip"] = torch.zeros(layer.taps * sp["N"] * sp["C0p"], dtype=torch.float32,
-                                            device=self.device)
+                sp["dw_skip"] = torch.zeros((36 if sp["wino_skip"] else layer.taps) * sp["N"] * sp["C0p"],
+                                            dtype=torch.float32, device=self.device)
+                if sp["wino_skip"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
+                    tiles = self.B * -(-layer.out_shape[1] // 4) * -(-layer.out_shape[2] // 4)
+                    sp["vcache_skip"] = torch.empty(36 * tiles * sp["C0p"], dtype=torch.float32, device=self.device)
                 sp["dw_z"] = torch.zeros(ztaps * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
                                          device=self.device)
                 if sp["wino"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
@@ -498,7 +520,7 @@ class UNetPlan:
         weff = self._phase_weights(layer, sp, wv[:, sp["C0"]:]).reshape(sp["P"] * sp["N"], sp["C1"], sp["ztaps"])
         weff = weff.contiguous()
         _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_fwd"]), layer.cout, sp["C0"],
-                  layer.taps, sp["C0p"], sp["N"], 0, st)
+                  layer.taps, sp["C0p"], sp["N"], 4 if sp["wino_skip"] else 0, st)
         _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_fwd"]), sp["P"] * sp["N"], sp["C1"],
                   sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 4 if sp["wino"] else 0, st)
         if need_dgrad:
@@ -532,6 +554,12 @@ class UNetPlan:
         ds.accumulate = 1
         ds.out = out.data_ptr()
         ds.ld_out = sp["N"]
+        sp["_vskip_fresh"] = False
+        if sp["wino_skip"]:
+            self._use_workspace(ds, sp["wino_skip"])
+            if self.keep and "vcache_skip" in sp:
+                ds.vcache = sp["vcache_skip"].data_ptr()
+                sp["_vskip_fresh"] = True
         _clx.call("clx_conv_fwd", ctypes.byref(ds), st)
 
     def _sp_backward(self, layer, sp, dy, gw, gb, st):
@@ -548,6 +576,11 @@ class UNetPlan:
         sp["dw_skip"].zero_()
         sp["dw_z"].zero_()
         ds.N = sp["N"]
+        if sp["wino_skip"]:
+            self._use_workspace(ds, sp["wino_skip"])
+            if sp.get("_vskip_fresh"):
+                ds.vcache = sp["vcache_skip"].data_ptr()
+                ds.vcache_valid = 1
         _clx.call("clx_conv_wgrad", ctypes.byref(ds), _clx.ptr(dy), sp["N"], _clx.ptr(sp["dw_skip"]),
                   _clx.ptr(gb) if gb is not None else None, st)
         if sp["wino"]:
@@ -557,8 +590,12 @@ class UNetPlan:
                 dz.vcache_valid = 1
         _clx.call("clx_conv_wgrad", ctypes.byref(dz), _clx.ptr(dzbuf), PN, _clx.ptr(sp["dw_z"]), None, st)
         g_skip = torch.empty((layer.cout, sp["C0"], layer.taps), dtype=torch.float32, device=self.device)
-        _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
-                  layer.taps, sp["N"], sp["C0p"], st)
+        if sp["wino_skip"]:
+            _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
+                      sp["N"], sp["C0p"], 4, 3, st)
+        else:
+            _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
+                      layer.taps, sp["N"], sp["C0p"], st)
         g_z = torch.empty((PN, sp["C1"], sp["ztaps"]), dtype=torch.float32, device=self.device)
         if sp["wino"]:
             _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], PN, sp["C1p"],
