@@ -87,7 +87,7 @@ PROTOTYPES = {
     "clx_conv_wgrad": (_I, [POINTER(ClxConvDesc), _P, _I, _P, _P, _P]),
     "clx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
     "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_pixel_to_planar": (_I, [_P, _P, _I, _I, _LL, _I, _P]),

@@ -73,7 +73,7 @@ int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st);
 int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
                    hipStream_t st);
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad, int tile,
-                  int ksize, hipStream_t st);
+                  int ksize, int kd, hipStream_t st);
 
 // in-library kernel timing (clx_core.hip); kinds match enum clx_profile_kind in clx.h
 bool clx_prof_enabled();

@@ -85,10 +85,11 @@ extern "C" int clx_pack_weights(const float* w, float* wp, int cout, int cin, in
   if (mode == CLX_PACK_WINO_FWD || mode == CLX_PACK_WINO_DGRAD || mode == CLX_PACK_WINO4_FWD ||
       mode == CLX_PACK_WINO4_DGRAD) {
     const bool four = mode == CLX_PACK_WINO4_FWD || mode == CLX_PACK_WINO4_DGRAD;
-    CLX_REQUIRE(taps == 9 || (taps == 4 && four),
-                "clx_pack_weights: Winograd packing needs a 3x3 kernel (or 2x2 with the F(4x4) modes)");
+    CLX_REQUIRE(taps == 9 || (four && (taps == 4 || taps == 27 || taps == 8)),
+                "clx_pack_weights: Winograd packing needs a 3x3 kernel (F(4x4) modes: also 2x2, 3x3x3, 2x2x2)");
+    const int ksize = (taps == 9 || taps == 27) ? 3 : 2, kd = (taps == 27 || taps == 8) ? ksize : 1;
     clx_wino_pack(w, wp, cout, cin, cin_pad, cout_pad, mode == CLX_PACK_WINO_DGRAD || mode == CLX_PACK_WINO4_DGRAD,
-                  four ? 4 : 2, taps == 4 ? 2 : 3, (hipStream_t)stream);
+                  four ? 4 : 2, ksize, kd, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_pack_weights(winograd)");
     return CLX_OK;
   }

@@ -29,7 +29,9 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 struct Geom {
-  int B, SH, SW, oy, ox;   // stored grid of the source and crop offset
+  int B, SH, SW, oy, ox;   // images (batch x z planes), stored grid of the source and crop offset
+  int ID, SD, oz;          // z planes per batch element (logical / stored) and z crop: image bi is
+                           // plane bi % ID of batch element bi / ID (2-D: ID = SD = 1, oz = 0)
   int IH, IW, P;           // logical input extent, zero padding
   int OH, OW, th, tw;      // output extent, tiles per image
   long long T;             // B * th * tw
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     const long long q = t / g.tw;
     const int ty = (int)(q % g.th);
     const int b = (int)(q / g.th);
+    const int bb = b / g.ID, bz = b - bb * g.ID;
     f32x4 d[A][A];
 #pragma unroll
     for (int r = 0; r < A; ++r) {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         const int lx = MT * tx - g.P + s;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if ((unsigned)ly < (unsigned)g.IH && (unsigned)lx < (unsigned)g.IW) {
-          const long long pix = ((long long)b * g.SH + ly + g.oy) * g.SW + lx + g.ox;
+          const long long pix = (((long long)bb * g.SD + bz + g.oz) * g.SH + ly + g.oy) * g.SW + lx + g.ox;
           v = ld4(x + pix * ld_x + c);
         }
         d[r][s] = v;
@@ -297,14 +300,18 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
 template <int MT, int R>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
-                                   int cin, int rows, int cols, int dgrad, long long total) {
+                                   int cin, int rows, int cols, int kdt, int dgrad, long long total) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
-  const long long plane = (long long)rows * cols;
+  // U[xi][row][dz][col]: the batched GEMM sees kdt "taps" along z (1 for 2-D layers)
+  const long long plane = (long long)rows * kdt * cols;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int col = (int)(i % cols), row = (int)(i / cols);
+    const int col = (int)(i % cols);
+    const long long q = i / cols;
+    const int dz = (int)(q % kdt), row = (int)(q / kdt);
     const int n = dgrad ? col : row, c = dgrad ? row : col;
+    const int wz = dgrad ? kdt - 1 - dz : dz;
     double g[R][R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -313,7 +320,7 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
         double v = 0.0;
         if (n < cout && c < cin) {
           const int rr = dgrad ? R - 1 - r : r, ss = dgrad ? R - 1 - s2 : s2;
-          v = (double)w[((long long)n * cin + c) * (R * R) + rr * R + ss];
+          v = (double)w[(((long long)n * cin + c) * kdt + wz) * (R * R) + rr * R + ss];
         }
         g[r][s2] = v;
       }
@@ -342,14 +349,17 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
 // dw[n][c][R x R] = G^T dU G
 template <int MT, int R>
 __global__ void wino_unpack_kernel(const float* __restrict__ dU, float* __restrict__ dw, int cout,
-                                   int cin, int rows, int cin_pad, long long total) {
+                                   int cin, int rows, int cin_pad, int kdt, long long total) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
-  const long long plane = (long long)rows * cin_pad;
+  // dU[xi][dz][row][cin_pad] (the weight-gradient kernel's [tap][n][c]) -> dw[n][c][dz][R][R]
+  const long long plane = (long long)kdt * rows * cin_pad;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % cin), n = (int)(i / cin);
-    const float* src = dU + (long long)n * cin_pad + c;
+    const int dz = (int)(i % kdt);
+    const long long q = i / kdt;
+    const int c = (int)(q % cin), n = (int)(q / cin);
+    const float* src = dU + ((long long)dz * rows + n) * cin_pad + c;
     double t[R][A];
 #pragma unroll
     for (int s2 = 0; s2 < A; ++s2) {
@@ -378,11 +388,19 @@ __global__ void wino_unpack_kernel(const float* __restrict__ dU, float* __restri
 }
 
 bool applicable(const clx_conv_desc* d) {
-  if (d->nsrc != 1 || d->KD != 1 || d->KH != d->KW || d->ID != 1 || d->PD != 0) return false;
+  // 2-D layers (KD = 1, one plane) or 3-D layers with a cubic kernel: the Winograd transform is
+  // applied in (y, x) per z plane, the z taps stay a plain contraction inside the batched GEMMs
+  if (d->nsrc != 1 || d->KH != d->KW) return false;
+  if (d->KD == 1) {
+    if (d->ID != 1 || d->PD != 0) return false;
+  } else {
+    if (d->KD != d->KH || d->algo != CLX_ALGO_WINOGRAD4 || d->PD != d->PH) return false;
+  }
   if (d->KH != 3 && !(d->KH == 2 && d->algo == CLX_ALGO_WINOGRAD4)) return false;
   if (d->PH != d->PW || (d->PH != 0 && d->PH != d->KH - 1)) return false;
   const clx_src& S = d->src[0];
-  if (S.fz != 1 || S.fy != 1 || S.fx != 1 || S.D != 1 || S.oz != 0) return false;
+  if (S.fz != 1 || S.fy != 1 || S.fx != 1) return false;
+  if (d->KD == 1 && (S.D != 1 || S.oz != 0)) return false;
   if (S.C % 4 != 0 || d->N <= 0) return false;
   return true;
 }
@@ -390,47 +408,52 @@ bool applicable(const clx_conv_desc* d) {
 // output tile size selected by the descriptor: CLX_ALGO_WINOGRAD = F(2x2), CLX_ALGO_WINOGRAD4 = F(4x4)
 inline int tile_of(const clx_conv_desc* d) { return d->algo == CLX_ALGO_WINOGRAD4 ? 4 : 2; }
 
-Geom geom(const clx_conv_desc* d, int mt) {
+// geometry of the (y, x) transforms; `planes` z planes per batch element are separate images
+Geom geom(const clx_conv_desc* d, int mt, int planes) {
   Geom g;
   const clx_src& S = d->src[0];
-  g.B = d->B; g.SH = S.H; g.SW = S.W; g.oy = S.oy; g.ox = S.ox;
+  g.B = d->B * planes; g.SH = S.H; g.SW = S.W; g.oy = S.oy; g.ox = S.ox;
+  g.ID = planes; g.SD = S.D; g.oz = S.oz;
   g.IH = d->IH; g.IW = d->IW; g.P = d->PH;
   g.OH = d->IH + 2 * d->PH - (d->KH - 1); g.OW = d->IW + 2 * d->PW - (d->KW - 1);
   g.th = (g.OH + mt - 1) / mt; g.tw = (g.OW + mt - 1) / mt;
   g.T = (long long)g.B * g.th * g.tw;
   return g;
 }
+inline int out_planes(const clx_conv_desc* d) { return d->ID + 2 * d->PD - (d->KD - 1); }
 
 inline int pad4(int n) { return (n + 3) / 4 * 4; }
 
-// the batched GEMM descriptor: A^2 problems [T x C] . [C x N] as 1x1 "convolutions" over T pixels
-clx_conv_desc gemm_desc(float* V, int C, long long T) {
+// the batched GEMM descriptor: A^2 problems over the transformed tensor V [B][ID planes][tiles][C]:
+// a (KD, 1, 1) "convolution" along z — a plain [T x C] . [C x N] product for 2-D layers
+clx_conv_desc gemm_desc(float* V, int C, const clx_conv_desc* d, const Geom& gin) {
   clx_conv_desc gd = {};
   gd.nsrc = 1;
   gd.src[0].ptr = V; gd.src[0].C = C; gd.src[0].ld = C;
-  gd.src[0].D = 1; gd.src[0].H = 1; gd.src[0].W = (int)T;
+  gd.src[0].D = d->ID; gd.src[0].H = 1; gd.src[0].W = gin.th * gin.tw;
   gd.src[0].fz = gd.src[0].fy = gd.src[0].fx = 1;
-  gd.B = 1; gd.ID = 1; gd.IH = 1; gd.IW = (int)T;
-  gd.KD = gd.KH = gd.KW = 1;
+  gd.B = d->B; gd.ID = d->ID; gd.IH = 1; gd.IW = gin.th * gin.tw;
+  gd.KD = d->KD; gd.KH = gd.KW = 1;
+  gd.PD = d->PD;
   return gd;
 }
 
 template <int MT, int R>
 int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   constexpr int AA = WT<MT, R>::A * WT<MT, R>::A;
-  const Geom g = geom(d, MT);
+  const Geom gin = geom(d, MT, d->ID), gout = geom(d, MT, out_planes(d));
   const clx_src& S = d->src[0];
   const int C = S.C, Np = pad4(d->N);
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
-  float* M = (float*)d->workspace + AA * g.T * C;
-  const long long tot_in = g.T * (C / 4);
-  wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
-  clx_conv_desc gd = gemm_desc(V, C, g.T);
+  float* M = (float*)d->workspace + AA * gin.T * C;
+  const long long tot_in = gin.T * (C / 4);
+  wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
+  clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
-  const int rc = clx_igemm_launch(&gd, AA, g.T * C, (long long)Np * C, g.T * Np, st);
+  const int rc = clx_igemm_launch(&gd, AA, gin.T * C, (long long)Np * d->KD * C, gout.T * Np, st);
   if (rc) return rc;
-  const long long tot_out = g.T * (Np / 4);
-  wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, g, d->bias, d->relu, d->mask,
+  const long long tot_out = gout.T * (Np / 4);
+  wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, gout, d->bias, d->relu, d->mask,
                                                                       d->ld_mask, d->out, d->ld_out, d->N, d->accumulate, tot_out);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
@@ -439,22 +462,23 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
 template <int MT, int R>
 int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias, hipStream_t st) {
   constexpr int AA = WT<MT, R>::A * WT<MT, R>::A;
-  const Geom g = geom(d, MT);
+  const Geom gin = geom(d, MT, d->ID), gout = geom(d, MT, out_planes(d));
   const clx_src& S = d->src[0];
   const int C = S.C, N = d->N;     // N is a multiple of 4 (validated by clx_conv_wgrad)
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
-  float* Md = (float*)d->workspace + AA * g.T * C;
+  float* Md = (float*)d->workspace + AA * gin.T * C;
   if (!(d->vcache && d->vcache_valid)) {
-    const long long tot_in = g.T * (C / 4);
-    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, g, V, tot_in);
+    const long long tot_in = gin.T * (C / 4);
+    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
   }
-  const long long tot_dy = g.T * (N / 4);
+  const long long tot_dy = gout.T * (N / 4);
   int blocks = grid_for(tot_dy, 256);
   if (blocks > 2048) blocks = 2048;
-  wino_dy_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, g, Md, dbias, N, tot_dy);
-  clx_conv_desc gd = gemm_desc(V, C, g.T);
+  wino_dy_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, gout, Md, dbias, N, tot_dy);
+  clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = N;
-  const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, g.T * C, g.T * N, (long long)N * C, st);
+  const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, gin.T * C, gout.T * N,
+                                  (long long)d->KD * N * C, st);
   if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_conv_wgrad(winograd)");
   return CLX_OK;
@@ -466,10 +490,10 @@ extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
   if (d == nullptr || !applicable(d)) return 0;
   if (pass == CLX_PASS_WGRAD && d->PH != 0) return 0;
   const int mt = tile_of(d), a = mt + d->KH - 1;
-  const Geom g = geom(d, mt);
-  if (g.OH <= 0 || g.OW <= 0 || g.T >= (1ll << 31)) return 0;
+  const Geom gin = geom(d, mt, d->ID), gout = geom(d, mt, out_planes(d));
+  if (gout.OH <= 0 || gout.OW <= 0 || out_planes(d) <= 0 || gin.T >= (1ll << 31) || gout.T >= (1ll << 31)) return 0;
   const long long C = d->src[0].C, N = pad4(d->N);
-  return (size_t)(a * a * g.T * (C + N)) * sizeof(float);
+  return (size_t)(a * a * (gin.T * C + gout.T * N)) * sizeof(float);
 }
 
 int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st) {
@@ -498,28 +522,29 @@ int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dw
 }
 
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad,
-                  int tile, int ksize, hipStream_t st) {
+                  int tile, int ksize, int kd, hipStream_t st) {
   const int rows = dgrad ? cin_pad : cout_pad, cols = dgrad ? cout_pad : cin_pad;
-  const long long total = (long long)rows * cols;
+  const long long total = (long long)rows * kd * cols;
   const int grid = grid_for(total, 256);
-  if (ksize == 2) wino_filter_kernel<4, 2><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
-  else if (tile == 4) wino_filter_kernel<4, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
-  else wino_filter_kernel<2, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, dgrad, total);
+  if (ksize == 2) wino_filter_kernel<4, 2><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
+  else if (tile == 4) wino_filter_kernel<4, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
+  else wino_filter_kernel<2, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
   return CLX_OK;
 }
 
 extern "C" int clx_unpack_wgrad_wino(const float* du, float* dw, int cout, int cin, int rows,
-                                     int cin_pad, int tile, int ksize, clx_stream stream) {
+                                     int cin_pad, int tile, int ksize, int kd, clx_stream stream) {
   CLX_REQUIRE(du && dw, "clx_unpack_wgrad_wino: null pointer");
   CLX_REQUIRE(cout > 0 && cin > 0 && rows >= cout && cin_pad >= cin, "clx_unpack_wgrad_wino: bad extents");
   CLX_REQUIRE((ksize == 3 && (tile == 2 || tile == 4)) || (ksize == 2 && tile == 4),
               "clx_unpack_wgrad_wino: (tile, ksize) must be (2, 3), (4, 3) or (4, 2)");
-  const long long total = (long long)cout * cin;
+  CLX_REQUIRE(kd == 1 || (kd == ksize && tile == 4), "clx_unpack_wgrad_wino: kd must be 1 or ksize (F(4x4) only)");
+  const long long total = (long long)cout * cin * kd;
   const int grid = grid_for(total, 256);
   hipStream_t st = (hipStream_t)stream;
-  if (ksize == 2) wino_unpack_kernel<4, 2><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, total);
-  else if (tile == 4) wino_unpack_kernel<4, 3><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, total);
-  else wino_unpack_kernel<2, 3><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, total);
+  if (ksize == 2) wino_unpack_kernel<4, 2><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, kd, total);
+  else if (tile == 4) wino_unpack_kernel<4, 3><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, kd, total);
+  else wino_unpack_kernel<2, 3><<<grid, 256, 0, st>>>(du, dw, cout, cin, rows, cin_pad, kd, total);
   CLX_CHECK_LAUNCH("clx_unpack_wgrad_wino");
   return CLX_OK;
 }

@@ -40,8 +40,22 @@ WINO_PACK_DGRAD = {1: 3, 2: 5}
 WINO_TILE = {1: 2, 2: 4}
 
 
+# 3-D layers (F(4x4) in (y, x) per z plane, the z taps inside the batched GEMMs): K = 3 * C per GEMM, so
+# it pays from fewer channels than in 2-D
+WINO_MIN_CHANNELS_3D = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS_3D", "64"))
+
+
 def winograd_code() -> int:
     return 2 if os.environ.get("CLX_WINOGRAD_TILE", "4") == "4" else 1
+
+
+def wino_taps(code, kernel):
+    """packed-weight / weight-gradient planes of a Winograd layer: a^2 transform points x z taps."""
+    return WINO_TAPS[code] * kernel[0]
+
+
+def wino_min_channels(kernel):
+    return WINO_MIN_CHANNELS_3D if kernel[0] > 1 else WINO_MIN_CHANNELS
 
 
 def winograd_enabled() -> bool:
@@ -251,7 +265,8 @@ class UNetPlan:
         ws_bytes = 0
         for layer in t.convs:
             a = dict(fwd=0, dgrad=0, wgrad=0)
-            if winograd_enabled() and min(layer.cin_pad, layer.cout) >= WINO_MIN_CHANNELS:
+            if (winograd_enabled() and min(layer.cin_pad, layer.cout) >= wino_min_channels(layer.kernel)
+                    and (layer.kernel[0] == 1 or winograd_code() == 2)):
                 lib = _clx.load()
                 code = winograd_code()
                 d = self._desc(layer)
@@ -281,8 +296,8 @@ class UNetPlan:
                 self.buf[sp["zname"]] = torch.zeros((n, sp["P"] * sp["N"]), dtype=torch.float32, device=self.device)
                 # the 2x2 convolution over the low-res tensor as Winograd F(4x4, 2x2)
                 sp["wino"] = 0
-                if (winograd_enabled() and winograd_code() == 2 and sp["zk"] == (1, 2, 2)
-                        and min(sp["C1p"], sp["P"] * sp["N"]) >= WINO_MIN_CHANNELS):
+                if (winograd_enabled() and winograd_code() == 2 and sp["zk"] in ((1, 2, 2), (2, 2, 2))
+                        and min(sp["C1p"], sp["P"] * sp["N"]) >= wino_min_channels(sp["zk"])):
                     lib = _clx.load()
                     dz, _ds = self._sp_descs(info["conv0"], sp)
                     dz.algo = 2
@@ -300,8 +315,9 @@ class UNetPlan:
                 # a contraction for the batched GEMMs to pay
                 sp["wino_skip"] = 0
                 conv0 = info["conv0"]
-                if (winograd_enabled() and winograd_code() == 2 and tuple(conv0.kernel) == (1, 3, 3)
-                        and sp["C0p"] >= WINO_MIN_CHANNELS and sp["N"] >= WINO_MIN_CHANNELS // 2):
+                if (winograd_enabled() and winograd_code() == 2 and tuple(conv0.kernel) in ((1, 3, 3), (3, 3, 3))
+                        and sp["C0p"] >= wino_min_channels(conv0.kernel)
+                        and sp["N"] >= wino_min_channels(conv0.kernel) // 2):
                     lib = _clx.load()
                     _dz, ds = self._sp_descs(conv0, sp)
                     ds.algo = 2
@@ -313,8 +329,8 @@ class UNetPlan:
                     if all(need):
                         sp["wino_skip"] = 2
                         ws_bytes = max([ws_bytes] + need)
-                ztaps = 25 if sp["wino"] else sp["ztaps"]
-                staps = 36 if sp["wino_skip"] else info["conv0"].taps
+                ztaps = 25 * sp["zk"][0] if sp["wino"] else sp["ztaps"]
+                staps = 36 * info["conv0"].kernel[0] if sp["wino_skip"] else info["conv0"].taps
                 sp["wp_skip_fwd"] = torch.empty(sp["N"] * staps * sp["C0p"],
                                                 dtype=torch.float32, device=self.device)
                 sp["wp_z_fwd"] = torch.empty(sp["P"] * sp["N"] * ztaps * sp["C1p"],
@@ -325,7 +341,8 @@ class UNetPlan:
         self.wpack_fwd = {}
         self.wpack_dgrad = {}
         for layer in t.convs:
-            taps = WINO_TAPS.get(self.algo[layer.name]["fwd"], layer.taps)
+            code = self.algo[layer.name]["fwd"]
+            taps = wino_taps(code, layer.kernel) if code else layer.taps
             self.wpack_fwd[layer.name] = torch.empty(
                 pad4(layer.cout) * taps * layer.cin_pad, dtype=torch.float32, device=self.device)
         self._packed_version = None
@@ -354,19 +371,19 @@ class UNetPlan:
                 self.gbuf[sp["zname"]] = torch.zeros_like(self.buf[sp["zname"]])
                 sp["wp_skip_dgrad"] = torch.empty(sp["C0p"] * layer.taps * sp["N"], dtype=torch.float32,
                                                   device=self.device)
-                ztaps = 25 if sp["wino"] else sp["ztaps"]
+                ztaps = 25 * sp["zk"][0] if sp["wino"] else sp["ztaps"]
                 sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * ztaps * sp["P"] * sp["N"],
                                                dtype=torch.float32, device=self.device)
-                sp["dw_skip"] = torch.zeros((36 if sp["wino_skip"] else layer.taps) * sp["N"] * sp["C0p"],
+                sp["dw_skip"] = torch.zeros((36 * layer.kernel[0] if sp["wino_skip"] else layer.taps) * sp["N"] * sp["C0p"],
                                             dtype=torch.float32, device=self.device)
                 if sp["wino_skip"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
-                    tiles = self.B * -(-layer.out_shape[1] // 4) * -(-layer.out_shape[2] // 4)
+                    tiles = self.B * layer.in_shape[0] * -(-layer.out_shape[1] // 4) * -(-layer.out_shape[2] // 4)
                     sp["vcache_skip"] = torch.empty(36 * tiles * sp["C0p"], dtype=torch.float32, device=self.device)
                 sp["dw_z"] = torch.zeros(ztaps * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
                                          device=self.device)
                 if sp["wino"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     zs = sp["zshape"]
-                    tiles = self.B * -(-zs[1] // 4) * -(-zs[2] // 4)
+                    tiles = self.B * (zs[0] + sp["zk"][0] - 1) * -(-zs[1] // 4) * -(-zs[2] // 4)
                     sp["vcache"] = torch.empty(25 * tiles * sp["C1p"], dtype=torch.float32, device=self.device)
         # forward and weight gradient of a Winograd layer transform the same input: keep V
         self.vcache = {}
@@ -374,16 +391,18 @@ class UNetPlan:
             a = self.algo[layer.name]
             if a["fwd"] and a["fwd"] == a["wgrad"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                 m = WINO_TILE[a["fwd"]]
-                tiles = self.B * -(-layer.out_shape[1] // m) * -(-layer.out_shape[2] // m)
+                tiles = self.B * layer.in_shape[0] * -(-layer.out_shape[1] // m) * -(-layer.out_shape[2] // m)
                 self.vcache[layer.name] = torch.empty(WINO_TAPS[a["fwd"]] * tiles * layer.cin_pad,
                                                       dtype=torch.float32, device=self.device)
         total = 0
         self.dw_off = {}
         for layer in t.convs:
             self.dw_off[layer.name] = total
-            total += WINO_TAPS.get(self.algo[layer.name]["wgrad"], layer.taps) * pad4(layer.cout) * layer.cin_pad
+            code = self.algo[layer.name]["wgrad"]
+            total += (wino_taps(code, layer.kernel) if code else layer.taps) * pad4(layer.cout) * layer.cin_pad
             if layer.param_index > 0:  # first layer needs no data gradient
-                taps = WINO_TAPS.get(self.algo[layer.name]["dgrad"], layer.taps)
+                code = self.algo[layer.name]["dgrad"]
+                taps = wino_taps(code, layer.kernel) if code else layer.taps
                 self.wpack_dgrad[layer.name] = torch.empty(
                     layer.cin_pad * taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
         self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
@@ -592,14 +611,14 @@ class UNetPlan:
         g_skip = torch.empty((layer.cout, sp["C0"], layer.taps), dtype=torch.float32, device=self.device)
         if sp["wino_skip"]:
             _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
-                      sp["N"], sp["C0p"], 4, 3, st)
+                      sp["N"], sp["C0p"], 4, 3, layer.kernel[0], st)
         else:
             _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
                       layer.taps, sp["N"], sp["C0p"], st)
         g_z = torch.empty((PN, sp["C1"], sp["ztaps"]), dtype=torch.float32, device=self.device)
         if sp["wino"]:
             _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], PN, sp["C1p"],
-                      4, 2, st)
+                      4, 2, sp["zk"][0], st)
         else:
             _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
                       sp["C1p"], st)
@@ -844,7 +863,7 @@ class UNetPlan:
             gb = grads[2 * layer.param_index + 1]
             off = self.dw_off[layer.name]
             wino_w = self.algo[layer.name]["wgrad"]
-            wtaps = WINO_TAPS.get(wino_w, layer.taps)
+            wtaps = wino_taps(wino_w, layer.kernel) if wino_w else layer.taps
             dwp = self.dwpack[off:off + wtaps * pad4(layer.cout) * layer.cin_pad]
             if wino_w:
                 self._use_workspace(d, wino_w)
@@ -856,7 +875,7 @@ class UNetPlan:
             gw = grads[2 * layer.param_index]
             if wino_w:
                 _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
-                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], 3, st)
+                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], 3, layer.kernel[0], st)
             elif len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
                 _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
                           layer.taps, pad4(layer.cout), layer.cin_pad, st)

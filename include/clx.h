@@ -114,7 +114,10 @@ enum clx_conv_algo {
    * output range on a 768-channel layer (F(2x2): ~7e-7, direct: ~4e-7).
    * wpack must come from clx_pack_weights(CLX_PACK_WINO4_FWD / _WINO4_DGRAD).
    * Also accepts 2x2 kernels (F(4x4, 2x2), points {0, 1, -1, 1/2}: 25 GEMMs per 4x4 outputs
-   * instead of 64 multiplications) — the low-resolution half of the sub-pixel upsample conv. */
+   * instead of 64 multiplications) — the low-resolution half of the sub-pixel upsample conv —
+   * and 3-D layers with cubic kernels (3x3x3, 2x2x2; PD = PH): the transform is applied in
+   * (y, x) per z plane and the z taps stay a contraction inside the batched GEMMs
+   * (K = KD * C), i.e. 4x / 2.56x fewer multiplications in 3-D as well. */
   CLX_ALGO_WINOGRAD4 = 2
 };
 enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
@@ -155,9 +158,10 @@ int clx_pack_weights(const float* w, float* wp, int cout, int cin, int taps,
 int clx_unpack_wgrad(const float* dwpack, float* dw, int cout, int cin, int taps,
                      int rows, int cin_pad, clx_stream stream);
 /* Winograd wgrad output dU[a*a][rows][cin_pad] (a = tile + ksize - 1; (tile, ksize) = (2, 3),
- * (4, 3) or (4, 2)) -> dw[n][c][ksize x ksize] = G^T dU G (torch layout). */
+ * (4, 3) or (4, 2)) -> dw[n][c][kd][ksize x ksize] = G^T dU G per z tap (torch layout);
+ * kd = 1 for 2-D layers, kd = ksize for the 3-D form of CLX_ALGO_WINOGRAD4. */
 int clx_unpack_wgrad_wino(const float* du, float* dw, int cout, int cin, int rows,
-                          int cin_pad, int tile, int ksize, clx_stream stream);
+                          int cin_pad, int tile, int ksize, int kd, clx_stream stream);
 
 /* (B, C, n) planar <-> (B, n, ld) pixel-major; channels c >= C of the
  * pixel-major side are written as zero / ignored. */

@@ -62,31 +62,63 @@ def test_random_config_forward_backward_match_oracle(seed, device):
     model = get_model(**cfg)
     model.load_state_dict({k: v.float() for k, v in oracle.state_dict().items()}, strict=True)
     model = model.to(device)
-    # A pre-activation that is ~0 can land on different sides of the ReLU in f32 (HIP) and f64
-    # (oracle); such a gate flip changes upstream gradients by a whole term and says nothing about
-    # the kernels (tools/diag_fuzz.py shows it as ONE differing element).  It is input dependent
-    # and rare, a real defect is not: a case fails only if three different inputs all disagree.
-    failures = []
-    for attempt in range(3):
-        raw = torch.rand(batch, cfg["in_channels"], *spatial)
-        oracle.zero_grad()
-        model.zero_grad()
-        ref = oracle(raw.double())
-        got = model(raw.to(device))
-        assert got.shape == ref.shape, (cfg, spatial)
-        scale = max(1.0, ref.abs().max().item())
-        err = (got.detach().cpu().double() - ref.detach()).abs().max().item()
-        assert err < 1e-4 * scale, f"{cfg} {spatial} B={batch}: forward err {err} (scale {scale})"
-        w = torch.randn_like(ref)
-        (ref * w).sum().backward()
-        (got * w.float().to(device)).sum().backward()
-        bad = []
-        for (n, po), (_, pm) in zip(oracle.named_parameters(), model.named_parameters()):
-            g_ref, g = po.grad, pm.grad.detach().cpu().double()
-            rel = (g - g_ref).norm().item() / max(g_ref.norm().item(), 1e-12)
-            if not (rel < 2e-4 or (g - g_ref).abs().max().item() < 1e-6):
-                bad.append((n, rel))
-        if not bad:
-            return
-        failures.append(bad[:3])
-    pytest.fail(f"{cfg} {spatial} B={batch}: gradients differ on 3 inputs: {failures}")
+    raw = torch.rand(batch, cfg["in_channels"], *spatial)
+    ref = oracle(raw.double())
+    got = model(raw.to(device))
+    assert got.shape == ref.shape, (cfg, spatial)
+    scale = max(1.0, ref.abs().max().item())
+    err = (got.detach().cpu().double() - ref.detach()).abs().max().item()
+    assert err < 1e-4 * scale, f"{cfg} {spatial} B={batch}: forward err {err} (scale {scale})"
+
+    # Gradients.  A pre-activation that is ~0 can land on different sides of the ReLU in f32 (HIP)
+    # and f64 (oracle); such a gate flip changes upstream gradients by a whole term (1e-4 .. 1e-2
+    # relative, see tools/diag_fuzz.py) and says nothing about the kernels.  So the oracle's backward
+    # runs through the SAME gates as the device: every ReLU of the oracle passes its input where the
+    # device's stored activation is positive.  With equal gates the two backward passes are the same
+    # linear map and must agree to rounding.
+    plan = [p for k, p in model._plans.items() if k[2]][0]
+    relu_layers = [layer for layer in plan.topo.convs if layer.relu]
+    modules = dict(oracle.named_modules())
+    relus = []
+    for layer in relu_layers:         # the ReLU that follows conv "<prefix>.<i>" is module "<prefix>.<i+1>"
+        prefix, idx = layer.name.rsplit(".", 1)
+        relus.append(modules[f"{prefix}.{int(idx) + 1}"])
+        assert isinstance(relus[-1], torch.nn.ReLU), layer.name
+    assert len(relus) == sum(isinstance(m, torch.nn.ReLU) for m in oracle.modules())
+    hooks = []
+    for m, layer in zip(relus, relu_layers):
+        shape, c = plan.topo.shapes[layer.out]
+        act = plan.buf[layer.out].view(batch, *shape, -1)[..., :c]
+        gate = (act > 0).permute(0, 4, 1, 2, 3).cpu()
+        if cfg["num_spatial_dims"] == 2:
+            gate = gate[:, :, 0]
+        hooks.append(m.register_forward_hook(lambda _m, inp, _out, gate=gate: inp[0] * gate))
+    # ... and every max-pool routes its gradient to the element the device selected (two nearly equal
+    # candidates are the same kind of discontinuity)
+    import torch.nn.functional as F
+
+    nd = cfg["num_spatial_dims"]
+    for i, pool in enumerate(plan.topo.pools):
+        shape, c = plan.topo.shapes[pool.src]
+        act = plan.buf[pool.src].view(batch, *shape, -1)[..., :c].permute(0, 4, 1, 2, 3).cpu().double()
+        fac = tuple(pool.factor)
+        if nd == 2:
+            _, idx = F.max_pool2d(act[:, :, 0], fac[1:], fac[1:], return_indices=True)
+        else:
+            _, idx = F.max_pool3d(act, fac, fac, return_indices=True)
+
+        def route(_m, inp, out, idx=idx):
+            return inp[0].flatten(2).gather(2, idx.flatten(2)).view_as(out)
+
+        hooks.append(oracle.backbone.l_down[i].register_forward_hook(route))
+    oracle.zero_grad()
+    ref = oracle(raw.double())
+    for h in hooks:
+        h.remove()
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    (got * w.float().to(device)).sum().backward()
+    for (n, po), (_, pm) in zip(oracle.named_parameters(), model.named_parameters()):
+        g_ref, g = po.grad, pm.grad.detach().cpu().double()
+        rel = (g - g_ref).norm().item() / max(g_ref.norm().item(), 1e-12)
+        assert rel < 1e-4 or (g - g_ref).abs().max().item() < 1e-6, f"{cfg} {spatial} B={batch}: grad {n} rel {rel}"

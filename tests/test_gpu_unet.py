@@ -141,7 +141,7 @@ def test_bad_shapes_raise(device):
 
 
 # ------------------------------------------------------- Winograd F(2x2, 3x3) and F(4x4, 3x3)
-WINO_CASES = ["2d_small", "2d_wide", "2d_odd_channels", "2d_two_levels"]
+WINO_CASES = ["2d_small", "2d_wide", "2d_odd_channels", "2d_two_levels", "3d_small", "3d_four_fmaps"]
 
 
 @pytest.mark.parametrize("tile", ["2", "4"])
@@ -152,7 +152,10 @@ def test_winograd_forward_backward_match_oracle(name, tile, device, monkeypatch)
     for both output tile sizes."""
     import cellulus_amd.models.plan as plan_mod
 
+    if name.startswith("3d") and tile == "2":
+        pytest.skip("3-D layers use the F(4x4) form only")
     monkeypatch.setattr(plan_mod, "WINO_MIN_CHANNELS", 4)
+    monkeypatch.setattr(plan_mod, "WINO_MIN_CHANNELS_3D", 4)
     monkeypatch.setenv("CLX_WINOGRAD", "1")
     monkeypatch.setenv("CLX_WINOGRAD_TILE", tile)
     oracle, model, raw = _make(name, device, seed=4)
@@ -277,9 +280,9 @@ def test_first_layer_weight_gradient_kernel(N, cin, shape, device):
     assert (db.double() - dyi.sum((0, 1, 2))).abs().max().item() < 1e-3 * max(1.0, dyi.abs().sum((0, 1, 2)).max().item())
 
 
-@pytest.mark.parametrize("k,algo", [(3, 1), (3, 2), (2, 2)])
+@pytest.mark.parametrize("k,algo,kd", [(3, 1, 1), (3, 2, 1), (2, 2, 1), (3, 2, 3), (2, 2, 2)])
 @pytest.mark.parametrize("pad", [False, True])
-def test_winograd_entry_points_vs_f64_convolution(k, algo, pad, device):
+def test_winograd_entry_points_vs_f64_convolution(k, algo, kd, pad, device):
     """clx_conv_fwd / clx_conv_wgrad with CLX_ALGO_WINOGRAD (F(2x2,3x3)) and CLX_ALGO_WINOGRAD4
     (F(4x4,3x3), F(4x4,2x2)) straight through the C ABI on extents that are not multiples of the
     tile: plain, zero-padded (the data-gradient form), bias + ReLU, ReLU-gate mask and accumulate
@@ -291,35 +294,36 @@ def test_winograd_entry_points_vs_f64_convolution(k, algo, pad, device):
     from cellulus_amd import _clx
     from cellulus_amd._clx import ClxConvDesc, ClxSrc
 
-    torch.manual_seed(10 * k + algo + int(pad))
-    B, H, W, C, N = 2, 19, 22, 8, 12
+    torch.manual_seed(10 * k + algo + int(pad) + 100 * kd)
+    B, D, H, W, C, N = 2, (5 if kd > 1 else 1), 19, 22, 8, 12
     P = k - 1 if pad else 0
-    OH, OW = H + 2 * P - k + 1, W + 2 * P - k + 1
-    x = torch.randn(B, H, W, C)
-    w = torch.randn(N, C, k, k) * 0.2
+    PDz = kd - 1 if pad else 0
+    OD, OH, OW = D + 2 * PDz - kd + 1, H + 2 * P - k + 1, W + 2 * P - k + 1
+    x = torch.randn(B, D, H, W, C)
+    w = torch.randn(N, C, kd, k, k) * 0.2
     bias = torch.randn(N)
-    prev = torch.randn(B, OH, OW, N)
-    gate = torch.randn(B, OH, OW, N)
-    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=P).permute(0, 2, 3, 1)
+    prev = torch.randn(B, OD, OH, OW, N)
+    gate = torch.randn(B, OD, OH, OW, N)
+    ref = F.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.double(), padding=(PDz, P, P)).permute(0, 2, 3, 4, 1)
     st = _clx.stream_ptr(device)
-    x_d, w_d = x.to(device).contiguous(), w.reshape(N, C, k * k).to(device).contiguous()
+    x_d, w_d = x.to(device).contiguous(), w.reshape(N, C, kd * k * k).to(device).contiguous()
     a = (2 if algo == 1 else 4) + k - 1
-    wp = torch.empty(a * a * N * C, device=device)
-    _clx.call("clx_pack_weights", _clx.ptr(w_d), _clx.ptr(wp), N, C, k * k, C, N, 2 if algo == 1 else 4, st)
+    wp = torch.empty(a * a * kd * N * C, device=device)
+    _clx.call("clx_pack_weights", _clx.ptr(w_d), _clx.ptr(wp), N, C, kd * k * k, C, N, 2 if algo == 1 else 4, st)
 
     def desc():
         d = ClxConvDesc()
         d.nsrc = 1
         s = ClxSrc()
         s.ptr, s.C, s.ld = x_d.data_ptr(), C, C
-        s.D, s.H, s.W = 1, H, W
+        s.D, s.H, s.W = D, H, W
         s.oz = s.oy = s.ox = 0
         s.fz = s.fy = s.fx = 1
         d.src[0] = s
         d.B = B
-        d.ID, d.IH, d.IW = 1, H, W
-        d.KD, d.KH, d.KW = 1, k, k
-        d.PD, d.PH, d.PW = 0, P, P
+        d.ID, d.IH, d.IW = D, H, W
+        d.KD, d.KH, d.KW = kd, k, k
+        d.PD, d.PH, d.PW = PDz, P, P
         d.N = N
         d.algo = algo
         return d
@@ -329,11 +333,12 @@ def test_winograd_entry_points_vs_f64_convolution(k, algo, pad, device):
     need = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 0))
     assert need > 0
     ws = torch.empty(need // 4 + 4, device=device)
-    vcache = torch.empty(a * a * B * -(-OH // (a - k + 1)) * -(-OW // (a - k + 1)) * C, device=device)
+    vcache = torch.empty(a * a * B * D * -(-OH // (a - k + 1)) * -(-OW // (a - k + 1)) * C, device=device)
     for mode in ("plain", "bias_relu", "mask", "accumulate"):
         d = desc()
         d.wpack, d.workspace, d.workspace_bytes = wp.data_ptr(), ws.data_ptr(), ws.numel() * 4
-        out = prev.to(device).clone().contiguous() if mode == "accumulate" else torch.empty(B, OH, OW, N, device=device)
+        out = (prev.to(device).clone().contiguous() if mode == "accumulate"
+               else torch.empty(B, OD, OH, OW, N, device=device))
         d.out, d.ld_out = out.data_ptr(), N
         want = ref
         if mode == "bias_relu":
@@ -352,10 +357,10 @@ def test_winograd_entry_points_vs_f64_convolution(k, algo, pad, device):
         err = (out.cpu().double() - want).abs().max().item()
         assert err < 2e-5 * max(1.0, want.abs().max().item()), (mode, err)
     if not pad:       # weight gradient (the layer form only)
-        dy = torch.randn(B, OH, OW, N)
-        xr = x.permute(0, 3, 1, 2).double().requires_grad_(False)
+        dy = torch.randn(B, OD, OH, OW, N)
+        xr = x.permute(0, 4, 1, 2, 3).double().requires_grad_(False)
         wr = w.double().requires_grad_(True)
-        (F.conv2d(xr, wr) * dy.permute(0, 3, 1, 2).double()).sum().backward()
+        (F.conv3d(xr, wr) * dy.permute(0, 4, 1, 2, 3).double()).sum().backward()
         dy_d = dy.to(device).contiguous()
         for cached in (False, True):
             d = desc()
@@ -364,11 +369,11 @@ def test_winograd_entry_points_vs_f64_convolution(k, algo, pad, device):
             d.workspace, d.workspace_bytes = wsw.data_ptr(), wsw.numel() * 4
             if cached:                       # V left behind by the accumulate forward above
                 d.vcache, d.vcache_valid = vcache.data_ptr(), 1
-            dwp = torch.zeros(a * a * N * C, device=device)
+            dwp = torch.zeros(a * a * kd * N * C, device=device)
             db = torch.zeros(N, device=device)
             _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy_d), N, _clx.ptr(dwp), _clx.ptr(db), st)
-            dw = torch.empty(N, C, k * k, device=device)
-            _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(dw), N, C, N, C, 2 if algo == 1 else 4, k, st)
-            err = (dw.cpu().double().reshape(N, C, k, k) - wr.grad).abs().max().item()
+            dw = torch.empty(N, C, kd * k * k, device=device)
+            _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(dw), N, C, N, C, 2 if algo == 1 else 4, k, kd, st)
+            err = (dw.cpu().double().reshape(N, C, kd, k, k) - wr.grad).abs().max().item()
             assert err < 2e-5 * wr.grad.abs().max().item(), (cached, err)
-            assert (db.cpu().double() - dy.double().sum((0, 1, 2))).abs().max().item() < 1e-3
+            assert (db.cpu().double() - dy.double().sum((0, 1, 2, 3))).abs().max().item() < 1e-3

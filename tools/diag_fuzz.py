@@ -9,7 +9,7 @@ from oracle.unet_oracle import OracleUNetModel
 
 seed = int(sys.argv[1])
 dev = torch.device("cuda:0")
-cfg, spatial, batch = F._random_case(seed)
+cfg, spatial, batch = F._random_case(seed, wide=seed >= 100)
 if len(sys.argv) > 2:
     batch = int(sys.argv[2])
 print(cfg, spatial, batch)
