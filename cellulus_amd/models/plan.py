@@ -329,6 +329,16 @@ class UNetPlan:
                     if all(need):
                         sp["wino_skip"] = 2
                         ws_bytes = max([ws_bytes] + need)
+                # its data gradient contracts over z taps x output channels: long enough only in 3-D
+                sp["wino_skip_dgrad"] = 0
+                if sp["wino_skip"] and self.keep and sp["N"] * conv0.kernel[0] >= WINO_MIN_CHANNELS:
+                    dd = self._dgrad_desc(conv0, None)
+                    dd.N = sp["C0p"]
+                    dd.algo = 2
+                    need = int(_clx.load().clx_conv_workspace_bytes(ctypes.byref(dd), 0))
+                    if need:
+                        sp["wino_skip_dgrad"] = 2
+                        ws_bytes = max(ws_bytes, need)
                 ztaps = 25 * sp["zk"][0] if sp["wino"] else sp["ztaps"]
                 staps = 36 * info["conv0"].kernel[0] if sp["wino_skip"] else info["conv0"].taps
                 sp["wp_skip_fwd"] = torch.empty(sp["N"] * staps * sp["C0p"],
@@ -369,7 +379,8 @@ class UNetPlan:
                 self.gbuf["dskip%d" % info["level"]] = torch.zeros(
                     (n, sp["C0p"]), dtype=torch.float32, device=self.device)
                 self.gbuf[sp["zname"]] = torch.zeros_like(self.buf[sp["zname"]])
-                sp["wp_skip_dgrad"] = torch.empty(sp["C0p"] * layer.taps * sp["N"], dtype=torch.float32,
+                sp["wp_skip_dgrad"] = torch.empty(sp["C0p"] * (36 * layer.kernel[0] if sp["wino_skip_dgrad"] else layer.taps)
+                                                  * sp["N"], dtype=torch.float32,
                                                   device=self.device)
                 ztaps = 25 * sp["zk"][0] if sp["wino"] else sp["ztaps"]
                 sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * ztaps * sp["P"] * sp["N"],
@@ -544,7 +555,7 @@ class UNetPlan:
                   sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 4 if sp["wino"] else 0, st)
         if need_dgrad:
             _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_dgrad"]), layer.cout, sp["C0"],
-                      layer.taps, sp["C0p"], sp["N"], 1, st)
+                      layer.taps, sp["C0p"], sp["N"], 5 if sp["wino_skip_dgrad"] else 1, st)
             _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_dgrad"]), sp["P"] * sp["N"],
                       sp["C1"], sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 5 if sp["wino"] else 1, st)
         sp["_keepalive"] = (w_skip, weff)
@@ -635,6 +646,8 @@ class UNetPlan:
         dd.ld_mask = 0
         dd.out = dskip.data_ptr()
         dd.ld_out = sp["C0p"]
+        if sp["wino_skip_dgrad"]:
+            self._use_workspace(dd, sp["wino_skip_dgrad"])
         _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
         # data gradient of the low-res tensor straight from dZ (replaces upsample backward)
         dl = self._sp_low_dgrad_desc(layer, sp, dzbuf)

@@ -176,6 +176,8 @@ def test_winograd_forward_backward_match_oracle(name, tile, device, monkeypatch)
     assert any(a["wgrad"] for a in plan.algo.values()) and any(a["dgrad"] for a in plan.algo.values())
     if tile == "4" and name != "2d_two_levels":      # the 2x2 low-res conv of the sub-pixel form: F(4x4, 2x2)
         assert plan.subpixel and all(sp["wino"] == 2 and sp["wino_skip"] == 2 for sp in plan.subpixel.values())
+        if name.startswith("3d"):          # ... and, in 3-D, the skip half's data gradient
+            assert all(sp["wino_skip_dgrad"] == 2 for sp in plan.subpixel.values())
     for (n, po), (_, pm) in zip(oracle.named_parameters(), model.named_parameters()):
         g_ref, g = po.grad, pm.grad.cpu().double()
         l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-12)).item()
