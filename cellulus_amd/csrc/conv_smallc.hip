@@ -72,10 +72,19 @@ __global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(const SmallP p) {
   float* Xs = smem + K * NG * 4;        // [PT][K]
   const int n0 = blockIdx.y * NG * 4;
   const int ng = threadIdx.x % NG, pl = threadIdx.x / NG;
+  // Channels whose packed weights are all zero (the padding of a 1-, 2- or 3-channel image up to 4)
+  // are skipped in the contraction below: 4x less LDS traffic and FMAs for grey-scale input.
+  __shared__ int used_channels;
+  if (threadIdx.x == 0) used_channels = 0;
+  __syncthreads();
+  int mine_used = 0;
   for (int idx = threadIdx.x; idx < K * NG * 4; idx += 256) {
     const int n = idx / K, k = idx % K;
-    Ws[k * NG * 4 + n] = (n0 + n < p.N) ? p.wpack[(size_t)(n0 + n) * K + k] : 0.f;
+    const float wv = (n0 + n < p.N) ? p.wpack[(size_t)(n0 + n) * K + k] : 0.f;
+    Ws[k * NG * 4 + n] = wv;
+    if (wv != 0.f) mine_used |= 1 << (k & 3);
   }
+  if (mine_used) atomicOr(&used_channels, mine_used);
   const int n = n0 + ng * 4;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (p.bias && n < p.N) {
@@ -91,12 +100,16 @@ __global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(const SmallP p) {
     f32x4 acc[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) acc[i] = bv;
-    for (int k = 0; k < K; ++k) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(&Ws[k * NG * 4 + ng * 4]);
+    const int used = used_channels;
+    for (int c = 0; c < 4; ++c) {
+      if (!((used >> c) & 1)) continue;
+      for (int k = c; k < K; k += 4) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(&Ws[k * NG * 4 + ng * 4]);
 #pragma unroll
-      for (int i = 0; i < PPT; ++i) {
-        const float xv = Xs[(pl + i * PL) * K + k];
-        acc[i] += xv * w;
+        for (int i = 0; i < PPT; ++i) {
+          const float xv = Xs[(pl + i * PL) * K + k];
+          acc[i] += xv * w;
+        }
       }
     }
     if (n < p.N) {
@@ -118,72 +131,7 @@ __global__ __launch_bounds__(256) void conv_smallc_fwd_kernel(const SmallP p) {
   }
 }
 
-// thread = (channel group ng, tap lane tl); owns taps tl, tl+TL, ... x 4 channels x 4 n
-template <int NG>
-__global__ __launch_bounds__(256) void conv_smallc_wgrad_kernel(const SmallP p) {
-  constexpr int TL = 256 / NG;                       // tap lanes
-  constexpr int TPT = (MAX_TAPS + TL - 1) / TL;      // taps per thread (upper bound)
-  constexpr int PTW = NG == 64 ? 32 : 64;            // pixels per tile (keeps LDS <= 64 KB)
-  extern __shared__ float smem[];
-  const int K = p.taps * 4;
-  float* Ys = smem;                     // [PTW][NG*4]
-  float* Xs = smem + PTW * NG * 4;      // [PTW][K]
-  const int n0 = blockIdx.y * NG * 4;
-  const int ng = threadIdx.x % NG, tl = threadIdx.x / NG;
-  f32x4 acc[TPT][4];                    // [tap][c] -> 4 n
-#pragma unroll
-  for (int a = 0; a < TPT; ++a)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < p.tiles_per_block; ++t) {
-    const int m0 = (blockIdx.x * p.tiles_per_block + t) * PTW;
-    if (m0 >= p.M) break;
-    __syncthreads();
-    stage_patch<PTW>(p, m0, Xs);
-    for (int idx = threadIdx.x; idx < PTW * NG; idx += 256) {
-      const int pl = idx / NG, g = idx % NG;
-      const int m = m0 + pl, n = n0 + g * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && n < p.N) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ld_dy + n);
-      *reinterpret_cast<f32x4*>(&Ys[(pl * NG + g) * 4]) = v;
-    }
-    __syncthreads();
-    for (int pl = 0; pl < PTW; ++pl) {
-      const f32x4 dyv = *reinterpret_cast<const f32x4*>(&Ys[(pl * NG + ng) * 4]);
-      if (tl == 0) bsum += dyv;
-#pragma unroll
-      for (int a = 0; a < TPT; ++a) {
-        const int tap = tl + a * TL;
-        if (tap < p.taps) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(&Xs[(pl * p.taps + tap) * 4]);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[a][c] += xv[c] * dyv;
-        }
-      }
-    }
-  }
-  const int n = n0 + ng * 4;
-#pragma unroll
-  for (int a = 0; a < TPT; ++a) {
-    const int tap = tl + a * TL;
-    if (tap >= p.taps) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (n + e >= p.N) continue;
-      float* dst = p.dwp + ((size_t)tap * p.N + n + e) * 4;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) atomicAdd(dst + c, acc[a][c][e]);
-    }
-  }
-  if (tl == 0 && p.dbias) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (n + e < p.N) atomicAdd(p.dbias + n + e, bsum[e]);
-  }
-}
-
-// Streaming form of the weight gradient for taps <= 9 (the 2-D first layer): the layer is bound
+// Weight gradient, streaming form: the layer is bound
 // by ONE read of dy [M][N], so no LDS staging and no barriers in the pixel loop — lane = 4 output
 // channels, the G lanes of a pixel read its dy row as one coalesced run and the (<= 9) input
 // patch values as same-address loads; partial sums meet in LDS once per block, then one global
@@ -196,7 +144,11 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
   const int g = threadIdx.x % G, q = threadIdx.x / G;
   const int NT = G * 4;
   const int n0 = blockIdx.y * NT, n = n0 + g * 4;
-  const int nred = p.taps * 4 * NT + NT;
+  // taps are handled in groups of <= 9 (blockIdx.z): a 3x3x3 kernel makes three passes over dy,
+  // still a third of the time of staging everything through LDS
+  const int tap0 = blockIdx.z * MT;
+  const int ntap = p.taps - tap0 < MT ? p.taps - tap0 : MT;
+  const int nred = ntap * 4 * NT + NT;
   for (int i = threadIdx.x; i < nred; i += 256) red[i] = 0.f;
   f32x4 acc[MT][4];
 #pragma unroll
@@ -209,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
   const long long m_end = m_begin + per < p.M ? m_begin + per : p.M;
   const bool live = n < p.N;
   // this lane's tap (lane g < taps loads tap g's input vector for its pixel)
-  const int gtap = g < p.taps ? g : 0;
+  const int gtap = tap0 + (g < ntap ? g : 0);
   const int my_tx = gtap % p.KW - p.PW, my_ty = (gtap / p.KW) % p.KH - p.PH, my_tz = gtap / (p.KW * p.KH) - p.PD;
   for (long long mm = m_begin + q; mm < m_end; mm += Q) {
     const uint32_t m = (uint32_t)mm;
@@ -222,13 +174,13 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
     const int b = (int)q3;
     f32x4 dyv = {0.f, 0.f, 0.f, 0.f};
     if (live) dyv = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ld_dy + n);
-    bsum += dyv;
+    if (tap0 == 0) bsum += dyv;
     if constexpr (G >= 16) {
       // lane a (< taps) of the pixel's G lanes fetches tap a's input vector: ONE vector load with
       // <= 9 active lanes per pixel instead of 9 same-address loads occupying all 64 lanes
       // (measured: 0.55 ms of the 1.1 ms kernel), then broadcast across the pixel's lanes.
       f32x4 mine = {0.f, 0.f, 0.f, 0.f};
-      if (g < p.taps) {
+      if (g < ntap) {
         const int lz = oz + my_tz, ly = oy + my_ty, lx = ox + my_tx;
         if ((unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW) {
           const long long pix = (((long long)b * p.D + lz + p.oz) * p.H + ly + p.oy) * p.W + lx + p.ox;
@@ -237,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
       }
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
-        if (a < p.taps) {
+        if (a < ntap) {
           f32x4 xv;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
@@ -250,8 +202,9 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
     } else {
 #pragma unroll
       for (int a = 0; a < MT; ++a) {
-        if (a < p.taps) {
-          const int lz = oz + a / (p.KW * p.KH) - p.PD, ly = oy + (a / p.KW) % p.KH - p.PH, lx = ox + a % p.KW - p.PW;
+        if (a < ntap) {
+          const int tap = tap0 + a;
+          const int lz = oz + tap / (p.KW * p.KH) - p.PD, ly = oy + (tap / p.KW) % p.KH - p.PH, lx = ox + tap % p.KW - p.PW;
           f32x4 xv = {0.f, 0.f, 0.f, 0.f};
           if ((unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW) {
             const long long pix = (((long long)b * p.D + lz + p.oz) * p.H + ly + p.oy) * p.W + lx + p.ox;
@@ -266,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
   __syncthreads();
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
-    if (a < p.taps) {
+    if (a < ntap) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -274,15 +227,15 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
     }
   }
 #pragma unroll
-  for (int e = 0; e < 4; ++e) atomicAdd(&red[p.taps * 4 * NT + g * 4 + e], bsum[e]);
+  for (int e = 0; e < 4; ++e) atomicAdd(&red[ntap * 4 * NT + g * 4 + e], bsum[e]);
   __syncthreads();
-  for (int i = threadIdx.x; i < p.taps * 4 * NT; i += 256) {
-    const int nl = i % NT, c = (i / NT) & 3, tap = i / (4 * NT);
+  for (int i = threadIdx.x; i < ntap * 4 * NT; i += 256) {
+    const int nl = i % NT, c = (i / NT) & 3, tap = tap0 + i / (4 * NT);
     if (n0 + nl < p.N) atomicAdd(p.dwp + ((size_t)tap * p.N + n0 + nl) * 4 + c, red[i]);
   }
-  if (p.dbias)
+  if (p.dbias && tap0 == 0)
     for (int i = threadIdx.x; i < NT; i += 256)
-      if (n0 + i < p.N) atomicAdd(p.dbias + n0 + i, red[p.taps * 4 * NT + i]);
+      if (n0 + i < p.N) atomicAdd(p.dbias + n0 + i, red[ntap * 4 * NT + i]);
 }
 
 bool fill(const clx_conv_desc* d, SmallP& p) {
@@ -345,36 +298,18 @@ int clx_smallc_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   fill(d, p);
   p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
   const int ng = pick_ng(p.N);
-  const int K = p.taps * 4;
-  if (p.taps <= 9) {
-    // 183 VGPRs -> 2 waves per SIMD = 2 blocks per CU resident: one round of 512 blocks, so every
-    // block pays its 36*N final global atomics once (0.22 ms of 0.62 at 1024 blocks)
-    int blocks = p.M < 512 * 64 ? cdiv(p.M, 64) : 512;
-    p.tiles_per_block = cdiv(p.M, blocks);
-    const dim3 grid(cdiv(p.M, p.tiles_per_block), cdiv(p.N, ng * 4));
-    const size_t lds = (size_t)(K * ng * 4 + ng * 4) * sizeof(float);
-    switch (ng) {
-      case 4: conv_smallc_wgrad_stream_kernel<4><<<grid, 256, lds, st>>>(p); break;
-      case 8: conv_smallc_wgrad_stream_kernel<8><<<grid, 256, lds, st>>>(p); break;
-      case 16: conv_smallc_wgrad_stream_kernel<16><<<grid, 256, lds, st>>>(p); break;
-      case 32: conv_smallc_wgrad_stream_kernel<32><<<grid, 256, lds, st>>>(p); break;
-      default: conv_smallc_wgrad_stream_kernel<64><<<grid, 256, lds, st>>>(p); break;
-    }
-    return CLX_OK;
-  }
-  const int ptw = ng == 64 ? 32 : 64;
-  const int tiles = cdiv(p.M, ptw);
-  int blocks = tiles < 1024 ? tiles : 1024;      // few blocks: one atomic round per block
-  p.tiles_per_block = cdiv(tiles, blocks);
-  blocks = cdiv(tiles, p.tiles_per_block);
-  const dim3 grid(blocks, cdiv(p.N, ng * 4));
-  const size_t lds = (size_t)(ptw * ng * 4 + ptw * K) * sizeof(float);
+  // 183 VGPRs -> 2 waves per SIMD = 2 blocks per CU resident: one round of 512 blocks per tap
+  // group, so every block pays its final global atomics once (0.22 ms of 0.62 at 1024 blocks)
+  const int blocks = p.M < 512 * 64 ? cdiv(p.M, 64) : 512;
+  p.tiles_per_block = cdiv(p.M, blocks);
+  const dim3 grid(cdiv(p.M, p.tiles_per_block), cdiv(p.N, ng * 4), cdiv(p.taps, 9));
+  const size_t lds = (size_t)((p.taps < 9 ? p.taps : 9) * 4 * ng * 4 + ng * 4) * sizeof(float);
   switch (ng) {
-    case 4: conv_smallc_wgrad_kernel<4><<<grid, 256, lds, st>>>(p); break;
-    case 8: conv_smallc_wgrad_kernel<8><<<grid, 256, lds, st>>>(p); break;
-    case 16: conv_smallc_wgrad_kernel<16><<<grid, 256, lds, st>>>(p); break;
-    case 32: conv_smallc_wgrad_kernel<32><<<grid, 256, lds, st>>>(p); break;
-    default: conv_smallc_wgrad_kernel<64><<<grid, 256, lds, st>>>(p); break;
+    case 4: conv_smallc_wgrad_stream_kernel<4><<<grid, 256, lds, st>>>(p); break;
+    case 8: conv_smallc_wgrad_stream_kernel<8><<<grid, 256, lds, st>>>(p); break;
+    case 16: conv_smallc_wgrad_stream_kernel<16><<<grid, 256, lds, st>>>(p); break;
+    case 32: conv_smallc_wgrad_stream_kernel<32><<<grid, 256, lds, st>>>(p); break;
+    default: conv_smallc_wgrad_stream_kernel<64><<<grid, 256, lds, st>>>(p); break;
   }
   return CLX_OK;
 }
