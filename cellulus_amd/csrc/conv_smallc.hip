@@ -36,27 +36,35 @@ constexpr int MAX_TAPS = 27;
 // gathers the input patch of PT output pixels into Xs[PT][taps*4] (zero outside the image)
 template <int PTILE>
 __device__ __forceinline__ void stage_patch(const SmallP& p, int m0, float* Xs) {
+  static_assert(256 % PTILE == 0, "a thread keeps one pixel of the tile");
   const int K4 = p.taps;                 // float4s per pixel
-  for (int idx = threadIdx.x; idx < PTILE * K4; idx += blockDim.x) {
-    const int pl = idx % PTILE, tap = idx / PTILE;
-    const uint32_t m = (uint32_t)(m0 + pl);
+  // 256 % PTILE == 0: every thread serves ONE pixel (decoded once) and walks over the taps
+  const int pl = threadIdx.x % PTILE;
+  const uint32_t m = (uint32_t)(m0 + pl);
+  const bool live = m < (uint32_t)p.M;
+  const uint32_t q1 = fdiv(m, p.dOW);
+  const int ox = (int)(m - q1 * p.OW);
+  const uint32_t q2 = fdiv(q1, p.dOH);
+  const int oy = (int)(q1 - q2 * p.OH);
+  const uint32_t q3 = fdiv(q2, p.dOD);
+  const int oz = (int)(q2 - q3 * p.OD);
+  const int b = (int)q3;
+  int tx = 0, ty = 0, tz = 0;
+  {
+    const int tap = threadIdx.x / PTILE;
+    tx = tap % p.KW; ty = (tap / p.KW) % p.KH; tz = tap / (p.KW * p.KH);
+  }
+  constexpr int STEP = 256 / PTILE;      // taps advanced per iteration
+  for (int tap = threadIdx.x / PTILE; tap < K4; tap += STEP) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (m < (uint32_t)p.M) {
-      const uint32_t q1 = fdiv(m, p.dOW);
-      const int ox = (int)(m - q1 * p.OW);
-      const uint32_t q2 = fdiv(q1, p.dOH);
-      const int oy = (int)(q1 - q2 * p.OH);
-      const uint32_t q3 = fdiv(q2, p.dOD);
-      const int oz = (int)(q2 - q3 * p.OD);
-      const int b = (int)q3;
-      const int tx = tap % p.KW, ty = (tap / p.KW) % p.KH, tz = tap / (p.KW * p.KH);
-      const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
-      if ((unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW) {
-        const long long pix = (((long long)b * p.D + lz + p.oz) * p.H + ly + p.oy) * p.W + lx + p.ox;
-        v = *reinterpret_cast<const f32x4*>(p.x + pix * p.ld_x);
-      }
+    const int lz = oz + tz - p.PD, ly = oy + ty - p.PH, lx = ox + tx - p.PW;
+    if (live && (unsigned)lz < (unsigned)p.ID && (unsigned)ly < (unsigned)p.IH && (unsigned)lx < (unsigned)p.IW) {
+      const long long pix = (((long long)b * p.D + lz + p.oz) * p.H + ly + p.oy) * p.W + lx + p.ox;
+      v = *reinterpret_cast<const f32x4*>(p.x + pix * p.ld_x);
     }
     *reinterpret_cast<f32x4*>(&Xs[(pl * K4 + tap) * 4]) = v;
+    tx += STEP;                           // advance (tz, ty, tx) by STEP taps without divisions
+    while (tx >= p.KW) { tx -= p.KW; if (++ty == p.KH) { ty = 0; ++tz; } }
   }
 }
 
