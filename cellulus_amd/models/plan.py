@@ -27,12 +27,13 @@ def pad4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
-# Winograd is used for 2-D 3x3 layers whose channel counts (both sides) reach this value: below it
-# the extra HBM traffic of the transformed tensors outweighs the fewer MFMA FLOPs.
+# Winograd is used for 3x3 layers whose channel counts (both sides) reach this value: below it the
+# extra HBM traffic of the transformed tensors and the short contraction (K = C per batched GEMM)
+# outweigh the fewer MFMA FLOPs (measured at the benchmark config: 64 beats 128 by 2 %).
 # CLX_WINOGRAD=0 forces the direct implicit-GEMM kernels everywhere; CLX_WINOGRAD_TILE selects
 # F(2x2, 3x3) (2.25x fewer multiplications, error ~7e-7 of the output range on a 768-channel
 # layer) or F(4x4, 3x3) (4x fewer, ~5e-6; the direct kernel: ~4e-7).
-WINO_MIN_CHANNELS = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS", "128"))
+WINO_MIN_CHANNELS = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS", "64"))
 # per-layer algorithm code = clx_conv_algo: 0 direct, 1 Winograd F(2x2), 2 Winograd F(4x4)
 WINO_TAPS = {1: 16, 2: 36}
 WINO_PACK_FWD = {1: 2, 2: 4}        # clx_pack_mode
