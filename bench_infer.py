@@ -25,13 +25,35 @@ def _sync_time(fn, reps):
     return (time.perf_counter() - t0) / reps, out
 
 
+def synthetic_embeddings(shape, spacing=48, radius=12, noise=0.3, seed=1):
+    """The benchmark's detection input: disc/ball objects on a jittered grid,
+    embedding = (centre - pixel) + N(0, noise) in (x, y[, z]) channel order, std = 0.01 inside / 1.0
+    outside.  Returns (mean (1, ND, *shape) f64, std (*shape) f64)."""
+    rs = np.random.RandomState(seed)
+    nd = len(shape)
+    grids = np.meshgrid(*[np.arange(s, dtype=np.float64) for s in shape], indexing="ij")
+    mean = np.zeros((nd,) + tuple(shape))
+    std = np.ones(shape)
+    centres = np.stack(np.meshgrid(*[np.arange(spacing // 2, s, spacing) for s in shape], indexing="ij"),
+                       -1).reshape(-1, nd)
+    for c in centres:
+        c = c + rs.randint(-6, 7, size=nd)
+        d2 = sum((g - ci) ** 2 for g, ci in zip(grids, c))
+        inside = d2 <= radius * radius
+        std[inside] = 0.01
+        for k in range(nd):            # channel 0 = x offset (last axis)
+            ax = nd - 1 - k
+            mean[k][inside] = (c[ax] - grids[ax])[inside]
+    mean += rs.normal(0, noise, size=mean.shape) * (std < 0.5)
+    return mean[np.newaxis].copy(), std
+
+
 def infer_bench(device, reps=2, with_cpu=True):
     from cellulus_amd.models import get_model
     from cellulus_amd.segment import grow_shrink_on_device
     from cellulus_amd.utils.mean_shift import mean_shift_on_device
     from cellulus_amd.utils.misc import label_on_device
     from cellulus_amd.utils.otsu import threshold_otsu
-    from oracle import infer_oracle as IO
 
     size, crop, n_it = 512, 528, 16
     cfg = dict(in_channels=1, out_channels=2, num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64,
@@ -52,7 +74,7 @@ def infer_bench(device, reps=2, with_cpu=True):
     t_embed, emb = _sync_time(lambda: model.infer_on_device(raw, noise=noise), reps)
     assert tuple(emb.shape) == (1, 3, size, size)
 
-    mean, std = IO.synthetic_embeddings((size, size), spacing=48, radius=12, noise=0.3, seed=1)
+    mean, std = synthetic_embeddings((size, size), spacing=48, radius=12, noise=0.3, seed=1)
     mean_d = torch.from_numpy(mean[0]).to(device)
     std_d = torch.from_numpy(std).to(device)
 
@@ -100,7 +122,10 @@ def infer_bench(device, reps=2, with_cpu=True):
         "clusters": int(len(centers)),
     }
     if with_cpu:
-        # oracle = sklearn's algorithm restated in C (1 thread, as the reference runs it) + C CC labelling
+        # CPU baseline leg: the oracle (sklearn's algorithm restated in C, 1 thread, as the reference
+        # runs it, + C connected-component labelling) on the same input — the only use of oracle/ here
+        from oracle import infer_oracle as IO
+
         np.random.seed(1)
         t0 = time.perf_counter()
         thr = IO.threshold_otsu(std)

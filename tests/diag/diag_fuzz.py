@@ -1,7 +1,7 @@
 """Per-parameter gradient error of one fuzz case (tests/test_gpu_fuzz.py) vs the f64 oracle."""
 import os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_fuzz as F
 from cellulus_amd.models import get_model

@@ -1,7 +1,7 @@
 """Diagnose g9 mismatch: offsets, gather, loss of the HIP path vs torch ops on the same device tensors."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cellulus_amd.models import get_model
 from cellulus_amd.criterions import get_loss
 from cellulus_amd.models.unet import UNetModel

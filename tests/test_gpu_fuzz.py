@@ -72,7 +72,7 @@ def test_random_config_forward_backward_match_oracle(seed, device):
 
     # Gradients.  A pre-activation that is ~0 can land on different sides of the ReLU in f32 (HIP)
     # and f64 (oracle); such a gate flip changes upstream gradients by a whole term (1e-4 .. 1e-2
-    # relative, see tools/diag_fuzz.py) and says nothing about the kernels.  So the oracle's backward
+    # relative, see tests/diag/diag_fuzz.py) and says nothing about the kernels.  So the oracle's backward
     # runs through the SAME gates as the device: every ReLU of the oracle passes its input where the
     # device's stored activation is positive.  With equal gates the two backward passes are the same
     # linear map and must agree to rounding.

@@ -5,7 +5,7 @@ the f32 CPU oracle.  Gradients are compared with the oracle evaluated in
 FLOAT64: in f32 a pre-activation within rounding of 0 flips a ReLU gate on either
 side, which moves a whole layer's gradient by ~1e-3 (measured: the f32 CPU oracle
 sits 1e-3 from the f64 result on the 3-D case while the HIP path sits 1e-6 from
-it, tools/diag_grad64.py) — so the f64 result is the truth both are judged by:
+it, tests/diag/diag_grad64.py) — so the f64 result is the truth both are judged by:
 relative L2 error < 1e-4 per parameter tensor."""
 
 import numpy as np
