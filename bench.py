@@ -303,10 +303,21 @@ def main():
     plan_algo = getattr(plan, "algo", {})
     n_wino = sum(1 for a in plan_algo.values() if a.get("fwd"))
     wino_tile = max([{1: 2, 2: 4}.get(a.get("fwd"), 0) for a in plan_algo.values()] or [0])
+    # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process, so the
+    # figure comes from the committed digest of the separate rocprofv3 --pmc passes (tools/hbm_traffic.py)
+    traffic, traffic_source = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"hbm_traffic_{args.workload}.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            tdoc = json.load(fh)
+        for kname, row in tdoc["kernels"].items():
+            if kname.replace(" ", "") == dom_name:
+                traffic, traffic_source = row["bytes_per_launch"], "profiles/" + os.path.basename(tpath)
     roofline = dict(
         bound="mfma", kernel=dom_name,
         achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-        frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+        frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+        traffic_unit="bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", traffic_source=traffic_source,
         launches_per_step=int(launches // args.steps),
         avg_launch_ms=round(ms / max(launches, 1), 4),
         note="achieved = FLOPs the kernel executes (2*M*N*K per GEMM, real extents) / HIP-event time of "

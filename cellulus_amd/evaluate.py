@@ -1,7 +1,8 @@
 """Evaluation against ground truth — same outputs as ``cellulus/evaluate.py:9-105``
 (per-sample F1 / SEG, ``results_bandwidth-<b>.txt``).  The reference builds the
 IoU table with O(#pred x #gt) full-image mask passes; one joint histogram of
-(prediction, ground-truth) id pairs gives the identical table."""
+(prediction, ground-truth) id pairs, taken on the device in a single pass over the two
+label maps (``clx_joint_histogram``), gives the identical table."""
 
 import numpy as np
 from tqdm import tqdm
@@ -50,14 +51,55 @@ def evaluate(inference_config: InferenceConfig) -> None:
             out.writelines(f"SEG for complete dataset is {SEG_dataset/n_ids_dataset:.05f} \n")
 
 
-def compute_pairwise_IoU(prediction, groundtruth):
-    prediction_ids, p_inv = np.unique(prediction, return_inverse=True)
-    groundtruth_ids, g_inv = np.unique(groundtruth, return_inverse=True)
+MAX_IDS = 1 << 16                      # label maps are stored as uint16 (detect.py:62-70, segment.py:24-32)
+
+
+def joint_histogram_on_device(prediction, groundtruth, device=None):
+    """(prediction ids, ground-truth ids, joint[#pred ids][#gt ids] int64) — ids ascending as
+    ``np.unique`` returns them, background 0 included when present; one pass over the two maps
+    on the device (``csrc/evaluate.hip``)."""
+    import torch
+
+    from . import _clx
+
+    if torch.is_tensor(prediction):
+        device = prediction.device
+    elif device is None:
+        if not torch.cuda.is_available():
+            raise _clx.ClxError("evaluate needs a HIP device; cellulus_amd has no CPU path")
+        device = torch.device("cuda", torch.cuda.current_device())
+
+    def up(a):
+        if not torch.is_tensor(a):
+            a = torch.from_numpy(np.ascontiguousarray(a).astype(np.int32))
+        return a.to(device=device, dtype=torch.int32).contiguous().reshape(-1)
+
+    p, g = up(prediction), up(groundtruth)
+    assert p.numel() == g.numel(), "prediction and ground truth differ in shape"
+    _clx.require_device(p, "prediction")
+    st = _clx.stream_ptr(device)
+    present = torch.zeros(2, MAX_IDS, dtype=torch.int32, device=device)
+    bad = torch.zeros(1, dtype=torch.int32, device=device)
+    _clx.call("clx_label_presence", _clx.ptr(p), p.numel(), MAX_IDS, _clx.ptr(present[0]), _clx.ptr(bad), st)
+    _clx.call("clx_label_presence", _clx.ptr(g), g.numel(), MAX_IDS, _clx.ptr(present[1]), _clx.ptr(bad), st)
+    index = (torch.cumsum(present, dim=1, dtype=torch.int32) - 1).contiguous()   # id -> row / column
+    count = present.sum(dim=1).tolist()
+    if int(bad.item()):
+        raise ValueError("label ids must lie in [0, 65536): the label maps are uint16 on disk")
+    joint = torch.zeros(count[0], count[1], dtype=torch.int64, device=device)
+    _clx.call("clx_joint_histogram", _clx.ptr(p), _clx.ptr(g), p.numel(), _clx.ptr(index[0]),
+              _clx.ptr(index[1]), count[1], _clx.ptr(joint), st)
+    ids = [torch.nonzero(present[k]).reshape(-1).cpu().numpy() for k in (0, 1)]
+    return ids[0], ids[1], joint.cpu().numpy()
+
+
+def iou_from_joint(prediction_ids, groundtruth_ids, joint):
+    """IoU table, SEG sum and #gt ids of ``evaluate.py:72-100`` from the joint histogram:
+    |P_j & G_k| = joint[j, k], |P_j| and |G_k| its row / column sums, |P_j | G_k| their sum minus
+    the intersection; the divisions are the reference's (integer counts -> float64)."""
     n_gt = int((groundtruth_ids != 0).sum())
     if n_gt == 0:
         return None
-    joint = np.zeros((len(prediction_ids), len(groundtruth_ids)), dtype=np.int64)
-    np.add.at(joint, (np.asarray(p_inv).ravel(), np.asarray(g_inv).ravel()), 1)
     p_size = joint.sum(axis=1, keepdims=True)
     g_size = joint.sum(axis=0, keepdims=True)
     p_keep, g_keep = prediction_ids != 0, groundtruth_ids != 0
@@ -66,6 +108,10 @@ def compute_pairwise_IoU(prediction, groundtruth):
     IoU_table = inter / union
     IoG_table = inter / g_size[:, g_keep]
     return IoU_table, np.sum(IoU_table[IoG_table > 0.5]), n_gt
+
+
+def compute_pairwise_IoU(prediction, groundtruth, device=None):
+    return iou_from_joint(*joint_histogram_on_device(prediction, groundtruth, device))
 
 
 def compute_F1(IoU_table, threshold=0.5):

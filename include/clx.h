@@ -387,6 +387,22 @@ int clx_inst_refine(const int32_t* seg, const void* raw, int raw_type, int ndim,
                     const double* thr, const long long* scratch_off,
                     unsigned char* scratch, int n, int32_t* out, clx_stream stream);
 
+/* ------------------------------------------------------------------------ */
+/* evaluation (cellulus/evaluate.py:72-100): compute_pairwise_IoU's          */
+/* #pred x #gt full-image mask passes as ONE joint histogram of id pairs     */
+/* ------------------------------------------------------------------------ */
+/* present[id] = 1 for every id in `labels` (np.unique, evaluate.py:73-76);
+ * *bad = 1 if an id lies outside [0, nid).  present / bad zeroed by the caller. */
+int clx_label_presence(const int32_t* labels, long long n, int nid,
+                       int32_t* present, int32_t* bad, clx_stream stream);
+/* joint[pred_row[pred[i]]][gt_col[gt[i]]] += 1 for all i: intersections
+ * (evaluate.py:84-86) directly, object sizes and unions (:87-94) from its row /
+ * column sums.  pred_row / gt_col: id -> row / column tables (every id present in
+ * the maps must have an entry); joint: u64 [rows][ncol], zeroed by the caller. */
+int clx_joint_histogram(const int32_t* pred, const int32_t* gt, long long n,
+                        const int32_t* pred_row, const int32_t* gt_col, int ncol,
+                        unsigned long long* joint, clx_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -383,16 +383,35 @@ def test_subpixel_phase_weights_equal_upsample_then_conv(nd):
 
 def test_evaluate_matches_real_reference_golden():
     """g10: the REAL cellulus.evaluate.compute_pairwise_IoU / compute_F1 (O(#pred x #gt) mask loops)
-    vs the joint-histogram implementation: identical IoU tables, SEG, F1, TP, FP, FN."""
-    from cellulus_amd.evaluate import compute_F1, compute_pairwise_IoU
+    vs (i) the oracle's restatement of those loops and (ii) the product's host step that turns a
+    joint histogram of id pairs into the same tables (the histogram itself is a HIP kernel —
+    tests/test_gpu_infer.py — here it comes from the oracle): identical IoU, SEG, F1, TP, FP, FN."""
+    from cellulus_amd.evaluate import compute_F1, iou_from_joint
+    from oracle import infer_oracle as IO
 
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_evaluate.npz"))
     for i in range(3):
-        iou, seg, n = compute_pairwise_IoU(g[f"{i}/pred"], g[f"{i}/gt"])
+        pred, gt = g[f"{i}/pred"], g[f"{i}/gt"]
+        iou_o, seg_o, n_o = IO.compute_pairwise_IoU(pred, gt)
+        np.testing.assert_array_equal(iou_o, g[f"{i}/iou"])
+        np.testing.assert_allclose([seg_o, n_o, *IO.compute_F1(iou_o)], g[f"{i}/scalars"], rtol=1e-15)
+        iou, seg, n = iou_from_joint(*IO.joint_histogram(pred, gt))
         np.testing.assert_array_equal(iou, g[f"{i}/iou"])
         f1, tp, fp, fn = compute_F1(iou)
         np.testing.assert_allclose([seg, n, f1, tp, fp, fn], g[f"{i}/scalars"], rtol=1e-15)
-    assert bool(g["none_for_empty_gt"]) and compute_pairwise_IoU(g["0/pred"], np.zeros_like(g["0/gt"])) is None
+    assert bool(g["none_for_empty_gt"])
+    assert IO.compute_pairwise_IoU(g["0/pred"], np.zeros_like(g["0/gt"])) is None
+    assert iou_from_joint(*IO.joint_histogram(g["0/pred"], np.zeros_like(g["0/gt"]))) is None
+
+
+def test_evaluate_has_no_cpu_path():
+    from cellulus_amd import _clx
+    from cellulus_amd.evaluate import compute_pairwise_IoU
+
+    if torch.cuda.is_available():
+        pytest.skip("HIP device present")
+    with pytest.raises(_clx.ClxError, match="no CPU path"):
+        compute_pairwise_IoU(np.ones((4, 4), np.uint16), np.ones((4, 4), np.uint16))
 
 
 @pytest.mark.parametrize("tag", ["2d", "3d", "2d_small"])

@@ -518,3 +518,59 @@ def test_fused_infer_writes_the_same_datasets_as_the_staged_path(device, tmp_pat
             assert {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in attrs.items()} == \
                    {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in ref_attrs.items()}, name
         assert results[post, "1"]["segmentation"][0].max() > 0
+
+
+# ------------------------------------------------------------------ evaluate (joint histogram on the device)
+def test_evaluate_on_device_matches_real_reference_golden(device):
+    """g10: IoU table, SEG, F1, TP, FP, FN of the REAL cellulus.evaluate functions (bit for bit: every
+    entry is a quotient of the same two integers)."""
+    from cellulus_amd.evaluate import compute_F1, compute_pairwise_IoU
+
+    g = np.load(os.path.join(G, "g10_evaluate.npz"))
+    for i in range(3):
+        iou, seg, n = compute_pairwise_IoU(g[f"{i}/pred"], g[f"{i}/gt"])
+        np.testing.assert_array_equal(iou, g[f"{i}/iou"])
+        f1, tp, fp, fn = compute_F1(iou)
+        np.testing.assert_allclose([seg, n, f1, tp, fp, fn], g[f"{i}/scalars"], rtol=1e-15)
+    assert compute_pairwise_IoU(g["0/pred"], np.zeros_like(g["0/gt"])) is None
+
+
+@pytest.mark.parametrize("shape", [(512, 512), (37, 53), (24, 40, 56), (1, 7)])
+def test_joint_histogram_matches_oracle_random(shape, device):
+    """Blocky random label maps with sparse ids up to 65535 (uint16 storage), odd extents (tails of
+    the 8-pixel runs), background present or absent: ids and counts equal np.unique / np.add.at."""
+    from cellulus_amd.evaluate import iou_from_joint, joint_histogram_on_device
+
+    rng = np.random.default_rng(sum(shape))
+    for trial in range(3):
+        def blocky(nids, block):
+            ids = np.concatenate([[0] if trial != 1 else [], rng.choice(np.arange(1, 65536), size=nids, replace=False)])
+            coarse = tuple(-(-s // block) for s in shape)
+            m = ids[rng.integers(0, len(ids), size=coarse)]
+            for ax in range(len(shape)):
+                m = np.repeat(m, block, axis=ax)
+            return np.ascontiguousarray(m[tuple(slice(0, s) for s in shape)]).astype(np.uint16)
+
+        pred, gt = blocky(40, 5), blocky(25, 7)
+        p_ids, g_ids, joint = joint_histogram_on_device(pred, gt)
+        rp, rg, rj = IO.joint_histogram(pred, gt)
+        np.testing.assert_array_equal(p_ids, rp)
+        np.testing.assert_array_equal(g_ids, rg)
+        np.testing.assert_array_equal(joint, rj)
+        assert joint.sum() == pred.size
+        got, ref = iou_from_joint(p_ids, g_ids, joint), IO.compute_pairwise_IoU(pred, gt) if pred.size < 5000 else None
+        if ref is not None and got is not None:
+            np.testing.assert_array_equal(got[0], ref[0])
+            assert got[1] == ref[1] and got[2] == ref[2]
+
+
+def test_joint_histogram_takes_device_tensors_and_rejects_wide_ids(device):
+    from cellulus_amd.evaluate import joint_histogram_on_device
+
+    a = torch.randint(0, 9, (64, 64), device=device, dtype=torch.int32)
+    p_ids, g_ids, joint = joint_histogram_on_device(a, a)
+    assert np.array_equal(p_ids, g_ids) and np.array_equal(joint, np.diag(np.diag(joint)))
+    np.testing.assert_array_equal(np.diag(joint), np.bincount(a.cpu().numpy().ravel())[p_ids])
+    a[3, 3] = 70000
+    with pytest.raises(ValueError, match="65536"):
+        joint_histogram_on_device(a, a)

@@ -16,3 +16,4 @@ python3 $R/tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels.txt
 python3 $R/tools/pmc_digest.py $O/pmc wino_ > $O/pmc_wino_kernels.txt
 rm -rf $O/pmc
 echo refresh done
+bash $R/tools/hbm_traffic.sh
