@@ -68,6 +68,7 @@ class ClxConvDesc(Structure):
         ("workspace_bytes", c_size_t),
         ("vcache", c_void_p),
         ("vcache_valid", c_int),
+        ("c_real", c_int),
     ]
 
 

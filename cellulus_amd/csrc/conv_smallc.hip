@@ -28,6 +28,8 @@ struct SmallP {
   float* dwp;            // wgrad: [taps][N][4]
   float* dbias;
   int tiles_per_block;
+  int RX, items;         // grey kernels: runs of 4 output pixels per row, runs in total
+  FastDiv dRX;
 };
 
 constexpr int PT = 64;          // pixels per tile
@@ -246,6 +248,199 @@ __global__ __launch_bounds__(256) void conv_smallc_wgrad_stream_kernel(const Sma
       if (n0 + i < p.N) atomicAdd(p.dbias + n0 + i, red[ntap * 4 * NT + i]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ONE real input channel (grey-scale raw image, c_real == 1) and a valid 3x3 / 3x3x3 kernel —
+// the first layer of every configuration BASELINE.json names.  A wavefront works on a run of four
+// consecutive output pixels along x: lane = (px, cq), pixel px of the run and channel quad cq
+// (16 quads = 64 output channels).  The run's input patch is KD*3 rows of 6 values: lane L < KD*18
+// fetches value L (ONE 4-byte load per lane and run instead of taps 16-byte loads per pixel, three
+// quarters of them padding), and every lane picks its 3 x 3 (x 3) taps out of the patch with
+// ds_bpermute.  Weights (forward) / weight-gradient sums (backward) live in registers for the
+// whole kernel, so per run a wave issues 1 load, TAPS permutes, 4*TAPS FMAs per lane and one
+// 16-byte-per-lane store (forward) or load (backward) of the [M][N] activation: HBM-bound on that
+// tensor.  No LDS staging, no barriers in the loop, loads run two runs ahead; addresses of dead
+// prefetches / of the patch columns past the row end are clamped instead of predicated (a guarded
+// load in the loop costs a vmcnt(0)) — such columns only ever reach pixels past the
+// row end, which are not stored (forward) or enter with dy = 0 (backward).
+struct Run {
+  int ox0, m0;           // first output pixel of the run: x position, linear index
+  long long base;        // its input pixel (stored grid, crop applied)
+};
+
+__device__ __forceinline__ Run decode_run(const SmallP& p, uint32_t item) {
+  const uint32_t q1 = fdiv(item, p.dRX);
+  const int rx = (int)(item - q1 * p.RX);
+  const uint32_t q2 = fdiv(q1, p.dOH);
+  const int oy = (int)(q1 - q2 * p.OH);
+  const uint32_t q3 = fdiv(q2, p.dOD);
+  const int oz = (int)(q2 - q3 * p.OD);
+  const int b = (int)q3;
+  Run r;
+  r.ox0 = rx * 4;
+  r.m0 = ((b * p.OD + oz) * p.OH + oy) * p.OW + r.ox0;
+  r.base = (((long long)b * p.D + oz + p.oz) * p.H + oy + p.oy) * p.W + r.ox0 + p.ox;
+  return r;
+}
+
+template <int KD>
+struct GreyLane {
+  static constexpr int R = KD * 3, NP = R * 6, TAPS = R * 3;
+  int px, cq, col;
+  long long poff;
+  __device__ __forceinline__ GreyLane(const SmallP& p) {
+    const int lane = threadIdx.x & 63;
+    px = lane >> 4; cq = lane & 15;
+    const int l = lane < NP ? lane : 0;          // lanes past the patch re-read value 0 (unused)
+    const int r = l / 6;
+    col = l - r * 6;
+    const int tz = r / 3, ty = r - tz * 3;
+    poff = ((long long)tz * p.H + ty) * p.W;
+  }
+  __device__ __forceinline__ float load_patch(const SmallP& p, const Run& r) const {
+    const int c = r.ox0 + col < p.IW ? col : p.IW - 1 - r.ox0;
+    return p.x[(r.base + poff + c) * p.ld_x];
+  }
+  // input value under tap (row, tx) of this lane's pixel
+  __device__ __forceinline__ float tap(float pv, int row, int tx) const {
+    return __shfl(pv, row * 6 + tx + px, 64);
+  }
+};
+
+template <int KD>
+__global__ __launch_bounds__(256) void conv_grey_fwd_kernel(const SmallP p) {
+  using L = GreyLane<KD>;
+  const L ln(p);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.y * 64 + ln.cq * 4;
+  const bool live_n = n < p.N;
+  f32x4 w[L::TAPS];
+#pragma unroll
+  for (int t = 0; t < L::TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[t][e] = live_n ? p.wpack[((size_t)(n + e) * L::TAPS + t) * 4] : 0.f;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && live_n) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+  const uint32_t last = (uint32_t)p.items - 1, stride = gridDim.x * 4;
+  uint32_t item = blockIdx.x * 4 + wave;
+  // three register sets in rotation, the loop unrolled by three so that no set is ever copied
+  // (a copy of a pending load makes the wait-count pass drain the queue: prefetch distance 1)
+  Run r[3];
+  float pv[3];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    r[s] = decode_run(p, item + s * stride < last ? item + s * stride : last);
+    pv[s] = ln.load_patch(p, r[s]);
+  }
+  while (true) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (item > last) return;
+      const int s2 = (s + 2) % 3;
+      const uint32_t nxt = item + 2 * stride;
+      r[s2] = decode_run(p, nxt < last ? nxt : last);
+      pv[s2] = ln.load_patch(p, r[s2]);
+      f32x4 acc = bv;
+#pragma unroll
+      for (int row = 0; row < L::R; ++row)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) acc += ln.tap(pv[s], row, tx) * w[row * 3 + tx];
+      if (p.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+      }
+      if (live_n && r[s].ox0 + ln.px < p.OW)
+        *reinterpret_cast<f32x4*>(p.out + (size_t)(r[s].m0 + ln.px) * p.ld_out + n) = acc;
+      item += stride;
+    }
+  }
+}
+
+template <int KD>
+__global__ __launch_bounds__(256) void conv_grey_wgrad_kernel(const SmallP p) {
+  using L = GreyLane<KD>;
+  __shared__ float red[(L::TAPS + 1) * 64];
+  const L ln(p);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n0 = blockIdx.y * 64, n = n0 + ln.cq * 4;
+  const bool live_n = n < p.N;
+  const int nld = live_n ? n : 0;
+  for (int i = threadIdx.x; i < (L::TAPS + 1) * 64; i += 256) red[i] = 0.f;
+  f32x4 acc[L::TAPS];
+#pragma unroll
+  for (int t = 0; t < L::TAPS; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const uint32_t last = (uint32_t)p.items - 1, stride = gridDim.x * 4;
+  uint32_t item = blockIdx.x * 4 + wave;
+  auto load_dy = [&](const Run& r) {
+    const int m = r.ox0 + ln.px < p.OW ? r.m0 + ln.px : r.m0;
+    return *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ld_dy + nld);
+  };
+  Run r[3];
+  float pv[3];
+  f32x4 dy[3];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    r[s] = decode_run(p, item + s * stride < last ? item + s * stride : last);
+    pv[s] = ln.load_patch(p, r[s]);
+    dy[s] = load_dy(r[s]);
+  }
+  bool more = item <= last;
+  while (more) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      if (more) {
+        const int s2 = (s + 2) % 3;
+        const uint32_t nxt = item + 2 * stride;
+        r[s2] = decode_run(p, nxt < last ? nxt : last);
+        pv[s2] = ln.load_patch(p, r[s2]);
+        dy[s2] = load_dy(r[s2]);
+        const bool ok = live_n && r[s].ox0 + ln.px < p.OW;
+        f32x4 dyv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dyv[e] = ok ? dy[s][e] : 0.f;
+        bsum += dyv;
+#pragma unroll
+        for (int row = 0; row < L::R; ++row)
+#pragma unroll
+          for (int tx = 0; tx < 3; ++tx) acc[row * 3 + tx] += ln.tap(pv[s], row, tx) * dyv;
+        item += stride;
+        more = item <= last;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < L::TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(&red[t * 64 + ln.cq * 4 + e], acc[t][e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) atomicAdd(&red[L::TAPS * 64 + ln.cq * 4 + e], bsum[e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < L::TAPS * 64; i += 256) {
+    const int nl = i & 63, t = i >> 6;
+    if (n0 + nl < p.N) atomicAdd(p.dwp + ((size_t)t * p.N + n0 + nl) * 4, red[i]);
+  }
+  if (p.dbias && threadIdx.x < 64 && n0 + threadIdx.x < p.N)
+    atomicAdd(p.dbias + n0 + threadIdx.x, red[L::TAPS * 64 + threadIdx.x]);
+}
+
+// grey kernels apply: one real channel, valid 3x3 or 3x3x3 kernel, channel quads stored whole
+bool grey_applicable(const clx_conv_desc* d, int ld_act) {
+  return d->c_real == 1 && d->KH == 3 && d->KW == 3 && (d->KD == 1 || d->KD == 3) && d->PD == 0 &&
+         d->PH == 0 && d->PW == 0 && d->N % 4 == 0 && ld_act % 4 == 0;
+}
+
+dim3 grey_grid(SmallP& p) {
+  p.RX = cdiv(p.OW, 4);
+  p.items = p.B * p.OD * p.OH * p.RX;
+  p.dRX = make_fastdiv(p.RX);
+  const int ny = cdiv(p.N, 64);
+  int nx = 768 / ny;                    // ~3 waves per SIMD over the whole chip
+  if (nx < 1) nx = 1;
+  if (nx > cdiv(p.items, 4)) nx = cdiv(p.items, 4);
+  return dim3(nx, ny);
+}
+
 bool fill(const clx_conv_desc* d, SmallP& p) {
   const clx_src& S = d->src[0];
   p.x = S.ptr; p.ld_x = S.ld; p.B = d->B; p.D = S.D; p.H = S.H; p.W = S.W;
@@ -284,6 +479,12 @@ int clx_smallc_fwd(const clx_conv_desc* d, hipStream_t st) {
   SmallP p{};
   fill(d, p);
   p.wpack = d->wpack; p.bias = d->bias; p.out = d->out; p.ld_out = d->ld_out; p.relu = d->relu;
+  if (grey_applicable(d, d->ld_out) && ((uintptr_t)d->out & 15) == 0 && (!d->bias || ((uintptr_t)d->bias & 15) == 0)) {
+    const dim3 grid = grey_grid(p);
+    if (d->KD == 1) conv_grey_fwd_kernel<1><<<grid, 256, 0, st>>>(p);
+    else conv_grey_fwd_kernel<3><<<grid, 256, 0, st>>>(p);
+    return CLX_OK;
+  }
   const int ng = pick_ng(p.N);
   const int K = p.taps * 4;
   const int tiles = cdiv(p.M, PT);
@@ -305,6 +506,12 @@ int clx_smallc_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   SmallP p{};
   fill(d, p);
   p.dy = dy; p.ld_dy = ld_dy; p.dwp = dwpack; p.dbias = dbias;
+  if (grey_applicable(d, ld_dy) && ((uintptr_t)dy & 15) == 0) {
+    const dim3 grid = grey_grid(p);
+    if (d->KD == 1) conv_grey_wgrad_kernel<1><<<grid, 256, 0, st>>>(p);
+    else conv_grey_wgrad_kernel<3><<<grid, 256, 0, st>>>(p);
+    return CLX_OK;
+  }
   const int ng = pick_ng(p.N);
   // 183 VGPRs -> 2 waves per SIMD = 2 blocks per CU resident: one round of 512 blocks per tap
   // group, so every block pays its final global atomics once (0.22 ms of 0.62 at 1024 blocks)

@@ -714,6 +714,8 @@ class UNetPlan:
         d.algo = 0
         d.workspace = None
         d.workspace_bytes = 0
+        # a raw image with 1-3 channels is stored padded to 4: tell the first-layer kernels
+        d.c_real = layer.sources[0].channels if len(layer.sources) == 1 else 0
         return d
 
     def _use_workspace(self, d, code):

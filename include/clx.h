@@ -100,6 +100,10 @@ typedef struct clx_conv_desc {
    * transform (the forward and the weight gradient transform the same tensor). */
   void* vcache;
   int vcache_valid;
+  /* Hint, 0 = unknown: only the first c_real channels of src[0] can be non-zero (the rest is the
+   * padding of a 1-, 2- or 3-channel raw image up to 4).  Kernels may skip the padding; the weight
+   * gradient then leaves the padded channels of dwpack untouched (clx_unpack_wgrad drops them). */
+  int c_real;
 } clx_conv_desc;
 
 enum clx_conv_algo {
