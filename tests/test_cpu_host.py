@@ -229,7 +229,13 @@ def test_dedup_centers_equals_oracle_dict_sort_dedup():
 
 # -------------------------------------------------------------- evaluation
 def test_pairwise_iou_equals_bruteforce_definition():
-    from cellulus_amd.evaluate import compute_F1, compute_pairwise_IoU
+    """Host half of evaluate (joint histogram -> IoU / SEG / F1); the histogram is a HIP kernel
+    (tests/test_gpu_infer.py) and comes from the oracle here."""
+    from cellulus_amd.evaluate import compute_F1, iou_from_joint
+    from oracle import infer_oracle as IO
+
+    def compute_pairwise_IoU(prediction, groundtruth):
+        return iou_from_joint(*IO.joint_histogram(prediction, groundtruth))
 
     rng = np.random.default_rng(0)
     pred = np.kron(rng.integers(0, 5, size=(6, 6)), np.ones((4, 4), dtype=np.int64)).astype(np.uint16)
