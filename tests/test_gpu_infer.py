@@ -574,3 +574,47 @@ def test_joint_histogram_takes_device_tensors_and_rejects_wide_ids(device):
     a[3, 3] = 70000
     with pytest.raises(ValueError, match="65536"):
         joint_histogram_on_device(a, a)
+
+
+def test_evaluate_over_zarr_writes_the_reference_report(device, tmp_path, monkeypatch):
+    """evaluate(): results_bandwidth-<b>.txt (evaluate.py:36-69) for two bandwidths over zarr label maps;
+    every number against the oracle's mask-loop restatement, samples without ground truth skipped."""
+    from cellulus_amd.configs import InferenceConfig
+    from cellulus_amd.evaluate import evaluate
+    from cellulus_amd.utils import zarr_io
+
+    monkeypatch.chdir(tmp_path)
+    container = str(tmp_path / "eval.zarr")
+    rng = np.random.default_rng(3)
+    S, shape = 3, (48, 40)
+
+    def blocky(nids, block):
+        m = rng.integers(0, nids + 1, size=tuple(-(-s // block) for s in shape))
+        return np.kron(m, np.ones((block, block), dtype=np.int64))[:shape[0], :shape[1]]
+
+    gt = np.stack([blocky(5, 8), np.zeros(shape, np.int64), blocky(4, 6)])[:, None].astype(np.uint16)
+    seg = np.stack([np.stack([np.roll(gt[s, 0], b + 1, axis=1) for b in range(2)]) for s in range(S)]).astype(np.uint16)
+    f = zarr_io.open(container)
+    f["raw"] = rng.random((S, 1) + shape).astype(np.float32)
+    f["raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    f["gt"] = gt
+    f["segmentation"] = seg
+    cfg = InferenceConfig(
+        dataset_config=dict(container_path=container, dataset_name="raw"),
+        evaluation_dataset_config=dict(container_path=container, dataset_name="gt",
+                                       secondary_dataset_name="segmentation"),
+        crop_size=[32, 32], num_bandwidths=2, device="cuda:0")
+    evaluate(cfg)
+    for b in range(2):
+        lines = open(f"results_bandwidth-{b}.txt").read().splitlines()
+        rows = [ln for ln in lines if ln[:1].isdigit()]
+        assert [int(r.split(",")[0]) for r in rows] == [0, 2]              # sample 1 has no ground truth
+        tps = fps = fns = 0
+        seg_sum = n_ids = 0
+        for r, s in zip(rows, (0, 2)):
+            iou, seg_img, n = IO.compute_pairwise_IoU(seg[s, b], gt[s, 0])
+            f1, tp, fp, fn = IO.compute_F1(iou)
+            assert r == f"{s}, {f1:.05f}, {seg_img / n:.05f}, {tp}, {fp}, {fn}"
+            tps, fps, fns, seg_sum, n_ids = tps + tp, fps + fp, fns + fn, seg_sum + seg_img, n_ids + n
+        assert lines[-2] == f"F1 for complete dataset is {2 * tps / (2 * tps + fps + fns):.05f} "
+        assert lines[-1] == f"SEG for complete dataset is {seg_sum / n_ids:.05f} "

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the end-of-round evidence under gpurun_out/ (run on the GPU box through gpurun from the repo
-# root); copy the results into profiles/ with tools/collect_profiles.py afterwards.
+# root); copy the results into profiles/ afterwards (names: profiles/README.md).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
