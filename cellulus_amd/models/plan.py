@@ -841,9 +841,12 @@ class UNetPlan:
         return out
 
     # ---------------------------------------------------------------- backward
-    def backward(self, dout, params, grads):
+    def backward(self, dout, params, grads, on_layer_done=None):
         """dout: (B, out_channels, *out_spatial) gradient of the loss w.r.t. forward()'s result.
-        grads: list aligned with params; every entry is OVERWRITTEN with the gradient."""
+        grads: list aligned with params; every entry is OVERWRITTEN with the gradient.
+        on_layer_done(param_index): called once the kernels that write a layer's weight and bias
+        gradient are enqueued (layers finish in reverse forward order: the data-parallel step
+        starts reducing the tail of the flat gradient while the rest is still being computed)."""
         t = self.topo
         st = _clx.stream_ptr(self.device)
         assert self._bwd_ready, "pack_weights(need_dgrad=True) must run before backward"
@@ -872,6 +875,8 @@ class UNetPlan:
                 dskip = self._sp_backward(layer, sp, dy, grads[2 * layer.param_index],
                                           grads[2 * layer.param_index + 1], st)
                 pending_skip[layer.sources[0].tensor] = (dskip, sp["C0p"], layer)
+                if on_layer_done is not None:
+                    on_layer_done(layer.param_index)
                 continue
             # ---- weight + bias gradient
             d = self._desc(layer)
@@ -901,6 +906,8 @@ class UNetPlan:
                 _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(tmp), layer.cout, layer.cin_pad,
                           layer.taps, pad4(layer.cout), layer.cin_pad, st)
                 gw.copy_(self._compress_cin(layer, tmp).reshape(gw.shape))
+            if on_layer_done is not None:
+                on_layer_done(layer.param_index)
             # ---- data gradient
             if layer.param_index == 0:
                 continue

@@ -4,8 +4,13 @@ The reference is single-device; the MI355X build shards
 crops across ranks.  The loss is a SUM over pairs (oce_loss.py:58-60), so the
 gradient of the global batch is the SUM of the per-rank gradients: one
 all-reduce(SUM) over the flat f32 gradient buffer, NO division by world size.
-xGMI is point-to-point, so a single large bucket (the whole 38.5 MB gradient at
-the benchmark config) is the right granularity for the ring.
+The backward pass completes that buffer from its tail to its head (the flat order
+is the forward order of the layers), so the reduction is issued in a few large
+contiguous buckets as soon as their layers are done and runs on RCCL's stream
+under the rest of the backward pass (``GradientBuckets``).  xGMI is point-to-point
+and the ring is per-link bound: buckets are few and large (>= CLX_GRAD_BUCKET_MB,
+default 4 MB; at the benchmark config the 21 MB 768x768x3x3 layer is one bucket),
+not the 25 MB / many-small-tensors scheme of an NVSwitch-tuned DDP.
 """
 
 import os
@@ -48,6 +53,63 @@ def all_reduce_sum_(flat, async_op=False):
     if world_size() == 1:
         return None
     return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def bucket_bytes():
+    """Smallest gradient bucket issued before the backward pass has finished; 0 = one all-reduce at the end."""
+    return int(float(os.environ.get("CLX_GRAD_BUCKET_MB", "4")) * (1 << 20))
+
+
+class GradientBuckets:
+    """SUM all-reduce of the flat gradient, overlapped with the backward pass.
+
+    ``views`` are the per-parameter views of ``flat`` in buffer order, without gaps.
+    ``params_done(i, ...)`` marks parameters whose gradient kernels are enqueued on the current
+    stream; whenever the completed SUFFIX of the buffer has grown by ``min_bytes`` the range is
+    all-reduced asynchronously (the collective waits for the current stream at issue time and then
+    runs on the backend's own stream).  ``finish()`` reduces what is left and makes the current
+    stream wait for every bucket.  Every rank issues the same ranges in the same order: they
+    depend on the launch plan only."""
+
+    def __init__(self, flat, views, min_bytes=None):
+        self.flat = flat
+        self.lo, off = [], 0
+        for v in views:
+            assert v.data_ptr() == flat.data_ptr() + off * flat.element_size(), "views must tile the flat buffer"
+            self.lo.append(off)
+            off += v.numel()
+        assert off == flat.numel()
+        self.done = [False] * len(views)
+        self.cursor = len(views)                 # parameters [cursor:] are complete
+        self.issued_lo = flat.numel()            # elements [issued_lo:] are already being reduced
+        self.min_elems = max(1, (bucket_bytes() if min_bytes is None else min_bytes) // flat.element_size())
+        self.works, self.issued = [], []
+
+    def _issue(self, lo):
+        if lo < self.issued_lo:
+            self.works.append(all_reduce_sum_(self.flat[lo:self.issued_lo], async_op=True))
+            self.issued.append((lo, self.issued_lo))
+            self.issued_lo = lo
+
+    def add(self, tensor):
+        """An extra tensor (the loss sums) reduced alongside."""
+        self.works.append(all_reduce_sum_(tensor, async_op=True))
+
+    def params_done(self, *indices):
+        for i in indices:
+            self.done[i] = True
+        while self.cursor > 0 and self.done[self.cursor - 1]:
+            self.cursor -= 1
+        lo = self.lo[self.cursor] if self.cursor < len(self.lo) else self.flat.numel()
+        if self.issued_lo - lo >= self.min_elems:
+            self._issue(lo)
+
+    def finish(self):
+        self._issue(0)
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works = []
 
 
 def broadcast_(flat, src=0):

@@ -273,10 +273,17 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
               _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
               float(criterion.temperature), float(criterion.regularization_weight),
               _clx.stream_ptr(device))
-    plan.backward(doffsets, params, grads)
-    if parallel.world_size() > 1:
-        parallel.all_reduce_sum_(model._flat_grad)
-        parallel.all_reduce_sum_(sums)
+    if parallel.world_size() > 1 and parallel.bucket_bytes() > 0:
+        # gradient buckets go out while the rest of the backward pass runs (parallel.GradientBuckets)
+        buckets = parallel.GradientBuckets(model._flat_grad, grads)
+        buckets.add(sums)
+        plan.backward(doffsets, params, grads, on_layer_done=lambda i: buckets.params_done(2 * i, 2 * i + 1))
+        buckets.finish()
+    else:
+        plan.backward(doffsets, params, grads)
+        if parallel.world_size() > 1:
+            parallel.all_reduce_sum_(model._flat_grad)
+            parallel.all_reduce_sum_(sums)
     optimizer.step()
     host = sums.to(torch.float32).cpu()       # the step's single host synchronisation
     return host[0].item(), host[1].item(), offsets

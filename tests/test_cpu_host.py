@@ -312,6 +312,30 @@ assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
 sums = torch.tensor([float(rank + 1)], dtype=torch.float64)
 parallel.all_reduce_sum_(sums)
 assert sums.item() == 3.0
+# gradient buckets: parameters complete from the tail of the flat buffer, out of order in places;
+# only the completed SUFFIX is reduced, every element exactly once, result = SUM over ranks
+sizes = [5, 1, 40, 3, 64, 7, 2]
+flat = torch.arange(float(sum(sizes))) * (rank + 1)
+views, off = [], 0
+for n in sizes:
+    views.append(flat[off:off + n]); off += n
+extra = torch.tensor([10.0 * (rank + 1)], dtype=torch.float64)
+gb = parallel.GradientBuckets(flat, views, min_bytes=40 * 4)
+gb.add(extra)
+gb.params_done(6); assert gb.issued == []                       # 2 elements < 40
+gb.params_done(4); assert gb.issued == []                       # 5 is missing: suffix still [6:]
+gb.params_done(5); assert gb.issued == [(49, 122)]              # 64 + 7 + 2 elements
+gb.params_done(3, 2); assert gb.issued[-1] == (6, 49)
+gb.params_done(1, 0); assert len(gb.issued) == 2                # 6 elements wait for finish()
+gb.finish()
+assert gb.issued == [(49, 122), (6, 49), (0, 6)] and gb.works == []
+assert torch.equal(flat, torch.arange(float(sum(sizes))) * 3) and extra.item() == 30.0
+gb0 = parallel.GradientBuckets(flat, views, min_bytes=1 << 30)   # nothing before finish
+for i in reversed(range(len(sizes))):
+    gb0.params_done(i)
+assert gb0.issued == []
+gb0.finish()
+assert gb0.issued == [(0, 122)] and torch.equal(flat, torch.arange(float(sum(sizes))) * 6)
 dist.barrier()
 print("rank", rank, "ok")
 """
