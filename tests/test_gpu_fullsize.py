@@ -157,3 +157,35 @@ def test_full_size_inference_postprocessing_matches_oracle(device):
     assert first == sorted(first)                        # raster order of first appearance
     again, n2 = label_on_device(out.clone(), 70)         # idempotent
     assert torch.equal(again, out) and int(n2.item()) == int(n.item())
+
+
+def test_full_size_3d_configuration(device):
+    """BASELINE cfg-4 (3-D 64^3 crops, num_fmaps=64, batch 8): sample independence and determinism of
+    the forward pass bit for bit (Winograd in (y, x) with the z taps inside the GEMMs, the one-channel
+    first-layer kernels), then four fused train steps with 2 418 pairs per crop: finite, loss down."""
+    cfg3 = dict(in_channels=1, out_channels=3, num_fmaps=64, fmap_inc_factor=3, features_in_last_layer=64,
+                downsampling_factors=[[2, 2, 2]], num_spatial_dims=3)
+    torch.manual_seed(6)
+    m = get_model(**cfg3)
+    for _n, layer in m.named_modules():
+        if isinstance(layer, torch.nn.modules.conv._ConvNd):
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+    m = m.to(device)
+    raw = torch.rand(8, 1, 64, 64, 64, device=device)
+    with torch.no_grad():
+        full = m(raw).clone()
+        assert full.shape == (8, 3, 48, 48, 48) and torch.isfinite(full).all()
+        assert torch.equal(full, m(raw))
+        for i in (0, 5):
+            assert torch.equal(m(raw[i:i + 1].contiguous())[0], full[i]), f"sample {i}"
+    crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=3, device=device)
+    opt = Adam(m.parameters(), lr=4e-5, weight_decay=0.01)
+    rng = np.random.default_rng(1)
+    B, out, kappa, n_anchor, n_ref = 8, 48, 10, 78, 31
+    anchors = np.repeat(rng.integers(kappa, out - kappa + 1, size=(B, n_anchor, 3)), n_ref, axis=1)
+    offs = rng.integers(-kappa + 1, kappa, size=anchors.shape)
+    offs[np.abs(offs).sum(-1) == 0] = 1
+    batch = (raw.cpu(), torch.from_numpy(anchors.astype(np.int64)), torch.from_numpy((anchors + offs).astype(np.int64)))
+    assert batch[1].shape == (8, 2418, 3)
+    losses = [train_iteration(batch, m, crit, opt, device)[0] for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
