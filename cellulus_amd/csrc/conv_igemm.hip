@@ -20,7 +20,15 @@ namespace {
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 constexpr int BK = 32;       // K chunk (floats)
-constexpr int LDS_LD = 36;   // padded LDS row (floats): conflict-free b128 reads
+// LDS row of the 128x128 kernel: one K chunk + 4 floats of padding (conflict-free b128 reads).
+// The 128x64 kernel stores unpadded rows and XOR-swizzles the 16-byte column index with
+// (row >> 1) & 7 instead: ds_read_b128 is serviced in 16-lane groups over the 16 16-byte slots of a
+// 256-byte line (MI355X_MICROARCH.md, LDS); a fragment read touches 16 rows at one column, slot =
+// 8 (row & 1) + (col ^ (row >> 1) & 7) — all distinct; a store's 8-lane group is one row, its 8
+// columns permuted.  32 instead of 36 floats per row = 48 KB per block: THREE blocks per CU
+// (132 VGPRs), which is what the short-K, narrow-N layers of the 3-D network need (26.5 -> 25.3 ms
+// per step); on the 128x128 kernel (two blocks per CU either way) the swizzle costs 3 %.
+template <int BN> constexpr int lds_ld() { return BN == 64 ? 32 : 36; }
 
 struct SrcP {
   const float* ptr;
@@ -44,7 +52,9 @@ struct ConvP {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const ConvP p) {
+  constexpr int LDS_LD = lds_ld<BN>();
+  constexpr bool SWZ = LDS_LD == 32;
   constexpr int TM = BM / WAVES_M / 32;
   constexpr int TN = BN / WAVES_N / 32;
   constexpr int A_PASSES = BM / 32;
@@ -68,6 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
   const int lrow = tid >> 3;        // 0..31
   const int lcol = (tid & 7) * 4;   // float offset inside the 32-wide chunk
+  const int lcol_lds = SWZ ? ((tid & 7) ^ ((lrow >> 1) & 7)) * 4 : lcol;   // its place in the LDS row
 
   // ---- decode this thread's A rows (output pixels) once
   int rb[A_PASSES], rz[A_PASSES], ry[A_PASSES], rx[A_PASSES];
@@ -145,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < A_PASSES; ++j)
-      *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * j) * LDS_LD + lcol]) = ra[j];
+      *reinterpret_cast<f32x4*>(&As[buf][(lrow + 32 * j) * LDS_LD + lcol_lds]) = ra[j];
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j)
-      *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * j) * LDS_LD + lcol]) = rw[j];
+      *reinterpret_cast<f32x4*>(&Bs[buf][(lrow + 32 * j) * LDS_LD + lcol_lds]) = rw[j];
   };
   // returns false when the K loop is exhausted
   auto advance = [&]() -> bool {
@@ -175,8 +186,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int li = lane & 31, lh = lane >> 5;
-  const int a_base = (wm * TM * 32 + li) * LDS_LD + 4 * lh;
-  const int b_base = (wn * TN * 32 + li) * LDS_LD + 4 * lh;
+  const int a_base = (wm * TM * 32 + li) * LDS_LD + (SWZ ? 0 : 4 * lh);
+  const int b_base = (wn * TN * 32 + li) * LDS_LD + (SWZ ? 0 : 4 * lh);
+  // k-group q reads 16-byte column 2q + lh of its row, swizzled: (2q + lh) ^ (row >> 1 & 7)
+  const int fsw = lh ^ ((li >> 1) & 7);
 
   set_source();
   load_chunk();
@@ -191,10 +204,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvP p) {
   auto load_frags = [&](int b, int q, int slot) {
 #pragma unroll
     for (int a = 0; a < TM; ++a)
-      af[slot][a] = *reinterpret_cast<const f32x4*>(&As[b][a_base + a * 32 * LDS_LD + 8 * q]);
+      af[slot][a] = *reinterpret_cast<const f32x4*>(&As[b][a_base + a * 32 * LDS_LD + (SWZ ? 4 * ((2 * q) ^ fsw) : 8 * q)]);
 #pragma unroll
     for (int c = 0; c < TN; ++c)
-      bf[slot][c] = *reinterpret_cast<const f32x4*>(&Bs[b][b_base + c * 32 * LDS_LD + 8 * q]);
+      bf[slot][c] = *reinterpret_cast<const f32x4*>(&Bs[b][b_base + c * 32 * LDS_LD + (SWZ ? 4 * ((2 * q) ^ fsw) : 8 * q)]);
   };
   auto mfma_group = [&](int slot) {
 #pragma unroll
