@@ -19,7 +19,8 @@
 
 namespace {
 
-constexpr int BKP = 32;  // pixels per chunk
+// pixels per chunk: 32, but 24 for the 128x128 tile — 48 instead of 64 KB of LDS, i.e. three blocks per CU
+template <int BMN, int BNC> constexpr int bkp() { return BMN == 128 && BNC == 128 ? 24 : 32; }
 
 __device__ __attribute__((aligned(16))) float g_wgrad_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -45,7 +46,8 @@ struct WgradP {
 };
 
 template <int BMN, int BNC, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
+__global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_wgrad_kernel(const WgradP p) {
+  constexpr int BKP = bkp<BMN, BNC>();
   constexpr int TM = BMN / WAVES_M / 32;
   constexpr int TN = BNC / WAVES_N / 32;
   constexpr int A_F4 = BMN / 4, A_RPP = 256 / A_F4, A_PASSES = BKP / A_RPP;
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradP p) {
       for (int k2 = 0; k2 < BKP / 2; ++k2) {
         if constexpr (MORE) {
           if (k2 == 0) load_dy(ch + 1);
-          if (k2 == 4) load_x(ch + 1);
-          if (k2 == 12) store_chunk(buf ^ 1);
+          if (k2 == BKP / 8) load_x(ch + 1);
+          if (k2 == 3 * BKP / 8) store_chunk(buf ^ 1);
         }
         if (k2 + 1 < BKP / 2) load_frags(buf, k2 + 1, (k2 + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -300,6 +302,7 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   p.tiles_c = cdiv(p.Ctot, bnc);
   const int T = p.tiles_n * p.tiles_c * p.taps;
   const int Tall = T * batch;
+  const int BKP = big_n && big_c ? bkp<128, 128>() : 32;
   const int total_chunks = cdiv(p.M, BKP);
   // Split-K so that the grid is a whole number of "rounds" of co-resident blocks: a grid of
   // 4 rounds + a few blocks would run 5 rounds (the tail alone costs 20 %).
