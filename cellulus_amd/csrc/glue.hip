@@ -14,22 +14,41 @@ inline int grid_for(long long total, int block) {
   return (int)g;
 }
 
+// Linear index -> (4-channel group, x, y, z, batch) with host-prepared multiply-shift divisors: the
+// 64-bit `%` / `/` chain this replaces cost more VALU time than the kernels' memory traffic
+// (launchers require the element count / 4 to stay below 2^31).
+struct Dec {
+  FastDiv c4, w, h, d;
+};
+inline Dec make_dec(int C4, int W, int H, int D) {
+  return Dec{make_fastdiv((uint32_t)C4), make_fastdiv((uint32_t)W), make_fastdiv((uint32_t)H), make_fastdiv((uint32_t)D)};
+}
+__device__ __forceinline__ void decode(uint32_t i, const Dec& dc, uint32_t& pixel, int& c4, int& x, int& y, int& z, int& b) {
+  pixel = fdiv(i, dc.c4);
+  c4 = (int)(i - pixel * dc.c4.d);
+  const uint32_t q1 = fdiv(pixel, dc.w);
+  x = (int)(pixel - q1 * dc.w.d);
+  const uint32_t q2 = fdiv(q1, dc.h);
+  y = (int)(q1 - q2 * dc.h.d);
+  const uint32_t q3 = fdiv(q2, dc.d);
+  z = (int)(q2 - q3 * dc.d.d);
+  b = (int)q3;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // replaces funlib Downsample = nn.MaxPool{2,3}d(f, stride=f) [unet.py:24-51]
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                    int D, int H, int W, int C4, int fz, int fy, int fx,
-                                   int OD, int OH, int OW, long long total) {
+                                   int OD, int OH, int OW, Dec dc, uint32_t total) {
   const int C = C4 * 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long q = i / C4;
-    const int ox = (int)(q % OW); q /= OW;
-    const int oy = (int)(q % OH); q /= OH;
-    const int oz = (int)(q % OD);
-    const long long b = q / OD;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t opix;
+    int c4, ox, oy, oz, bi;
+    decode(i, dc, opix, c4, ox, oy, oz, bi);
+    const int c = c4 * 4;
+    const long long b = bi;
     f32x4 m;
     bool first = true;
     for (int dz = 0; dz < fz; ++dz)
@@ -43,7 +62,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
             for (int e = 0; e < 4; ++e) m[e] = (v[e] > m[e]) ? v[e] : m[e];
           }
         }
-    st4(y + (i / C4) * C + c, m);
+    st4(y + (size_t)opix * C + c, m);
   }
 }
 
@@ -51,19 +70,18 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
                                    const float* __restrict__ dyp, const float* __restrict__ dskip,
                                    int ld_skip, int SD, int SH, int SW, int cz, int cy, int cx,
                                    float* __restrict__ dxo, int D, int H, int W, int C4,
-                                   int fz, int fy, int fx, long long total) {
+                                   int fz, int fy, int fx, Dec dc, FastDiv dfz, FastDiv dfy, FastDiv dfx,
+                                   uint32_t total) {
   const int C = C4 * 4;
   const int OD = D / fz, OH = H / fy, OW = W / fx;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long q = i / C4;
-    const int px = (int)(q % W); q /= W;
-    const int py = (int)(q % H); q /= H;
-    const int pz = (int)(q % D);
-    const long long b = q / D;
-    const int wz = pz / fz, wy = py / fy, wx = px / fx;
-    const f32x4 xv = ld4(x + (i / C4) * C + c);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t pixel;
+    int c4, px, py, pz, bi;
+    decode(i, dc, pixel, c4, px, py, pz, bi);
+    const int c = c4 * 4;
+    const long long b = bi;
+    const int wz = (int)fdiv((uint32_t)pz, dfz), wy = (int)fdiv((uint32_t)py, dfy), wx = (int)fdiv((uint32_t)px, dfx);
+    const f32x4 xv = ld4(x + (size_t)pixel * C + c);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (wz < OD && wy < OH && wx < OW) {
       const long long win = ((b * OD + wz) * OH + wy) * OW + wx;
@@ -94,7 +112,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __r
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = (xv[e] > 0.f) ? g[e] : 0.f;
-    st4(dxo + (i / C4) * C + c, g);
+    st4(dxo + (size_t)pixel * C + c, g);
   }
 }
 
@@ -102,16 +120,14 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dcat, int ld_cat, 
                                     int LD, int LH, int LW, int oz, int oy, int ox,
                                     const float* __restrict__ y, float* __restrict__ dy,
                                     int D, int H, int W, int C4, int fz, int fy, int fx,
-                                    long long total) {
+                                    Dec dc, uint32_t total) {
   const int C = C4 * 4;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    long long q = i / C4;
-    const int qx = (int)(q % W); q /= W;
-    const int qy = (int)(q % H); q /= H;
-    const int qz = (int)(q % D);
-    const long long b = q / D;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    uint32_t pixel;
+    int c4, qx, qy, qz, bi;
+    decode(i, dc, pixel, c4, qx, qy, qz, bi);
+    const int c = c4 * 4;
+    const long long b = bi;
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     for (int dz = 0; dz < fz; ++dz) {
       const int lz = qz * fz + dz - oz;
@@ -127,10 +143,10 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dcat, int ld_cat, 
         }
       }
     }
-    const f32x4 yv = ld4(y + (i / C4) * C + c);
+    const f32x4 yv = ld4(y + (size_t)pixel * C + c);
 #pragma unroll
     for (int e = 0; e < 4; ++e) g[e] = (yv[e] > 0.f) ? g[e] : 0.f;
-    st4(dy + (i / C4) * C + c, g);
+    st4(dy + (size_t)pixel * C + c, g);
   }
 }
 
@@ -221,8 +237,9 @@ extern "C" int clx_maxpool_fwd(const float* x, float* y, int B, int D, int H, in
               "clx_maxpool_fwd: extent (%d,%d,%d) not divisible by factor (%d,%d,%d)", D, H, W, fz, fy, fx);
   const int OD = D / fz, OH = H / fy, OW = W / fx;
   const long long total = (long long)B * OD * OH * OW * (C / 4);
+  CLX_REQUIRE((long long)B * D * H * W * (C / 4) < (1ll << 31), "clx_maxpool_fwd: tensor too large");
   maxpool_fwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
-      x, y, D, H, W, C / 4, fz, fy, fx, OD, OH, OW, total);
+      x, y, D, H, W, C / 4, fz, fy, fx, OD, OH, OW, make_dec(C / 4, OW, OH, OD), (uint32_t)total);
   CLX_CHECK_LAUNCH("clx_maxpool_fwd");
   return CLX_OK;
 }
@@ -236,8 +253,11 @@ extern "C" int clx_maxpool_bwd(const float* x, const float* y, const float* dy_p
   CLX_REQUIRE(D % fz == 0 && H % fy == 0 && W % fx == 0, "clx_maxpool_bwd: extent not divisible");
   CLX_REQUIRE(dskip == nullptr || (ld_skip % 4 == 0 && ld_skip >= C), "clx_maxpool_bwd: bad ld_skip");
   const long long total = (long long)B * D * H * W * (C / 4);
+  CLX_REQUIRE(total < (1ll << 31), "clx_maxpool_bwd: tensor too large");
   maxpool_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
-      x, y, dy_pool, dskip, ld_skip, SD, SH, SW, cz, cy, cx, dx, D, H, W, C / 4, fz, fy, fx, total);
+      x, y, dy_pool, dskip, ld_skip, SD, SH, SW, cz, cy, cx, dx, D, H, W, C / 4, fz, fy, fx,
+      make_dec(C / 4, W, H, D), make_fastdiv((uint32_t)fz), make_fastdiv((uint32_t)fy), make_fastdiv((uint32_t)fx),
+      (uint32_t)total);
   CLX_CHECK_LAUNCH("clx_maxpool_bwd");
   return CLX_OK;
 }
@@ -250,8 +270,10 @@ extern "C" int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD,
   CLX_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "clx_upsample_bwd: bad extents");
   CLX_REQUIRE(ld_cat % 4 == 0 && coff % 4 == 0 && coff + C <= ld_cat, "clx_upsample_bwd: bad ld/coff");
   const long long total = (long long)B * D * H * W * (C / 4);
+  CLX_REQUIRE(total < (1ll << 31), "clx_upsample_bwd: tensor too large");
   upsample_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
-      dcat, ld_cat, coff, LD, LH, LW, oz, oy, ox, y, dy, D, H, W, C / 4, fz, fy, fx, total);
+      dcat, ld_cat, coff, LD, LH, LW, oz, oy, ox, y, dy, D, H, W, C / 4, fz, fy, fx, make_dec(C / 4, W, H, D),
+      (uint32_t)total);
   CLX_CHECK_LAUNCH("clx_upsample_bwd");
   return CLX_OK;
 }
