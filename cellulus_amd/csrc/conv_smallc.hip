@@ -1,8 +1,12 @@
 // Convolution with <= 4 input channels (the network's first layer: raw image ->
 // num_fmaps): K = taps * 4 is far too short for an MFMA tile, and the layer is bound by
-// writing (forward) / reading (weight gradient) the [M][N] activation once.  Both kernels
-// stage the gathered input patch [pixels][taps*4] and the packed weights in LDS and keep
-// the per-thread work on 16-byte channel runs, so HBM traffic is one pass over [M][N].
+// writing (forward) / reading (weight gradient) the [M][N] activation once.  Two families:
+//   conv_smallc_*  any 1-4 channels, any padding: the forward kernel stages the gathered patch
+//                  [pixels][taps*4] and the packed weights in LDS, the weight gradient streams dy
+//                  with lane-broadcast tap loads; 16-byte channel runs throughout;
+//   conv_grey_*    ONE real channel (clx_conv_desc.c_real == 1) and a valid 3x3 / 3x3x3 kernel — every
+//                  BASELINE configuration: one 4-byte patch load per lane, taps by ds_bpermute,
+//                  weights / gradient sums in registers (below).
 //
 // Selected by clx_conv_fwd / clx_conv_wgrad when nsrc == 1, C == 4, no upsampling, no
 // accumulate / mask epilogue (those go to the implicit-GEMM kernel whatever the width).
