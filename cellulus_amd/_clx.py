@@ -97,8 +97,8 @@ PROTOTYPES = {
     "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_maxpool_bwd": (_I, [_P, _P, _P, _P] + [_I] * 7 + [_P] + [_I] * 8 + [_P]),
     "clx_upsample_bwd": (_I, [_P] + [_I] * 8 + [_P, _P] + [_I] * 8 + [_P]),
-    "clx_gather_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "clx_gather_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_gather_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "clx_gather_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "clx_oce_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _LL, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     "clx_oce_pairs_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
     "clx_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P]),

@@ -32,6 +32,16 @@ def _check_coords(outputs, coordinates):
     return B, ND, Z, Y, X
 
 
+def raise_on_bad_coordinates(count, spatial):
+    """The reference indexes ``outputs[b, :, (z,) y, x]`` (unet.py:113-118): torch raises
+    IndexError for a coordinate outside [-n, n).  The kernels skip and count such rows."""
+    if count:
+        raise IndexError(
+            f"{count} coordinate row(s) index outside the network output of extent {tuple(spatial)} "
+            "(coordinate column 0 is x = the LAST axis; the dataset's output_shape must equal the "
+            "model's output extent)")
+
+
 class _GatherAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, outputs, coordinates):
@@ -42,8 +52,10 @@ class _GatherAdd(torch.autograd.Function):
         coordinates = coordinates.contiguous()
         P = coordinates.shape[1]
         sel = torch.empty((B, P, ND), dtype=torch.float32, device=outputs.device)
+        oob = torch.zeros(1, dtype=torch.int32, device=outputs.device)
         _clx.call("clx_gather_add_fwd", _clx.ptr(outputs), _clx.ptr(coordinates), _clx.ptr(sel),
-                  B, P, ND, Z, Y, X, _clx.stream_ptr(outputs.device))
+                  B, P, ND, Z, Y, X, _clx.ptr(oob), _clx.stream_ptr(outputs.device))
+        raise_on_bad_coordinates(int(oob.item()), (Z, Y, X)[3 - ND:])
         ctx.save_for_backward(coordinates)
         ctx.shape = tuple(outputs.shape)
         return sel
@@ -58,7 +70,7 @@ class _GatherAdd(torch.autograd.Function):
         dsel = dsel.contiguous()
         dout = torch.zeros(shape, dtype=torch.float32, device=dsel.device)
         _clx.call("clx_gather_add_bwd", _clx.ptr(dsel), _clx.ptr(coordinates), _clx.ptr(dout),
-                  B, coordinates.shape[1], ND, Z, Y, X, _clx.stream_ptr(dsel.device))
+                  B, coordinates.shape[1], ND, Z, Y, X, None, _clx.stream_ptr(dsel.device))
         return dout, None
 
 

@@ -13,23 +13,35 @@ inline int grid_for(long long total, int block) {
   return (int)g;
 }
 
-// linear index of coordinate row `co` (x = last axis first) in a (Z, Y, X) grid
-__device__ __forceinline__ long long coord_index(const long long* co, int ND, int Y, int X) {
-  const long long x = co[0], y = co[1];
-  const long long z = (ND == 3) ? co[2] : 0;
-  return (z * Y + y) * X + x;
+// linear index of coordinate row `co` (x = last axis first) in a (Z, Y, X) grid, with the
+// index rules of the advanced indexing the reference uses (unet.py:113-118): -n..-1 wrap
+// around once, anything else outside [0, n) is an IndexError -> -1 here.
+__device__ __forceinline__ long long coord_index(const long long* co, int ND, int Z, int Y, int X) {
+  long long x = co[0], y = co[1];
+  long long z = (ND == 3) ? co[2] : 0;
+  x += (x < 0) ? X : 0;
+  y += (y < 0) ? Y : 0;
+  z += (z < 0) ? Z : 0;
+  const bool ok = (unsigned long long)x < (unsigned long long)X && (unsigned long long)y < (unsigned long long)Y &&
+                  (unsigned long long)z < (unsigned long long)Z;
+  return ok ? (z * Y + y) * X + x : -1;
 }
 
 // UNetModel.select_and_add_coordinates [cellulus/models/unet.py:108-124]
 __global__ void gather_add_fwd_kernel(const float* __restrict__ offsets,
                                       const long long* __restrict__ coords,
-                                      float* __restrict__ sel, int P, int ND, int Y, int X,
-                                      long long npix, long long total) {
+                                      float* __restrict__ sel, int P, int ND, int Z, int Y, int X,
+                                      long long npix, long long total, int* __restrict__ oob) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / P;
     const long long* co = coords + i * ND;
-    const long long idx = coord_index(co, ND, Y, X);
+    const long long idx = coord_index(co, ND, Z, Y, X);
+    if (idx < 0) {                      // never dereferenced; the host raises IndexError
+      if (oob) atomicAdd(oob, 1);
+      for (int c = 0; c < ND; ++c) sel[i * ND + c] = __builtin_nanf("");
+      continue;
+    }
     const float* ob = offsets + b * ND * npix + idx;
     for (int c = 0; c < ND; ++c) sel[i * ND + c] = ob[(long long)c * npix] + (float)co[c];
   }
@@ -37,13 +49,17 @@ __global__ void gather_add_fwd_kernel(const float* __restrict__ offsets,
 
 __global__ void gather_add_bwd_kernel(const float* __restrict__ dsel,
                                       const long long* __restrict__ coords,
-                                      float* __restrict__ doffsets, int P, int ND, int Y, int X,
-                                      long long npix, long long total) {
+                                      float* __restrict__ doffsets, int P, int ND, int Z, int Y, int X,
+                                      long long npix, long long total, int* __restrict__ oob) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / P;
     const long long* co = coords + i * ND;
-    const long long idx = coord_index(co, ND, Y, X);
+    const long long idx = coord_index(co, ND, Z, Y, X);
+    if (idx < 0) {
+      if (oob) atomicAdd(oob, 1);
+      continue;
+    }
     float* ob = doffsets + b * ND * npix + idx;
     for (int c = 0; c < ND; ++c) atomicAdd(ob + (long long)c * npix, dsel[i * ND + c]);
   }
@@ -120,14 +136,19 @@ template <int ND>
 __global__ __launch_bounds__(256) void oce_pairs_fused_kernel(
     const float* __restrict__ offsets, const long long* __restrict__ anchor,
     const long long* __restrict__ reference, float* __restrict__ doffsets, double* sums,
-    int P, int Y, int X, long long npix, long long total, float T, float w) {
+    int P, int Z, int Y, int X, long long npix, long long total, float T, float w) {
   double oce_acc = 0., reg_acc = 0.;
+  int bad = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const long long b = i / P;
     const long long* ca = anchor + i * ND;
     const long long* cr = reference + i * ND;
-    const long long ia = coord_index(ca, ND, Y, X), ir = coord_index(cr, ND, Y, X);
+    const long long ia = coord_index(ca, ND, Z, Y, X), ir = coord_index(cr, ND, Z, Y, X);
+    if (ia < 0 || ir < 0) {             // skipped and counted: sums[3], the host raises IndexError
+      ++bad;
+      continue;
+    }
     const float* ob = offsets + b * ND * npix;
     float av[ND], rv[ND], g[ND], oce, reg;
 #pragma unroll
@@ -141,6 +162,7 @@ __global__ __launch_bounds__(256) void oce_pairs_fused_kernel(
 #pragma unroll
     for (int c = 0; c < ND; ++c) atomicAdd(gb + (long long)c * npix, g[c]);
   }
+  if (bad) atomicAdd(sums + 3, (double)bad);
   block_accumulate(oce_acc, reg_acc, sums);
 }
 
@@ -168,7 +190,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
 }  // namespace
 
 extern "C" int clx_gather_add_fwd(const float* offsets, const long long* coords, float* sel,
-                                  int B, int P, int ND, int Z, int Y, int X, clx_stream stream) {
+                                  int B, int P, int ND, int Z, int Y, int X, int* oob_count,
+                                  clx_stream stream) {
   CLX_REQUIRE(offsets && coords && sel, "clx_gather_add_fwd: null pointer");
   CLX_REQUIRE(B > 0 && P >= 0 && (ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0,
               "clx_gather_add_fwd: bad extents");
@@ -176,20 +199,21 @@ extern "C" int clx_gather_add_fwd(const float* offsets, const long long* coords,
   if (P == 0) return CLX_OK;
   const long long total = (long long)B * P;
   gather_add_fwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
-      offsets, coords, sel, P, ND, Y, X, (long long)Z * Y * X, total);
+      offsets, coords, sel, P, ND, Z, Y, X, (long long)Z * Y * X, total, oob_count);
   CLX_CHECK_LAUNCH("clx_gather_add_fwd");
   return CLX_OK;
 }
 
 extern "C" int clx_gather_add_bwd(const float* dsel, const long long* coords, float* doffsets,
-                                  int B, int P, int ND, int Z, int Y, int X, clx_stream stream) {
+                                  int B, int P, int ND, int Z, int Y, int X, int* oob_count,
+                                  clx_stream stream) {
   CLX_REQUIRE(dsel && coords && doffsets, "clx_gather_add_bwd: null pointer");
   CLX_REQUIRE(B > 0 && P >= 0 && (ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0,
               "clx_gather_add_bwd: bad extents");
   if (P == 0) return CLX_OK;
   const long long total = (long long)B * P;
   gather_add_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
-      dsel, coords, doffsets, P, ND, Y, X, (long long)Z * Y * X, total);
+      dsel, coords, doffsets, P, ND, Z, Y, X, (long long)Z * Y * X, total, oob_count);
   CLX_CHECK_LAUNCH("clx_gather_add_bwd");
   return CLX_OK;
 }
@@ -223,10 +247,10 @@ extern "C" int clx_oce_pairs_fused(const float* offsets, const long long* anchor
   const int grid = grid_for(total, 256);
   if (ND == 2)
     oce_pairs_fused_kernel<2><<<grid, 256, 0, (hipStream_t)stream>>>(
-        offsets, anchor, reference, doffsets, sums, P, Y, X, npix, total, temperature, reg_weight);
+        offsets, anchor, reference, doffsets, sums, P, Z, Y, X, npix, total, temperature, reg_weight);
   else
     oce_pairs_fused_kernel<3><<<grid, 256, 0, (hipStream_t)stream>>>(
-        offsets, anchor, reference, doffsets, sums, P, Y, X, npix, total, temperature, reg_weight);
+        offsets, anchor, reference, doffsets, sums, P, Z, Y, X, npix, total, temperature, reg_weight);
   CLX_CHECK_LAUNCH("clx_oce_pairs_fused");
   return CLX_OK;
 }

@@ -13,8 +13,11 @@ from typing import List, Tuple
 import torch
 import torch.nn as nn
 
+import ctypes
+
 from .. import _clx
-from .plan import UNetPlan, build_topology
+from .._clx import ClxConvDesc, ClxSrc
+from .plan import UNetPlan, build_topology, pad4
 
 
 class _ConvPass(nn.Module):
@@ -69,6 +72,110 @@ class _UNetFunction(torch.autograd.Function):
         grads = model._grad_views()
         plan.backward(dout, ctx.params, grads)
         return (None, None) + tuple(grads)
+
+
+def _pointwise_desc(x, B, shape3, cin_p, n):
+    """clx_conv_desc of a 1x1(x1) convolution over a pixel-major (M, cin_p) tensor."""
+    d = ClxConvDesc()
+    d.nsrc = 1
+    src = ClxSrc()
+    src.ptr = x.data_ptr()
+    src.C = cin_p
+    src.ld = cin_p
+    src.D, src.H, src.W = shape3
+    src.oz = src.oy = src.ox = 0
+    src.fz = src.fy = src.fx = 1
+    d.src[0] = src
+    d.B = B
+    d.ID, d.IH, d.IW = shape3
+    d.KD = d.KH = d.KW = 1
+    d.PD = d.PH = d.PW = 0
+    d.N = n
+    return d
+
+
+class _HeadFunction(torch.autograd.Function):
+    """``self.head(backbone_output)`` (unet.py:52-67: Conv1x1 -> ReLU -> Conv1x1) on the
+    libclx convolution entry points: forward = two clx_conv_fwd launches, backward = their
+    data-gradient form (ReLU gate fused) + two clx_conv_wgrad launches."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1):
+        _clx.require_device(x, "backbone_output")
+        dev = x.device
+        st = _clx.stream_ptr(dev)
+        B, C = x.shape[0], x.shape[1]
+        spatial = tuple(x.shape[2:])
+        shape3 = (1,) + spatial if len(spatial) == 2 else spatial
+        n = shape3[0] * shape3[1] * shape3[2]
+        F, Dout = w0.shape[0], w1.shape[0]
+        Cp, Fp, Dp = pad4(C), pad4(F), pad4(Dout)
+        xp = torch.empty((B * n, Cp), dtype=torch.float32, device=dev)
+        _clx.call("clx_planar_to_pixel", _clx.ptr(x.contiguous()), _clx.ptr(xp), B, C, n, Cp, st)
+        h0 = torch.zeros((B * n, Fp), dtype=torch.float32, device=dev)
+        h1 = torch.zeros((B * n, Dp), dtype=torch.float32, device=dev)
+        packs = []
+        for w, cin, cin_p, cout, cout_p, src, dst, bias, relu in (
+                (w0, C, Cp, F, Fp, xp, h0, b0, 1), (w1, F, Fp, Dout, Dp, h0, h1, b1, 0)):
+            wv = w.detach().reshape(cout, cin, 1).contiguous()
+            wp = torch.empty(cout_p * cin_p, dtype=torch.float32, device=dev)
+            _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(wp), cout, cin, 1, cin_p, cout_p, 0, st)
+            d = _pointwise_desc(src, B, shape3, cin_p, cout)
+            d.wpack = wp.data_ptr()
+            d.bias = bias.data_ptr() if bias is not None else None
+            d.relu = relu
+            d.out = dst.data_ptr()
+            d.ld_out = cout_p
+            _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+            packs.append((wv, wp))
+        out = torch.empty((B, Dout) + spatial, dtype=torch.float32, device=dev)
+        _clx.call("clx_pixel_to_planar", _clx.ptr(h1), _clx.ptr(out), B, Dout, n, Dp, st)
+        ctx.save_for_backward(xp, h0, w0, w1)
+        ctx.geom = (B, C, F, Dout, shape3, spatial, b0 is not None, b1 is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xp, h0, w0, w1 = ctx.saved_tensors
+        B, C, F, Dout, shape3, spatial, has_b0, has_b1 = ctx.geom
+        dev = dout.device
+        st = _clx.stream_ptr(dev)
+        n = shape3[0] * shape3[1] * shape3[2]
+        Cp, Fp, Dp = pad4(C), pad4(F), pad4(Dout)
+        dh1 = torch.empty((B * n, Dp), dtype=torch.float32, device=dev)
+        _clx.call("clx_planar_to_pixel", _clx.ptr(dout.contiguous()), _clx.ptr(dh1), B, Dout, n, Dp, st)
+        dh0 = torch.zeros((B * n, Fp), dtype=torch.float32, device=dev)
+        dxp = torch.zeros((B * n, Cp), dtype=torch.float32, device=dev)
+        grads = {}
+        for tag, w, cin, cin_p, cout, cout_p, src, dy, gate, dsrc, has_b in (
+                ("1", w1, F, Fp, Dout, Dp, h0, dh1, h0, dh0, has_b1),
+                ("0", w0, C, Cp, F, Fp, xp, dh0, None, dxp, has_b0)):
+            dwp = torch.zeros(cout_p * cin_p, dtype=torch.float32, device=dev)
+            gb = torch.zeros(cout, dtype=torch.float32, device=dev) if has_b else None
+            d = _pointwise_desc(src, B, shape3, cin_p, cout_p)
+            _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), cout_p, _clx.ptr(dwp), _clx.ptr(gb), st)
+            gw = torch.empty_like(w)
+            _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), cout, cin, 1, cout_p, cin_p, st)
+            grads[tag] = (gw, gb)
+            if tag == "0" and not ctx.needs_input_grad[0]:
+                continue
+            wv = w.detach().reshape(cout, cin, 1).contiguous()
+            wpd = torch.empty(cin_p * cout_p, dtype=torch.float32, device=dev)
+            _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(wpd), cout, cin, 1, cin_p, cout_p, 1, st)
+            dd = _pointwise_desc(dy, B, shape3, cout_p, cin_p)
+            dd.wpack = wpd.data_ptr()
+            dd.bias = None
+            dd.relu = 0
+            dd.mask = gate.data_ptr() if gate is not None else None
+            dd.ld_mask = cin_p if gate is not None else 0
+            dd.out = dsrc.data_ptr()
+            dd.ld_out = cin_p
+            _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, C) + spatial, dtype=torch.float32, device=dev)
+            _clx.call("clx_pixel_to_planar", _clx.ptr(dxp), _clx.ptr(dx), B, C, n, Cp, st)
+        return dx, grads["0"][0], grads["0"][1], grads["1"][0], grads["1"][1]
 
 
 class UNetModel(nn.Module):  # type: ignore
@@ -201,8 +308,17 @@ class UNetModel(nn.Module):  # type: ignore
 
     # ------------------------------------------------------------- forward
     def head_forward(self, backbone_output):
-        raise NotImplementedError(
-            "cellulus_amd fuses backbone and head into one launch plan; call the model itself")
+        """``self.head(backbone_output)`` (unet.py:65-67) for callers that hold a backbone
+        output of their own; ``forward`` itself runs backbone + head as one launch plan."""
+        if backbone_output.ndim != self.num_spatial_dims + 2 or \
+                backbone_output.shape[1] != self.features_in_last_layer:
+            raise ValueError(
+                f"backbone_output must be (B, {self.features_in_last_layer}, *{self.num_spatial_dims} "
+                f"spatial dims), got {tuple(backbone_output.shape)}")
+        if backbone_output.dtype != torch.float32:
+            raise TypeError(f"backbone_output must be float32, got {backbone_output.dtype}")
+        return _HeadFunction.apply(backbone_output, self.head[0].weight, self.head[0].bias,
+                                   self.head[2].weight, self.head[2].bias)
 
     def _forward_nograd(self, raw):
         params = self._ordered_params()

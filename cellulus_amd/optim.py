@@ -72,8 +72,11 @@ class Adam(Optimizer):
             steps = set()
             for p in params:
                 st = self.state[p]
-                st["step"] += 1
-                steps.add(int(st["step"].item()))
+                # torch.optim.Adam keeps `step` as a CPU float tensor; checkpoints written by older
+                # torch versions hold a Python int — accept both, store back torch's layout
+                n = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+                st["step"] = torch.tensor(float(n + 1), dtype=torch.float32)
+                steps.add(n + 1)
             b1, b2 = group["betas"]
             args = (float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                     float(group["weight_decay"]))

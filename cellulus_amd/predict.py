@@ -87,11 +87,17 @@ def predict(model: torch.nn.Module, inference_config: InferenceConfig, normaliza
 
     raw_ds = zarr_io.open(dataset_config.container_path, "r")[dataset_config.dataset_name]
     f = zarr_io.open(inference_config.prediction_dataset_config.container_path)
-    ds = f.create_dataset(
-        inference_config.prediction_dataset_config.dataset_name,
-        shape=(meta.num_samples, nd + 1, *meta.spatial_array),
-        dtype=float,
-    )
+    # one creator: create_dataset replaces what is there, so a second rank calling it would delete
+    # chunks the first one has already written (detect.py / segment.py follow the same order)
+    if parallel.rank() == 0:
+        f.create_dataset(
+            inference_config.prediction_dataset_config.dataset_name,
+            shape=(meta.num_samples, nd + 1, *meta.spatial_array),
+            dtype=float,
+        )
+    if parallel.world_size() > 1:
+        torch.distributed.barrier()
+    ds = f[inference_config.prediction_dataset_config.dataset_name]
 
     scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)
     lo, hi = parallel.shard_range(meta.num_samples)

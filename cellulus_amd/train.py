@@ -267,7 +267,7 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         raise ValueError(f"coordinates must be (B={B}, P, {ND}); got {tuple(anchor.shape)} and "
                          f"{tuple(reference.shape)}")
     Z, Y, X = (1, offsets.shape[2], offsets.shape[3]) if ND == 2 else tuple(offsets.shape[2:])
-    sums = torch.zeros(3, dtype=torch.float64, device=device)
+    sums = torch.zeros(4, dtype=torch.float64, device=device)     # loss, oce, reg, bad-coordinate count
     doffsets = torch.zeros_like(offsets)
     _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
               _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
@@ -284,8 +284,14 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         if parallel.world_size() > 1:
             parallel.all_reduce_sum_(model._flat_grad)
             parallel.all_reduce_sum_(sums)
+    # the loss kernel has run long before: a bad coordinate is known before the parameters move
+    # only if we look now, and looking is a host synchronisation — the step has exactly one, here
+    host = sums.cpu()
+    from .criterions.oce_loss import raise_on_bad_coordinates
+
+    raise_on_bad_coordinates(int(host[3].item()), (Z, Y, X)[3 - ND:])
     optimizer.step()
-    host = sums.to(torch.float32).cpu()       # the step's single host synchronisation
+    host = host.to(torch.float32)
     return host[0].item(), host[1].item(), offsets
 
 

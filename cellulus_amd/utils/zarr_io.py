@@ -21,6 +21,10 @@ class ZarrError(RuntimeError):
     pass
 
 
+class ContainsArrayError(ZarrError, ValueError):
+    """zarr.errors.ContainsArrayError: create_dataset on an existing path without overwrite."""
+
+
 def _json_dump(path, obj):
     tmp = path + ".tmp"
     with io.open(tmp, "w") as f:
@@ -238,6 +242,13 @@ class Group:
             return Group(p)
         raise KeyError(name)
 
+    def __delitem__(self, name):
+        import shutil
+
+        if name not in self:
+            raise KeyError(name)
+        shutil.rmtree(os.path.join(self.path, name))
+
     def _make_parents(self, name):
         parts = name.strip("/").split("/")
         cur = self.path
@@ -247,7 +258,10 @@ class Group:
         return os.path.join(cur, parts[-1])
 
     def create_dataset(self, name, shape, dtype, chunks=None, compressor=None, fill_value=0,
-                       overwrite=True):
+                       overwrite=False):
+        """zarr's ``Group.create_dataset``: raises when `name` exists unless ``overwrite=True``
+        (zarr-python's ContainsArrayError; the reference's stages therefore refuse to clobber
+        an existing ``embeddings`` / ``detection`` / ``segmentation`` dataset)."""
         p = self._make_parents(name)
         dtype = np.dtype(dtype)
         shape = tuple(int(s) for s in shape)
@@ -255,7 +269,9 @@ class Group:
             # one chunk per leading index keeps per-sample writes cheap
             chunks = (1,) + shape[1:] if len(shape) > 1 else shape
         chunks = tuple(max(1, int(min(c, s))) if s > 0 else 1 for c, s in zip(chunks, shape))
-        if os.path.exists(p) and overwrite:
+        if os.path.exists(os.path.join(p, ".zarray")) or os.path.exists(os.path.join(p, ".zgroup")):
+            if not overwrite:
+                raise ContainsArrayError(f"path {name!r} contains an array")
             import shutil
 
             shutil.rmtree(p)
@@ -275,7 +291,8 @@ class Group:
 
     def __setitem__(self, name, value):
         value = np.asarray(value)
-        arr = self.create_dataset(name, shape=value.shape, dtype=value.dtype)
+        # zarr: group[name] = value  ==  group.array(name, value, overwrite=True)
+        arr = self.create_dataset(name, shape=value.shape, dtype=value.dtype, overwrite=True)
         arr[...] = value
 
 

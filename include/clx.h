@@ -221,12 +221,18 @@ int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD, int LH,
 /* sel[b][p][c] = offsets[b][c][coord...] + coord[b][p][c]
  * replaces UNetModel.select_and_add_coordinates (cellulus/models/unet.py:108-124).
  * offsets: planar (B, ND, [Z,] Y, X) f32; coords: (B, P, ND) int64, column 0
- * indexes the LAST spatial axis. */
+ * indexes the LAST spatial axis.  Index rules of the reference's advanced indexing: -n..-1
+ * wrap around, anything else outside [0, n) is an IndexError there; here such a row is never
+ * dereferenced, its selection is NaN and *oob_count (device int, zeroed by the caller, may be
+ * NULL) counts it so that the host can raise. */
 int clx_gather_add_fwd(const float* offsets, const long long* coords, float* sel,
-                       int B, int P, int ND, int Z, int Y, int X, clx_stream stream);
-/* doffsets[b][c][coord] += dsel[b][p][c]  (float atomics; zero doffsets first) */
+                       int B, int P, int ND, int Z, int Y, int X, int* oob_count,
+                       clx_stream stream);
+/* doffsets[b][c][coord] += dsel[b][p][c]  (float atomics; zero doffsets first); out-of-range
+ * rows are skipped and counted as above */
 int clx_gather_add_bwd(const float* dsel, const long long* coords, float* doffsets,
-                       int B, int P, int ND, int Z, int Y, int X, clx_stream stream);
+                       int B, int P, int ND, int Z, int Y, int X, int* oob_count,
+                       clx_stream stream);
 /* OCE loss forward + gradient, replaces OCELoss.forward
  * (cellulus/criterions/oce_loss.py:45-63) and its autograd backward:
  *   d = |a - r|, oce = sum(1 - exp(-d^2/T)), reg = w * sum |a|
@@ -239,7 +245,9 @@ int clx_oce_loss_fwd_bwd(const float* a, const float* r, float* da, double* sums
 /* Fused train-step tail: gather(anchor), gather(reference), OCE loss, and the
  * scatter-add of the anchor gradient straight into doffsets (planar, zeroed by
  * the caller). Equivalent to the three calls above composed as in
- * cellulus/train.py:170-178. */
+ * cellulus/train.py:170-178.  sums: FOUR doubles, zeroed by the caller: (loss, oce, reg) and
+ * the number of pairs with an out-of-range coordinate (skipped, never dereferenced; the
+ * reference raises IndexError there, so must the caller when sums[3] != 0). */
 int clx_oce_pairs_fused(const float* offsets, const long long* anchor,
                         const long long* reference, float* doffsets, double* sums,
                         int B, int P, int ND, int Z, int Y, int X,

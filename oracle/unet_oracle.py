@@ -208,3 +208,61 @@ def train_step(model, optimizer, raw, anchor, reference, temperature, regulariza
     loss.backward()
     optimizer.step()
     return loss.item(), oce.item(), offsets
+
+
+# ---------------------------------------------------------------------------------------------
+# The same convolutions as one matrix product per filter tap, so that the float64 oracle runs at dgemm
+# speed at BASELINE sizes: torch's native float64 convolution (no oneDNN path) manages ~2-6
+# GFLOP/s, i.e. minutes per 256^2 crop at 256 feature maps; MKL dgemm is 20-50x faster.  The
+# arithmetic is nn.ConvNd's (valid cross-correlation + bias) up to summation order;
+# tests/test_cpu_oracle_golden.py holds the two forms together in float64 (values and gradients).
+# ---------------------------------------------------------------------------------------------
+def conv_as_gemm(x, weight, bias):
+    """valid N-d cross-correlation of x (B, C, *spatial) with weight (N, C, *k), + bias, as one
+    dgemm per filter tap WITHOUT an im2col copy: with the image flattened to one axis, tap
+    (dz, dy, dx) reads the same flat range shifted by dz*H*W + dy*W + dx, so every tap's operand is
+    a column-offset view of the (C, D*H*W) matrix; the (few) flat positions that wrap around a row
+    end are computed and dropped."""
+    import itertools
+
+    B, C = x.shape[0], x.shape[1]
+    N, k = weight.shape[0], tuple(weight.shape[2:])
+    spatial = tuple(x.shape[2:])
+    nd = len(k)
+    out_shape = tuple(s - kk + 1 for s, kk in zip(spatial, k))
+    strides = [math.prod(spatial[d + 1:]) for d in range(nd)]
+    length = sum((o - 1) * st for o, st in zip(out_shape, strides)) + 1      # last valid flat index + 1
+    outs = []
+    for b in range(B):
+        flat = x[b].reshape(C, -1)
+        acc = None
+        for tap in itertools.product(*[range(kk) for kk in k]):
+            off = sum(t * st for t, st in zip(tap, strides))
+            part = torch.mm(weight[(slice(None), slice(None)) + tap], flat[:, off:off + length])
+            acc = part if acc is None else acc + part
+        full = torch.cat([acc, acc.new_zeros(N, out_shape[0] * strides[0] - length)], dim=1)
+        full = full.reshape((N, out_shape[0]) + spatial[1:])
+        outs.append(full[(slice(None), slice(None)) + tuple(slice(0, o) for o in out_shape[1:])])
+    out = torch.stack(outs, dim=0)
+    if bias is not None:
+        out = out + bias.reshape((1, N) + (1,) * nd)
+    return out
+
+
+class gemm_convolutions:
+    """Context manager: every nn.Conv2d / nn.Conv3d of `model` computes through conv_as_gemm."""
+
+    def __init__(self, model):
+        self.convs = [m for m in model.modules() if isinstance(m, nn.modules.conv._ConvNd)]
+
+    def __enter__(self):
+        for m in self.convs:
+            assert m.padding in ((0,) * len(m.kernel_size), "valid") and set(m.stride) == {1} \
+                and set(m.dilation) == {1} and m.groups == 1
+            m.forward = (lambda x, m=m: conv_as_gemm(x, m.weight, m.bias))
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.convs:
+            del m.forward
+        return False

@@ -176,3 +176,32 @@ def test_train_step_oracle_matches_reference_train_iteration(nd):
     post = f"w{nd}/final/"
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(v.numpy(), g[post + k], atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_gemm_form_of_the_oracle_convolutions_equals_nn_conv(nd):
+    """oracle.unet_oracle.gemm_convolutions (one dgemm per filter tap, used so that the float64
+    oracle is fast enough at BASELINE sizes) against nn.Conv2d / nn.Conv3d in float64: values and
+    every parameter gradient to rounding."""
+    import torch
+
+    from oracle.unet_oracle import OracleUNetModel, gemm_convolutions
+
+    cfg = dict(in_channels=2, out_channels=nd, num_fmaps=6, fmap_inc_factor=3, features_in_last_layer=8,
+               downsampling_factors=[[2] * nd], num_spatial_dims=nd)
+    torch.manual_seed(0)
+    m = OracleUNetModel(**cfg).double()
+    x = torch.rand(2, 2, *((44, 52) if nd == 2 else (28, 24, 32)), dtype=torch.float64)
+    y = m(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    ref = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    with gemm_convolutions(m):
+        y2 = m(x)
+        y2.backward(g)
+    assert (y - y2).abs().max().item() < 1e-13
+    for p, r in zip(m.parameters(), ref):
+        assert ((p.grad - r).abs().max() / r.abs().max()).item() < 1e-12
+    assert torch.equal(m(x), y)            # the patch is gone after the with-block

@@ -124,6 +124,29 @@ def test_bench_multi_rank_control_flow(tmp_path):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 4
     assert rec["value"] > 0 and "roofline" in rec and "cpu_baseline" not in rec
     assert not [l for l in outs[1][0].split("\n") if l.startswith("{")]     # only rank 0 prints the JSON line
+    assert rec["ranks_seen"] == 2 and len(rec["per_rank_ms_per_step"]) == 2 and "allreduce_ms_exposed" in rec
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO rank environment (the driver's scaling command): bench.py
+    itself starts one fresh child per rank before touching the GPU, relays rank 0's line and
+    reports how many ranks the collective backend saw.  (gloo: two ranks share the one GPU here.)"""
+    env = dict(os.environ, CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--workload", "tiny"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+    assert rec["config"]["global_batch"] == 4 and rec["value"] > 0
+    # a failing rank makes the launcher exit non-zero instead of hanging
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--workload", "tiny"], env=dict(env, CLX_LOCAL_DEVICE="99"), cwd=str(tmp_path),
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode != 0
 
 
 _RCCL_SCRIPT = r"""

@@ -1,0 +1,244 @@
+"""GPU tier: NUMERICAL parity with the oracle at BASELINE.json's real sizes.
+
+* cfg-2 (2-D 256^2, num_fmaps=256, fmap_inc_factor=3) and cfg-4 (3-D 64^3, num_fmaps=64) at batch 1,
+  on the DEFAULT launch plan (Winograd F(4x4) + sub-pixel upsample convolution + V cache): forward
+  against the float32 CPU oracle and the float64 one (< 1e-4 absolute, the north-star tolerance for
+  embeddings), every parameter gradient against the float64 oracle (relative L2 < 1e-4).
+* cfg-1 (2-D 256^2 synthetic zarr, num_fmaps=16, one level, 50 iterations of train()): the driver's
+  own batches replayed through the oracle's train step — loss trajectory and final weights.
+* cfg-5: one 512^2 sample through predict() at 256 feature maps against the oracle's tiled scan.
+
+The float64 oracle runs its convolutions as one dgemm per filter tap (oracle.unet_oracle.
+gemm_convolutions; held against nn.ConvNd in tests/test_cpu_oracle_golden.py) — torch's native
+float64 convolution would take minutes per crop at these sizes.
+"""
+
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cellulus_amd.models import get_model
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFG2 = dict(in_channels=1, out_channels=2, num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64,
+            downsampling_factors=[[2, 2]], num_spatial_dims=2)
+CFG4 = dict(in_channels=1, out_channels=3, num_fmaps=64, fmap_inc_factor=3, features_in_last_layer=64,
+            downsampling_factors=[[2, 2, 2]], num_spatial_dims=3)
+
+
+def _kaiming(model):
+    for _n, layer in model.named_modules():
+        if isinstance(layer, torch.nn.modules.conv._ConvNd):
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")     # train.py:65-68
+
+
+def _blobs(crop, seed):
+    """the benchmark's synthetic crop (bench.py::synthetic_raw)"""
+    rs = np.random.RandomState(seed)
+    nd = len(crop)
+    grids = np.meshgrid(*[np.arange(c, dtype=np.float32) for c in crop], indexing="ij")
+    img = np.zeros(crop, dtype=np.float32)
+    for c in np.stack(np.meshgrid(*[np.arange(24, c, 48) for c in crop], indexing="ij"), -1).reshape(-1, nd):
+        c = c + rs.randint(-6, 7, size=nd)
+        img += np.exp(-sum((g - ci) ** 2 for g, ci in zip(grids, c)) / (2 * 6.0 ** 2))
+    img += rs.normal(0, 0.02, size=crop).astype(np.float32)
+    return torch.from_numpy(np.clip(img, 0, 1)[None, None])
+
+
+@pytest.mark.parametrize("name,cfg,crop", [("cfg2", CFG2, (256, 256)), ("cfg4", CFG4, (64, 64, 64))])
+def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, device):
+    torch.manual_seed(0)
+    oracle = O.OracleUNetModel(**cfg)
+    _kaiming(oracle)
+    model = get_model(**cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.to(device)
+    raw = _blobs(crop, seed=3)
+
+    # the default plan at this size is the one the benchmark runs
+    got = model(raw.to(device))
+    plan = next(iter(model._plans.values()))
+    assert sum(1 for a in plan.algo.values() if a["fwd"] == 2) >= 3, "Winograd F(4x4) expected on the wide layers"
+    assert plan.subpixel, "the sub-pixel form of the upsample convolution is expected here"
+
+    # ---- forward: float32 oracle (the reference's own arithmetic) and float64 oracle
+    with torch.no_grad():
+        ref32 = oracle(raw)
+    o64 = O.OracleUNetModel(**cfg).double()
+    o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
+    with O.gemm_convolutions(o64):
+        ref64 = o64(raw.double())
+        torch.manual_seed(2)
+        dout = torch.randn(ref64.shape)
+        ref64.backward(dout.double())
+    out = got.detach().cpu()
+    assert out.shape == ref32.shape == tuple(ref64.shape)
+    scale = ref64.abs().max().item()
+    err32 = (out - ref32).abs().max().item()
+    err64 = (out.double() - ref64.detach()).abs().max().item()
+    cpu_err = (ref32.double() - ref64.detach()).abs().max().item()
+    print(f"{name}: output range {scale:.3f}, |hip - f32 oracle| {err32:.2e}, |hip - f64 oracle| {err64:.2e}, "
+          f"|f32 oracle - f64 oracle| {cpu_err:.2e}")
+    assert err32 < 1e-4 and err64 < 1e-4
+
+    # ---- gradients of every parameter against the float64 oracle
+    got.backward(dout.to(device))
+    worst = 0.0
+    for (n, po), (n2, pm) in zip(o64.named_parameters(), model.named_parameters()):
+        assert n == n2
+        g_ref, g = po.grad, pm.grad.cpu().double()
+        l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-30)).item()
+        worst = max(worst, l2)
+        assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
+    print(f"{name}: worst relative L2 error of a parameter gradient {worst:.2e}")
+
+
+def test_cfg1_train_driver_50_iterations_replayed_through_the_oracle(device, tmp_path, monkeypatch):
+    """BASELINE configs[0]: 2-D 1-channel 256x256 synthetic zarr, num_fmaps=16, 1-level U-Net, 50
+    iterations of train() (the reference's CPU plumbing case; here the same toml on cuda:0 —
+    cellulus_amd has no CPU path).  Every batch the driver hands to train_iteration is replayed
+    through the oracle's train step (cellulus/train.py:160-180 restated on the CPU) from the same
+    initial weights: loss trajectory within 1e-4 relative, final weights equal."""
+    import tomli
+
+    import cellulus_amd.train as T
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.utils import zarr_io
+
+    monkeypatch.chdir(tmp_path)
+    container = str(tmp_path / "data.zarr")
+    f = zarr_io.open(container)
+    f["train/raw"] = np.concatenate([_blobs((256, 256), seed=s).numpy() for s in range(4)], axis=0)
+    f["train/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    toml = f"""
+normalization_factor = 1.0
+[model_config]
+num_fmaps = 16
+fmap_inc_factor = 3
+downsampling_factors = [[2, 2]]
+
+[train_config]
+crop_size = [256, 256]
+batch_size = 2
+max_iterations = 50
+num_workers = 0
+elastic_deform = false
+save_model_every = 1000
+save_best_model_every = 1000
+save_snapshot_every = 1000
+device = "cuda:0"
+
+[train_config.train_data_config]
+container_path = "{container}"
+dataset_name = "train/raw"
+"""
+    cfg = ExperimentConfig(**tomli.loads(toml))
+    mc = cfg.model_config
+    ocfg = dict(in_channels=1, out_channels=2, num_fmaps=mc.num_fmaps, fmap_inc_factor=mc.fmap_inc_factor,
+                features_in_last_layer=mc.features_in_last_layer,
+                downsampling_factors=[tuple(x) for x in mc.downsampling_factors], num_spatial_dims=2)
+    state = {}
+    real_step = T.train_iteration
+
+    def spy(batch, model, criterion, optimizer, device):
+        if "oracle" not in state:                        # initial weights = the driver's, before step 0
+            oracle = O.OracleUNetModel(**ocfg)
+            oracle.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=True)
+            state["oracle"] = oracle
+            state["opt"] = torch.optim.Adam(oracle.parameters(), lr=cfg.train_config.initial_learning_rate,
+                                            weight_decay=0.01)                    # train.py:80-82
+            state["hip"], state["ref"] = [], []
+            state["model"] = model
+        cpu_batch = tuple(t.detach().cpu().clone() for t in batch)
+        assert cpu_batch[0].shape == (2, 1, 256, 256) and cpu_batch[1].shape == (2, 150040, 2)
+        out = real_step(batch, model, criterion, optimizer, device)
+        l_ref, _o, _off = O.train_step(state["oracle"], state["opt"], cpu_batch[0], cpu_batch[1], cpu_batch[2],
+                                       criterion.temperature, criterion.regularization_weight)
+        state["hip"].append(out[0])
+        state["ref"].append(l_ref)
+        return out
+
+    monkeypatch.setattr(T, "train_iteration", spy)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    import random
+
+    random.seed(0)
+    T.train(cfg)
+    hip, ref = np.array(state["hip"]), np.array(state["ref"])
+    assert len(hip) == 50 and np.isfinite(hip).all()
+    rel = np.abs(hip - ref) / np.abs(ref)
+    print(f"cfg-1: loss {ref[0]:.3f} -> {ref[-1]:.3f}; max relative loss difference over 50 iterations {rel.max():.2e}")
+    assert rel.max() < 1e-4, (rel.argmax(), rel.max())
+    assert ref[-1] < ref[0]
+    lines = open("loss.csv").read().strip().split("\n")
+    assert len(lines) == 51
+    # final weights: 50 Adam steps of at most lr = 4e-5 each; an element whose gradient is rounding
+    # noise may move by a few lr in either direction, everything else must agree closely
+    worst = 0.0
+    for (n, po), (n2, pm) in zip(state["oracle"].named_parameters(), state["model"].named_parameters()):
+        assert n == n2
+        d = (pm.detach().cpu() - po.detach()).abs()
+        worst = max(worst, d.max().item())
+        assert d.max().item() < 2e-4, (n, d.max().item())
+        assert (d.norm() / po.detach().norm()).item() < 1e-4, n
+    print(f"cfg-1: largest weight difference after 50 iterations {worst:.2e}")
+
+
+def test_cfg5_predict_tile_at_256_feature_maps_matches_the_oracle_scan(device, tmp_path, monkeypatch):
+    """BASELINE configs[4]: a 512^2 sample through predict() with the cfg-2 network (one 528^2
+    reflect-padded tile, the benchmark's inference tile) against the oracle's restatement of the
+    scan: same weights, same torch.rand call sequence on the CPU generator.  num_infer_iterations
+    is 2 here (4 noisy forwards, 7 TFLOP on the CPU side) instead of the default 16."""
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.datasets.meta_data import DatasetMetaData
+    from cellulus_amd.predict import predict, tile_offsets
+    from cellulus_amd.utils import zarr_io
+
+    monkeypatch.chdir(tmp_path)
+    container = str(tmp_path / "data.zarr")
+    raw = _blobs((512, 512), seed=5).numpy()
+    f = zarr_io.open(container)
+    f["test/raw"] = raw
+    f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    torch.manual_seed(0)
+    oracle = O.OracleUNetModel(**CFG2)
+    _kaiming(oracle)
+    model = get_model(**CFG2)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.to(device).eval()
+    n_it, p = 2, 0.05
+    cfg = ExperimentConfig(
+        model_config=dict(num_fmaps=256, fmap_inc_factor=3, downsampling_factors=[[2, 2]]),
+        object_size=30, normalization_factor=1.0,
+        inference_config=dict(
+            dataset_config=dict(container_path=container, dataset_name="test/raw"),
+            prediction_dataset_config=dict(container_path=container, dataset_name="embeddings"),
+            crop_size=[528, 528], num_infer_iterations=n_it, p_salt_pepper=p, device="cuda:0"))
+    torch.manual_seed(42)
+    predict(model, cfg.inference_config, 1.0)
+    emb = zarr_io.open(container, "r")["embeddings"][...]
+    assert emb.dtype == np.float64 and emb.shape == (1, 3, 512, 512)
+
+    oracle.set_infer(p, n_it)
+    torch.manual_seed(42)
+    padded = np.pad(raw[0], [(0, 0), (8, 8), (8, 8)], mode="reflect")
+    ref = np.zeros_like(emb)
+    offs = [tile_offsets(512, 512)] * 2
+    assert offs == [[0], [0]]
+    for off in itertools.product(*offs):
+        sl = (slice(None),) + tuple(slice(o, o + 528) for o in off)
+        with torch.no_grad():
+            e = oracle(torch.from_numpy(padded[sl][None]))[0].numpy()
+        ref[(0, slice(None)) + tuple(slice(o, o + 512) for o in off)] = e
+    err_mean = np.abs(emb[:, :2] - ref[:, :2]).max()
+    err_std = np.abs(emb[:, 2] - ref[:, 2]).max()
+    print(f"cfg-5: embedding range {np.abs(ref[:, :2]).max():.3f}, |mean - oracle| {err_mean:.2e}, "
+          f"|std - oracle| {err_std:.2e}")
+    assert err_mean < 1e-4 and err_std < 1e-4
+    assert DatasetMetaData.from_dataset_config(cfg.inference_config.prediction_dataset_config).num_samples == 1

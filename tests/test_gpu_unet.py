@@ -124,6 +124,34 @@ def test_infer_mode_matches_oracle(device):
     assert (got2 - ref2).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["2d_small", "3d_small"])
+def test_head_forward_matches_reference_head(name, device):
+    """UNetModel.head_forward (unet.py:65-67) = head(backbone_output), values and all gradients."""
+    oracle, model, _raw = _make(name, device)
+    c = CONFIGS[name]["cfg"]
+    nd = c["num_spatial_dims"]
+    torch.manual_seed(3)
+    x = torch.randn(2, c["features_in_last_layer"], *((9, 11) if nd == 2 else (5, 6, 7)))
+    x_ref = x.clone().requires_grad_(True)
+    ref = oracle.head(x_ref)                      # unet.py:65-67: head_forward = self.head(...)
+    w = torch.randn_like(ref)
+    (ref * w).sum().backward()
+    x_d = x.to(device).requires_grad_(True)
+    got = model.head_forward(x_d)
+    assert got.shape == ref.shape
+    assert (got.cpu() - ref.detach()).abs().max().item() < 1e-5
+    for p in model.parameters():
+        p.grad = None
+    (got * w.to(device)).sum().backward()
+    assert (x_d.grad.cpu() - x_ref.grad).abs().max().item() < 1e-5
+    for i in (0, 2):
+        for pn in ("weight", "bias"):
+            g, r = getattr(model.head[i], pn).grad.cpu(), getattr(oracle.head[i], pn).grad
+            assert (g - r).norm().item() <= 1e-5 * max(r.norm().item(), 1e-3), (i, pn)
+    with pytest.raises(ValueError):
+        model.head_forward(x_d[:, :3])
+
+
 def test_rejects_cpu_tensors():
     from cellulus_amd._clx import ClxError
 
