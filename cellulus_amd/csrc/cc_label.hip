@@ -41,51 +41,107 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   } while (!done);
 }
 
-__global__ void cc_init(const int* __restrict__ seg, int* __restrict__ L, int* __restrict__ size,
-                        long long npix) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
-       i += (long long)gridDim.x * blockDim.x) {
-    L[i] = (int)i;
-    size[i] = 0;
-  }
+// Wave w of the grid owns 64 consecutive pixels of one row ("segment").  Returns the pixel index
+// of lane 0, the row's first pixel index and x of this lane; valid = inside the row.
+struct SegPos { long long i; int x; bool valid; };
+__device__ __forceinline__ SegPos seg_pos(long long w, int nseg, int X, int lane) {
+  const long long row = w / nseg;
+  const int sg = (int)(w - row * nseg);
+  SegPos p;
+  p.x = sg * 64 + lane;
+  p.valid = p.x < X;
+  p.i = row * X + p.x;
+  return p;
 }
 
-__global__ void cc_merge(const int* __restrict__ seg, int* L, int Z, int Y, int X, long long npix) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int v = seg[i];
-    if (v == 0) continue;
-    const int x = (int)(i % X);
-    const long long t = i / X;
-    const int y = (int)(t % Y);
-    const int z = (int)(t / Y);
-    // the 13 (3-D) / 4 (2-D) neighbours that precede i in raster order
-    for (int dz = -1; dz <= 0; ++dz) {
-      const int zz = z + dz;
-      if (zz < 0) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        if (dz == 0 && dy > 0) break;
-        const int yy = y + dy;
-        if (yy < 0 || yy >= Y) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-          if (dz == 0 && dy == 0 && dx >= 0) break;
-          const int xx = x + dx;
-          if (xx < 0 || xx >= X) continue;
-          const long long j = ((long long)zz * Y + yy) * X + xx;
-          if (seg[j] == v) uf_union(L, (int)i, (int)j);
-        }
-      }
+// lane of the first pixel of this lane's horizontal run of equal non-zero values inside the
+// segment (background lanes: themselves)
+__device__ __forceinline__ int run_start_lane(int v, int lane, unsigned long long* starts_out) {
+  const int vl = __shfl_up(v, 1, 64);
+  const bool same_left = lane > 0 && v != 0 && vl == v;
+  const unsigned long long starts = __ballot(!same_left);
+  if (starts_out) *starts_out = starts;
+  const unsigned long long upto = starts & ((2ull << lane) - 1ull);
+  return 63 - __builtin_clzll(upto);
+}
+
+// pass 1: L[i] = first pixel of i's run inside its 64-pixel segment (background: -1).  Runs,
+// not pixels, are what the union-find links: a 32-pixel-wide object costs one union per row
+// instead of ~100 (every pixel with each of its 4 / 13 backward neighbours).
+__global__ __launch_bounds__(256) void cc_init_runs(const int* __restrict__ seg, int* __restrict__ L,
+                                                    int* __restrict__ size, int X, int nseg,
+                                                    long long nwaves) {
+  const int lane = threadIdx.x & 63;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const SegPos p = seg_pos(w, nseg, X, lane);
+    const int v = p.valid ? seg[p.i] : 0;
+    const int s = run_start_lane(v, lane, nullptr);
+    if (p.valid) {
+      L[p.i] = v ? (int)(p.i - lane + s) : -1;
+      if (s == lane) size[p.i] = 0;        // sizes live at run starts (the only possible roots)
     }
   }
 }
 
-__global__ void cc_flatten_count(const int* __restrict__ seg, int* L, int* size, long long npix) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
-       i += (long long)gridDim.x * blockDim.x) {
-    if (seg[i] == 0) continue;
-    const int r = uf_find(L, (int)i);
-    L[i] = r;   // only shortens i's own chain; roots are never rewritten
-    atomicAdd(&size[r], 1);
+// pass 2: link the runs.  For pixel (x, y) and a preceding row r (2-D: y-1; 3-D also the three
+// rows of slice z-1) with a = same(r, x-1), b = same(r, x), c = same(r, x+1):
+//   b and not (left pixel in my run and a)  -> union with (r, x)    [else the left pixel did it]
+//   a and not b and no left pixel in my run -> union with (r, x-1)
+//   c and not b and no right pixel in my run-> union with (r, x+1)  [else the right pixel does]
+// plus the run continuation across a segment boundary.  Every adjacency is covered by a chain
+// of these unions; nothing else touches an atomic.
+__global__ __launch_bounds__(256) void cc_merge_runs(const int* __restrict__ seg, int* L, int Z, int Y,
+                                                     int X, int nseg, long long nwaves) {
+  const int lane = threadIdx.x & 63;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const SegPos p = seg_pos(w, nseg, X, lane);
+    const int v = p.valid ? seg[p.i] : 0;
+    if (v == 0) continue;
+    const int x = p.x;
+    const long long row = (p.i - x) / X;
+    const int y = (int)(row % Y), z = (int)(row / Y);
+    const bool left = x > 0 && seg[p.i - 1] == v;
+    const bool right = x + 1 < X && seg[p.i + 1] == v;
+    if (lane == 0 && left) uf_union(L, (int)p.i, (int)p.i - 1);
+    for (int k = 0; k < 4; ++k) {
+      // k = 0: (z, y-1); 1..3: (z-1, y-1 .. y+1)
+      const int zz = (k == 0) ? z : z - 1;
+      const int yy = (k == 0) ? y - 1 : y + (k - 2);
+      if (zz < 0 || yy < 0 || yy >= Y) continue;
+      const long long r = ((long long)zz * Y + yy) * X + x;
+      const bool b = seg[r] == v;
+      const bool a = x > 0 && seg[r - 1] == v;
+      const bool c = x + 1 < X && seg[r + 1] == v;
+      if (b && !(left && a)) uf_union(L, (int)p.i, (int)r);
+      if (a && !b && !left) uf_union(L, (int)p.i, (int)r - 1);
+      if (c && !b && !right) uf_union(L, (int)p.i, (int)r + 1);
+    }
+  }
+}
+
+// pass 3: every pixel learns its root (one find per run, broadcast inside the wave) and every
+// run adds its length to the root's size (one atomic per run)
+__global__ __launch_bounds__(256) void cc_flatten_count(const int* __restrict__ seg, int* L, int* size,
+                                                        int X, int nseg, long long nwaves) {
+  const int lane = threadIdx.x & 63;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const SegPos p = seg_pos(w, nseg, X, lane);
+    const int v = p.valid ? seg[p.i] : 0;
+    unsigned long long starts;
+    const int s = run_start_lane(v, lane, &starts);
+    int root = -1;
+    if (v != 0 && s == lane) {
+      root = uf_find(L, (int)p.i);
+      // run length = distance to the next run start (or the end of the segment)
+      const unsigned long long above = (lane == 63) ? 0ull : (starts >> (lane + 1));
+      const int len = above ? __builtin_ctzll(above) + 1 : 64 - lane;
+      atomicAdd(&size[root], len);
+    }
+    root = __shfl(root, s, 64);
+    if (v != 0) L[p.i] = root;    // roots keep pointing at themselves
   }
 }
 
@@ -99,7 +155,7 @@ __global__ __launch_bounds__(256) void cc_count_roots(const int* __restrict__ se
   int local = 0;
   for (int k = 0; k < SCAN_BLOCK / 256; ++k) {
     const long long i = base + k * 256 + threadIdx.x;
-    if (i < npix && seg[i] != 0 && L[i] == (int)i && size[i] >= min_size) ++local;
+    if (i < npix && L[i] == (int)i && size[i] >= min_size) ++local;
   }
   for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
@@ -145,7 +201,7 @@ __global__ __launch_bounds__(256) void cc_number_roots(const int* __restrict__ s
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   for (int k = 0; k < SCAN_BLOCK / 256; ++k) {
     const long long i = base + k * 256 + threadIdx.x;
-    const bool root = i < npix && seg[i] != 0 && L[i] == (int)i && size[i] >= min_size;
+    const bool root = i < npix && L[i] == (int)i && size[i] >= min_size;
     const unsigned long long ball = __ballot(root);
     const int before = __popcll(ball & ((1ull << lane) - 1ull));
     if (lane == 0) wcount[wid] = __popcll(ball);
@@ -164,8 +220,9 @@ __global__ void cc_write(const int* __restrict__ seg, const int* __restrict__ L,
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix;
        i += (long long)gridDim.x * blockDim.x) {
     int v = 0;
-    if (seg[i] != 0) {
-      const int s = size[L[i]];
+    const int r = L[i];
+    if (r >= 0) {
+      const int s = size[r];
       v = (s < 0) ? -s : 0;   // positive sizes = removed (too small) components
     }
     out[i] = v;
@@ -200,9 +257,12 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
   const int grid = grid_for(npix, 256);
   hipStream_t st = (hipStream_t)stream;
   if (min_size < 1) min_size = 1;   // every component has >= 1 pixel: keep all
-  cc_init<<<grid, 256, 0, st>>>(seg, L, size, npix);
-  cc_merge<<<grid, 256, 0, st>>>(seg, L, Z, Y, X, npix);
-  cc_flatten_count<<<grid, 256, 0, st>>>(seg, L, size, npix);
+  const int nseg = (X + 63) / 64;
+  const long long nwaves = (long long)Z * Y * nseg;
+  const int wgrid = grid_for(nwaves * 64, 256);
+  cc_init_runs<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
+  cc_merge_runs<<<wgrid, 256, 0, st>>>(seg, L, Z, Y, X, nseg, nwaves);
+  cc_flatten_count<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
   cc_count_roots<<<nblocks, 256, 0, st>>>(seg, L, size, min_size, npix, counts);
   cc_scan_counts<<<1, 1024, 0, st>>>(counts, nblocks, ncomp_out);
   cc_number_roots<<<nblocks, 256, 0, st>>>(seg, L, size, min_size, npix, counts);

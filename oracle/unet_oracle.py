@@ -266,3 +266,51 @@ class gemm_convolutions:
         for m in self.convs:
             del m.forward
         return False
+
+
+# ---------------------------------------------------------------------------------------------
+# Gradients through ReLU / max-pool are discontinuous in the forward values: a pre-activation
+# within rounding distance of 0 (or two window entries within rounding distance of each other)
+# takes one branch in float32 and the other in float64, and that ONE decision moves the gradient
+# by a whole term.  At BASELINE sizes (1.3e8 activations per crop) a few hundred such decisions
+# differ between ANY float32 forward pass and the float64 one — the float32 CPU path of the
+# reference included — which bounds the agreement of float32 and float64 gradients at ~1e-3
+# (relative L2) however exact the kernels are.  To check the ARITHMETIC of a float32 backward
+# pass against float64 at those sizes, the float64 oracle therefore takes the discrete decisions
+# (ReLU gates, pooling winners) from the forward pass under test and computes everything else
+# itself.
+# ---------------------------------------------------------------------------------------------
+class forced_decisions:
+    """Context manager: the nn.ReLU modules of `model` multiply by the given 0/1 masks (in call
+    order) and the max-pool modules gather the given flat window-winner indices (the
+    `return_indices` convention of F.max_pool{2,3}d), instead of deciding on their own input."""
+
+    def __init__(self, model, relu_masks, pool_indices):
+        self.relus = [m for m in model.modules() if isinstance(m, nn.ReLU)]
+        self.pools = [m for m in model.modules() if isinstance(m, Downsample)]
+        self.relu_masks, self.pool_indices = list(relu_masks), list(pool_indices)
+        assert len(self.relus) == len(self.relu_masks) and len(self.pools) == len(self.pool_indices)
+
+    def __enter__(self):
+        masks, idxs = iter(self.relu_masks), iter(self.pool_indices)
+
+        def relu_forward(x):
+            m = next(masks)
+            assert m.shape == x.shape, (m.shape, x.shape)
+            return x * m.to(x.dtype)
+
+        def pool_forward(x):
+            idx = next(idxs)
+            flat = x.reshape(x.shape[0], x.shape[1], -1)
+            return torch.gather(flat, 2, idx.reshape(idx.shape[0], idx.shape[1], -1)).reshape(idx.shape)
+
+        for m in self.relus:
+            m.forward = relu_forward
+        for m in self.pools:
+            m.forward = pool_forward
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.relus + self.pools:
+            del m.forward
+        return False

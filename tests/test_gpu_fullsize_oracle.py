@@ -3,7 +3,10 @@
 * cfg-2 (2-D 256^2, num_fmaps=256, fmap_inc_factor=3) and cfg-4 (3-D 64^3, num_fmaps=64) at batch 1,
   on the DEFAULT launch plan (Winograd F(4x4) + sub-pixel upsample convolution + V cache): forward
   against the float32 CPU oracle and the float64 one (< 1e-4 absolute, the north-star tolerance for
-  embeddings), every parameter gradient against the float64 oracle (relative L2 < 1e-4).
+  embeddings); every parameter gradient against the float64 oracle evaluated on the same ReLU /
+  max-pool decisions (relative L2 < 1e-4), and against the free-running float64 oracle no farther
+  than the reference's own float32 CPU arithmetic is (~1e-3 at these sizes: a few hundred of the
+  1.3e8 gate decisions differ between any float32 forward pass and the float64 one).
 * cfg-1 (2-D 256^2 synthetic zarr, num_fmaps=16, one level, 50 iterations of train()): the driver's
   own batches replayed through the oracle's train step — loss trajectory and final weights.
 * cfg-5: one 512^2 sample through predict() at 256 feature maps against the oracle's tiled scan.
@@ -50,8 +53,24 @@ def _blobs(crop, seed):
     return torch.from_numpy(np.clip(img, 0, 1)[None, None])
 
 
+def _planar(plan, name, nd):
+    """a stored activation of the launch plan (pixel-major, padded channels) as (B, C, *spatial) on the CPU"""
+    shape, c = plan.topo.shapes[name]
+    t = plan.buf[name].view((plan.B,) + tuple(shape) + (-1,))[..., :c].permute(0, 4, 1, 2, 3).contiguous().cpu()
+    return t[:, :, 0] if nd == 2 else t
+
+
 @pytest.mark.parametrize("name,cfg,crop", [("cfg2", CFG2, (256, 256)), ("cfg4", CFG4, (64, 64, 64))])
 def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, device):
+    """Forward: < 1e-4 against the float32 AND the float64 oracle.  Gradients: every parameter
+    within 1e-4 (relative L2) of the float64 oracle run with the HIP forward pass's ReLU gates and
+    pooling winners (oracle.unet_oracle.forced_decisions explains why: ~2e-6 of the 1.3e8 gate
+    decisions differ between any float32 forward pass and the float64 one, which alone moves
+    gradients by ~1e-3 — measured below for the reference's own float32 CPU arithmetic too); and
+    against the free-running float64 oracle no farther than the float32 CPU oracle is."""
+    import torch.nn.functional as F
+
+    nd = len(crop)
     torch.manual_seed(0)
     oracle = O.OracleUNetModel(**cfg)
     _kaiming(oracle)
@@ -65,37 +84,70 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, devic
     plan = next(iter(model._plans.values()))
     assert sum(1 for a in plan.algo.values() if a["fwd"] == 2) >= 3, "Winograd F(4x4) expected on the wide layers"
     assert plan.subpixel, "the sub-pixel form of the upsample convolution is expected here"
+    torch.manual_seed(2)
+    dout = torch.randn(got.shape)
+    got.backward(dout.to(device))
+    out = got.detach().cpu()
+    hip_grads = [p.grad.detach().cpu().double() for p in model.parameters()]
 
     # ---- forward: float32 oracle (the reference's own arithmetic) and float64 oracle
-    with torch.no_grad():
-        ref32 = oracle(raw)
+    oracle(raw).backward(dout)
+    ref32 = oracle(raw).detach()
+    cpu32_grads = [p.grad.double() for p in oracle.parameters()]
     o64 = O.OracleUNetModel(**cfg).double()
     o64.load_state_dict({k: v.double() for k, v in oracle.state_dict().items()})
     with O.gemm_convolutions(o64):
         ref64 = o64(raw.double())
-        torch.manual_seed(2)
-        dout = torch.randn(ref64.shape)
         ref64.backward(dout.double())
-    out = got.detach().cpu()
+    free64 = [p.grad.clone() for p in o64.parameters()]
+    ref64 = ref64.detach()
     assert out.shape == ref32.shape == tuple(ref64.shape)
     scale = ref64.abs().max().item()
     err32 = (out - ref32).abs().max().item()
-    err64 = (out.double() - ref64.detach()).abs().max().item()
-    cpu_err = (ref32.double() - ref64.detach()).abs().max().item()
+    err64 = (out.double() - ref64).abs().max().item()
+    cpu_err = (ref32.double() - ref64).abs().max().item()
     print(f"{name}: output range {scale:.3f}, |hip - f32 oracle| {err32:.2e}, |hip - f64 oracle| {err64:.2e}, "
           f"|f32 oracle - f64 oracle| {cpu_err:.2e}")
     assert err32 < 1e-4 and err64 < 1e-4
 
-    # ---- gradients of every parameter against the float64 oracle
-    got.backward(dout.to(device))
-    worst = 0.0
-    for (n, po), (n2, pm) in zip(o64.named_parameters(), model.named_parameters()):
-        assert n == n2
-        g_ref, g = po.grad, pm.grad.cpu().double()
-        l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-30)).item()
+    # ---- gradients: float64 arithmetic on the HIP forward pass's discrete decisions
+    relu_layers = [layer for layer in plan.topo.convs if layer.relu]
+    masks = [_planar(plan, layer.out, nd) > 0 for layer in relu_layers]
+    pool = F.max_pool2d if nd == 2 else F.max_pool3d
+    winners = [pool(_planar(plan, p.src, nd), p.factor[3 - nd:], stride=p.factor[3 - nd:], return_indices=True)[1]
+               for p in plan.topo.pools]
+    for p in o64.parameters():
+        p.grad = None
+    with O.gemm_convolutions(o64), O.forced_decisions(o64, masks, winners):
+        forced = o64(raw.double())
+        forced.backward(dout.double())
+    assert (out.double() - forced.detach()).abs().max().item() < 1e-4
+    worst = worst_free = worst_cpu = 0.0
+    for (n, po), g, g32, gf in zip(o64.named_parameters(), hip_grads, cpu32_grads, free64):
+        l2 = ((g - po.grad).norm() / (po.grad.norm() + 1e-30)).item()
         worst = max(worst, l2)
-        assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
-    print(f"{name}: worst relative L2 error of a parameter gradient {worst:.2e}")
+        assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2} against float64 on the same decisions"
+        worst_free = max(worst_free, ((g - gf).norm() / gf.norm()).item())
+        worst_cpu = max(worst_cpu, ((g32 - gf).norm() / gf.norm()).item())
+    flipped = sum(int((m != (a > 0)).sum()) for m, a in zip(
+        masks, _relu_inputs_of(o64, raw.double())))
+    total = sum(m.numel() for m in masks)
+    print(f"{name}: worst relative L2 error of a parameter gradient: {worst:.2e} on the same decisions; "
+          f"free-running float64: HIP {worst_free:.2e}, float32 CPU oracle {worst_cpu:.2e}; "
+          f"{flipped} of {total} ReLU gates differ between the HIP and the float64 forward pass")
+    assert worst_free < 3 * worst_cpu + 1e-4
+
+
+def _relu_inputs_of(o64, raw64):
+    """post-ReLU activations of the free-running float64 forward pass, in call order"""
+    acts = []
+    hooks = [m.register_forward_hook(lambda _m, _i, o: acts.append(o.detach()))
+             for m in o64.modules() if isinstance(m, torch.nn.ReLU)]
+    with torch.no_grad(), O.gemm_convolutions(o64):
+        o64(raw64)
+    for h in hooks:
+        h.remove()
+    return acts
 
 
 def test_cfg1_train_driver_50_iterations_replayed_through_the_oracle(device, tmp_path, monkeypatch):

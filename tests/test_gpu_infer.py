@@ -122,6 +122,26 @@ def test_size_filter_matches_oracle_random(shape, device):
     np.testing.assert_array_equal(size_filter(once.copy(), 9, device=device), once)
 
 
+@pytest.mark.parametrize("shape", [(70, 130), (130, 70), (5, 129, 67), (64, 64), (3, 3, 200)])
+def test_size_filter_run_based_union_find_structured_images(shape, device):
+    """the run-based union-find (one link per pair of touching runs) on images made of runs: blocks,
+    diagonal and anti-diagonal one-pixel lines (8-/26-connected only through corners), runs that
+    cross the 64-pixel segments a wavefront owns, equal labels on different objects"""
+    rng = np.random.default_rng(3)
+    idx = np.indices(shape)
+    images = [np.kron(rng.integers(0, 3, size=tuple(-(-n // 5) for n in shape)),
+                      np.ones((5,) * len(shape), int))[tuple(slice(0, n) for n in shape)]]
+    images.append(((idx.sum(0) % 3) == 0) * 1)                       # anti-diagonal lines
+    images.append(((idx[-1] - idx[-2]) % 4 == 0) * 2)                 # diagonal lines
+    images.append(((idx[-2] % 2 == 0) * 5))                           # full-width runs, every other row
+    images.append(((idx[-1] + 2 * idx[-2] + (idx[0] if len(shape) == 3 else 0)) % 5 < 2) * (1 + idx[-1] // 50))
+    images.append(np.ones(shape, int))
+    for seg in images:
+        seg = seg.astype(np.int32)
+        for ms in (1, 6):
+            np.testing.assert_array_equal(size_filter(seg.copy(), ms, device=device), IO.size_filter(seg.copy(), ms))
+
+
 def test_long_snake_component(device):
     """A single serpentine component: worst case for union-find chains."""
     seg = np.zeros((64, 65), dtype=np.int32)
@@ -187,6 +207,25 @@ def test_grow_shrink_bit_exact(shape, device):
     np.testing.assert_array_equal(
         grow_shrink_on_device(torch.from_numpy(full.copy()).to(device), 3, 6).cpu().numpy(),
         IO.grow_shrink(full, 3, 6))
+
+
+@pytest.mark.parametrize("shape", [(97, 131), (33, 64), (1, 5), (70, 300), (9, 21, 45), (24, 8, 33), (3, 70, 70)])
+def test_grow_shrink_tile_kernel_random_images(shape, device):
+    """the one-kernel grow/shrink (tile + halo in LDS) against the scipy-EDT oracle: ragged extents,
+    sparse / dense / empty / full label images, bounds from 0 to the fall-back of the generic path"""
+    from cellulus_amd.segment import grow_shrink_on_device
+
+    rng = np.random.default_rng(7)
+    images = [np.zeros(shape, np.int32), np.ones(shape, np.int32)]
+    for density in (0.003, 0.05, 0.6):
+        images.append(((rng.random(shape) < density) * rng.integers(1, 9, size=shape)).astype(np.int32))
+    blocks = np.kron(rng.integers(0, 3, size=tuple(-(-s // 7) for s in shape)), np.ones((7,) * len(shape), int))
+    images.append(blocks[tuple(slice(0, s) for s in shape)].astype(np.int32))
+    for seg in images:
+        for grow, shrink in ((3, 6), (1, 1), (0, 0), (0, 3), (2, 0), (6, 3), (-1, 4), (9, 9), (14, 14)):
+            ref = IO.grow_shrink(seg, grow, shrink)
+            got = grow_shrink_on_device(torch.from_numpy(seg.copy()).to(device), grow, shrink).cpu().numpy()
+            np.testing.assert_array_equal(got, ref, err_msg=f"shape {shape} grow {grow} shrink {shrink}")
 
 
 # -------------------------------------------------------- end-to-end pipeline
