@@ -2,18 +2,29 @@
 MI355X: embeddings (2 x 16 salt/pepper-noised U-Net forwards + mean/std), mean-shift
 detection and cell post-processing (grow/shrink + connected components + size filter).
 
-The embedding stage runs the benchmark network (num_fmaps=256, inc 3) with random
-weights on one 528^2 reflect-padded tile (output 512^2).  Clustering quality depends
-on trained weights, so the detect/segment stages are timed on the synthetic
-disc embeddings of SURVEY.md §8d (512^2, ~100 objects, bandwidth 15,
-reduction_probability 0.1) — the same input the CPU oracle is timed on.
-Mpixels/s = 512*512 / (embed + detect + segment) per image.
+Three views, all in the `infer` object of the bench line:
+
+* kernel-level stage times on one 528^2 reflect-padded tile (output 512^2) of the benchmark
+  network (num_fmaps=256, inc 3) with random weights and device-resident noise; clustering
+  quality depends on trained weights, so detect / segment are timed on the synthetic disc
+  embeddings of SURVEY.md §8d (512^2, ~100 objects, bandwidth 15, reduction_probability 0.1) —
+  the input the CPU leg is timed on.  value = 512*512 / (embed + detect + segment).
+* `e2e`: the real `cellulus_amd.infer.infer()` (fused predict -> detect -> segment, zarr in, five
+  zarr datasets out, CPU-generator noise drawn one tile ahead) over a synthetic S x 512^2 zarr.
+* `roofline` (the embedding GEMM kernel, f32 MFMA) and `streaming` (every HBM-bound kernel of
+  detect / segment at batch scale: one launch over 4096^2 pixels = 64 samples of 512^2;
+  algorithmic bytes / HIP-event time against the 8 TB/s HBM3E peak).
 """
 
+import os
+import tempfile
 import time
 
 import numpy as np
 import torch
+
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md
+F32_MFMA_PEAK_TFLOPS = 157.3
 
 
 def _sync_time(fn, reps):
@@ -23,6 +34,18 @@ def _sync_time(fn, reps):
         out = fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps, out
+
+
+def _event_time(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
 
 
 def synthetic_embeddings(shape, spacing=48, radius=12, noise=0.3, seed=1):
@@ -48,7 +71,163 @@ def synthetic_embeddings(shape, spacing=48, radius=12, noise=0.3, seed=1):
     return mean[np.newaxis].copy(), std
 
 
-def infer_bench(device, reps=2, with_cpu=True):
+def streaming_rooflines(device, size=4096):
+    """Every HBM-bound kernel of detect / segment on one size x size image (batch scale: size^2 /
+    512^2 samples per launch).  bytes = the algorithm's compulsory traffic (stated per kernel)."""
+    from cellulus_amd import _clx
+    from cellulus_amd.segment import grow_shrink_on_device
+    from cellulus_amd.utils import mean_shift as MS
+    from cellulus_amd.utils.misc import label_on_device
+
+    import ctypes
+
+    lib = _clx.load()
+    st = _clx.stream_ptr(device)
+    Y = X = size
+    npix = Y * X
+    rng = np.random.default_rng(0)
+    out = {}
+
+    def row(name, seconds, nbytes, what, **extra):
+        out[name] = dict(ms=round(seconds * 1e3, 4), GBs=round(nbytes / seconds / 1e9, 1),
+                         frac=round(nbytes / seconds / HBM_PEAK, 4), bytes=what, **extra)
+
+    # --- the benchmark's detection input, tiled up to size^2 (objects every 48 px, ~17 % foreground)
+    mean, std = synthetic_embeddings((512, 512), spacing=48, radius=12, noise=0.3, seed=1)
+    reps = size // 512
+    emb0 = torch.from_numpy(np.tile(mean[0], (1, reps, reps))).to(device)
+    sd = torch.from_numpy(np.tile(std, (reps, reps))).to(device)
+    ws = torch.empty(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)
+    pts = torch.empty((npix, 2), dtype=torch.float64, device=device)
+    idx = torch.empty(npix, dtype=torch.int32, device=device)
+    nfg = torch.zeros(1, dtype=torch.int32, device=device)
+    emb = emb0.clone()
+    t = _event_time(lambda: _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts),
+                                      _clx.ptr(idx), _clx.ptr(nfg), _clx.ptr(ws), st))
+    n_fg = int(nfg.item())
+    row("ms_prepare", t, npix * (3 * 8 + 2 * 8) + n_fg * (2 * 8 + 4),
+        "per pixel 24 B read + 16 B written, per foreground pixel 20 B more", nfg=n_fg)
+    # centres: one per object (their true centres), assignment of all foreground pixels
+    emb = emb0.clone()
+    _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts), _clx.ptr(idx),
+              _clx.ptr(nfg), _clx.ptr(ws), st)
+    labels = torch.zeros(npix, dtype=torch.int32, device=device)
+    cy, cx = np.meshgrid(np.arange(24, size, 48), np.arange(24, size, 48), indexing="ij")
+    centers = np.stack([cx.ravel(), cy.ravel()], 1).astype(np.float64) + rng.uniform(-6, 6, size=(cx.size, 2))
+    cc = torch.from_numpy(centers).to(device)
+    order, cstart, corigin, (gx, gy, gz) = MS._center_grid(centers, 15.0)
+    order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)
+    corigin_c = (ctypes.c_double * 2)(*corigin.tolist())
+    t = _event_time(lambda: _clx.call("clx_ms_assign_grid", _clx.ptr(pts), _clx.ptr(idx), n_fg, _clx.ptr(cc),
+                                      len(centers), 2, _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, 15.0,
+                                      gx, gy, gz, _clx.ptr(labels), st))
+    row("ms_assign", t, n_fg * (16 + 4 + 4), "per foreground pixel 20 B read + 4 B label written",
+        centres=len(centers))
+    seg = labels.view(Y, X).clone()
+    del emb, emb0, pts, idx
+    # --- grow / shrink and connected components + size filter on that label map
+    t = _event_time(lambda: grow_shrink_on_device(seg.clone(), 3, 6), reps=3)
+    t_clone = _event_time(lambda: seg.clone(), reps=3)
+    row("grow_shrink", max(t - t_clone, 1e-9), npix * 8, "per pixel 4 B read + 4 B written")
+    grown = grow_shrink_on_device(seg.clone(), 3, 6)
+    t = _event_time(lambda: label_on_device(grown, 70), reps=3)
+    row("cc_label_filter", t, npix * 8, "per pixel 4 B read + 4 B written")
+    # --- Otsu: min/max + 256-bin histogram of the float64 std channel
+    mm = torch.empty(2, dtype=torch.float64, device=device)
+    x = sd.reshape(-1)
+    t = _event_time(lambda: _clx.call("clx_minmax_f64", _clx.ptr(x), npix, _clx.ptr(mm), st))
+    row("minmax_f64", t, npix * 8, "per pixel 8 B read")
+    edges = torch.linspace(0, 1, 257, dtype=torch.float64, device=device)
+    counts = torch.zeros(256, dtype=torch.int64, device=device)
+    t = _event_time(lambda: _clx.call("clx_histogram_f64", _clx.ptr(x), npix, _clx.ptr(edges), 256, _clx.ptr(counts), st))
+    row("histogram_f64", t, npix * 8, "per pixel 8 B read")
+    # --- mean / std over the 32 noisy predictions
+    T, C, n = 32, 2, 2048 * 2048
+    preds = torch.randn(T, C, n, device=device)
+    o = torch.empty(C + 1, n, device=device)
+    t = _event_time(lambda: _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(o), T, C, n, st))
+    row("noise_stats", t, n * (T * C * 4 + (C + 1) * 4), "per pixel 256 B read + 12 B written")
+    return dict(pixels_per_launch=npix, samples_of_512x512_per_launch=npix // (512 * 512), peak_GBs=HBM_PEAK / 1e9,
+                kernels=out)
+
+
+def e2e_infer(device, samples=8, size=512):
+    """The product's infer() on a synthetic zarr: S x 512^2 raw images in, embeddings / detection /
+    binary-segmentation / centered-embeddings / segmentation out, default inference settings
+    (16 noise iterations, reduction_probability 0.1, cell post-processing)."""
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.infer import infer
+    from cellulus_amd.models import get_model
+    from cellulus_amd.utils import zarr_io
+
+    from bench import synthetic_raw
+
+    mcfg = dict(num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64, downsampling_factors=[[2, 2]])
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory(prefix="clx_e2e_") as tmp:
+        os.chdir(tmp)
+        try:
+            container = os.path.join(tmp, "data.zarr")
+            raw = np.concatenate([synthetic_raw(1, (size, size), seed=s).numpy() for s in range(samples)], axis=0)
+            f = zarr_io.open(container)
+            f["test/raw"] = raw
+            f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+            torch.manual_seed(0)
+            m = get_model(in_channels=1, out_channels=2, num_spatial_dims=2, **mcfg)
+            for _n, layer in m.named_modules():
+                if isinstance(layer, torch.nn.modules.conv._ConvNd):
+                    torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+            os.makedirs("models", exist_ok=True)
+            torch.save({"model_state_dict": m.state_dict()}, "models/best_loss.pth")
+            del m
+
+            def config(name):
+                return ExperimentConfig(
+                    model_config=dict(checkpoint="models/best_loss.pth", **mcfg), object_size=30,
+                    normalization_factor=1.0,
+                    inference_config=dict(
+                        dataset_config=dict(container_path=container, dataset_name="test/raw"),
+                        prediction_dataset_config=dict(container_path=container, dataset_name=f"{name}/embeddings"),
+                        detection_dataset_config=dict(container_path=container, dataset_name=f"{name}/detection",
+                                                      secondary_dataset_name=f"{name}/embeddings"),
+                        segmentation_dataset_config=dict(container_path=container,
+                                                         dataset_name=f"{name}/segmentation",
+                                                         secondary_dataset_name=f"{name}/detection"),
+                        crop_size=[size + 16, size + 16], device=str(device)))
+
+            import contextlib
+            import io
+
+            times = []
+            for run in ("warm", "timed"):
+                torch.manual_seed(1)
+                np.random.seed(1)
+                f_out = zarr_io.open(container)
+                for extra in ("binary-segmentation", "centered-embeddings"):
+                    if extra in f_out:
+                        del f_out[extra]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    infer(config(run))
+                torch.cuda.synchronize()
+                times.append(time.perf_counter() - t0)
+            seg = zarr_io.open(container, "r")["timed/segmentation"][...]
+        finally:
+            os.chdir(cwd)
+    dt = times[1]
+    return dict(mpixels_s=round(samples * size * size / dt / 1e6, 4), seconds=round(dt, 3), samples=samples,
+                ms_per_sample=round(dt / samples * 1e3, 2), first_run_seconds=round(times[0], 3),
+                objects_per_sample=round(float(np.mean([len(np.unique(s)) - 1 for s in seg[:, 0]])), 1),
+                what="cellulus_amd.infer.infer(): zarr -> predict (32 noisy forwards per tile, CPU-generator noise "
+                     "prefetched) -> detect (Otsu + mean-shift) -> segment (grow/shrink + size filter) -> 5 zarr "
+                     "datasets, random-weight network, model load and plan build included")
+
+
+def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=True):
+    import ctypes
+
+    from cellulus_amd import _clx
     from cellulus_amd.models import get_model
     from cellulus_amd.segment import grow_shrink_on_device
     from cellulus_amd.utils.mean_shift import mean_shift_on_device
@@ -71,7 +250,15 @@ def infer_bench(device, reps=2, with_cpu=True):
                                   [(0, 0), (0, 0), (8, 8), (8, 8)], mode="reflect")).to(device)
     noise = torch.rand(1, 2 * n_it, 1, crop, crop, device=device)
     model.infer_on_device(raw, noise=noise)                       # warm-up (plan + packing)
+    _clx.call("clx_profile_enable", 2)
     t_embed, emb = _sync_time(lambda: model.infer_on_device(raw, noise=noise), reps)
+    lib = _clx.load()
+    prof = {}
+    for kind, kname in {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>"}.items():
+        n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        lib.clx_profile_read(kind, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+        prof[kname] = (n_l.value, ms_l.value, fl_l.value)
+    _clx.call("clx_profile_enable", 0)
     assert tuple(emb.shape) == (1, 3, size, size)
 
     mean, std = synthetic_embeddings((size, size), spacing=48, radius=12, noise=0.3, seed=1)
@@ -110,6 +297,8 @@ def infer_bench(device, reps=2, with_cpu=True):
     from bench import conv_flops
     plan = next(iter(model._plans.values()))
     fwd_flops, _, _ = conv_flops(plan.topo, 1)
+    dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     out = {
         "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 512x512, 1 GPU",
         "value": round(size * size / total / 1e6, 4),
@@ -117,13 +306,34 @@ def infer_bench(device, reps=2, with_cpu=True):
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
+        "roofline": dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=F32_MFMA_PEAK_TFLOPS,
+                         unit="TFLOP/s", frac=round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         launches_per_tile=int(launches // reps), avg_launch_ms=round(ms / max(launches, 1), 4),
+                         forwards_per_launch=model.max_infer_batch,
+                         note="the embedding stage is 99 % of a tile's time and is this kernel (executed "
+                              "FLOPs / HIP-event time); the HBM-bound kernels of detect / segment are under "
+                              "`streaming`"),
         "meanshift_rp1": {"ms": round(t_full * 1e3, 2), "seeds": nfg, "clusters": int(len(centers_full))},
         "objects": int(ncomp.item()),
         "clusters": int(len(centers)),
     }
+    del model, plan, noise, emb
+    torch.cuda.empty_cache()
+    if with_streaming:
+        try:
+            out["streaming"] = streaming_rooflines(device)
+        except Exception as e:
+            out["streaming"] = {"error": f"{type(e).__name__}: {e}"}
+    if with_e2e:
+        try:
+            out["e2e"] = e2e_infer(device)
+            out["e2e"]["vs_kernel_only"] = round(out["e2e"]["mpixels_s"] / out["value"], 3)
+        except Exception as e:
+            out["e2e"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:
-        # CPU baseline leg: the oracle (sklearn's algorithm restated in C, 1 thread, as the reference
-        # runs it, + C connected-component labelling) on the same input — the only use of oracle/ here
+        # CPU baseline leg — the only use of oracle/ here.  (1) the reference's own library call:
+        # sklearn.cluster.MeanShift exactly as cellulus/utils/mean_shift.py:62-76 drives it (serial),
+        # when scikit-learn is importable; (2) the oracle's C restatement of the same algorithm on 1 core
         from oracle import infer_oracle as IO
 
         np.random.seed(1)
@@ -136,5 +346,28 @@ def infer_bench(device, reps=2, with_cpu=True):
         t_sf = time.perf_counter() - t0
         same = bool(np.array_equal(ref_seg, seg.cpu().numpy()))
         out["cpu_oracle"] = {"detect_ms": round(t_ms * 1e3, 1), "segment_ms": round(t_sf * 1e3, 1),
-                             "cores": 1, "labels_identical": same}
+                             "cores": 1, "kind": "port (C restatement of sklearn MeanShift + scipy EDT + C labelling)",
+                             "labels_identical": same}
+        try:
+            import sklearn
+            from sklearn.cluster import MeanShift
+
+            m = mean[0].copy()
+            m[0] += np.arange(size)[None, :]
+            m[1] += np.arange(size)[:, None]
+            Xall = np.moveaxis(m, 0, -1)[std < thr].reshape(-1, 2)
+            np.random.seed(1)
+            t0 = time.perf_counter()
+            keep = np.random.rand(len(Xall)) < 0.1
+            ms_ = MeanShift(bandwidth=15.0, cluster_all=False, seeds=None)      # mean_shift.py:62-66
+            ms_.fit(Xall[keep])
+            lab = ms_.predict(Xall)
+            t_sk = time.perf_counter() - t0
+            out["cpu_sklearn"] = {"detect_ms": round(t_sk * 1e3, 1), "cores": 1, "kind": "reference library",
+                                  "what": f"sklearn {sklearn.__version__} MeanShift(bandwidth=15, cluster_all=False)"
+                                          ".fit(10 % of the foreground).predict(all), n_jobs=None as the reference",
+                                  "clusters": int(len(ms_.cluster_centers_)), "foreground": int(len(Xall)),
+                                  "labels_used": int(lab.max() + 1)}
+        except Exception as e:
+            out["cpu_sklearn"] = {"error": f"{type(e).__name__}: {e}"}
     return out

@@ -109,6 +109,9 @@ PROTOTYPES = {
     "clx_ms_iterate_grid": (_I, [_P, _I, _P, POINTER(c_double), _D, _I, _I, _I, _P, _I, _I, _D, _I,
                                  _P, _P, _P, _P]),
     "clx_ms_assign": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "clx_ms_assign_grid": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _P]),
+    "clx_ms_bucket_workspace": (c_size_t, [_I, _LL]),
+    "clx_ms_bucket": (_I, [_P, _I, _I, POINTER(c_double), _D, _I, _I, _I, _P, _P, _P, _P]),
     "clx_greedy_cluster": (_I, [_P, _P, _I, _I, _I, _D, _I, _D, _I, _P, _P, _P, _P]),
     "clx_cc_workspace": (c_size_t, [_LL]),
     "clx_cc_label_filter": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

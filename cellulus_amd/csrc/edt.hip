@@ -190,14 +190,18 @@ __device__ __forceinline__ void gs_axis_pass(const unsigned short* in, unsigned 
   }
 }
 
-template <int ND>
+// GC / SC >= 0: grow / shrink known at compile time (the reference's defaults 3 and 6 are
+// instantiated) — every region extent is then a constant, the index divisions become
+// multiply-shifts and the tap loops unroll; -1: taken from the arguments.
+template <int ND, int GC, int SC>
 __global__ __launch_bounds__(256) void grow_shrink_tile_kernel(int* __restrict__ seg,
                                                                const unsigned char* __restrict__ fgm,
-                                                               int Z, int Y, int X, int grow, int shrink,
+                                                               int Z, int Y, int X, int grow_rt, int shrink_rt,
                                                                int* __restrict__ flag_nonexp) {
   using T = GsTile<ND>;
   extern __shared__ unsigned char gs_smem[];
   const int tid = threadIdx.x;
+  const int grow = GC >= 0 ? GC : grow_rt, shrink = SC >= 0 ? SC : shrink_rt;
   const int g1 = grow > 0 ? grow - 1 : 0, s1 = shrink > 0 ? shrink - 1 : 0, H = g1 + s1;
   const int hz = (ND == 3) ? 1 : 0;        // no halo / pass along z in 2-D
   // region 0 (foreground mask): tile + H; region 1 (expanded mask): tile + s1
@@ -210,13 +214,21 @@ __global__ __launch_bounds__(256) void grow_shrink_tile_kernel(int* __restrict__
   unsigned short* pa = reinterpret_cast<unsigned short*>(ne + ((Z1 * Y1 * X1 + 15) & ~15));
   unsigned short* pb = pa + ((Z0 * Y0 * X1 + 7) & ~7);           // pa: Z0*Y0*X1, pb: Z0*Y1*X1
 
+  int any_fg = 0;
   for (int idx = tid; idx < Z0 * Y0 * X0; idx += 256) {
     const int rx = idx % X0, t = idx / X0, ry = t % Y0, rz = t / Y0;
     const int z = tz0 - H * hz + rz, y = ty0 - H + ry, x = tx0 - H + rx;
     const bool in = (unsigned)z < (unsigned)Z && (unsigned)y < (unsigned)Y && (unsigned)x < (unsigned)X;
-    fg[idx] = in ? fgm[((long long)z * Y + y) * X + x] : 0;
+    const unsigned char v = in ? fgm[((long long)z * Y + y) * X + x] : 0;
+    fg[idx] = v;
+    any_fg |= v;
   }
-  __syncthreads();
+  if (!__syncthreads_or(any_fg)) {
+    // no foreground within reach: nothing is expanded, nothing can be cleared; every pixel of
+    // the (never empty) tile is a zero of the second transform
+    if (tid == 0) atomicOr(flag_nonexp, 1);
+    return;
+  }
   // ---- d1 < grow^2: x pass (rows of region 0, columns of region 1), y pass, z pass
   gs_row_pass(fg, X0, pa, X1, Z0 * Y0, grow, tid);      // out col c <-> region-0 col c + g1
   __syncthreads();
@@ -294,6 +306,17 @@ size_t gs_smem_bytes(int grow, int shrink) {
          2 * (size_t)(((Z0 * Y0 * X1 + 7) & ~7) + Z0 * Y1 * X1 + 8);
 }
 
+template <int ND, int GC, int SC>
+int gs_launch(dim3 grid, size_t smem, int* seg, const unsigned char* mask, int Z, int Y, int X, int grow, int shrink,
+              int* flag, hipStream_t st) {
+  if (smem > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&grow_shrink_tile_kernel<ND, GC, SC>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return CLX_ERR_LAUNCH;
+  grow_shrink_tile_kernel<ND, GC, SC><<<grid, 256, smem, st>>>(seg, mask, Z, Y, X, grow, shrink, flag);
+  return CLX_OK;
+}
+
 template <int ND>
 int grow_shrink_tiled(int* seg, int Z, int Y, int X, int grow, int shrink, void* workspace, hipStream_t st) {
   using T = GsTile<ND>;
@@ -304,12 +327,10 @@ int grow_shrink_tiled(int* seg, int Z, int Y, int X, int grow, int shrink, void*
   fg_mask_kernel<<<grid_for((npix + 3) / 4, 256), 256, 0, st>>>(seg, mask, npix);
   const dim3 grid((X + T::TX - 1) / T::TX, (Y + T::TY - 1) / T::TY, (Z + T::TZ - 1) / T::TZ);
   const size_t smem = gs_smem_bytes<ND>(grow, shrink);
-  if (smem > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&grow_shrink_tile_kernel<ND>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return CLX_ERR_LAUNCH;
-  grow_shrink_tile_kernel<ND><<<grid, 256, smem, st>>>(seg, mask, Z, Y, X, grow,
-                                                                                  shrink, flag);
+  const int rc = (grow == 3 && shrink == 6)      // segment.py's defaults (inference_config.py:158-159)
+                     ? gs_launch<ND, 3, 6>(grid, smem, seg, mask, Z, Y, X, grow, shrink, flag, st)
+                     : gs_launch<ND, -1, -1>(grid, smem, seg, mask, Z, Y, X, grow, shrink, flag, st);
+  if (rc) return rc;
   grow_shrink_phantom<<<grid_for(npix, 256) < 1024 ? grid_for(npix, 256) : 1024, 256, 0, st>>>(seg, Z, Y, X,
                                                                                                shrink, flag);
   return CLX_OK;

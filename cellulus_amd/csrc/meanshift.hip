@@ -9,141 +9,127 @@
 
 namespace {
 
-constexpr int PREP_BLOCK = 1024;   // pixels per compaction block
+constexpr int PREP_TILE = 2048;    // pixels per block of the compaction (256 threads x 4 x 2)
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// pass 1: add coordinates in place, count foreground per block.  Each thread owns two
-// adjacent pixels so every access is a 16-byte load/store (npix even; odd sizes take the
-// scalar tail below).
-__global__ __launch_bounds__(256) void ms_prepare_count(double* __restrict__ emb,
-                                                        const double* __restrict__ sd,
-                                                        double thr, int ND, int Y, int X,
-                                                        long long npix, int vec,
-                                                        int* __restrict__ counts) {
-  __shared__ int wsum[4];
-  const long long base = (long long)blockIdx.x * PREP_BLOCK;
-  int local = 0;
-  if (vec) {
-    for (int k = 0; k < PREP_BLOCK / 512; ++k) {
-      const long long i = base + (long long)(k * 256 + threadIdx.x) * 2;
-      if (i < npix) {      // npix is even here, so i + 1 < npix too
-        const int x0 = (int)(i % X);
-        const long long t = i / X;
-        const int y0 = (int)(t % Y);
-        const int z0 = (int)(t / Y);
-        int x1 = x0 + 1, y1 = y0, z1 = z0;
-        if (x1 == X) { x1 = 0; if (++y1 == Y) { y1 = 0; ++z1; } }
-        f64x2 v = *reinterpret_cast<f64x2*>(emb + i);
-        v[0] += (double)x0; v[1] += (double)x1;
-        *reinterpret_cast<f64x2*>(emb + i) = v;
-        v = *reinterpret_cast<f64x2*>(emb + npix + i);
-        v[0] += (double)y0; v[1] += (double)y1;
-        *reinterpret_cast<f64x2*>(emb + npix + i) = v;
-        if (ND == 3) {
-          v = *reinterpret_cast<f64x2*>(emb + 2 * npix + i);
-          v[0] += (double)z0; v[1] += (double)z1;
-          *reinterpret_cast<f64x2*>(emb + 2 * npix + i) = v;
+// Coordinate add + stable (raster-order) compaction of the foreground pixels in ONE pass over
+// the image [mean_shift.py:15-32,83-90]: every block takes the next tile (atomic ticket), adds the
+// pixel coordinates to the embedding in place, counts its foreground pixels, publishes the count
+// and obtains the number of foreground pixels before its tile by decoupled look-back over the
+// predecessors' published counts / prefixes (one 64-bit word each: status in the high half,
+// value in the low half, so a reader never sees one without the other), then writes its points.
+// Per pixel: (ND + 1) * 8 B read, ND * 8 B written; per foreground pixel ND * 8 + 4 B more.
+template <int ND>
+__global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ emb,
+                                                         const double* __restrict__ sd, double thr,
+                                                         FastDiv dX, FastDiv dY, int Y, int X,
+                                                         long long npix, int vec, int ntiles,
+                                                         unsigned int* __restrict__ ticket,
+                                                         unsigned long long* __restrict__ desc,
+                                                         double* __restrict__ Xout,
+                                                         int* __restrict__ index, int* __restrict__ nfg_out) {
+  __shared__ int s_tile, s_excl;
+  __shared__ int wcount[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int tile = s_tile;
+  const long long base = (long long)tile * PREP_TILE;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+
+  double v[4][2][ND];
+  bool fg[4][2];
+  int before[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long long i = base + (long long)(k * 256 + tid) * 2;
+    fg[k][0] = fg[k][1] = false;
+    if (i < npix) {
+      const bool two = i + 1 < npix;
+      const unsigned int t = fdiv((unsigned int)i, dX);
+      const int x0 = (int)((unsigned int)i - t * (unsigned int)X);
+      const unsigned int z0u = fdiv(t, dY);
+      const int y0 = (int)(t - z0u * (unsigned int)Y), z0 = (int)z0u;
+      int x1 = x0 + 1, y1 = y0, z1 = z0;
+      if (x1 == X) { x1 = 0; if (++y1 == Y) { y1 = 0; ++z1; } }
+      const int c0[3] = {x0, y0, z0}, c1[3] = {x1, y1, z1};
+      if (vec) {              // npix even and 16-byte aligned: i + 1 < npix, 16-byte accesses
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+          f64x2 e = *reinterpret_cast<const f64x2*>(emb + (long long)c * npix + i);
+          e[0] += (double)c0[c]; e[1] += (double)c1[c];
+          *reinterpret_cast<f64x2*>(emb + (long long)c * npix + i) = e;
+          v[k][0][c] = e[0]; v[k][1][c] = e[1];
         }
         const f64x2 s2 = *reinterpret_cast<const f64x2*>(sd + i);
-        local += (s2[0] < thr ? 1 : 0) + (s2[1] < thr ? 1 : 0);
+        fg[k][0] = s2[0] < thr; fg[k][1] = s2[1] < thr;
+      } else {
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+          double e0 = emb[(long long)c * npix + i] + (double)c0[c];
+          emb[(long long)c * npix + i] = e0;
+          v[k][0][c] = e0;
+          if (two) {
+            double e1 = emb[(long long)c * npix + i + 1] + (double)c1[c];
+            emb[(long long)c * npix + i + 1] = e1;
+            v[k][1][c] = e1;
+          }
+        }
+        fg[k][0] = sd[i] < thr;
+        fg[k][1] = two && sd[i + 1] < thr;
       }
     }
-  } else {
-    for (int k = 0; k < PREP_BLOCK / 256; ++k) {
-      const long long i = base + k * 256 + threadIdx.x;
-      if (i < npix) {
-        const int x = (int)(i % X);
-        const long long t = i / X;
-        const int y = (int)(t % Y);
-        const int z = (int)(t / Y);
-        emb[i] += (double)x;
-        emb[npix + i] += (double)y;
-        if (ND == 3) emb[2 * npix + i] += (double)z;
-        local += (sd[i] < thr) ? 1 : 0;
-      }
+    const unsigned long long b0 = __ballot(fg[k][0]), b1 = __ballot(fg[k][1]);
+    // raster order inside the wave: lane l owns pixels 2l, 2l+1
+    before[k] = __popcll(b0 & lower) + __popcll(b1 & lower);
+    if (lane == 0) wcount[k][wid] = __popcll(b0) + __popcll(b1);
+  }
+  __syncthreads();
+  int total = 0, mine[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w == wid) mine[k] = total;
+      total += wcount[k][w];
     }
-  }
-  for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// pass 2: exclusive scan of the block counts (single block), total -> nfg_out
-__global__ __launch_bounds__(1024) void scan_counts(int* __restrict__ counts, int nblocks,
-                                                    int* __restrict__ total_out) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const int per = (nblocks + 1023) / 1024;
-  const int lo = tid * per, hi = min(lo + per, nblocks);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) s += counts[i];
-  part[tid] = s;
-  __syncthreads();
-  // Hillis-Steele inclusive scan over 1024 partials
-  for (int o = 1; o < 1024; o <<= 1) {
-    int v = (tid >= o) ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = (tid == 0) ? 0 : part[tid - 1];
-  for (int i = lo; i < hi; ++i) {
-    const int c = counts[i];
-    counts[i] = run;
-    run += c;
-  }
-  if (tid == 1023 && total_out) *total_out = part[1023];
-}
-
-// pass 3: stable (raster-order) compaction of the foreground pixels (two adjacent pixels per
-// thread when `vec`, so the std read is a 16-byte load)
-__global__ __launch_bounds__(256) void ms_prepare_scatter(const double* __restrict__ emb,
-                                                          const double* __restrict__ sd,
-                                                          double thr, int ND, long long npix, int vec,
-                                                          const int* __restrict__ offsets,
-                                                          double* __restrict__ Xout,
-                                                          int* __restrict__ index) {
-  __shared__ int wcount[4];
-  __shared__ int running;
-  if (threadIdx.x == 0) running = offsets[blockIdx.x];
-  __syncthreads();
-  const long long base = (long long)blockIdx.x * PREP_BLOCK;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const unsigned long long lower = (1ull << lane) - 1ull;
-  const int per = vec ? 2 : 1;
-  for (int k = 0; k < PREP_BLOCK / (256 * per); ++k) {
-    const long long i = base + (long long)(k * 256 + threadIdx.x) * per;
-    bool fg0 = false, fg1 = false;
-    if (vec) {
-      if (i < npix) {
-        const f64x2 s2 = *reinterpret_cast<const f64x2*>(sd + i);
-        fg0 = s2[0] < thr;
-        fg1 = s2[1] < thr;
-      }
+  if (tid == 0) {
+    int excl = 0;
+    if (tile == 0) {
+      __hip_atomic_store(&desc[0], (2ull << 32) | (unsigned int)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      fg0 = (i < npix) && (sd[i] < thr);
+      __hip_atomic_store(&desc[tile], (1ull << 32) | (unsigned int)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int j = tile - 1;
+      while (true) {
+        const unsigned long long d = __hip_atomic_load(&desc[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int st = (unsigned int)(d >> 32);
+        if (st == 0) { __builtin_amdgcn_s_sleep(1); continue; }     // predecessor has not published yet
+        excl += (int)(unsigned int)d;
+        if (st == 2) break;
+        --j;
+      }
+      __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
-    const unsigned long long b0 = __ballot(fg0), b1 = __ballot(fg1);
-    const int before = __popcll(b0 & lower) + __popcll(b1 & lower);
-    if (lane == 0) wcount[wid] = __popcll(b0) + __popcll(b1);
-    __syncthreads();
-    int woff = running;
-    for (int w = 0; w < wid; ++w) woff += wcount[w];
-    int pos = woff + before;
-    if (fg0) {
-      for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = emb[(long long)c * npix + i];
-      index[pos] = (int)i;
-      ++pos;
+    s_excl = excl;
+    if (tile == ntiles - 1) *nfg_out = excl + total;
+  }
+  __syncthreads();
+  const int excl = s_excl;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int pos = excl + mine[k] + before[k];
+    const long long i = base + (long long)(k * 256 + tid) * 2;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      if (fg[k][e]) {
+#pragma unroll
+        for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = v[k][e][c];
+        index[pos] = (int)(i + e);
+        ++pos;
+      }
     }
-    if (fg1) {
-      for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = emb[(long long)c * npix + i + 1];
-      index[pos] = (int)(i + 1);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) running += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    __syncthreads();
   }
 }
 
@@ -323,11 +309,145 @@ __global__ __launch_bounds__(256) void ms_assign_kernel(const double* __restrict
   if (i < nfg) labels[index[i]] = arg + 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bucketing of the fit points for ms_iterate_grid_kernel: counting sort by uniform-grid cell
+// (x fastest), points of one cell in their original (raster) order — the order a stable sort
+// by cell id produces, so the sums of the iteration do not depend on the run.
+//   count:   cell id per point + histogram (atomics; counts do not depend on arrival order)
+//   scan:    exclusive prefix -> cell_start
+//   scatter: arrival-order slot inside the cell (atomic cursor)
+//   order:   one wavefront per cell ranks the cell's points by original index (rank sort:
+//            n^2 / 64 comparisons per cell, cells hold tens to a few thousand points) and writes
+//            the point into its final slot
+// ---------------------------------------------------------------------------------------------
+template <int ND>
+__global__ void bucket_count_kernel(const double* __restrict__ fit, int n, double ox, double oy, double oz,
+                                    double h, int nx, int ny, int nz, int* __restrict__ cid,
+                                    int* __restrict__ counts) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // the division by h is the one the host used to size the grid: floor((x - origin) / h)
+    int c = min(max((int)floor((fit[(long long)i * ND] - ox) / h), 0), nx - 1);
+    c += nx * min(max((int)floor((fit[(long long)i * ND + 1] - oy) / h), 0), ny - 1);
+    if (ND == 3) c += nx * ny * min(max((int)floor((fit[(long long)i * ND + 2] - oz) / h), 0), nz - 1);
+    cid[i] = c;
+    atomicAdd(&counts[c], 1);
+  }
+}
+
+// exclusive scan of counts[0..n) into start[0..n], start[n] = total; counts are zeroed for reuse
+// as the scatter cursors
+__global__ __launch_bounds__(1024) void bucket_scan_kernel(int* __restrict__ counts, int n, int* __restrict__ start) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(tid * per, n), hi = min(lo + per, n);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += counts[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (tid >= o) ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = (tid == 0) ? 0 : part[tid - 1];
+  for (int i = lo; i < hi; ++i) {
+    const int c = counts[i];
+    start[i] = run;
+    counts[i] = 0;
+    run += c;
+  }
+  if (tid == 1023) start[n] = part[1023];
+}
+
+__global__ void bucket_scatter_kernel(const int* __restrict__ cid, int n, const int* __restrict__ start,
+                                      int* __restrict__ cursor, int* __restrict__ slot_idx) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = cid[i];
+    slot_idx[start[c] + atomicAdd(&cursor[c], 1)] = i;
+  }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256) void bucket_order_kernel(const double* __restrict__ fit,
+                                                           const int* __restrict__ start, int ncells,
+                                                           const int* __restrict__ slot_idx,
+                                                           double* __restrict__ fit_sorted) {
+  const int lane = threadIdx.x & 63;
+  for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < ncells; c += (gridDim.x * blockDim.x) >> 6) {
+    const int lo = start[c], hi = start[c + 1];
+    for (int j = lo + lane; j < hi; j += 64) {
+      const int me = slot_idx[j];
+      int rank = 0;
+      for (int k = lo; k < hi; ++k) rank += (slot_idx[k] < me) ? 1 : 0;
+#pragma unroll
+      for (int d = 0; d < ND; ++d) fit_sorted[(long long)(lo + rank) * ND + d] = fit[(long long)me * ND + d];
+    }
+  }
+}
+
+// The same assignment with the centres bucketed into a uniform grid of edge h: a pixel looks at
+// the 3^ND cells around its own; every centre outside that block is at least h away, so a
+// candidate closer than h (strictly) is the exact nearest centre — ties inside the block are broken
+// towards the smaller index, which is the "first minimum" of the plain loop.  A pixel farther
+// than h from all its candidates falls back to the plain loop over all centres (rare: pixels
+// cluster around their centre by construction).  Cuts nfg x ncentres pair evaluations to
+// nfg x (centres in 3^ND cells).
+template <int ND>
+__global__ __launch_bounds__(256) void ms_assign_grid_kernel(
+    const double* __restrict__ X, const int* __restrict__ index, int nfg, const double* __restrict__ centers,
+    int ncenters, const int* __restrict__ order, const int* __restrict__ cell_start, double ox, double oy,
+    double oz, double h, int nx, int ny, int nz, int* __restrict__ labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nfg) return;
+  double x[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) x[c] = X[(long long)i * ND + c];
+  const double inv = 1.0 / h;
+  const int cx = min(max((int)floor((x[0] - ox) * inv), 0), nx - 1);
+  const int cy = min(max((int)floor((x[1] - oy) * inv), 0), ny - 1);
+  const int cz = (ND == 3) ? min(max((int)floor((x[2] - oz) * inv), 0), nz - 1) : 0;
+  double best = 0.0;
+  int arg = -1;
+  for (int zz = (ND == 3 ? cz - 1 : 0); zz <= (ND == 3 ? cz + 1 : 0); ++zz) {
+    if (zz < 0 || zz >= nz) continue;
+    for (int yy = cy - 1; yy <= cy + 1; ++yy) {
+      if (yy < 0 || yy >= ny) continue;
+      const long long row = ((long long)zz * ny + yy) * nx;
+      const int lo = cell_start[row + max(cx - 1, 0)], hi = cell_start[row + min(cx + 1, nx - 1) + 1];
+      for (int j = lo; j < hi; ++j) {
+        const int k = order[j];
+        double d2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+          const double df = x[c] - centers[(long long)k * ND + c];
+          d2 += df * df;
+        }
+        if (arg < 0 || d2 < best || (d2 == best && k < arg)) { best = d2; arg = k; }
+      }
+    }
+  }
+  if (arg < 0 || !(best < h * h)) {
+    arg = -1;
+    for (int k = 0; k < ncenters; ++k) {
+      double d2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        const double df = x[c] - centers[(long long)k * ND + c];
+        d2 += df * df;
+      }
+      if (arg < 0 || d2 < best) { best = d2; arg = k; }
+    }
+  }
+  labels[index[i]] = arg + 1;
+}
+
 }  // namespace
 
 extern "C" size_t clx_ms_prepare_workspace(long long npix) {
-  const long long nblocks = (npix + PREP_BLOCK - 1) / PREP_BLOCK;
-  return (size_t)(nblocks + 1) * sizeof(int);
+  const long long ntiles = (npix + PREP_TILE - 1) / PREP_TILE;
+  return (size_t)(ntiles + 2) * sizeof(unsigned long long);
 }
 
 extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
@@ -336,15 +456,25 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   CLX_REQUIRE(emb && std && Xout && index && nfg_out && workspace, "clx_ms_prepare: null pointer");
   CLX_REQUIRE((ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0, "clx_ms_prepare: bad extents");
   CLX_REQUIRE(ND == 3 || Z == 1, "clx_ms_prepare: Z must be 1 for 2-D data");
+  CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare: workspace must be 8-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare: too many pixels");
-  const int nblocks = (int)((npix + PREP_BLOCK - 1) / PREP_BLOCK);
-  int* counts = (int*)workspace;
+  const int ntiles = (int)((npix + PREP_TILE - 1) / PREP_TILE);
   hipStream_t st = (hipStream_t)stream;
+  unsigned int* ticket = (unsigned int*)workspace;
+  unsigned long long* desc = (unsigned long long*)workspace + 1;
+  if (hipMemsetAsync(workspace, 0, (size_t)(ntiles + 1) * sizeof(unsigned long long), st) != hipSuccess) {
+    clx_set_error("clx_ms_prepare: memset failed");
+    return CLX_ERR_LAUNCH;
+  }
   const int vec = (npix % 2 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
-  ms_prepare_count<<<nblocks, 256, 0, st>>>(emb, std, threshold, ND, Y, X, npix, vec, counts);
-  scan_counts<<<1, 1024, 0, st>>>(counts, nblocks, nfg_out);
-  ms_prepare_scatter<<<nblocks, 256, 0, st>>>(emb, std, threshold, ND, npix, vec, counts, Xout, index);
+  const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
+  if (ND == 2)
+    ms_prepare_kernel<2><<<ntiles, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket,
+                                                  desc, Xout, index, nfg_out);
+  else
+    ms_prepare_kernel<3><<<ntiles, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket,
+                                                  desc, Xout, index, nfg_out);
   CLX_CHECK_LAUNCH("clx_ms_prepare");
   return CLX_OK;
 }
@@ -406,5 +536,67 @@ extern "C" int clx_ms_assign(const double* X, const int* index, int nfg, const d
   else
     ms_assign_kernel<3><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, labels);
   CLX_CHECK_LAUNCH("clx_ms_assign");
+  return CLX_OK;
+}
+
+extern "C" int clx_ms_assign_grid(const double* X, const int* index, int nfg, const double* centers,
+                                  int ncenters, int ND, const int* order, const int* cell_start,
+                                  const double* origin, double cell, int nx, int ny, int nz, int* labels,
+                                  clx_stream stream) {
+  CLX_REQUIRE(X && index && centers && labels && order && cell_start && origin, "clx_ms_assign_grid: null pointer");
+  CLX_REQUIRE((ND == 2 || ND == 3) && nfg >= 0 && ncenters > 0, "clx_ms_assign_grid: bad extents");
+  CLX_REQUIRE(cell > 0.0 && nx > 0 && ny > 0 && nz > 0 && (ND == 3 || nz == 1), "clx_ms_assign_grid: bad grid");
+  if (nfg == 0) return CLX_OK;
+  const int grid = (nfg + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  if (ND == 2)
+    ms_assign_grid_kernel<2><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, order, cell_start, origin[0],
+                                                    origin[1], 0.0, cell, nx, ny, nz, labels);
+  else
+    ms_assign_grid_kernel<3><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, order, cell_start, origin[0],
+                                                    origin[1], origin[2], cell, nx, ny, nz, labels);
+  CLX_CHECK_LAUNCH("clx_ms_assign_grid");
+  return CLX_OK;
+}
+
+extern "C" size_t clx_ms_bucket_workspace(int n, long long ncells) {
+  return (size_t)(2 * (long long)n + ncells + 4) * sizeof(int);
+}
+
+extern "C" int clx_ms_bucket(const double* fit, int n, int ND, const double* origin, double cell, int nx,
+                             int ny, int nz, double* fit_sorted, int* cell_start, void* workspace,
+                             clx_stream stream) {
+  CLX_REQUIRE(fit && origin && fit_sorted && cell_start && workspace, "clx_ms_bucket: null pointer");
+  CLX_REQUIRE((ND == 2 || ND == 3) && n >= 0 && cell > 0.0, "clx_ms_bucket: bad extents");
+  CLX_REQUIRE(nx > 0 && ny > 0 && nz > 0 && (ND == 3 || nz == 1), "clx_ms_bucket: bad grid");
+  const long long ncells = (long long)nx * ny * nz;
+  CLX_REQUIRE(ncells < (1ll << 30), "clx_ms_bucket: too many cells");
+  hipStream_t st = (hipStream_t)stream;
+  int* cid = (int*)workspace;
+  int* slot_idx = cid + n;
+  int* counts = slot_idx + n;
+  if (hipMemsetAsync(counts, 0, (size_t)ncells * sizeof(int), st) != hipSuccess) {
+    clx_set_error("clx_ms_bucket: memset failed");
+    return CLX_ERR_LAUNCH;
+  }
+  const int grid = n > 0 ? (n + 255) / 256 : 1;
+  const double oz = ND == 3 ? origin[2] : 0.0;
+  if (n > 0) {
+    if (ND == 2)
+      bucket_count_kernel<2><<<grid, 256, 0, st>>>(fit, n, origin[0], origin[1], oz, cell, nx, ny, nz, cid, counts);
+    else
+      bucket_count_kernel<3><<<grid, 256, 0, st>>>(fit, n, origin[0], origin[1], oz, cell, nx, ny, nz, cid, counts);
+  }
+  bucket_scan_kernel<<<1, 1024, 0, st>>>(counts, (int)ncells, cell_start);
+  if (n > 0) {
+    bucket_scatter_kernel<<<grid, 256, 0, st>>>(cid, n, cell_start, counts, slot_idx);
+    long long waves = ncells < 65536 ? ncells : 65536;
+    const int ogrid = (int)((waves * 64 + 255) / 256);
+    if (ND == 2)
+      bucket_order_kernel<2><<<ogrid, 256, 0, st>>>(fit, cell_start, (int)ncells, slot_idx, fit_sorted);
+    else
+      bucket_order_kernel<3><<<ogrid, 256, 0, st>>>(fit, cell_start, (int)ncells, slot_idx, fit_sorted);
+  }
+  CLX_CHECK_LAUNCH("clx_ms_bucket");
   return CLX_OK;
 }

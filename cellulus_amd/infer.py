@@ -57,6 +57,7 @@ def fused_stages(model, inference_config, normalization_factor, device):
                      (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
 
     scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)
+    scan.start_noise(meta.num_samples)      # the noise of sample i+1 is drawn while sample i computes
     pending = []
     with ThreadPoolExecutor(max_workers=1) as writer:
         def write(ds, key, value):
@@ -88,6 +89,7 @@ def fused_stages(model, inference_config, normalization_factor, device):
                 pending.pop(0).result()
         for job in pending:
             job.result()
+    scan.noise.finish()
 
 
 def infer(experiment_config):

@@ -361,8 +361,11 @@ class UNetModel(nn.Module):  # type: ignore
             else:
                 rnd = noise[sample]
             rnd = rnd.to(raw.device, non_blocking=True)
-            vals = torch.tensor([0.5] * n_it + [1.0] * n_it, dtype=torch.float32, device=raw.device)
-            vals = vals.view((T,) + (1,) * (raw_sample.ndim - 1))
+            key = (n_it, raw.device)
+            if getattr(self, "_noise_vals_key", None) != key:    # built once: a host list -> device copy synchronises
+                self._noise_vals = torch.tensor([0.5] * n_it + [1.0] * n_it, dtype=torch.float32, device=raw.device)
+                self._noise_vals_key = key
+            vals = self._noise_vals.view((T,) + (1,) * (raw_sample.ndim - 1))
             noisy = torch.where(rnd <= self.p_salt_pepper, vals, raw_sample.expand_as(rnd))
             preds = []
             step = max(1, min(T, int(self.max_infer_batch)))

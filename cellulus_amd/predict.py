@@ -38,6 +38,52 @@ def tile_offsets(size, tile):
     return offs
 
 
+class NoisePrefetcher:
+    """The uniform random numbers of the infer-mode forward (unet.py:81: one ``torch.rand`` per noisy
+    copy on the CPU generator), drawn by a background thread one tile ahead of the GPU.
+
+    The calls are the reference's, in the reference's order (tile after tile, copy after copy, each
+    ``torch.rand(1, C, *crop)``), so a seeded run reproduces the same numbers and leaves the generator
+    in the same state; what changes is WHEN they are drawn: while the previous tile's forwards run,
+    into pinned memory, so that neither the draw (tens of ms per 512^2 tile) nor the upload sits
+    between two tiles' kernels."""
+
+    def __init__(self, num_tiles, copies, tile_shape, depth=2):
+        import queue
+        import threading
+
+        self.q = queue.Queue(maxsize=depth)
+        self.remaining = num_tiles
+        pin = torch.cuda.is_available()
+
+        def work():
+            try:
+                for _ in range(num_tiles):
+                    buf = torch.empty((copies,) + tuple(tile_shape), dtype=torch.float32, pin_memory=pin)
+                    for t in range(copies):
+                        torch.rand(*tile_shape, out=buf[t])
+                    self.q.put(buf)
+            except BaseException as e:          # surfaces in the consumer
+                self.q.put(e)
+
+        self.thread = threading.Thread(target=work, name="clx-noise", daemon=True)
+        self.thread.start()
+
+    def next(self):
+        assert self.remaining > 0, "more tiles requested than announced"
+        self.remaining -= 1
+        item = self.q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def finish(self):
+        """Blocks until every announced draw has happened (the generator state is then final)."""
+        while self.remaining > 0:
+            self.next()
+        self.thread.join()
+
+
 class PredictScan:
     """The tile scan of one sample (predict.py:28-135 restated): reflect-pad by the network
     context, visit tiles of ``crop_size`` with the stride of the output tile, (mean, std) of the
@@ -60,6 +106,14 @@ class PredictScan:
         self.spatial = tuple(meta.spatial_array)
         self.offsets = [tile_offsets(s, t) for s, t in zip(self.spatial, self.out_tile)]
         self.pad = [(0, 0)] + [(c, c) for c in self.context]
+        self.tiles_per_sample = int(np.prod([len(o) for o in self.offsets]))
+        self.noise = None
+
+    def start_noise(self, num_samples):
+        """Announce how many samples will be predicted: their noise is then drawn ahead of the GPU."""
+        tile_shape = (1, self.model.in_channels) + self.crop
+        self.noise = NoisePrefetcher(num_samples * self.tiles_per_sample, 2 * int(self.model.num_infer_iterations),
+                                     tile_shape)
 
     def predict_sample(self, raw):
         raw = raw.astype(np.float32) * np.float32(self.factor)             # gp.Normalize
@@ -69,7 +123,11 @@ class PredictScan:
         for off in itertools.product(*self.offsets):
             in_sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, self.crop))
             tile = raw_d[in_sl].unsqueeze(0).contiguous()
-            emb = self.model.infer_on_device(tile)[0]
+            rnd = None
+            if self.noise is not None:           # (T, 1, C, *crop) -> (1, T, C, *crop)
+                buf = self.noise.next()
+                rnd = buf.view((1, buf.shape[0]) + tuple(buf.shape[2:]))
+            emb = self.model.infer_on_device(tile, noise=rnd)[0]
             out_sl = (slice(None),) + tuple(slice(o, o + t) for o, t in zip(off, self.out_tile))
             result[out_sl] = emb
         return result
@@ -101,8 +159,18 @@ def predict(model: torch.nn.Module, inference_config: InferenceConfig, normaliza
 
     scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)
     lo, hi = parallel.shard_range(meta.num_samples)
+    scan.start_noise(hi - lo)
+    # sample i's copy back to the host and its zarr write happen after sample i+1's kernels are
+    # enqueued, so the GPU never waits for the host between samples
+    pending = None
     for sample in range(lo, hi):
-        ds[sample] = scan.predict_sample(raw_ds[sample]).cpu().numpy().astype(np.float64)
+        result = scan.predict_sample(raw_ds[sample])
+        if pending is not None:
+            ds[pending[0]] = pending[1].cpu().numpy().astype(np.float64)
+        pending = (sample, result)
+    if pending is not None:
+        ds[pending[0]] = pending[1].cpu().numpy().astype(np.float64)
+    scan.noise.finish()
 
     if parallel.world_size() > 1:
         torch.distributed.barrier()

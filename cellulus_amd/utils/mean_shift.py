@@ -21,23 +21,47 @@ GRID_MIN_POINTS = 2048   # below this a brute-force sweep of the (L2-resident) f
 
 
 def _bucket(fit, bandwidth):
-    """Sort the fit points by uniform-grid cell (stable, x fastest). Torch ops = plumbing:
-    returns (sorted points, cell_start int32 (ncells+1), origin (host), cell edge, (nx, ny, nz))."""
-    nd = fit.shape[1]
+    """Bucket the fit points into uniform-grid cells of edge just above the bandwidth
+    (clx_ms_bucket: counting sort by cell, original order inside a cell).  Returns (sorted points,
+    cell_start int32 (ncells+1), origin (host), cell edge, (nx, ny, nz))."""
+    import ctypes
+
+    n, nd = fit.shape
     cell = float(bandwidth) * (1.0 + 1e-9)        # strictly larger than the query radius
-    origin = fit.min(dim=0).values
-    coords = torch.floor((fit - origin) / cell).to(torch.int64)
-    dims = (coords.max(dim=0).values + 1).cpu().tolist()
+    lo = fit.amin(dim=0)
+    hi = fit.amax(dim=0)
+    ext = torch.stack([lo, hi]).cpu().numpy().astype(np.float64)      # one small D2H copy
+    origin = ext[0]
+    dims = np.floor((ext[1] - origin) / cell).astype(np.int64) + 1
     nx, ny = int(dims[0]), int(dims[1])
     nz = int(dims[2]) if nd == 3 else 1
-    cid = coords[:, 0] + nx * coords[:, 1]
-    if nd == 3:
-        cid = cid + nx * ny * coords[:, 2]
-    order = torch.sort(cid, stable=True).indices
-    counts = torch.bincount(cid, minlength=nx * ny * nz)
-    cell_start = torch.zeros(nx * ny * nz + 1, dtype=torch.int32, device=fit.device)
-    cell_start[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return fit[order].contiguous(), cell_start, origin.cpu().numpy().astype(np.float64), cell, (nx, ny, nz)
+    ncells = nx * ny * nz
+    lib = _clx.load()
+    ws = torch.empty(int(lib.clx_ms_bucket_workspace(n, ncells)), dtype=torch.uint8, device=fit.device)
+    fit_sorted = torch.empty_like(fit)
+    cell_start = torch.empty(ncells + 1, dtype=torch.int32, device=fit.device)
+    origin_c = (ctypes.c_double * nd)(*origin.tolist())
+    _clx.call("clx_ms_bucket", _clx.ptr(fit), n, nd, origin_c, cell, nx, ny, nz, _clx.ptr(fit_sorted),
+              _clx.ptr(cell_start), _clx.ptr(ws), _clx.stream_ptr(fit.device))
+    return fit_sorted, cell_start, origin, cell, (nx, ny, nz)
+
+
+ASSIGN_GRID_MIN_CENTERS = 32      # below this the plain loop over the (LDS-resident) centres is as fast
+
+
+def _center_grid(centers, cell):
+    """Host side of clx_ms_assign_grid: the (few hundred) centres sorted by uniform-grid cell."""
+    nd = centers.shape[1]
+    origin = centers.min(axis=0)
+    coords = np.floor((centers - origin) / cell).astype(np.int64)
+    dims = coords.max(axis=0) + 1
+    nx, ny = int(dims[0]), int(dims[1])
+    nz = int(dims[2]) if nd == 3 else 1
+    cid = coords[:, 0] + nx * coords[:, 1] + (nx * ny * coords[:, 2] if nd == 3 else 0)
+    order = np.argsort(cid, kind="stable").astype(np.int32)
+    cell_start = np.zeros(nx * ny * nz + 1, dtype=np.int32)
+    np.cumsum(np.bincount(cid, minlength=nx * ny * nz), out=cell_start[1:])
+    return order, cell_start, origin.astype(np.float64), (nx, ny, nz)
 
 
 def dedup_centers(centers, counts, bandwidth):
@@ -134,8 +158,23 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
                   float(bandwidth), MAX_ITER, _clx.ptr(centers), _clx.ptr(counts), _clx.ptr(iters), st)
     cluster_centers = dedup_centers(centers.cpu().numpy(), counts.cpu().numpy(), float(bandwidth))
     cc = torch.from_numpy(np.ascontiguousarray(cluster_centers)).to(dev)
-    _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), cc.shape[0], nd,
-              _clx.ptr(labels), st)
+    ncc = cc.shape[0]
+    grid_cells = 0
+    if ncc >= ASSIGN_GRID_MIN_CENTERS:
+        cell = float(bandwidth)
+        order, cstart, corigin, (gx, gy, gz) = _center_grid(cluster_centers, cell)
+        grid_cells = gx * gy * gz
+    if ncc >= ASSIGN_GRID_MIN_CENTERS and grid_cells <= 1 << 26:
+        import ctypes
+
+        order_d = torch.from_numpy(order).to(dev)
+        cstart_d = torch.from_numpy(cstart).to(dev)
+        corigin_c = (ctypes.c_double * nd)(*corigin.tolist())
+        _clx.call("clx_ms_assign_grid", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,
+                  _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, cell, gx, gy, gz, _clx.ptr(labels), st)
+    else:
+        _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,
+                  _clx.ptr(labels), st)
     return labels, cluster_centers
 
 

@@ -301,11 +301,28 @@ int clx_ms_iterate_grid(const double* fit_sorted, int nfit, const int* cell_star
                         const double* seeds, int nseeds, int ND, double bandwidth,
                         int max_iter, double* centers, int* counts, int* iters,
                         clx_stream stream);
+/* Bucketing for clx_ms_iterate_grid: counting sort of the fit points by uniform-grid cell
+ * (cell id = x + nx * (y + ny * z), cell index = clamp(floor((p - origin) / cell))), the points of
+ * one cell in their original order (what a stable sort by cell id gives).  fit_sorted: (n, ND) f64
+ * out; cell_start: (nx*ny*nz + 1) int32 out; `origin` is a HOST pointer to ND doubles;
+ * workspace: clx_ms_bucket_workspace(n, nx*ny*nz) bytes. */
+size_t clx_ms_bucket_workspace(int n, long long ncells);
+int clx_ms_bucket(const double* fit, int n, int ND, const double* origin, double cell, int nx,
+                  int ny, int nz, double* fit_sorted, int* cell_start, void* workspace,
+                  clx_stream stream);
 /* labels[index[i]] = 1 + argmin_k |X[i] - centers[k]|  (first minimum);
  * labels (npix) int32 must be zero-filled by the caller (background = 0). */
 int clx_ms_assign(const double* X, const int* index, int nfg,
                   const double* centers, int ncenters, int ND, int* labels,
                   clx_stream stream);
+/* The same result with the centres bucketed into a uniform grid (order: centre ids sorted by
+ * cell, cell_start: (nx*ny*nz + 1) offsets into it, cell index = clamp(floor((c - origin) /
+ * cell))): a pixel examines the 3^ND cells around it and falls back to all centres only when
+ * no candidate is closer than `cell`.  `origin` is a HOST pointer to ND doubles. */
+int clx_ms_assign_grid(const double* X, const int* index, int nfg, const double* centers,
+                       int ncenters, int ND, const int* order, const int* cell_start,
+                       const double* origin, double cell, int nx, int ny, int nz, int* labels,
+                       clx_stream stream);
 
 /* ------------------------------------------------------------------------ */
 /* Greedy clustering (cellulus/utils/greedy_cluster.py:46-120,176-253)      */

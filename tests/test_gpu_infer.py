@@ -365,6 +365,67 @@ def test_mean_shift_grid_kernel_equals_bruteforce(nd, device):
     assert int(n2.item()) == 0 and int(i2.item()) == 0
 
 
+@pytest.mark.parametrize("nd", [2, 3])
+def test_bucket_kernel_is_a_stable_sort_by_cell(nd, device):
+    """clx_ms_bucket == stable sort of the points by uniform-grid cell id (x fastest) + exclusive
+    scan of the cell histogram, for clustered points (thousands per cell) and scattered ones."""
+    from cellulus_amd.utils import mean_shift as MS
+
+    rng = np.random.default_rng(nd)
+    clustered = np.concatenate([rng.normal(loc=c, scale=2.0, size=(3000, nd)) for c in rng.uniform(0, 300, size=(12, nd))])
+    scattered = rng.uniform(-50, 400, size=(5000, nd))
+    pts = np.concatenate([clustered, scattered, clustered[:7]])[rng.permutation(41007)]
+    bw = 11.0
+    fs, cell_start, origin, cell, (nx, ny, nz) = MS._bucket(torch.from_numpy(pts).to(device), bw)
+    coords = np.floor((pts - pts.min(axis=0)) / cell).astype(np.int64)
+    assert (nx, ny) == (coords[:, 0].max() + 1, coords[:, 1].max() + 1) and nz == (coords[:, 2].max() + 1 if nd == 3 else 1)
+    cid = coords[:, 0] + nx * coords[:, 1] + (nx * ny * coords[:, 2] if nd == 3 else 0)
+    order = np.argsort(cid, kind="stable")
+    np.testing.assert_array_equal(fs.cpu().numpy(), pts[order])
+    ref_start = np.concatenate([[0], np.cumsum(np.bincount(cid, minlength=nx * ny * nz))])
+    np.testing.assert_array_equal(cell_start.cpu().numpy(), ref_start)
+    np.testing.assert_array_equal(origin, pts.min(axis=0))
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_grid_assignment_equals_the_plain_nearest_centre_loop(nd, device):
+    """clx_ms_assign_grid == clx_ms_assign (first minimum over all centres): pixels near their centre,
+    pixels far from every centre (fall back to the full loop), exact ties between two centres
+    (the smaller index wins), centres sharing a cell."""
+    import ctypes
+
+    from cellulus_amd import _clx
+    from cellulus_amd.utils import mean_shift as MS
+
+    rng = np.random.default_rng(10 + nd)
+    K, bw = 150, 9.0
+    centers = rng.uniform(0, 400, size=(K, nd))
+    centers[5] = centers[4] + 0.5                      # two centres in one cell
+    centers[7] = centers[6]
+    centers[7, 0] += 4.0                                # tie partners: (6, 7) around their midpoint
+    near = centers[rng.integers(0, K, size=20000)] + rng.normal(0, 2.0, size=(20000, nd))
+    far = rng.uniform(-200, 800, size=(3000, nd))
+    mid = np.repeat((0.5 * (centers[6] + centers[7]))[None], 16, axis=0)
+    mid[:, 1] += np.arange(16) * 0.25                    # equidistant to centres 6 and 7, exactly
+    pts = np.concatenate([near, far, mid])
+    n = len(pts)
+    X = torch.from_numpy(pts).to(device)
+    index = torch.arange(n, dtype=torch.int32, device=device)
+    cc = torch.from_numpy(centers).to(device)
+    st = _clx.stream_ptr(device)
+    ref = torch.zeros(n, dtype=torch.int32, device=device)
+    _clx.call("clx_ms_assign", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc), K, nd, _clx.ptr(ref), st)
+    order, cstart, origin, (gx, gy, gz) = MS._center_grid(centers, bw)
+    got = torch.zeros(n, dtype=torch.int32, device=device)
+    _clx.call("clx_ms_assign_grid", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc), K, nd,
+              _clx.ptr(torch.from_numpy(order).to(device)), _clx.ptr(torch.from_numpy(cstart).to(device)),
+              (ctypes.c_double * nd)(*origin.tolist()), bw, gx, gy, gz, _clx.ptr(got), st)
+    np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    d2 = ((pts[:, None, :] - centers[None]) ** 2).sum(-1)
+    np.testing.assert_array_equal(ref.cpu().numpy()[:-16], d2.argmin(1)[:-16] + 1)
+    assert set(ref.cpu().numpy()[-16:].tolist()) <= {7, 8}
+
+
 # ------------------------------------------------------------------ greedy clustering
 @pytest.mark.parametrize("case", ["2d", "3d"])
 def test_greedy_cluster_matches_reference_golden(case, device):
