@@ -112,8 +112,12 @@ def streaming_rooflines(device, size=4096):
     _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts), _clx.ptr(idx),
               _clx.ptr(nfg), _clx.ptr(ws), st)
     labels = torch.zeros(npix, dtype=torch.int32, device=device)
-    cy, cx = np.meshgrid(np.arange(24, size, 48), np.arange(24, size, 48), indexing="ij")
-    centers = np.stack([cx.ravel(), cy.ravel()], 1).astype(np.float64) + rng.uniform(-6, 6, size=(cx.size, 2))
+    # the cluster centres mean-shift finds on one 512^2 tile, repeated for every tile of the image
+    np.random.seed(1)
+    _lab, base_centers = MS.mean_shift_on_device(torch.from_numpy(mean[0]).to(device), torch.from_numpy(std).to(device),
+                                                 15.0, 0.1, 0.5, None)
+    shifts = np.stack(np.meshgrid(np.arange(reps) * 512.0, np.arange(reps) * 512.0, indexing="ij"), -1).reshape(-1, 2)
+    centers = (base_centers[None, :, :] + shifts[:, None, ::-1]).reshape(-1, 2)       # (x, y) columns
     cc = torch.from_numpy(centers).to(device)
     order, cstart, corigin, (gx, gy, gz) = MS._center_grid(centers, 15.0)
     order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)

@@ -94,26 +94,38 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
       if (w == wid) mine[k] = total;
       total += wcount[k][w];
     }
-  if (tid == 0) {
-    int excl = 0;
-    if (tile == 0) {
-      __hip_atomic_store(&desc[0], (2ull << 32) | (unsigned int)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      __hip_atomic_store(&desc[tile], (1ull << 32) | (unsigned int)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      int j = tile - 1;
-      while (true) {
-        const unsigned long long d = __hip_atomic_load(&desc[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned int st = (unsigned int)(d >> 32);
-        if (st == 0) { __builtin_amdgcn_s_sleep(1); continue; }     // predecessor has not published yet
-        excl += (int)(unsigned int)d;
-        if (st == 2) break;
-        --j;
-      }
-      __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELEASE,
+  // decoupled look-back by the first wavefront: lane l inspects predecessor tile - 1 - l of the
+  // current window of 64; the nearest predecessor that already knows its inclusive prefix ends
+  // the walk, the aggregates in front of it are summed (a single thread doing this one
+  // descriptor at a time serialises the whole grid)
+  if (wid == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)total, __ATOMIC_RELEASE,
                          __HIP_MEMORY_SCOPE_AGENT);
+    int excl = 0;
+    for (int hi = tile - 1; hi >= 0; hi -= 64) {
+      const int j = hi - lane;
+      unsigned long long d = 2ull << 32;              // tiles before the first: prefix 0
+      if (j >= 0) {
+        do {
+          d = __hip_atomic_load(&desc[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned int)(d >> 32) == 0);       // predecessor has not published yet
+      }
+      const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
+      const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 64;      // nearest tile with a prefix
+      int v = (lane <= stop) ? (int)(unsigned int)d : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      excl += v;
+      if (has_prefix) break;
     }
-    s_excl = excl;
-    if (tile == ntiles - 1) *nfg_out = excl + total;
+    if (lane == 0) {
+      if (tile > 0)
+        __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELEASE,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_excl = excl;
+      if (tile == ntiles - 1) *nfg_out = excl + total;
+    }
   }
   __syncthreads();
   const int excl = s_excl;
@@ -391,8 +403,9 @@ __global__ __launch_bounds__(256) void bucket_order_kernel(const double* __restr
 // the 3^ND cells around its own; every centre outside that block is at least h away, so a
 // candidate closer than h (strictly) is the exact nearest centre — ties inside the block are broken
 // towards the smaller index, which is the "first minimum" of the plain loop.  A pixel farther
-// than h from all its candidates falls back to the plain loop over all centres (rare: pixels
-// cluster around their centre by construction).  Cuts nfg x ncentres pair evaluations to
+// than h from all its candidates doubles the block radius r (centres outside are >= r h away)
+// until the candidate is closer than that or the block is the whole grid (rare: pixels cluster
+// around their centre by construction).  Cuts nfg x ncentres pair evaluations to
 // nfg x (centres in 3^ND cells).
 template <int ND>
 __global__ __launch_bounds__(256) void ms_assign_grid_kernel(
@@ -410,35 +423,30 @@ __global__ __launch_bounds__(256) void ms_assign_grid_kernel(
   const int cz = (ND == 3) ? min(max((int)floor((x[2] - oz) * inv), 0), nz - 1) : 0;
   double best = 0.0;
   int arg = -1;
-  for (int zz = (ND == 3 ? cz - 1 : 0); zz <= (ND == 3 ? cz + 1 : 0); ++zz) {
-    if (zz < 0 || zz >= nz) continue;
-    for (int yy = cy - 1; yy <= cy + 1; ++yy) {
-      if (yy < 0 || yy >= ny) continue;
-      const long long row = ((long long)zz * ny + yy) * nx;
-      const int lo = cell_start[row + max(cx - 1, 0)], hi = cell_start[row + min(cx + 1, nx - 1) + 1];
-      for (int j = lo; j < hi; ++j) {
-        const int k = order[j];
-        double d2 = 0.0;
-#pragma unroll
-        for (int c = 0; c < ND; ++c) {
-          const double df = x[c] - centers[(long long)k * ND + c];
-          d2 += df * df;
-        }
-        if (arg < 0 || d2 < best || (d2 == best && k < arg)) { best = d2; arg = k; }
-      }
-    }
-  }
-  if (arg < 0 || !(best < h * h)) {
+  // block of cells within r of the pixel's own: every centre outside it is at least r * h away
+  for (int r = 1;; r *= 2) {
+    const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
+    const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
+    const int z0 = (ND == 3) ? max(cz - r, 0) : 0, z1 = (ND == 3) ? min(cz + r, nz - 1) : 0;
     arg = -1;
-    for (int k = 0; k < ncenters; ++k) {
-      double d2 = 0.0;
+    for (int zz = z0; zz <= z1; ++zz)
+      for (int yy = y0; yy <= y1; ++yy) {
+        const long long row = ((long long)zz * ny + yy) * nx;
+        const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];
+        for (int j = lo; j < hi; ++j) {
+          const int k = order[j];
+          double d2 = 0.0;
 #pragma unroll
-      for (int c = 0; c < ND; ++c) {
-        const double df = x[c] - centers[(long long)k * ND + c];
-        d2 += df * df;
+          for (int c = 0; c < ND; ++c) {
+            const double df = x[c] - centers[(long long)k * ND + c];
+            d2 += df * df;
+          }
+          if (arg < 0 || d2 < best || (d2 == best && k < arg)) { best = d2; arg = k; }
+        }
       }
-      if (arg < 0 || d2 < best) { best = d2; arg = k; }
-    }
+    const bool whole = x0 == 0 && x1 == nx - 1 && y0 == 0 && y1 == ny - 1 && z0 == 0 && z1 == nz - 1;
+    const double reach = (double)r * h;
+    if (whole || (arg >= 0 && best < reach * reach)) break;
   }
   labels[index[i]] = arg + 1;
 }

@@ -417,8 +417,9 @@ def test_grid_assignment_equals_the_plain_nearest_centre_loop(nd, device):
     _clx.call("clx_ms_assign", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc), K, nd, _clx.ptr(ref), st)
     order, cstart, origin, (gx, gy, gz) = MS._center_grid(centers, bw)
     got = torch.zeros(n, dtype=torch.int32, device=device)
+    order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)
     _clx.call("clx_ms_assign_grid", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc), K, nd,
-              _clx.ptr(torch.from_numpy(order).to(device)), _clx.ptr(torch.from_numpy(cstart).to(device)),
+              _clx.ptr(order_d), _clx.ptr(cstart_d),
               (ctypes.c_double * nd)(*origin.tolist()), bw, gx, gy, gz, _clx.ptr(got), st)
     np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
     d2 = ((pts[:, None, :] - centers[None]) ** 2).sum(-1)
