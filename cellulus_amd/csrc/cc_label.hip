@@ -22,11 +22,25 @@ __device__ __forceinline__ int uf_find(const int* L, int a) {
   return a;
 }
 
+// find with path halving: every visited node is re-pointed at its grandparent.  A plain store is
+// enough: only non-roots are written (a root is changed by the atomicMin of a union alone), and any
+// ancestor is a valid parent, so a lost or stale write merely leaves a longer path.
+__device__ __forceinline__ int uf_find_halve(int* L, int a) {
+  int p = L[a];
+  while (p != a) {
+    const int gp = L[p];
+    if (gp != p) L[a] = gp;
+    a = p;
+    p = gp;
+  }
+  return a;
+}
+
 __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   bool done;
   do {
-    a = uf_find(L, a);
-    b = uf_find(L, b);
+    a = uf_find_halve(L, a);
+    b = uf_find_halve(L, b);
     if (a < b) {
       const int old = atomicMin(&L[b], a);
       done = (old == b);

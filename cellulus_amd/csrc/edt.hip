@@ -295,6 +295,139 @@ __global__ void grow_shrink_phantom(int* __restrict__ seg, int Z, int Y, int X, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2-D grow / shrink on BIT rows.  "d1 < grow" is a dilation of the foreground by the disc
+// {dx^2 + dy^2 < grow^2}, "d2 < shrink" a dilation of the non-expanded set by the disc of the shrink
+// bound; on a row packed 64 pixels per word a horizontal dilation by r is 2r shift-ORs, and with one
+// image row per LANE the vertical part is cross-lane shuffles — no LDS, no per-pixel work at all:
+//   gs_bits_kernel : seg -> 1 bit per pixel (wave ballot), 4 B read + 1/8 B written per pixel
+//   gs_rows_kernel : a wavefront owns 64 rows (H = grow - 1 + shrink - 1 halo rows on either side)
+//                    of one 64-pixel word column, reads the word and its two neighbours per row
+//                    (a 128-bit window: 32 halo pixels each side), computes the pixels to clear
+//                    and stores zeros there — the only 4-byte traffic after the first pass.
+// The phantom-zero cases are the ones of the tile kernel above.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned __int128 u128;
+
+__global__ __launch_bounds__(256) void gs_bits_kernel(const int* __restrict__ seg, unsigned long long* __restrict__ bits,
+                                                      int Y, int X, int W64) {
+  const int lane = threadIdx.x & 63;
+  const long long nwaves = (long long)Y * W64;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const int y = (int)(w / W64), wx = (int)(w - (long long)y * W64);
+    const int x = wx * 64 + lane;
+    const bool f = x < X && seg[(long long)y * X + x] != 0;
+    const unsigned long long b = __ballot(f);
+    if (lane == 0) bits[w] = b;
+  }
+}
+
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+  const int lo = __shfl((int)(unsigned int)v, src, 64), hi = __shfl((int)(unsigned int)(v >> 32), src, 64);
+  return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+}
+
+// largest dx >= 0 with dx^2 + dy^2 < bound^2, -1 if none (dy >= bound)
+__device__ __forceinline__ int disc_halfwidth(int dy, int bound) {
+  if (bound <= 0) return -1;          // "distance < bound" never holds
+  int r = -1;
+  while ((r + 1) * (r + 1) + dy * dy < bound * bound) ++r;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void gs_rows_kernel(int* __restrict__ seg, const unsigned long long* __restrict__ bits,
+                                                      int Y, int X, int W64, int grow, int shrink, int rows_per_wave,
+                                                      int ntiles_y, int* __restrict__ flag_nonexp) {
+  const int lane = threadIdx.x & 63;
+  const int g1 = grow > 0 ? grow - 1 : 0, s1 = shrink > 0 ? shrink - 1 : 0, H = g1 + s1;
+  const long long nwaves = (long long)ntiles_y * W64;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const int ty = (int)(w / W64), wx = (int)(w - (long long)ty * W64);
+    const int y = ty * rows_per_wave - H + lane;               // this lane's image row
+    const bool row_in = (unsigned)y < (unsigned)Y;
+    unsigned long long wl = 0, wm = 0, wr = 0;
+    if (row_in) {
+      const unsigned long long* row = bits + (long long)y * W64;
+      wm = row[wx];
+      if (wx > 0) wl = row[wx - 1];
+      if (wx + 1 < W64) wr = row[wx + 1];
+    }
+    // window of pixels [64 wx - 32, 64 wx + 96): bit 32 + k is pixel 64 wx + k
+    const u128 fg = ((u128)wr << 96) | ((u128)wm << 32) | (u128)(wl >> 32);
+    // pixels of the window that exist
+    u128 inimg = 0;
+    if (row_in) {
+      const int x_lo = wx * 64 - 32;
+      const int first = x_lo < 0 ? -x_lo : 0;
+      const int last = min(128, X - x_lo);                       // exclusive
+      inimg = (last >= 128 ? ~(u128)0 : (((u128)1 << last) - 1)) & ~(((u128)1 << first) - 1);
+    }
+    // ---- expanded = foreground dilated by the disc of `grow`
+    u128 expanded = 0;
+    {
+      u128 D = 0;
+      int cur = -1;
+      for (int ady = g1; ady >= 0; --ady) {
+        const int R = disc_halfwidth(ady, grow);
+        if (R < 0) continue;
+        while (cur < R) { ++cur; D |= (fg << cur) | (fg >> cur); }
+        const unsigned long long dlo = (unsigned long long)D, dhi = (unsigned long long)(D >> 64);
+        const u128 up = ((u128)shfl_u64(dhi, lane - ady) << 64) | shfl_u64(dlo, lane - ady);
+        expanded |= up;
+        if (ady) expanded |= ((u128)shfl_u64(dhi, lane + ady) << 64) | shfl_u64(dlo, lane + ady);
+      }
+    }
+    const u128 nonexp = ~expanded & inimg;
+    const bool interior = lane >= H && lane < H + rows_per_wave && row_in;
+    const unsigned long long ne_mid = (unsigned long long)(nonexp >> 32);
+    if (__any(interior && ne_mid != 0) && lane == 0) atomicOr(flag_nonexp, 1);
+    // ---- cleared = non-expanded set dilated by the disc of `shrink` (middle word only)
+    unsigned long long clear = 0;
+    {
+      u128 D = 0;
+      int cur = -1;
+      for (int ady = s1; ady >= 0; --ady) {
+        const int R = disc_halfwidth(ady, shrink);
+        if (R < 0) continue;
+        while (cur < R) { ++cur; D |= (nonexp << cur) | (nonexp >> cur); }
+        const unsigned long long dm = (unsigned long long)(D >> 32);
+        clear |= shfl_u64(dm, lane - ady);
+        if (ady) clear |= shfl_u64(dm, lane + ady);
+      }
+    }
+    clear &= wm;                                  // only foreground pixels hold anything to clear
+    if (!interior) clear = 0;
+    // ---- apply: one row per iteration, the wavefront's lanes are the 64 pixels of the word
+    unsigned long long rows = __ballot(clear != 0);
+    while (rows) {
+      const int src = __builtin_ctzll(rows);
+      rows &= rows - 1;
+      const unsigned long long m = shfl_u64(clear, src);
+      const int yy = ty * rows_per_wave - H + src;
+      if ((m >> lane) & 1ull) seg[(long long)yy * X + wx * 64 + lane] = 0;
+    }
+  }
+}
+
+int grow_shrink_bitrows(int* seg, int Y, int X, int grow, int shrink, void* workspace, hipStream_t st) {
+  const int g1 = grow > 0 ? grow - 1 : 0, s1 = shrink > 0 ? shrink - 1 : 0, H = g1 + s1;
+  const int W64 = (X + 63) / 64;
+  const int rows_per_wave = 64 - 2 * H;
+  const int ntiles_y = (Y + rows_per_wave - 1) / rows_per_wave;
+  int* flag = (int*)workspace;
+  unsigned long long* bits = (unsigned long long*)((unsigned char*)workspace + 16);
+  if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return CLX_ERR_LAUNCH;
+  const long long w1 = (long long)Y * W64, w2 = (long long)ntiles_y * W64;
+  gs_bits_kernel<<<grid_for(w1 * 64, 256), 256, 0, st>>>(seg, bits, Y, X, W64);
+  gs_rows_kernel<<<grid_for(w2 * 64, 256), 256, 0, st>>>(seg, bits, Y, X, W64, grow, shrink, rows_per_wave, ntiles_y,
+                                                         flag);
+  const long long npix = (long long)Y * X;
+  grow_shrink_phantom<<<grid_for(npix, 256) < 1024 ? grid_for(npix, 256) : 1024, 256, 0, st>>>(seg, 1, Y, X, shrink, flag);
+  return CLX_OK;
+}
+
 template <int ND>
 size_t gs_smem_bytes(int grow, int shrink) {
   using T = GsTile<ND>;
@@ -364,6 +497,12 @@ extern "C" int clx_grow_shrink(int* seg, int Z, int Y, int X, int grow, int shri
   {
     const int g1 = grow > 0 ? grow - 1 : 0, s1 = shrink > 0 ? shrink - 1 : 0;
     const bool three_d = Z > 1;
+    if (!three_d && g1 + s1 <= 16 && ((uintptr_t)workspace & 15) == 0) {
+      const int rc = grow_shrink_bitrows(seg, Y, X, grow, shrink, workspace, st0);
+      if (rc) { clx_set_error("clx_grow_shrink: memset failed"); return rc; }
+      CLX_CHECK_LAUNCH("clx_grow_shrink(bit rows)");
+      return CLX_OK;
+    }
     const size_t smem = three_d ? gs_smem_bytes<3>(grow, shrink) : gs_smem_bytes<2>(grow, shrink);
     if (g1 + s1 <= 24 && smem <= 150 * 1024 && ((uintptr_t)seg & 15) == 0 && ((uintptr_t)workspace & 15) == 0) {
       const int rc = three_d ? grow_shrink_tiled<3>(seg, Z, Y, X, grow, shrink, workspace, st0)

