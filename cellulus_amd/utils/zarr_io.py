@@ -3,7 +3,8 @@
 Covers what the hot path's callers need (``cellulus/datasets/meta_data.py``,
 ``predict.py:103-142``, ``detect.py:18-80``, ``segment.py:19-38``,
 ``train.py:194-224``): C-order arrays of bool/int/uint/float dtypes, chunked,
-``compressor`` null / zlib / gzip (Blosc chunks cannot be decoded here and raise),
+``compressor`` null / zlib / gzip / blosc (read only: the LZ4 and zlib codecs, i.e. what
+zarr-python writes by default; decoded by libclx's host-side LZ4 block decoder),
 ``fill_value``, ``.zattrs``.  Groups are plain directories with a ``.zgroup``.
 """
 
@@ -69,6 +70,86 @@ class Attributes:
         return self._load().keys()
 
 
+_BLOSC_CODECS = {0: "blosclz", 1: "lz4", 2: "snappy", 3: "zlib", 4: "zstd"}
+
+
+def blosc_decode(raw):
+    """One Blosc (format 2, c-blosc 1.x — what numcodecs.Blosc writes) chunk -> bytes.
+
+    Layout: 16-byte header (version, versionlz, flags, typesize, nbytes, blocksize, cbytes), then —
+    unless the chunk is stored verbatim (flag 0x02) — a table of block start offsets and the
+    blocks.  A block is `typesize` separately compressed byte planes ("splits") when it was
+    byte-shuffled into planes of >= 128 bytes and the don't-split flag (0x10) is clear, else one
+    stream; every stream is an int32 length followed by the codec's output (or the bytes
+    themselves when the length equals the plain size); the last, shorter block is never split.
+    Codecs: LZ4 / LZ4HC (zarr's default, decoded by libclx's clx_lz4_decompress) and zlib;
+    byte shuffle is undone by clx_unshuffle_bytes.  blosclz, snappy, zstd and bit-shuffle are
+    not implemented and raise."""
+    import ctypes
+
+    from .. import _clx
+
+    raw = bytes(raw)
+    if len(raw) < 16:
+        raise ZarrError("Blosc chunk shorter than its header")
+    flags, typesize = raw[2], raw[3]
+    nbytes, blocksize, cbytes = (int.from_bytes(raw[o:o + 4], "little") for o in (4, 8, 12))
+    if cbytes > len(raw) or typesize < 1:
+        raise ZarrError("corrupt Blosc header")
+    if nbytes == 0:
+        return b""
+    if flags & 0x02:                                     # memcpyed
+        return raw[16:16 + nbytes]
+    if flags & 0x04:
+        raise ZarrError("Blosc bit-shuffle is not supported by this reader (byte shuffle and no shuffle are)")
+    codec = _BLOSC_CODECS.get(flags >> 5, "?")
+    if codec not in ("lz4", "zlib"):
+        raise ZarrError(f"Blosc codec {codec!r} is not supported by this reader (lz4, lz4hc and zlib are); "
+                        "re-save the array with Blosc(cname='lz4') (zarr's default) or an uncompressed / zlib compressor")
+    if blocksize <= 0:
+        raise ZarrError("corrupt Blosc header (block size)")
+    nblocks = -(-nbytes // blocksize)
+    leftover = nbytes % blocksize
+    shuffle = bool(flags & 0x01) and typesize > 1
+    dont_split = bool(flags & 0x10)
+    lib = _clx.load()
+    src = np.frombuffer(raw, dtype=np.uint8)
+    out = np.empty(nbytes, dtype=np.uint8)
+    tmp = np.empty(blocksize, dtype=np.uint8)
+    u8p = ctypes.c_void_p
+    for b in range(nblocks):
+        bsize = leftover if (b == nblocks - 1 and leftover) else blocksize
+        is_leftover = b == nblocks - 1 and leftover > 0
+        pos = int.from_bytes(raw[16 + 4 * b:20 + 4 * b], "little")
+        nsplits = typesize if (not dont_split and typesize <= 16 and blocksize // typesize >= 128
+                               and not is_leftover) else 1
+        neblock = bsize // nsplits
+        target = tmp if shuffle else out[b * blocksize:]
+        done = 0
+        for _ in range(nsplits):
+            clen = int.from_bytes(raw[pos:pos + 4], "little", signed=True)
+            pos += 4
+            if clen < 0 or pos + clen > len(raw):
+                raise ZarrError("corrupt Blosc block")
+            if clen == neblock:
+                target[done:done + neblock] = src[pos:pos + neblock]
+            elif codec == "lz4":
+                n = lib.clx_lz4_decompress(u8p(src.ctypes.data + pos), clen, u8p(target.ctypes.data + done), neblock)
+                if n != neblock:
+                    raise ZarrError(f"LZ4 stream of a Blosc block decoded to {n} bytes, expected {neblock}")
+            else:
+                piece = zlib.decompress(raw[pos:pos + clen])
+                if len(piece) != neblock:
+                    raise ZarrError("zlib stream of a Blosc block has the wrong length")
+                target[done:done + neblock] = np.frombuffer(piece, dtype=np.uint8)
+            pos += clen
+            done += neblock
+        if shuffle:
+            dst = out[b * blocksize:]
+            lib.clx_unshuffle_bytes(u8p(tmp.ctypes.data), u8p(dst.ctypes.data), bsize, typesize)
+    return out.tobytes()
+
+
 def _decode(raw, compressor):
     if compressor is None:
         return raw
@@ -77,7 +158,9 @@ def _decode(raw, compressor):
         return zlib.decompress(raw)
     if cid == "gzip":
         return gzip.decompress(raw)
-    raise ZarrError(f"unsupported zarr compressor {cid!r} (only null, zlib and gzip can be read here)")
+    if cid == "blosc":
+        return blosc_decode(raw)
+    raise ZarrError(f"unsupported zarr compressor {cid!r} (null, zlib, gzip and blosc[lz4 | zlib] can be read here)")
 
 
 def _encode(raw, compressor):

@@ -432,6 +432,16 @@ int clx_joint_histogram(const int32_t* pred, const int32_t* gt, long long n,
                         const int32_t* pred_row, const int32_t* gt_col, int ncol,
                         unsigned long long* joint, clx_stream stream);
 
+/* ------------------------------------------------------------------------ */
+/* Input decoding (host side): the Blosc/LZ4 chunks zarr writes by default    */
+/* (docs/examples/2d/01-data.py:35-50, read by zarr_dataset.py:104-121)       */
+/* ------------------------------------------------------------------------ */
+/* LZ4 block decoder on HOST buffers; returns the bytes written (<= dst_capacity) or < 0. */
+long long clx_lz4_decompress(const unsigned char* src, long long src_bytes, unsigned char* dst,
+                             long long dst_capacity);
+/* inverse of Blosc's byte shuffle for n bytes of elements of `typesize` bytes (HOST buffers) */
+int clx_unshuffle_bytes(const unsigned char* src, unsigned char* dst, long long n, int typesize);
+
 #ifdef __cplusplus
 }
 #endif

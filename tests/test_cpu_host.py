@@ -502,3 +502,43 @@ def test_pair_sampler_matches_real_reference_golden(tag):
     np.testing.assert_array_equal(references, g[f"{tag}/references"])
     np.testing.assert_array_equal([ds.get_num_anchors(), ds.get_num_references(), ds.get_num_samples()],
                                   g[f"{tag}/counts"])
+
+
+# ------------------------------------------------------------------ Blosc input
+def test_blosc_chunks_written_by_the_real_c_blosc_decode(tmp_path):
+    """g12: chunks compressed by the real c-blosc (tests/golden/make_golden_blosc.py, conda's
+    imagecodecs) — LZ4 / LZ4HC / zlib, byte shuffle on and off, split and unsplit blocks, several
+    blocks with a shorter last one, an incompressible (stored) chunk, a tiny one — decode to the
+    original arrays, directly and through a zarr array whose compressor is zarr's default Blosc."""
+    import json
+
+    from cellulus_amd.utils import zarr_io
+
+    g = np.load(os.path.join(G, "g12_blosc.npz"))
+    names = sorted({k.split("/")[0] for k in g.files})
+    assert len(names) >= 9
+    for name in names:
+        arr, chunk = g[f"{name}/array"], g[f"{name}/chunk"].tobytes()
+        assert zarr_io.blosc_decode(chunk) == arr.tobytes(), name
+    # a zarr array as zarr-python lays it out: one chunk per sample, compressor = Blosc(lz4, 5, SHUFFLE)
+    arr = g["u8_lz4_shuffle/array"]                       # (2, 1, 64, 80): the whole array is one chunk here
+    path = tmp_path / "c.zarr" / "train" / "raw"
+    os.makedirs(path)
+    (tmp_path / "c.zarr" / ".zgroup").write_text('{"zarr_format": 2}')
+    (tmp_path / "c.zarr" / "train" / ".zgroup").write_text('{"zarr_format": 2}')
+    (path / ".zarray").write_text(json.dumps({
+        "zarr_format": 2, "shape": list(arr.shape), "chunks": list(arr.shape), "dtype": arr.dtype.str,
+        "compressor": {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0},
+        "fill_value": 0, "order": "C", "filters": None}))
+    (path / ".zattrs").write_text(json.dumps({"axis_names": ["s", "c", "y", "x"]}))
+    (path / "0.0.0.0").write_bytes(g["u8_lz4_shuffle/chunk"].tobytes())
+    ds = zarr_io.open(tmp_path / "c.zarr", "r")["train/raw"]
+    np.testing.assert_array_equal(ds[...], arr)
+    np.testing.assert_array_equal(ds[1, 0, 10:20, 5:9], arr[1, 0, 10:20, 5:9])
+    # corrupt / unsupported input fails loudly
+    bad = bytearray(g["f32_lz4_shuffle/chunk"].tobytes())
+    bad[2] = (bad[2] & 0x1f) | (4 << 5)                   # claims zstd
+    with pytest.raises(zarr_io.ZarrError, match="zstd"):
+        zarr_io.blosc_decode(bytes(bad))
+    with pytest.raises(zarr_io.ZarrError):
+        zarr_io.blosc_decode(g["f32_lz4_shuffle/chunk"].tobytes()[:40] + b"\x00" * 100)
