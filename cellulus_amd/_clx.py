@@ -94,6 +94,8 @@ PROTOTYPES = {
     "clx_pixel_to_planar": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_depth_to_space": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_space_to_depth": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_subpixel_split_weights": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    "clx_subpixel_fold_grads": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
     "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_maxpool_bwd": (_I, [_P, _P, _P, _P] + [_I] * 7 + [_P] + [_I] * 8 + [_P]),
     "clx_upsample_bwd": (_I, [_P] + [_I] * 8 + [_P, _P] + [_I] * 8 + [_P]),

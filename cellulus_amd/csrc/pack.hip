@@ -67,6 +67,85 @@ __global__ void pixel_to_planar_kernel(const float* __restrict__ pixel, float* _
   }
 }
 
+// ---- sub-pixel form of the convolution over a nearest-upsampled tensor ----
+// Along an axis with factor 2 the three taps of an output pixel of parity a fall on two low-res
+// rows: a = 0: taps {0, 1} -> row 0, {2} -> row 1;  a = 1: {0} -> row 0, {1, 2} -> row 1.
+// Axes with factor 1 keep their taps (one "phase", low tap = tap).
+__device__ __forceinline__ int sp_low_tap(int f, int a, int tap) {
+  if (f == 1) return tap;
+  return a == 0 ? (tap == 2 ? 1 : 0) : (tap == 0 ? 0 : 1);
+}
+
+struct SpGeom {
+  int cout, cin, C0, C1, N;      // N = padded cout (rows per phase)
+  int k[3], f[3], zk[3];         // kernel, factors, low-res kernel per axis (z, y, x)
+};
+
+// w (cout, cin, kd, kh, kw) -> w_skip (cout, C0, taps) and weff (P*N, C1, ztaps), weff = the taps of
+// the upsampled half summed per phase; rows of padded output channels are zero
+__global__ void subpixel_split_kernel(const float* __restrict__ w, float* __restrict__ w_skip,
+                                      float* __restrict__ weff, SpGeom g, long long n_skip, long long n_eff) {
+  const int taps = g.k[0] * g.k[1] * g.k[2], ztaps = g.zk[0] * g.zk[1] * g.zk[2];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_skip + n_eff;
+       i += (long long)gridDim.x * blockDim.x) {
+    if (i < n_skip) {
+      const int tap = (int)(i % taps);
+      const long long t = i / taps;
+      const int c = (int)(t % g.C0), n = (int)(t / g.C0);
+      w_skip[i] = w[((long long)n * g.cin + c) * taps + tap];
+      continue;
+    }
+    const long long j = i - n_skip;
+    const int zt = (int)(j % ztaps);
+    const long long t = j / ztaps;
+    const int c = (int)(t % g.C1);
+    const int row = (int)(t / g.C1);
+    const int n = row % g.N, ph = row / g.N;
+    float v = 0.f;
+    if (n < g.cout) {
+      const int r[3] = {zt / (g.zk[1] * g.zk[2]), (zt / g.zk[2]) % g.zk[1], zt % g.zk[2]};
+      const int a[3] = {ph / (g.f[1] * g.f[2]), (ph / g.f[2]) % g.f[1], ph % g.f[2]};
+      const float* src = w + ((long long)n * g.cin + g.C0 + c) * taps;
+      for (int d = 0; d < g.k[0]; ++d) {
+        if (sp_low_tap(g.f[0], a[0], d) != r[0]) continue;
+        for (int h = 0; h < g.k[1]; ++h) {
+          if (sp_low_tap(g.f[1], a[1], h) != r[1]) continue;
+          for (int x = 0; x < g.k[2]; ++x)
+            if (sp_low_tap(g.f[2], a[2], x) == r[2]) v += src[(d * g.k[1] + h) * g.k[2] + x];
+        }
+      }
+    }
+    weff[j] = v;
+  }
+}
+
+// the adjoint: g_skip (cout, C0, taps), g_eff (P*N, C1, ztaps) -> gw (cout, cin, taps)
+__global__ void subpixel_fold_kernel(const float* __restrict__ g_skip, const float* __restrict__ g_eff,
+                                     float* __restrict__ gw, SpGeom g, long long total) {
+  const int taps = g.k[0] * g.k[1] * g.k[2], ztaps = g.zk[0] * g.zk[1] * g.zk[2];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % taps);
+    const long long t = i / taps;
+    const int c = (int)(t % g.cin), n = (int)(t / g.cin);
+    if (c < g.C0) {
+      gw[i] = g_skip[((long long)n * g.C0 + c) * taps + tap];
+      continue;
+    }
+    const int d = tap / (g.k[1] * g.k[2]), h = (tap / g.k[2]) % g.k[1], x = tap % g.k[2];
+    float v = 0.f;
+    for (int a0 = 0; a0 < g.f[0]; ++a0)
+      for (int a1 = 0; a1 < g.f[1]; ++a1)
+        for (int a2 = 0; a2 < g.f[2]; ++a2) {
+          const int ph = (a0 * g.f[1] + a1) * g.f[2] + a2;
+          const int zt = (sp_low_tap(g.f[0], a0, d) * g.zk[1] + sp_low_tap(g.f[1], a1, h)) * g.zk[2] +
+                         sp_low_tap(g.f[2], a2, x);
+          v += g_eff[(((long long)ph * g.N + n) * g.C1 + (c - g.C0)) * ztaps + zt];
+        }
+    gw[i] = v;
+  }
+}
+
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -133,5 +212,45 @@ extern "C" int clx_pixel_to_planar(const float* pixel, float* planar, int B, int
   pixel_to_planar_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
       pixel, planar, C, n, ld, total);
   CLX_CHECK_LAUNCH("clx_pixel_to_planar");
+  return CLX_OK;
+}
+
+static int sp_geom(SpGeom& g, int cout, int cin, int C0, int N, const int* k, const int* f, const char* who) {
+  CLX_REQUIRE(cout > 0 && cin > C0 && C0 > 0 && N >= cout, "%s: bad channel counts", who);
+  g.cout = cout; g.cin = cin; g.C0 = C0; g.C1 = cin - C0; g.N = N;
+  for (int d = 0; d < 3; ++d) {
+    CLX_REQUIRE((f[d] == 1 || (f[d] == 2 && k[d] == 3)) && k[d] >= 1 && k[d] <= 3,
+                "%s: factor must be 1, or 2 with a 3-tap axis", who);
+    g.k[d] = k[d]; g.f[d] = f[d]; g.zk[d] = f[d] == 2 ? 2 : k[d];
+  }
+  return CLX_OK;
+}
+
+extern "C" int clx_subpixel_split_weights(const float* w, float* w_skip, float* weff, int cout, int cin,
+                                          int C0, int N, int kd, int kh, int kw, int fz, int fy, int fx,
+                                          clx_stream stream) {
+  CLX_REQUIRE(w && w_skip && weff, "clx_subpixel_split_weights: null pointer");
+  SpGeom g;
+  const int k[3] = {kd, kh, kw}, f[3] = {fz, fy, fx};
+  const int rc = sp_geom(g, cout, cin, C0, N, k, f, "clx_subpixel_split_weights");
+  if (rc) return rc;
+  const long long n_skip = (long long)cout * C0 * kd * kh * kw;
+  const long long n_eff = (long long)fz * fy * fx * N * g.C1 * g.zk[0] * g.zk[1] * g.zk[2];
+  subpixel_split_kernel<<<grid_for(n_skip + n_eff, 256), 256, 0, (hipStream_t)stream>>>(w, w_skip, weff, g, n_skip, n_eff);
+  CLX_CHECK_LAUNCH("clx_subpixel_split_weights");
+  return CLX_OK;
+}
+
+extern "C" int clx_subpixel_fold_grads(const float* g_skip, const float* g_eff, float* gw, int cout, int cin,
+                                       int C0, int N, int kd, int kh, int kw, int fz, int fy, int fx,
+                                       clx_stream stream) {
+  CLX_REQUIRE(g_skip && g_eff && gw, "clx_subpixel_fold_grads: null pointer");
+  SpGeom g;
+  const int k[3] = {kd, kh, kw}, f[3] = {fz, fy, fx};
+  const int rc = sp_geom(g, cout, cin, C0, N, k, f, "clx_subpixel_fold_grads");
+  if (rc) return rc;
+  const long long total = (long long)cout * cin * kd * kh * kw;
+  subpixel_fold_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(g_skip, g_eff, gw, g, total);
+  CLX_CHECK_LAUNCH("clx_subpixel_fold_grads");
   return CLX_OK;
 }

@@ -342,6 +342,9 @@ class UNetPlan:
                         ws_bytes = max(ws_bytes, need)
                 ztaps = 25 * sp["zk"][0] if sp["wino"] else sp["ztaps"]
                 staps = 36 * info["conv0"].kernel[0] if sp["wino_skip"] else info["conv0"].taps
+                sp["w_skip"] = torch.empty(conv0.cout * sp["C0"] * conv0.taps, dtype=torch.float32, device=self.device)
+                sp["weff"] = torch.empty(sp["P"] * sp["N"] * sp["C1"] * sp["ztaps"], dtype=torch.float32,
+                                         device=self.device)
                 sp["wp_skip_fwd"] = torch.empty(sp["N"] * staps * sp["C0p"],
                                                 dtype=torch.float32, device=self.device)
                 sp["wp_z_fwd"] = torch.empty(sp["P"] * sp["N"] * ztaps * sp["C1p"],
@@ -386,13 +389,14 @@ class UNetPlan:
                 ztaps = 25 * sp["zk"][0] if sp["wino"] else sp["ztaps"]
                 sp["wp_z_dgrad"] = torch.empty(sp["C1p"] * ztaps * sp["P"] * sp["N"],
                                                dtype=torch.float32, device=self.device)
-                sp["dw_skip"] = torch.zeros((36 * layer.kernel[0] if sp["wino_skip"] else layer.taps) * sp["N"] * sp["C0p"],
-                                            dtype=torch.float32, device=self.device)
+                sp["_dw_skip_n"] = (36 * layer.kernel[0] if sp["wino_skip"] else layer.taps) * sp["N"] * sp["C0p"]
+                sp["g_skip"] = torch.empty(layer.cout * sp["C0"] * layer.taps, dtype=torch.float32, device=self.device)
+                sp["g_z"] = torch.empty(sp["P"] * sp["N"] * sp["C1"] * sp["ztaps"], dtype=torch.float32,
+                                        device=self.device)
                 if sp["wino_skip"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     tiles = self.B * layer.in_shape[0] * -(-layer.out_shape[1] // 4) * -(-layer.out_shape[2] // 4)
                     sp["vcache_skip"] = torch.empty(36 * tiles * sp["C0p"], dtype=torch.float32, device=self.device)
-                sp["dw_z"] = torch.zeros(ztaps * sp["P"] * sp["N"] * sp["C1p"], dtype=torch.float32,
-                                         device=self.device)
+                sp["_dw_z_n"] = ztaps * sp["P"] * sp["N"] * sp["C1p"]
                 if sp["wino"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     zs = sp["zshape"]
                     tiles = self.B * (zs[0] + sp["zk"][0] - 1) * -(-zs[1] // 4) * -(-zs[2] // 4)
@@ -417,7 +421,16 @@ class UNetPlan:
                 taps = wino_taps(code, layer.kernel) if code else layer.taps
                 self.wpack_dgrad[layer.name] = torch.empty(
                     layer.cin_pad * taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
+        # the sub-pixel layers' weight-gradient accumulators live behind the others: one fill zeroes all
+        sp_off = {}
+        for name, sp in self.subpixel.items():
+            sp_off[name] = (total, total + sp["_dw_skip_n"])
+            total += sp["_dw_skip_n"] + sp["_dw_z_n"]
         self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
+        for name, sp in self.subpixel.items():
+            a, b = sp_off[name]
+            sp["dw_skip"] = self.dwpack[a:b]
+            sp["dw_z"] = self.dwpack[b:b + sp["_dw_z_n"]]
         self._bwd_ready = True
 
     # --------------------------------------------------------------- sub-pixel
@@ -546,10 +559,14 @@ class UNetPlan:
         return dz, ds
 
     def _sp_pack(self, layer, sp, w, need_dgrad, st):
-        wv = w.detach().reshape((layer.cout, layer.cin) + tuple(layer.kernel))
-        w_skip = wv[:, :sp["C0"]].reshape(layer.cout, sp["C0"], layer.taps).contiguous()
-        weff = self._phase_weights(layer, sp, wv[:, sp["C0"]:]).reshape(sp["P"] * sp["N"], sp["C1"], sp["ztaps"])
-        weff = weff.contiguous()
+        # one launch: the skip half's weights and the phase-summed weights of the upsampled half
+        # (_phase_weights is the same algebra in torch ops, kept as the CPU-testable statement)
+        wv = w.detach()
+        if not wv.is_contiguous():
+            wv = wv.contiguous()
+        w_skip, weff = sp["w_skip"], sp["weff"]
+        _clx.call("clx_subpixel_split_weights", _clx.ptr(wv), _clx.ptr(w_skip), _clx.ptr(weff), layer.cout,
+                  layer.cin, sp["C0"], sp["N"], *layer.kernel, *sp["fac"], st)
         _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_fwd"]), layer.cout, sp["C0"],
                   layer.taps, sp["C0p"], sp["N"], 4 if sp["wino_skip"] else 0, st)
         _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_fwd"]), sp["P"] * sp["N"], sp["C1"],
@@ -559,7 +576,6 @@ class UNetPlan:
                       layer.taps, sp["C0p"], sp["N"], 5 if sp["wino_skip_dgrad"] else 1, st)
             _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_dgrad"]), sp["P"] * sp["N"],
                       sp["C1"], sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 5 if sp["wino"] else 1, st)
-        sp["_keepalive"] = (w_skip, weff)
 
     def _sp_forward(self, layer, sp, bias, st):
         dz, ds = self._sp_descs(layer, sp)
@@ -603,9 +619,7 @@ class UNetPlan:
         dzbuf = self.gbuf[sp["zname"]]
         _clx.call("clx_space_to_depth", _clx.ptr(dy), sp["N"], _clx.ptr(dzbuf), PN, self.B,
                   zs[0], zs[1], zs[2], sp["N"], *sp["fac"], st)
-        # weight gradients
-        sp["dw_skip"].zero_()
-        sp["dw_z"].zero_()
+        # weight gradients (dw_skip / dw_z are slices of self.dwpack: zeroed with it)
         ds.N = sp["N"]
         if sp["wino_skip"]:
             self._use_workspace(ds, sp["wino_skip"])
@@ -620,24 +634,22 @@ class UNetPlan:
                 dz.vcache = sp["vcache"].data_ptr()
                 dz.vcache_valid = 1
         _clx.call("clx_conv_wgrad", ctypes.byref(dz), _clx.ptr(dzbuf), PN, _clx.ptr(sp["dw_z"]), None, st)
-        g_skip = torch.empty((layer.cout, sp["C0"], layer.taps), dtype=torch.float32, device=self.device)
+        g_skip, g_z = sp["g_skip"], sp["g_z"]
         if sp["wino_skip"]:
             _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
                       sp["N"], sp["C0p"], 4, 3, layer.kernel[0], st)
         else:
             _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
                       layer.taps, sp["N"], sp["C0p"], st)
-        g_z = torch.empty((PN, sp["C1"], sp["ztaps"]), dtype=torch.float32, device=self.device)
         if sp["wino"]:
             _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], PN, sp["C1p"],
                       4, 2, sp["zk"][0], st)
         else:
             _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
                       sp["C1p"], st)
-        gwv = gw.view(layer.cout, layer.cin, layer.taps)
-        gwv[:, :sp["C0"]] = g_skip
-        gwv[:, sp["C0"]:] = self._fold_phase_grads(layer, sp, g_z.reshape((PN, sp["C1"]) + sp["zk"])).reshape(
-            layer.cout, sp["C1"], layer.taps)
+        # adjoint of the weight split (one launch; _fold_phase_grads states the same in torch ops)
+        _clx.call("clx_subpixel_fold_grads", _clx.ptr(g_skip), _clx.ptr(g_z), _clx.ptr(gw), layer.cout, layer.cin,
+                  sp["C0"], sp["N"], *layer.kernel, *sp["fac"], st)
         # data gradient of the skip branch (gated later, together with the max-pool gradient)
         dskip = self.gbuf["dskip%d" % sp["level"]]
         dd = self._dgrad_desc(layer, dy)
@@ -841,9 +853,10 @@ class UNetPlan:
         return out
 
     # ---------------------------------------------------------------- backward
-    def backward(self, dout, params, grads, on_layer_done=None):
+    def backward(self, dout, params, grads, on_layer_done=None, flat_grad=None):
         """dout: (B, out_channels, *out_spatial) gradient of the loss w.r.t. forward()'s result.
         grads: list aligned with params; every entry is OVERWRITTEN with the gradient.
+        flat_grad: the flat buffer the entries of `grads` are views of, if there is one.
         on_layer_done(param_index): called once the kernels that write a layer's weight and bias
         gradient are enqueued (layers finish in reverse forward order: the data-parallel step
         starts reducing the tail of the flat gradient while the rest is still being computed)."""
@@ -855,9 +868,12 @@ class UNetPlan:
         _clx.call("clx_planar_to_pixel", _clx.ptr(dout), _clx.ptr(self.gbuf["h1"]), self.B,
                   t.out_channels, npix_out, pad4(t.out_channels), st)
         self.dwpack.zero_()
-        for g in grads[1::2]:
-            if g is not None:
-                g.zero_()
+        if flat_grad is not None:          # `grads` tile this buffer: one fill instead of one per bias
+            flat_grad.zero_()
+        else:
+            for g in grads[1::2]:
+                if g is not None:
+                    g.zero_()
 
         by_out = {layer.out: layer for layer in t.convs}
         pool_by_out = {p.out: p for p in t.pools}

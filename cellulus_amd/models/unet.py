@@ -70,7 +70,17 @@ class _UNetFunction(torch.autograd.Function):
     def backward(ctx, dout):
         model, plan = ctx.model, ctx.plan
         grads = model._grad_views()
-        plan.backward(dout, ctx.params, grads)
+        flat = model._flat_grad
+        if any(p.grad is not None and p.grad.data_ptr() == g.data_ptr() for p, g in zip(ctx.params, grads)):
+            # a parameter's .grad IS its slice of the flat buffer (zero_grad(set_to_none=False), or a second
+            # backward): autograd is about to ADD what we return to it, so the result must live elsewhere
+            flat = torch.empty_like(flat)
+            views, off = [], 0
+            for g in grads:
+                views.append(flat[off:off + g.numel()].view(g.shape))
+                off += g.numel()
+            grads = views
+        plan.backward(dout, ctx.params, grads, flat_grad=flat)
         return (None, None) + tuple(grads)
 
 

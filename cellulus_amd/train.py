@@ -277,10 +277,11 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         # gradient buckets go out while the rest of the backward pass runs (parallel.GradientBuckets)
         buckets = parallel.GradientBuckets(model._flat_grad, grads)
         buckets.add(sums)
-        plan.backward(doffsets, params, grads, on_layer_done=lambda i: buckets.params_done(2 * i, 2 * i + 1))
+        plan.backward(doffsets, params, grads, on_layer_done=lambda i: buckets.params_done(2 * i, 2 * i + 1),
+                      flat_grad=model._flat_grad)
         buckets.finish()
     else:
-        plan.backward(doffsets, params, grads)
+        plan.backward(doffsets, params, grads, flat_grad=model._flat_grad)
         if parallel.world_size() > 1:
             parallel.all_reduce_sum_(model._flat_grad)
             parallel.all_reduce_sum_(sums)

@@ -187,6 +187,18 @@ int clx_depth_to_space(const float* lo, int ld_lo, float* hi, int ld_hi, int B, 
 int clx_space_to_depth(const float* hi, int ld_hi, float* lo, int ld_lo, int B, int D, int H,
                        int W, int N, int fz, int fy, int fx, clx_stream stream);
 
+/* Weights of the sub-pixel form: w (cout, cin, kd, kh, kw) with cin = C0 (skip half) + C1
+ * (upsampled half) -> w_skip (cout, C0, taps) and weff (P*N, C1, ztaps), P = fz*fy*fx phases, N >=
+ * cout rows per phase (padding rows zero), low-res kernel 2 along axes with factor 2 (taps {0,1} |
+ * {2} for even, {0} | {1,2} for odd output positions summed), unchanged along axes with factor 1.
+ * clx_subpixel_fold_grads is the adjoint: gradients of w_skip / weff -> gradient of w. */
+int clx_subpixel_split_weights(const float* w, float* w_skip, float* weff, int cout, int cin,
+                               int C0, int N, int kd, int kh, int kw, int fz, int fy, int fx,
+                               clx_stream stream);
+int clx_subpixel_fold_grads(const float* g_skip, const float* g_eff, float* gw, int cout, int cin,
+                            int C0, int N, int kd, int kh, int kw, int fz, int fy, int fx,
+                            clx_stream stream);
+
 /* ------------------------------------------------------------------------ */
 /* Max pooling / upsample backward (funlib Downsample / Upsample,           */
 /* cellulus/models/unet.py:24-51)                                           */

@@ -152,6 +152,64 @@ def test_head_forward_matches_reference_head(name, device):
         model.head_forward(x_d[:, :3])
 
 
+@pytest.mark.parametrize("kernel,fac", [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2)), ((3, 3, 3), (1, 2, 2)),
+                                        ((1, 3, 3), (1, 2, 1))])
+def test_subpixel_weight_split_and_gradient_fold_kernels(kernel, fac, device):
+    """clx_subpixel_split_weights / clx_subpixel_fold_grads against the torch statement of the same
+    algebra (UNetPlan._phase_weights / _fold_phase_grads, itself held against upsample-then-convolve
+    on the CPU by tests/test_cpu_host.py)."""
+    from cellulus_amd import _clx
+    from cellulus_amd.models.plan import UNetPlan
+
+    torch.manual_seed(0)
+    cout, C0, C1, N = 10, 12, 20, 12
+    cin = C0 + C1
+    taps = kernel[0] * kernel[1] * kernel[2]
+    zk = tuple(2 if f == 2 else k for k, f in zip(kernel, fac))
+    ztaps, P = zk[0] * zk[1] * zk[2], fac[0] * fac[1] * fac[2]
+
+    class L:           # the two attributes the torch helpers read
+        pass
+    layer = L()
+    layer.cout, layer.kernel = cout, kernel
+    sp = dict(fac=fac, N=N, P=P, C1=C1, zk=zk)
+    w = torch.randn((cout, cin) + kernel, device=device)
+    ref_eff = UNetPlan._phase_weights(None, layer, sp, w[:, C0:])
+    w_skip = torch.empty(cout * C0 * taps, device=device)
+    weff = torch.empty(P * N * C1 * ztaps, device=device)
+    st = _clx.stream_ptr(device)
+    _clx.call("clx_subpixel_split_weights", _clx.ptr(w), _clx.ptr(w_skip), _clx.ptr(weff), cout, cin, C0, N,
+              *kernel, *fac, st)
+    assert torch.equal(w_skip.view(cout, C0, taps), w[:, :C0].reshape(cout, C0, taps))
+    assert torch.allclose(weff.view(ref_eff.shape), ref_eff, atol=1e-6)
+    g_skip = torch.randn(cout, C0, taps, device=device)
+    g_eff = torch.randn((P * N, C1) + zk, device=device)
+    gw = torch.empty((cout, cin) + kernel, device=device)
+    _clx.call("clx_subpixel_fold_grads", _clx.ptr(g_skip), _clx.ptr(g_eff), _clx.ptr(gw), cout, cin, C0, N,
+              *kernel, *fac, st)
+    ref = UNetPlan._fold_phase_grads(None, layer, sp, g_eff)
+    assert torch.equal(gw[:, :C0].reshape(cout, C0, taps), g_skip)
+    assert torch.allclose(gw[:, C0:], ref, atol=1e-5)
+
+
+def test_second_backward_accumulates_like_torch(device):
+    """.grad that aliases the model's flat gradient buffer (zero_grad(set_to_none=False), or two
+    backward passes in a row) must still ACCUMULATE, as autograd does for any module."""
+    oracle, model, raw = _make("2d_small", device)
+    x = raw.to(device)
+    out = model(x)
+    out.sum().backward()
+    g1 = [p.grad.clone() for p in model.parameters()]
+    model(x).sum().backward()                                  # second backward: grads add up
+    for p, g in zip(model.parameters(), g1):
+        assert torch.allclose(p.grad, 2 * g, rtol=1e-4, atol=1e-5)
+    for p in model.parameters():
+        p.grad.zero_()                                          # set_to_none=False style
+    model(x).sum().backward()
+    for p, g in zip(model.parameters(), g1):
+        assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-5)
+
+
 def test_rejects_cpu_tensors():
     from cellulus_amd._clx import ClxError
 
