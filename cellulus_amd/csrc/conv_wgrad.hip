@@ -15,6 +15,7 @@
 // reference train step (cellulus/train.py:178).
 #include "clx_common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -42,7 +43,12 @@ struct WgradP {
   float* dwp;
   float* dbias;
   int tiles_n, tiles_c, taps, nslices, chunks_per_slice;
-  long long bs_x, bs_dy, bs_out;   // per-batch strides in floats (gridDim.y batches)
+  long long bs_x, bs_dy, bs_out;   // per-batch strides in floats
+  // 1-D grid: blocks [0, n_main) are batches [0, batch_split) cut into `nslices` pixel slices;
+  // blocks [n_main, ..) are the remaining batches — the launch's last, partial round of
+  // co-resident blocks — cut into `nslices_tail` >= nslices shorter slices so that the partial
+  // round fills the chip and ends early instead of holding a few CUs for a whole block time
+  int n_main, batch_split, nslices_tail, chunks_per_slice_tail;
 };
 
 template <int BMN, int BNC, int WAVES_M, int WAVES_N>
@@ -58,7 +64,13 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   __shared__ float Xs[2][BKP * BNC];
 
   const int T = p.tiles_n * p.tiles_c * p.taps;
-  const int v = xcd_remap(blockIdx.x, T * p.nslices);
+  const bool tail = (int)blockIdx.x >= p.n_main;
+  const int ns = tail ? p.nslices_tail : p.nslices;
+  const int cps = tail ? p.chunks_per_slice_tail : p.chunks_per_slice;
+  const int u = tail ? xcd_remap((int)blockIdx.x - p.n_main, (int)gridDim.x - p.n_main) : xcd_remap((int)blockIdx.x, p.n_main);
+  const int per_batch = T * ns;
+  const int batch = u / per_batch + (tail ? p.batch_split : 0);
+  const int v = u % per_batch;
   const int slice = v / T;
   int t = v - slice * T;
   const int tile_c = t % p.tiles_c; t /= p.tiles_c;
@@ -78,17 +90,17 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   const bool c_ok = c_g < p.Ctot;
   const int s = (p.nsrc == 2 && c_g >= p.src[0].C) ? 1 : 0;
   SrcP S = p.src[s];
-  S.ptr += blockIdx.y * p.bs_x;
-  const float* dyp = p.dy + blockIdx.y * p.bs_dy;
+  S.ptr += batch * p.bs_x;
+  const float* dyp = p.dy + batch * p.bs_dy;
   const int c_l = c_g - (s ? p.src[0].C : 0);
 
-  const int chunk0 = slice * p.chunks_per_slice;
+  const int chunk0 = slice * cps;
   int nchunks = (p.M + BKP - 1) / BKP - chunk0;
-  if (nchunks > p.chunks_per_slice) nchunks = p.chunks_per_slice;
+  if (nchunks > cps) nchunks = cps;
 
   f32x4 ra[A_PASSES], rb[B_PASSES];
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0 && blockIdx.y == 0;
+  const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0 && batch == 0;
 
   // out-of-range rows read 16 zero bytes instead of branching around the load
   auto load_dy = [&](int chunk) {
@@ -202,7 +214,7 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   }
 
   // ---- combine: float atomics into dwpack[tap][n][c]
-  float* dst = p.dwp + blockIdx.y * p.bs_out + (size_t)tap * p.N * p.Ctot;
+  float* dst = p.dwp + batch * p.bs_out + (size_t)tap * p.N * p.Ctot;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -323,7 +335,30 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   if (nslices < 1) nslices = 1;
   p.chunks_per_slice = cdiv(total_chunks, nslices);
   p.nslices = cdiv(total_chunks, p.chunks_per_slice);
-  const dim3 grid(T * p.nslices, batch), block(256);
+  // the last, partial round of co-resident blocks: its batches get more, shorter slices
+  p.batch_split = batch; p.nslices_tail = p.nslices; p.chunks_per_slice_tail = p.chunks_per_slice;
+  {
+    const int per_batch = T * p.nslices;
+    const long long blocks = (long long)per_batch * batch;
+    const int full = (int)(blocks / slots);
+    const long long rest = blocks - (long long)full * slots;
+    static const bool enabled = getenv("CLX_WGRAD_TAIL_SPLIT") == nullptr || atoi(getenv("CLX_WGRAD_TAIL_SPLIT")) != 0;
+    if (enabled && batch > 1 && full >= 1 && rest > 0 && rest * 10 < (long long)slots * 9) {
+      int split = (int)(((long long)full * slots) / per_batch);          // batches that fit the full rounds
+      if (split >= batch) split = batch - 1;
+      const int tail_tiles = (batch - split) * T;
+      int ns_tail = slots / tail_tiles;
+      const int max_tail = total_chunks / 4 > 0 ? total_chunks / 4 : 1;
+      if (ns_tail > max_tail) ns_tail = max_tail;
+      if (split > 0 && ns_tail > p.nslices) {
+        p.batch_split = split;
+        p.chunks_per_slice_tail = cdiv(total_chunks, ns_tail);
+        p.nslices_tail = cdiv(total_chunks, p.chunks_per_slice_tail);
+      }
+    }
+  }
+  p.n_main = T * p.nslices * p.batch_split;
+  const dim3 grid(p.n_main + T * p.nslices_tail * (batch - p.batch_split)), block(256);
   const bool prof = clx_prof_enabled();
   if (prof) clx_prof_begin(CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, st);
   if (big_n && big_c)

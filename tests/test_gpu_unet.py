@@ -174,7 +174,7 @@ def test_subpixel_weight_split_and_gradient_fold_kernels(kernel, fac, device):
     layer.cout, layer.kernel = cout, kernel
     sp = dict(fac=fac, N=N, P=P, C1=C1, zk=zk)
     w = torch.randn((cout, cin) + kernel, device=device)
-    ref_eff = UNetPlan._phase_weights(None, layer, sp, w[:, C0:])
+    ref_eff = UNetPlan._phase_weights(UNetPlan, layer, sp, w[:, C0:])
     w_skip = torch.empty(cout * C0 * taps, device=device)
     weff = torch.empty(P * N * C1 * ztaps, device=device)
     st = _clx.stream_ptr(device)
@@ -187,7 +187,7 @@ def test_subpixel_weight_split_and_gradient_fold_kernels(kernel, fac, device):
     gw = torch.empty((cout, cin) + kernel, device=device)
     _clx.call("clx_subpixel_fold_grads", _clx.ptr(g_skip), _clx.ptr(g_eff), _clx.ptr(gw), cout, cin, C0, N,
               *kernel, *fac, st)
-    ref = UNetPlan._fold_phase_grads(None, layer, sp, g_eff)
+    ref = UNetPlan._fold_phase_grads(UNetPlan, layer, sp, g_eff)
     assert torch.equal(gw[:, :C0].reshape(cout, C0, taps), g_skip)
     assert torch.allclose(gw[:, C0:], ref, atol=1e-5)
 
