@@ -206,3 +206,85 @@ def test_bucketed_all_reduce_runs_on_rccl(tmp_path, device):
                        text=True, timeout=600)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     assert "rccl buckets ok" in p.stdout
+
+
+_INFER_SCRIPT = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+os.chdir(sys.argv[2])
+from cellulus_amd.configs import ExperimentConfig
+from cellulus_amd.infer import infer
+import tomli
+cfg = ExperimentConfig(**tomli.load(open(sys.argv[3], "rb")))
+torch.manual_seed(42)
+np.random.seed(42)
+infer(cfg)
+"""
+
+
+def test_two_rank_inference_shards_samples_and_writes_one_dataset(tmp_path, device):
+    """infer() under two ranks (samples sharded, no collective on the data path; ADVICE r1: every rank
+    used to create — i.e. replace — the prediction dataset): rank 0 creates each dataset once, both
+    ranks fill their samples, nothing a faster rank wrote is lost.  The post-processing of each
+    sample equals the single-process result on the embeddings that were written."""
+    from cellulus_amd.utils import zarr_io
+    from oracle import infer_oracle as IO
+    from oracle.unet_oracle import OracleUNetModel
+
+    container = str(tmp_path / "data.zarr")
+    rng = np.random.default_rng(0)
+    raw = rng.random((5, 1, 72, 80)).astype(np.float32)          # 5 samples: ranks get 3 + 2
+    f = zarr_io.open(container)
+    f["test/raw"] = raw
+    f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    torch.manual_seed(0)
+    oracle = OracleUNetModel(in_channels=1, out_channels=2, num_spatial_dims=2, num_fmaps=8, fmap_inc_factor=2,
+                             features_in_last_layer=16, downsampling_factors=[[2, 2]])
+    os.makedirs(tmp_path / "models")
+    torch.save({"model_state_dict": oracle.state_dict()}, tmp_path / "models" / "best_loss.pth")
+    (tmp_path / "infer.toml").write_text(f"""
+object_size = 12
+normalization_factor = 1.0
+[model_config]
+num_fmaps = 8
+fmap_inc_factor = 2
+features_in_last_layer = 16
+downsampling_factors = [[2, 2]]
+checkpoint = "models/best_loss.pth"
+[inference_config]
+crop_size = [56, 56]
+num_infer_iterations = 2
+p_salt_pepper = 0.05
+reduction_probability = 0.5
+min_size = 6
+grow_distance = 2
+shrink_distance = 3
+device = "cuda:0"
+[inference_config.dataset_config]
+container_path = "{container}"
+dataset_name = "test/raw"
+[inference_config.prediction_dataset_config]
+container_path = "{container}"
+dataset_name = "embeddings"
+[inference_config.detection_dataset_config]
+container_path = "{container}"
+dataset_name = "detection"
+secondary_dataset_name = "embeddings"
+[inference_config.segmentation_dataset_config]
+container_path = "{container}"
+dataset_name = "segmentation"
+secondary_dataset_name = "detection"
+""")
+    script = tmp_path / "infer_rank.py"
+    script.write_text(_INFER_SCRIPT)
+    _launch(str(script), [ROOT, str(tmp_path), str(tmp_path / "infer.toml")], {})
+    g = zarr_io.open(container, "r")
+    emb, det, seg = g["embeddings"][...], g["detection"][...], g["segmentation"][...]
+    assert emb.shape == (5, 3, 72, 80) and det.shape == seg.shape == (5, 1, 72, 80)
+    for s in range(5):                                   # every sample was written by exactly one rank
+        assert np.abs(emb[s, :2]).max() > 0 and emb[s, 2].max() > 0, f"sample {s} was lost"
+        thr = IO.threshold_otsu(emb[s, -1])
+        np.testing.assert_array_equal(g["binary-segmentation"][s, 0], (emb[s, -1] < thr).astype(np.uint16))
+        ref_seg = IO.size_filter(IO.grow_shrink(det[s, 0].astype(np.int32), 2, 3), 6)
+        np.testing.assert_array_equal(seg[s, 0], ref_seg.astype(np.uint16))
+    assert g["embeddings"].attrs["axis_names"] == ["s", "c", "y", "x"]
