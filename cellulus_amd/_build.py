@@ -29,6 +29,7 @@ COMMON_FLAGS = [
 # test d^2 <= bw^2 is compared with the reference's un-fused arithmetic.
 PER_FILE_FLAGS = {
     "meanshift.hip": ["-ffp-contract=off"],
+    "seeds.hip": ["-ffp-contract=off"],
 }
 
 

@@ -114,6 +114,10 @@ PROTOTYPES = {
     "clx_ms_assign_grid": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _P]),
     "clx_ms_bucket_workspace": (c_size_t, [_I, _LL]),
     "clx_ms_bucket": (_I, [_P, _I, _I, POINTER(c_double), _D, _I, _I, _I, _P, _P, _P, _P]),
+    "clx_offset_magnitude": (_I, [_P, _P, _I, _LL, _P]),
+    "clx_gaussian_filter_f64": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _P]),
+    "clx_negate_f64": (_I, [_P, _P, _LL, _P]),
+    "clx_peak_local_max": (_I, [_P, _I, _I, _I, _P, _P, _I, _P, _P]),
     "clx_greedy_cluster": (_I, [_P, _P, _I, _I, _I, _D, _I, _D, _I, _P, _P, _P, _P]),
     "clx_cc_workspace": (c_size_t, [_LL]),
     "clx_cc_label_filter": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P]),

@@ -5,11 +5,12 @@
 //
 // Replaces cellulus/utils/mean_shift.py:6-121 -> sklearn.cluster.MeanShift
 // (fit: _mean_shift_single_seed per seed; predict: nearest centre).
+#include <stdlib.h>
 #include "clx_common.h"
 
 namespace {
 
-constexpr int PREP_TILE = 2048;    // pixels per block of the compaction (256 threads x 4 x 2)
+constexpr int PREP_TILE_MAX = 4096;   // pixels per block of the compaction: 256 threads x KP pairs, KP = 4 or 8
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -22,7 +23,7 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 // ALL the blocks tell each other, the atomics are relaxed: an agent-scope release / acquire on this
 // 8-XCD part writes back / invalidates a whole L2 per descriptor), then writes its points.
 // Per pixel: (ND + 1) * 8 B read, ND * 8 B written; per foreground pixel ND * 8 + 4 B more.
-template <int ND>
+template <int ND, int KP>
 __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ emb,
                                                          const double* __restrict__ sd, double thr,
                                                          FastDiv dX, FastDiv dY, int Y, int X,
@@ -31,8 +32,9 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
                                                          unsigned long long* __restrict__ desc,
                                                          double* __restrict__ Xout,
                                                          int* __restrict__ index, int* __restrict__ nfg_out) {
+  constexpr int PREP_TILE = 512 * KP;
   __shared__ int s_tile, s_excl;
-  __shared__ int wcount[4][4];
+  __shared__ int wcount[KP][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
   __syncthreads();
@@ -40,11 +42,11 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
   const long long base = (long long)tile * PREP_TILE;
   const unsigned long long lower = (1ull << lane) - 1ull;
 
-  double v[4][2][ND];
-  bool fg[4][2];
-  int before[4];
+  double v[KP][2][ND];
+  bool fg[KP][2];
+  int before[KP];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KP; ++k) {
     const long long i = base + (long long)(k * 256 + tid) * 2;
     fg[k][0] = fg[k][1] = false;
     if (i < npix) {
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
     if (lane == 0) wcount[k][wid] = __popcll(b0) + __popcll(b1);
   }
   __syncthreads();
-  int total = 0, mine[4];
+  int total = 0, mine[KP];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < KP; ++k)
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       if (w == wid) mine[k] = total;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void ms_prepare_kernel(double* __restrict__ em
   __syncthreads();
   const int excl = s_excl;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < KP; ++k) {
     int pos = excl + mine[k] + before[k];
     const long long i = base + (long long)(k * 256 + tid) * 2;
 #pragma unroll
@@ -455,8 +457,13 @@ __global__ __launch_bounds__(256) void ms_assign_grid_kernel(
 
 }  // namespace
 
+static int prep_pairs() {      // pairs of pixels per thread: 4 (2048-pixel tiles) unless CLX_MS_PREP_K=8
+  static const int kp = (getenv("CLX_MS_PREP_K") && atoi(getenv("CLX_MS_PREP_K")) == 8) ? 8 : 4;
+  return kp;
+}
+
 extern "C" size_t clx_ms_prepare_workspace(long long npix) {
-  const long long ntiles = (npix + PREP_TILE - 1) / PREP_TILE;
+  const long long ntiles = (npix + 2048 - 1) / 2048;          // the smaller tile: enough for either
   return (size_t)(ntiles + 2) * sizeof(unsigned long long);
 }
 
@@ -469,7 +476,8 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare: workspace must be 8-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare: too many pixels");
-  const int ntiles = (int)((npix + PREP_TILE - 1) / PREP_TILE);
+  const int kp = prep_pairs();
+  const int ntiles = (int)((npix + 512 * kp - 1) / (512 * kp));
   hipStream_t st = (hipStream_t)stream;
   unsigned int* ticket = (unsigned int*)workspace;
   unsigned long long* desc = (unsigned long long*)workspace + 1;
@@ -479,12 +487,12 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   }
   const int vec = (npix % 2 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
   const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
-  if (ND == 2)
-    ms_prepare_kernel<2><<<ntiles, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket,
-                                                  desc, Xout, index, nfg_out);
-  else
-    ms_prepare_kernel<3><<<ntiles, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket,
-                                                  desc, Xout, index, nfg_out);
+#define CLX_PREP(ND_, KP_)                                                                                   \
+  ms_prepare_kernel<ND_, KP_><<<ntiles, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, \
+                                                      desc, Xout, index, nfg_out)
+  if (ND == 2) { if (kp == 8) CLX_PREP(2, 8); else CLX_PREP(2, 4); }
+  else         { if (kp == 8) CLX_PREP(3, 8); else CLX_PREP(3, 4); }
+#undef CLX_PREP
   CLX_CHECK_LAUNCH("clx_ms_prepare");
   return CLX_OK;
 }

@@ -49,6 +49,59 @@ def peak_local_max(image):
     return coords[order]
 
 
+def gaussian_weights(sigma, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius) with radius = int(truncate * sigma
+    + 0.5), centre first (the kernel is symmetric): the weights gaussian_filter correlates with."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:]), radius
+
+
+def seeds_on_device(emb_d, nd):
+    """detect.py:128-132 on the device: emb_d (ND, *spatial) float64 device tensor of centred
+    embeddings -> seeds (n, ND) int64 host array in (x, y[, z]) order, sorted like
+    np.flip(peak_local_max(-gaussian_filter(norm(emb, axis=0), sigma=2)), 1)."""
+    from . import _clx
+
+    spatial = tuple(emb_d.shape[1:])
+    Z, Y, X = (1,) * (3 - nd) + spatial
+    npix = Z * Y * X
+    dev = emb_d.device
+    st = _clx.stream_ptr(dev)
+    emb_d = emb_d.contiguous()
+    mag = torch.empty(npix, dtype=torch.float64, device=dev)
+    smooth = torch.empty_like(mag)
+    tmp = torch.empty_like(mag)
+    w, radius = gaussian_weights(2.0)
+    w_d = torch.from_numpy(w).to(dev)
+    _clx.call("clx_offset_magnitude", _clx.ptr(emb_d), _clx.ptr(mag), nd, npix, st)
+    _clx.call("clx_gaussian_filter_f64", _clx.ptr(mag), _clx.ptr(smooth), _clx.ptr(tmp), Z, Y, X,
+              _clx.ptr(w_d), radius, st)
+    _clx.call("clx_negate_f64", _clx.ptr(smooth), _clx.ptr(mag), npix, st)        # mag := -smooth
+    if min(spatial) < 3:
+        return np.zeros((0, nd), dtype=np.int64)             # every pixel is on the excluded border
+    mm = torch.empty(2, dtype=torch.float64, device=dev)
+    _clx.call("clx_minmax_f64", _clx.ptr(mag), npix, _clx.ptr(mm), st)
+    capacity = max(1024, npix // 9 + 16)                     # a 3^ND maximum per 3^ND block at most ...
+    peaks = torch.empty(capacity, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    _clx.call("clx_peak_local_max", _clx.ptr(mag), Z, Y, X, _clx.ptr(mm), _clx.ptr(peaks), capacity,
+              _clx.ptr(count), st)
+    n = int(count.item())
+    if n > capacity:                                         # ... unless plateaus: rerun with room for all
+        capacity = n
+        peaks = torch.empty(capacity, dtype=torch.int32, device=dev)
+        _clx.call("clx_peak_local_max", _clx.ptr(mag), Z, Y, X, _clx.ptr(mm), _clx.ptr(peaks), capacity,
+                  _clx.ptr(count), st)
+    idx = np.sort(peaks[:n].cpu().numpy().astype(np.int64))          # raster order = np.nonzero order
+    vals = mag[torch.from_numpy(idx).to(dev)].cpu().numpy() if n else np.zeros(0)
+    order = np.argsort(-vals, kind="stable")
+    coords = np.stack(np.unravel_index(idx[order], spatial), axis=1).astype(np.int64).reshape(-1, nd)
+    return np.flip(coords, 1)
+
+
 def detect(inference_config: InferenceConfig) -> None:
     dataset_config = inference_config.dataset_config
     meta = DatasetMetaData.from_dataset_config(dataset_config)
@@ -145,12 +198,8 @@ def detect_sample(embeddings, inference_config, nd, device, sample=0, emb_d=None
     for bandwidth_factor in range(inference_config.num_bandwidths):
         bandwidth = inference_config.bandwidth / (2 ** bandwidth_factor)
         if inference_config.use_seeds:
-            from scipy.ndimage import gaussian_filter
-
-            offset_magnitude = np.linalg.norm(embeddings_centered[:-1], axis=0)
-            smooth = gaussian_filter(offset_magnitude, sigma=2)
-            seeds = np.flip(peak_local_max(-smooth), 1)
             src = torch.from_numpy(np.ascontiguousarray(embeddings_centered)).to(device)
+            seeds = seeds_on_device(src[:nd], nd)
             mean_d, sd_d = src[:nd].contiguous().clone(), src[-1].contiguous()
         else:
             seeds = None

@@ -65,26 +65,45 @@ def fused_stages(model, inference_config, normalization_factor, device):
                 ds[key] = value
             pending.append(writer.submit(job))
 
-        for sample in range(meta.num_samples):
+        # Two streams: the embeddings of sample i+1 are enqueued on the main stream BEFORE sample i's
+        # detection / post-processing (small kernels with host round trips in between: foreground
+        # count, centre de-duplication) run on a second stream — the U-Net forwards never wait for
+        # the host.  Every stage still sees its samples in order and draws from its own generator.
+        main = torch.cuda.current_stream(device)
+        post = torch.cuda.Stream(device)
+
+        def enqueue_predict(sample):
             raw = raw_ds[sample]
-            emb_d = scan.predict_sample(raw).double()            # == astype(float64) of the f32 result
-            embeddings = emb_d.cpu().numpy()
-            write(ds_emb, sample, embeddings)
+            emb = scan.predict_sample(raw).double()              # == astype(float64) of the f32 result
+            done = torch.cuda.Event()
+            done.record(main)
+            return raw, emb, done
 
-            def emit(kind, index, value, sample=sample):
-                if kind == "binary":
-                    write(ds_bin, (sample, 0, Ellipsis), value)
-                elif kind == "centered":
-                    write(ds_cen, sample, value)
-                else:
-                    write(ds_det, (sample, index, Ellipsis), _labels_to_host(value))
+        nxt = enqueue_predict(0) if meta.num_samples else None
+        for sample in range(meta.num_samples):
+            raw, emb_d, done = nxt
+            nxt = enqueue_predict(sample + 1) if sample + 1 < meta.num_samples else None
+            with torch.cuda.stream(post):
+                post.wait_event(done)
+                emb_d.record_stream(post)
+                embeddings = emb_d.cpu().numpy()
+                write(ds_emb, sample, embeddings)
 
-            detections = detect_sample(embeddings, inference_config, nd, device, sample, emb_d=emb_d, emit=emit)
-            for bandwidth_factor, labels in enumerate(detections):
-                # through the uint16 storage type, as segment() reads it back
-                seg_d = (labels.to(device=device, dtype=torch.int32) & 0xFFFF).contiguous()
-                out = segment_sample(seg_d, raw[0], inference_config, device)
-                write(ds_seg, (sample, bandwidth_factor, Ellipsis), out.cpu().numpy())
+                def emit(kind, index, value, sample=sample):
+                    if kind == "binary":
+                        write(ds_bin, (sample, 0, Ellipsis), value)
+                    elif kind == "centered":
+                        write(ds_cen, sample, value)
+                    else:
+                        write(ds_det, (sample, index, Ellipsis), _labels_to_host(value))
+
+                detections = detect_sample(embeddings, inference_config, nd, device, sample, emb_d=emb_d, emit=emit)
+                for bandwidth_factor, labels in enumerate(detections):
+                    # through the uint16 storage type, as segment() reads it back
+                    seg_d = (labels.to(device=device, dtype=torch.int32) & 0xFFFF).contiguous()
+                    out = segment_sample(seg_d, raw[0], inference_config, device)
+                    write(ds_seg, (sample, bandwidth_factor, Ellipsis), out.cpu().numpy())
+                post.synchronize()
             while len(pending) > 16:                              # bound the host copies in flight
                 pending.pop(0).result()
         for job in pending:

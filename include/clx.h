@@ -336,6 +336,25 @@ int clx_ms_assign_grid(const double* X, const int* index, int nfg, const double*
                        const double* origin, double cell, int nx, int ny, int nz, int* labels,
                        clx_stream stream);
 
+/* Seeds for use_seeds = true (cellulus/detect.py:128-132), float64, the libraries' operation order:
+ *   clx_offset_magnitude    np.linalg.norm(emb[:ND], axis=0): emb (ND, npix) -> out (npix)
+ *   clx_gaussian_filter_f64 scipy.ndimage.gaussian_filter(in, sigma) with mode "reflect": `weights`
+ *                           (DEVICE, radius + 1 doubles: centre first) are the normalised kernel scipy
+ *                           builds (the caller computes them as scipy does); axes in scipy's order;
+ *                           in / out / tmp: three distinct npix-buffers
+ *   clx_negate_f64          out = -in
+ *   clx_peak_local_max      skimage.feature.peak_local_max(img) defaults: pixels equal to the maximum
+ *                           of their 3^ND neighbourhood, > min(img) (minmax[0], DEVICE, e.g. from
+ *                           clx_minmax_f64), not on the image border; raster indices appended to
+ *                           `peaks` in arrival order, *npeaks = how many (may exceed capacity:
+ *                           only the first `capacity` are stored) */
+int clx_offset_magnitude(const double* emb, double* out, int ND, long long npix, clx_stream stream);
+int clx_gaussian_filter_f64(const double* in, double* out, double* tmp, int Z, int Y, int X,
+                            const double* weights, int radius, clx_stream stream);
+int clx_negate_f64(const double* in, double* out, long long n, clx_stream stream);
+int clx_peak_local_max(const double* img, int Z, int Y, int X, const double* minmax, int* peaks,
+                       int capacity, int* npeaks, clx_stream stream);
+
 /* ------------------------------------------------------------------------ */
 /* Greedy clustering (cellulus/utils/greedy_cluster.py:46-120,176-253)      */
 /* ------------------------------------------------------------------------ */

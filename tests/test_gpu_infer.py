@@ -427,6 +427,44 @@ def test_grid_assignment_equals_the_plain_nearest_centre_loop(nd, device):
     assert set(ref.cpu().numpy()[-16:].tolist()) <= {7, 8}
 
 
+@pytest.mark.parametrize("shape", [(64, 80), (97, 33), (5, 300), (20, 24, 28), (3, 40, 9)])
+def test_seeds_on_device_equal_scipy_and_skimage_semantics(shape, device):
+    """use_seeds = true (detect.py:128-132): np.linalg.norm -> scipy gaussian_filter(sigma=2) ->
+    peak_local_max of the negated map, on the device in float64 with the libraries' operation order:
+    the smoothed map bit for bit, the seed list element for element (order included)."""
+    from scipy.ndimage import gaussian_filter
+
+    from cellulus_amd import _clx
+    from cellulus_amd.detect import gaussian_weights, peak_local_max, seeds_on_device
+
+    nd = len(shape)
+    rng = np.random.default_rng(sum(shape))
+    emb = rng.normal(size=(nd,) + shape) * 5.0
+    emb[:, tuple(s // 2 for s in shape)] = 0.0                       # an exact zero of the magnitude
+    mag = np.linalg.norm(emb, axis=0)
+    smooth = gaussian_filter(mag, sigma=2)
+    ref = np.flip(peak_local_max(-smooth), 1)
+    emb_d = torch.from_numpy(emb).to(device)
+    got = seeds_on_device(emb_d, nd)
+    np.testing.assert_array_equal(got, ref)
+    # the intermediate maps, bit for bit
+    Z, Y, X = (1,) * (3 - nd) + shape
+    npix = mag.size
+    st = _clx.stream_ptr(device)
+    m_d = torch.empty(npix, dtype=torch.float64, device=device)
+    s_d, t_d = torch.empty_like(m_d), torch.empty_like(m_d)
+    w, radius = gaussian_weights(2.0)
+    assert radius == 8
+    w_d = torch.from_numpy(w).to(device)
+    _clx.call("clx_offset_magnitude", _clx.ptr(emb_d), _clx.ptr(m_d), nd, npix, st)
+    _clx.call("clx_gaussian_filter_f64", _clx.ptr(m_d), _clx.ptr(s_d), _clx.ptr(t_d), Z, Y, X, _clx.ptr(w_d), radius, st)
+    np.testing.assert_array_equal(m_d.cpu().numpy().reshape(shape), mag)
+    np.testing.assert_array_equal(s_d.cpu().numpy().reshape(shape), smooth)
+    # a constant map has no peak (nothing exceeds the minimum); plateaus keep every pixel of the plateau
+    flat = seeds_on_device(torch.ones((nd,) + shape, dtype=torch.float64, device=device), nd)
+    assert flat.shape == (0, nd)
+
+
 # ------------------------------------------------------------------ greedy clustering
 @pytest.mark.parametrize("case", ["2d", "3d"])
 def test_greedy_cluster_matches_reference_golden(case, device):
