@@ -155,7 +155,7 @@ def streaming_rooflines(device, size=4096):
                 kernels=out)
 
 
-def e2e_infer(device, samples=8, size=512):
+def e2e_infer(device, samples=16, size=512):
     """The product's infer() on a synthetic zarr: S x 512^2 raw images in, embeddings / detection /
     binary-segmentation / centered-embeddings / segmentation out, default inference settings
     (16 noise iterations, reduction_probability 0.1, cell post-processing)."""

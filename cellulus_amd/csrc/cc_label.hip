@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void cc_flatten_count(const int* __restrict__ 
 // each — status in the high half, value in the low half — so relaxed atomics suffice), and numbers
 // its own: surviving root r gets id = 1 + (number of surviving roots before r), stored as -id
 // in size[r].
-constexpr int NUM_TILE = 2048;
+constexpr int NUM_TILE = 8192;    // big tiles: the look-back costs per tile, the scan of L does not
 
 __global__ __launch_bounds__(256) void cc_number_roots(const int* __restrict__ L, int* size, int min_size,
                                                        long long npix, int ntiles, unsigned int* __restrict__ ticket,

@@ -457,8 +457,8 @@ __global__ __launch_bounds__(256) void ms_assign_grid_kernel(
 
 }  // namespace
 
-static int prep_pairs() {      // pairs of pixels per thread: 4 (2048-pixel tiles) unless CLX_MS_PREP_K=8
-  static const int kp = (getenv("CLX_MS_PREP_K") && atoi(getenv("CLX_MS_PREP_K")) == 8) ? 8 : 4;
+static int prep_pairs() {      // pairs of pixels per thread: 8 (4096-pixel tiles, measured 0.74 vs 0.82 ms at
+  static const int kp = (getenv("CLX_MS_PREP_K") && atoi(getenv("CLX_MS_PREP_K")) == 4) ? 4 : 8;   // 8192^2) or 4
   return kp;
 }
 

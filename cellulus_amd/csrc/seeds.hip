@@ -5,7 +5,7 @@
 // in float64 with the libraries' own operation order (this file is compiled with
 // -ffp-contract=off), so the seeds — integer pixel coordinates — are the reference's:
 //   norm:     sqrt((x0*x0 + x1*x1) + x2*x2)                       (numpy add.reduce over axis 0)
-//   gaussian: per axis, in axis order,  t = x[c]*w[0];  t += (x[c-j] + x[c+j]) * w[j], j = 1..r
+//   gaussian: per axis, in axis order,  t = x[c]*w[0];  t += (x[c-j] + x[c+j]) * w[j], j = r..1
 //             (scipy NI_Correlate1D's symmetric branch), boundary mode "reflect" (d c b a | a b c d)
 //   peaks:    x == max over the 3^ND neighbourhood (edge-clamped) and x > min(image), one pixel
 //             of border excluded (skimage defaults: min_distance 1, exclude_border True)
@@ -51,10 +51,11 @@ __global__ void gaussian_axis_kernel(const double* __restrict__ in, double* __re
     const int c = (int)((i / stride) % n);
     const long long base = i - (long long)c * stride;
     double t = in[i] * w[0];
+    // scipy's loop runs from the outermost tap inwards (jj = -size1 .. -1)
     if (c - radius >= 0 && c + radius < n) {
-      for (int j = 1; j <= radius; ++j) t += (in[i - j * stride] + in[i + j * stride]) * w[j];
+      for (int j = radius; j >= 1; --j) t += (in[i - j * stride] + in[i + j * stride]) * w[j];
     } else {
-      for (int j = 1; j <= radius; ++j)
+      for (int j = radius; j >= 1; --j)
         t += (in[base + (long long)reflect_index(c - j, n) * stride] +
               in[base + (long long)reflect_index(c + j, n) * stride]) * w[j];
     }
