@@ -440,7 +440,7 @@ def test_seeds_on_device_equal_scipy_and_skimage_semantics(shape, device):
     nd = len(shape)
     rng = np.random.default_rng(sum(shape))
     emb = rng.normal(size=(nd,) + shape) * 5.0
-    emb[:, tuple(s // 2 for s in shape)] = 0.0                       # an exact zero of the magnitude
+    emb[(slice(None),) + tuple(s // 2 for s in shape)] = 0.0        # an exact zero of the magnitude
     mag = np.linalg.norm(emb, axis=0)
     smooth = gaussian_filter(mag, sigma=2)
     ref = np.flip(peak_local_max(-smooth), 1)
