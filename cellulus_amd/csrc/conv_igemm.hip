@@ -13,7 +13,6 @@
 //
 // Replaces nn.Conv{2,3}d(+ReLU) forward/backward-data of the reference U-Net
 // (cellulus/models/unet.py:24-63, funlib ConvPass) — exact f32 arithmetic.
-#include <stdlib.h>
 #include "clx_common.h"
 
 namespace {
@@ -49,7 +48,6 @@ struct ConvP {
   float* out;
   int relu, ld_mask, ld_out, accumulate;
   int nbm, nbn;
-  int tile_m0;                     // first M tile of this launch (a layer may be split into two launches)
   long long bs_in, bs_w, bs_out;   // per-batch strides in floats (gridDim.y batches; 0 = none)
 };
 
@@ -73,7 +71,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
 
   const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
   const int tile_n = v % p.nbn;
-  const int tile_m = v / p.nbn + p.tile_m0;
+  const int tile_m = v / p.nbn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -388,7 +386,6 @@ static void fill_params(const clx_conv_desc* d, ConvP& p) {
   p.relu = d->relu; p.ld_mask = d->ld_mask; p.ld_out = d->ld_out;
   p.accumulate = d->accumulate;
   p.bs_in = p.bs_w = p.bs_out = 0;
-  p.tile_m0 = 0;
 }
 
 extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
@@ -432,28 +429,7 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
                            2.0 * p.M * p.N * p.Ktot * batch, st);
   if (wide) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
-    // Tiles run in rounds of 2 x CUs co-resident blocks.  When the last round would be less than
-    // 60 % full (e.g. 5766 tiles = 11.26 rounds on the 768-wide 1x1 layers), the M tiles of that
-    // round go to a second launch of the 128x64 kernel instead: twice the blocks, half the work
-    // each, three per CU — the partial round costs about half a round instead of a whole one.
-    static const bool split_tail = getenv("CLX_IGEMM_TAIL_SPLIT") == nullptr || atoi(getenv("CLX_IGEMM_TAIL_SPLIT")) != 0;
-    int m_main = p.nbm;
-    if (split_tail && batch == 1) {
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) == hipSuccess &&
-          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-        const long long slots = 2ll * cus, tiles = (long long)p.nbm * p.nbn;
-        const long long full = tiles / slots, rest = tiles - full * slots;
-        if (full >= 2 && rest > 0 && rest * 10 < slots * 6) m_main = (int)((full * slots) / p.nbn);
-      }
-    }
-    const int nbm_all = p.nbm;
-    p.nbm = m_main;
     conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
-    if (m_main < nbm_all) {
-      p.tile_m0 = m_main; p.nbm = nbm_all - m_main; p.nbn = cdiv(p.N, 64);
-      conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
-    }
   } else {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
     conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
