@@ -1,19 +1,36 @@
 #!/bin/bash
-# Regenerates the end-of-round evidence under gpurun_out/ (run on the GPU box through gpurun from the repo
-# root); copy the results into profiles/ afterwards (names: profiles/README.md).
+# Regenerates the end-of-round evidence under gpurun_out/refresh (run on the GPU box through gpurun from
+# the repo root: `gpurun -- bash tools/refresh_profiles.sh`); copy the results into profiles/ afterwards
+# (names: profiles/README.md).  PMC passes are separate rocprofv3 runs with --kernel-trace only.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/refresh
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
+export TMPDIR=/tmp
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 CLX_BENCH_DETAIL=1 python bench.py --steps 6 --warmup 2 --no-infer --no-cpu-baseline > $O/per_layer.txt 2>&1
-python bench.py --workload train3d --steps 6 --warmup 2 --no-infer --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_train3d.json
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python3 $R/bench.py --steps 4 --warmup 2 --no-infer --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline > /dev/null 2>&1
-python3 $R/tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels.txt
-python3 $R/tools/pmc_digest.py $O/pmc wino_ > $O/pmc_wino_kernels.txt
+# kernel statistics of the same command, 2-D (+ the 3-D workload the default line also times)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python3 bench.py --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train3d > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof3d -o t -- python3 bench.py --workload train3d --steps 4 --warmup 2 --no-infer --no-cpu-baseline > $O/bench3d_under_rocprof.json 2>/dev/null
+# matrix-pipe busy per kernel
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train3d > /dev/null 2>&1
+python3 tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels.txt
+python3 tools/pmc_digest.py $O/pmc wino_ > $O/pmc_wino_kernels.txt
 rm -rf $O/pmc
+# HBM bytes per launch: training kernels ...
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train3d > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train3d > /dev/null 2>&1
+python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train2d.json > $O/hbm_traffic_train2d.txt
+rm -rf $O/pmc_rd $O/pmc_wr
+# ... and the streaming kernels of detect / segment (one 8192^2 image = 256 samples of 512^2 per launch)
+python tools/bench_stream.py 8192 > $O/streaming_kernels.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
+python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_streaming.json ms_ cc_ gs_ grow_shrink bucket_ histogram_kernel minmax_kernel noise_stats > $O/hbm_traffic_streaming.txt
+rm -rf $O/pmc_rd $O/pmc_wr
+find $O -name "*kernel_stats.csv" | while read f; do d=$(basename $(dirname $(dirname $f))); cp $f $O/${d}_kernel_stats.csv; done
+rm -rf $O/prof $O/prof3d $O/prof_stream
+ls -la $O
 echo refresh done
-bash $R/tools/hbm_traffic.sh
