@@ -103,6 +103,8 @@ PROTOTYPES = {
     "clx_gather_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "clx_oce_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _LL, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
     "clx_oce_pairs_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
+    "clx_sample_pairs": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, POINTER(c_int), ctypes.c_ulonglong,
+                              ctypes.c_ulonglong, _P]),
     "clx_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P]),
     "clx_noise_stats": (_I, [_P, _P, _I, _I, _LL, _P]),
     "clx_ms_prepare_workspace": (c_size_t, [_LL]),

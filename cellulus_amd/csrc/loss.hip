@@ -187,7 +187,66 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Optional on-device pair sampler (the distribution of ZarrDataset.sample_coordinates /
+// sample_offsets_within_radius, cellulus/datasets/zarr_dataset.py:177-242): anchor column d uniform
+// on the integers [lo, hi[d]], every anchor repeated `num_refs` times, reference = anchor + an
+// offset uniform over the table of admissible offsets (|o|^2 < kappa^2, o != 0).  Counter-based
+// generator (splitmix64 of seed, stream, batch row, pair, column): any (seed, stream) reproduces
+// its pairs, no state.  NOT the reference's random stream — an opt-in that removes the 38 MB of
+// int64 coordinates per step from the host pipeline.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9e3779b97f4a7c15ull;
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+// uniform integer in [0, n) from 32 random bits (multiply-shift: bias < n / 2^32)
+__device__ __forceinline__ unsigned int below(unsigned long long r, unsigned int n) {
+  return (unsigned int)(((r >> 32) * (unsigned long long)n) >> 32);
+}
+
+__global__ void sample_pairs_kernel(long long* __restrict__ anchor, long long* __restrict__ reference,
+                                    const int* __restrict__ offsets, int noffsets, int num_anchors,
+                                    int num_refs, int ND, int lo, int hi0, int hi1, int hi2,
+                                    unsigned long long seed, unsigned long long stream, long long total) {
+  const int hi[3] = {hi0, hi1, hi2};
+  const long long P = (long long)num_anchors * num_refs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / P, p = i - b * P;
+    const long long a = p / num_refs;
+    const unsigned long long key = splitmix64(seed ^ splitmix64(stream * 0x100000001b3ull + (unsigned long long)b));
+    const unsigned long long ra = splitmix64(key ^ (0xa5a5a5a5ull + 2ull * (unsigned long long)a));
+    const unsigned long long rb = splitmix64(ra);
+    const unsigned long long ro = splitmix64(key ^ (0x5a5a5a5a00000000ull + (unsigned long long)p));
+    const int o = (int)below(ro, (unsigned int)noffsets);
+    const unsigned long long bits[3] = {ra, ra << 32, rb};       // three independent 32-bit fields
+    for (int d = 0; d < ND; ++d) {
+      const long long c = lo + (long long)below(bits[d], (unsigned int)(hi[d] - lo + 1));
+      anchor[i * ND + d] = c;
+      reference[i * ND + d] = c + offsets[o * ND + d];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int clx_sample_pairs(long long* anchor, long long* reference, const int* offsets, int noffsets,
+                                int B, int num_anchors, int num_refs, int ND, int lo, const int* hi,
+                                unsigned long long seed, unsigned long long stream_id, clx_stream stream) {
+  CLX_REQUIRE(anchor && reference && offsets && hi, "clx_sample_pairs: null pointer");
+  CLX_REQUIRE(B > 0 && num_anchors > 0 && num_refs > 0 && noffsets > 0 && (ND == 2 || ND == 3),
+              "clx_sample_pairs: bad extents");
+  for (int d = 0; d < ND; ++d) CLX_REQUIRE(hi[d] >= lo, "clx_sample_pairs: empty anchor range");
+  const long long total = (long long)B * num_anchors * num_refs;
+  sample_pairs_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      anchor, reference, offsets, noffsets, num_anchors, num_refs, ND, lo, hi[0], hi[1], ND == 3 ? hi[2] : hi[1],
+      seed, stream_id, total);
+  CLX_CHECK_LAUNCH("clx_sample_pairs");
+  return CLX_OK;
+}
 
 extern "C" int clx_gather_add_fwd(const float* offsets, const long long* coords, float* sel,
                                   int B, int P, int ND, int Z, int Y, int X, int* oob_count,

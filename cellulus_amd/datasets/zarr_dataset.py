@@ -65,6 +65,9 @@ class ZarrDataset(IterableDataset):  # type: ignore
         self.output_shape = tuple(int(_ - 16) for _ in self.crop_size)
         self.unbiased_shape = tuple(int(_ - (2 * self.kappa)) for _ in self.output_shape)
         self._array = None
+        # opt-in (CLX_DEVICE_PAIRS=1, set by train()): the crops come without coordinates and the pairs
+        # are drawn on the device (DevicePairSampler) — same distribution, not the reference's stream
+        self.skip_pairs = False
 
     def __iter__(self):
         return iter(self.__yield_sample())
@@ -132,7 +135,10 @@ class ZarrDataset(IterableDataset):  # type: ignore
                 if np.max(sample_data) <= 0.0:
                     continue
                 array_is_zero = False
-                anchor_samples, reference_samples = self.sample_coordinates()
+                if self.skip_pairs:
+                    anchor_samples = reference_samples = np.zeros((0, self.num_spatial_dims), dtype=np.int64)
+                else:
+                    anchor_samples, reference_samples = self.sample_coordinates()
             yield sample_data, anchor_samples, reference_samples
 
     def __read_meta_data(self):
@@ -181,3 +187,49 @@ class ZarrDataset(IterableDataset):  # type: ignore
 
     def get_num_samples(self):
         return self.get_num_anchors() * self.get_num_references()
+
+
+class DevicePairSampler:
+    """Pairs with the distribution of ``ZarrDataset.sample_coordinates`` drawn by ``clx_sample_pairs``
+    on the device: anchor column d uniform on the integers [kappa, output_shape[d] - kappa], every
+    anchor repeated ``get_num_references()`` times, reference = anchor + an offset uniform over
+    {o integer: |o|^2 < kappa^2, o != 0} (what the rejection loop of ``sample_offsets_within_radius``
+    converges to).  Counter-based generator: (seed, step) reproduces a batch.  Opt-in: the numbers
+    are NOT the reference's ``np.random`` stream."""
+
+    def __init__(self, dataset, device, seed):
+        import ctypes
+        import itertools
+
+        import torch
+
+        self.device = device
+        self.nd = dataset.num_spatial_dims
+        kappa = float(dataset.kappa)
+        self.lo = int(math.ceil(kappa))
+        self.hi = [int(math.floor(s - kappa)) for s in dataset.output_shape]
+        if any(h < self.lo for h in self.hi):
+            raise ValueError(f"kappa={kappa} leaves no anchor position in an output of extent {dataset.output_shape}")
+        r = range(int(math.ceil(-kappa)), int(math.floor(kappa)) + 1)
+        table = [o for o in itertools.product(r, repeat=self.nd)
+                 if sum(v * v for v in o) < kappa * kappa and sum(abs(v) for v in o) > 0]
+        if not table:
+            raise ValueError(f"kappa={kappa} admits no offset")
+        self.offsets = torch.tensor(table, dtype=torch.int32, device=device).contiguous()
+        self.num_anchors = dataset.get_num_anchors()
+        self.num_refs = dataset.get_num_references()
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._hi_c = (ctypes.c_int * self.nd)(*self.hi)
+
+    def sample(self, batch_size, step):
+        import torch
+
+        from .. import _clx
+
+        P = self.num_anchors * self.num_refs
+        anchor = torch.empty((batch_size, P, self.nd), dtype=torch.int64, device=self.device)
+        reference = torch.empty_like(anchor)
+        _clx.call("clx_sample_pairs", _clx.ptr(anchor), _clx.ptr(reference), _clx.ptr(self.offsets),
+                  self.offsets.shape[0], batch_size, self.num_anchors, self.num_refs, self.nd, self.lo, self._hi_c,
+                  self.seed, int(step) & 0xFFFFFFFFFFFFFFFF, _clx.stream_ptr(self.device))
+        return anchor, reference

@@ -71,6 +71,15 @@ def train(experiment_config):
         normalization_factor=experiment_config.normalization_factor,
     )
 
+    # opt-in: pair coordinates drawn on the device instead of in the loader processes (same distribution,
+    # another random stream): 2 x B x 150 040 x 2 int64 = 38 MB per step less to sample, pickle and upload
+    pair_sampler = None
+    if os.environ.get("CLX_DEVICE_PAIRS", "0") == "1":
+        from .datasets.zarr_dataset import DevicePairSampler
+
+        train_dataset.skip_pairs = True
+        pair_sampler = DevicePairSampler(train_dataset, device, seed=torch.initial_seed() + 7919 * rank)
+
     # create train dataloader (every rank draws its own random crops)
     train_dataloader = torch.utils.data.DataLoader(
         dataset=train_dataset,
@@ -131,7 +140,8 @@ def train(experiment_config):
 
     # call `train_iteration`
     for iteration, batch in tqdm(
-        zip(range(start_iteration, train_config.max_iterations), _DevicePrefetcher(train_dataloader, device)),
+        zip(range(start_iteration, train_config.max_iterations),
+            _DevicePrefetcher(train_dataloader, device, pair_sampler, start_iteration)),
         disable=not is_main,
     ):
         loss, oce_loss, prediction = train_iteration(
@@ -173,11 +183,13 @@ class _DevicePrefetcher:
     the step's critical path; the batches come out as device tensors, which
     ``train_iteration``'s ``.to(device)`` passes through."""
 
-    def __init__(self, loader, device):
+    def __init__(self, loader, device, pair_sampler=None, first_step=0):
         self.it = iter(loader)
         self.device = device
         self.stream = torch.cuda.Stream(device)
         self.next = None
+        self.pair_sampler = pair_sampler
+        self.step = first_step
         self._stage()
 
     def _stage(self):
@@ -187,7 +199,13 @@ class _DevicePrefetcher:
             self.next = None
             return
         with torch.cuda.stream(self.stream):
-            self.next = tuple(t.to(self.device, non_blocking=True) for t in batch)
+            if self.pair_sampler is not None:            # the loader sent crops only: draw the pairs here
+                raw = batch[0].to(self.device, non_blocking=True)
+                anchor, reference = self.pair_sampler.sample(raw.shape[0], self.step)
+                self.next = (raw, anchor, reference)
+            else:
+                self.next = tuple(t.to(self.device, non_blocking=True) for t in batch)
+            self.step += 1
 
     def __iter__(self):
         return self

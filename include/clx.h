@@ -264,6 +264,15 @@ int clx_oce_pairs_fused(const float* offsets, const long long* anchor,
                         const long long* reference, float* doffsets, double* sums,
                         int B, int P, int ND, int Z, int Y, int X,
                         float temperature, float reg_weight, clx_stream stream);
+/* Optional on-device pair sampler with the distribution of ZarrDataset.sample_coordinates
+ * (cellulus/datasets/zarr_dataset.py:177-242) — NOT its random stream: anchor column d uniform on
+ * the integers [lo, hi[d]] (hi: HOST array of ND ints), each anchor repeated num_refs times,
+ * reference = anchor + a uniformly chosen row of `offsets` (DEVICE, noffsets x ND int32: the
+ * admissible offsets |o|^2 < kappa^2, o != 0).  anchor / reference: (B, num_anchors*num_refs, ND)
+ * int64 out.  Counter-based: the same (seed, stream_id) gives the same pairs. */
+int clx_sample_pairs(long long* anchor, long long* reference, const int* offsets, int noffsets,
+                     int B, int num_anchors, int num_refs, int ND, int lo, const int* hi,
+                     unsigned long long seed, unsigned long long stream_id, clx_stream stream);
 /* torch.optim.Adam(lr, betas, eps, weight_decay) single step with coupled L2
  * (cellulus/train.py:80-82,179) over flat buffers of n floats.
  * step = 1-based step count AFTER increment. */

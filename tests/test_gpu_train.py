@@ -258,3 +258,63 @@ def test_train_iteration_matches_real_reference_golden(nd, device):
         # parameters travel ~4 * lr = 4e-3; agree to 1 % of that
         assert np.abs(v.cpu().numpy() - ref).max() < 4e-5, k
     assert moved > 1e-3
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_device_pair_sampler_has_the_reference_distribution(nd, device):
+    """clx_sample_pairs (opt-in, CLX_DEVICE_PAIRS=1): the support and the structure of
+    ZarrDataset.sample_coordinates — anchors in [kappa, out - kappa] per column, each repeated
+    num_references times, reference - anchor in the open kappa-ball without the origin — uniform use
+    of the offsets, reproducible per (seed, step), and usable by the fused train step."""
+    from cellulus_amd.datasets.zarr_dataset import DevicePairSampler, ZarrDataset
+
+    ds = ZarrDataset.__new__(ZarrDataset)
+    ds.num_spatial_dims, ds.kappa, ds.density = nd, 6.0, 0.1
+    ds.output_shape = (40, 48) if nd == 2 else (24, 20, 28)
+    ds.unbiased_shape = tuple(int(s - 2 * ds.kappa) for s in ds.output_shape)
+    sampler = DevicePairSampler(ds, device, seed=123)
+    B = 4
+    a, r = sampler.sample(B, step=5)
+    na, nr = ds.get_num_anchors(), ds.get_num_references()
+    assert a.shape == r.shape == (B, na * nr, nd) and a.dtype == torch.int64
+    a_c, r_c = a.cpu().numpy(), r.cpu().numpy()
+    np.random.seed(0)
+    ref_a, ref_r = ds.sample_coordinates()                      # the reference's sampler: same shapes / support
+    assert ref_a.shape == a_c.shape[1:]
+    for d in range(nd):
+        assert a_c[..., d].min() >= 6 and a_c[..., d].max() <= ds.output_shape[d] - 6
+        assert a_c[..., d].min() == 6 and a_c[..., d].max() == ds.output_shape[d] - 6     # both ends are reached
+    blocks = a_c.reshape(B, na, nr, nd)
+    assert (blocks == blocks[:, :, :1]).all()                   # np.repeat structure
+    off = r_c - a_c
+    d2 = (off ** 2).sum(-1)
+    assert d2.max() < 36 and d2.min() >= 1
+    table = sampler.offsets.cpu().numpy()
+    ref_off = ref_r - ref_a
+    assert {tuple(o) for o in ref_off} <= {tuple(o) for o in table}
+    # uniform over the table: every offset used, counts within 6 sigma of the mean
+    keys = (off.reshape(-1, nd) + 6) @ (13 ** np.arange(nd))
+    counts = np.bincount(keys, minlength=13 ** nd)
+    used = counts[(table + 6) @ (13 ** np.arange(nd))]
+    mean = off.reshape(-1, nd).shape[0] / len(table)
+    assert used.min() > 0 and np.abs(used - mean).max() < 6 * np.sqrt(mean) + 1
+    assert counts.sum() == used.sum()
+    # anchors of different batch rows / steps differ, the same (seed, step) repeats
+    a2, r2 = sampler.sample(B, step=5)
+    assert torch.equal(a, a2) and torch.equal(r, r2)
+    a3, _ = sampler.sample(B, step=6)
+    assert not torch.equal(a, a3) and not np.array_equal(a_c[0], a_c[1])
+    if nd == 2:
+        cfg = dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=2, features_in_last_layer=8,
+                   downsampling_factors=[[2, 2]], num_spatial_dims=2)
+        model = get_model(**cfg).to(device)
+        crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=2, device=device)
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=0.01)
+        # coordinate column 0 ranges over output_shape[0] but indexes the LAST axis (the reference's
+        # convention): a square output keeps every pair inside
+        ds.output_shape = (40, 40)
+        ds.unbiased_shape = (28, 28)
+        sq = DevicePairSampler(ds, device, seed=1)
+        a4, r4 = sq.sample(2, step=0)
+        loss, _, _ = train_iteration((torch.rand(2, 1, 56, 56), a4, r4), model, crit, opt, device)
+        assert np.isfinite(loss)

@@ -30,7 +30,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
 python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_streaming.json ms_ cc_ gs_ grow_shrink bucket_ histogram_kernel minmax_kernel noise_stats > $O/hbm_traffic_streaming.txt
 rm -rf $O/pmc_rd $O/pmc_wr
-find $O -name "*kernel_stats.csv" | while read f; do d=$(basename $(dirname $(dirname $f))); cp $f $O/${d}_kernel_stats.csv; done
+for d in prof prof3d prof_stream; do
+  f=$(find $O/$d -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
+done
 rm -rf $O/prof $O/prof3d $O/prof_stream
 ls -la $O
 echo refresh done
