@@ -297,8 +297,9 @@ def test_device_pair_sampler_has_the_reference_distribution(nd, device):
     counts = np.bincount(keys, minlength=13 ** nd)
     used = counts[(table + 6) @ (13 ** np.arange(nd))]
     mean = off.reshape(-1, nd).shape[0] / len(table)
-    assert used.min() > 0 and np.abs(used - mean).max() < 6 * np.sqrt(mean) + 1
-    assert counts.sum() == used.sum()
+    assert counts.sum() == used.sum()                            # nothing outside the table
+    if mean >= 20:                                               # enough draws per offset to say "uniform"
+        assert used.min() > 0 and np.abs(used - mean).max() < 6 * np.sqrt(mean) + 1
     # anchors of different batch rows / steps differ, the same (seed, step) repeats
     a2, r2 = sampler.sample(B, step=5)
     assert torch.equal(a, a2) and torch.equal(r, r2)
