@@ -47,17 +47,23 @@ def fused_stages(model, inference_config, normalization_factor, device):
                     num_infer_iterations=inference_config.num_infer_iterations, device=device)
     raw_ds = zarr_io.open(dataset_config.container_path, "r")[dataset_config.dataset_name]
     f = zarr_io.open(inference_config.prediction_dataset_config.container_path)
-    ds_emb = _create(f, inference_config.prediction_dataset_config.dataset_name,
-                     (meta.num_samples, nd + 1, *spatial), float, nd)
-    ds_det = _create(f, inference_config.detection_dataset_config.dataset_name,
-                     (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
-    ds_bin = _create(f, "binary-segmentation", (meta.num_samples, 1, *spatial), np.uint16, nd)
-    ds_cen = _create(f, "centered-embeddings", (meta.num_samples, nd + 1, *spatial), float, nd)
-    ds_seg = _create(f, inference_config.segmentation_dataset_config.dataset_name,
-                     (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
+    names = dict(emb=inference_config.prediction_dataset_config.dataset_name,
+                 det=inference_config.detection_dataset_config.dataset_name, bin="binary-segmentation",
+                 cen="centered-embeddings", seg=inference_config.segmentation_dataset_config.dataset_name)
+    if parallel.rank() == 0:         # one creator (create_dataset refuses / replaces an existing dataset)
+        _create(f, names["emb"], (meta.num_samples, nd + 1, *spatial), float, nd)
+        _create(f, names["det"], (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
+        _create(f, names["bin"], (meta.num_samples, 1, *spatial), np.uint16, nd)
+        _create(f, names["cen"], (meta.num_samples, nd + 1, *spatial), float, nd)
+        _create(f, names["seg"], (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
+    if parallel.world_size() > 1:
+        torch.distributed.barrier()
+    ds_emb, ds_det, ds_bin, ds_cen, ds_seg = (f[names[k]] for k in ("emb", "det", "bin", "cen", "seg"))
+    # samples are independent units: every rank takes a contiguous block, no collective on the data path
+    lo, hi = parallel.shard_range(meta.num_samples)
 
     scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)
-    scan.start_noise(meta.num_samples)      # the noise of sample i+1 is drawn while sample i computes
+    scan.start_noise(hi - lo)               # the noise of sample i+1 is drawn while sample i computes
     pending = []
     with ThreadPoolExecutor(max_workers=1) as writer:
         def write(ds, key, value):
@@ -79,10 +85,10 @@ def fused_stages(model, inference_config, normalization_factor, device):
             done.record(main)
             return raw, emb, done
 
-        nxt = enqueue_predict(0) if meta.num_samples else None
-        for sample in range(meta.num_samples):
+        nxt = enqueue_predict(lo) if hi > lo else None
+        for sample in range(lo, hi):
             raw, emb_d, done = nxt
-            nxt = enqueue_predict(sample + 1) if sample + 1 < meta.num_samples else None
+            nxt = enqueue_predict(sample + 1) if sample + 1 < hi else None
             with torch.cuda.stream(post):
                 post.wait_event(done)
                 emb_d.record_stream(post)
@@ -109,6 +115,8 @@ def fused_stages(model, inference_config, normalization_factor, device):
         for job in pending:
             job.result()
     scan.noise.finish()
+    if parallel.world_size() > 1:
+        torch.distributed.barrier()
 
 
 def infer(experiment_config):
@@ -158,7 +166,7 @@ def infer(experiment_config):
     # set in eval mode
     model.eval()
 
-    if world == 1 and _stages_chain(inference_config) and os.environ.get("CLX_FUSED_INFER", "1") != "0":
+    if _stages_chain(inference_config) and os.environ.get("CLX_FUSED_INFER", "1") != "0":
         # predict -> detect -> segment per sample with the hand-off in device memory
         fused_stages(model, inference_config, normalization_factor, device)
     else:

@@ -222,7 +222,8 @@ infer(cfg)
 """
 
 
-def test_two_rank_inference_shards_samples_and_writes_one_dataset(tmp_path, device):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_two_rank_inference_shards_samples_and_writes_one_dataset(tmp_path, device, fused):
     """infer() under two ranks (samples sharded, no collective on the data path; ADVICE r1: every rank
     used to create — i.e. replace — the prediction dataset): rank 0 creates each dataset once, both
     ranks fill their samples, nothing a faster rank wrote is lost.  The post-processing of each
@@ -277,7 +278,9 @@ secondary_dataset_name = "detection"
 """)
     script = tmp_path / "infer_rank.py"
     script.write_text(_INFER_SCRIPT)
-    _launch(str(script), [ROOT, str(tmp_path), str(tmp_path / "infer.toml")], {})
+    # fused = "1": predict -> detect -> segment per sample in device memory on each rank's samples;
+    # "0": the reference's dataset-by-dataset order (three sharded passes over the zarr container)
+    _launch(str(script), [ROOT, str(tmp_path), str(tmp_path / "infer.toml")], {"CLX_FUSED_INFER": fused})
     g = zarr_io.open(container, "r")
     emb, det, seg = g["embeddings"][...], g["detection"][...], g["segmentation"][...]
     assert emb.shape == (5, 3, 72, 80) and det.shape == seg.shape == (5, 1, 72, 80)
