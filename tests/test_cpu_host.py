@@ -542,3 +542,64 @@ def test_blosc_chunks_written_by_the_real_c_blosc_decode(tmp_path):
         zarr_io.blosc_decode(bytes(bad))
     with pytest.raises(zarr_io.ZarrError):
         zarr_io.blosc_decode(g["f32_lz4_shuffle/chunk"].tobytes()[:40] + b"\x00" * 100)
+
+
+# ------------------------------------------------------- round-2 host pieces
+def test_noise_prefetcher_draws_the_reference_sequence():
+    """predict.NoisePrefetcher: the background thread makes exactly the torch.rand calls of the
+    reference's infer-mode forward (unet.py:81: one per noisy copy, tile after tile) — same numbers,
+    same final generator state — only earlier."""
+    from cellulus_amd.predict import NoisePrefetcher
+
+    tile = (1, 1, 20, 24)
+    torch.manual_seed(7)
+    ref = [torch.stack([torch.rand(*tile) for _ in range(6)]) for _tile in range(3)]
+    after = torch.rand(4)
+    torch.manual_seed(7)
+    pre = NoisePrefetcher(num_tiles=3, copies=6, tile_shape=tile, depth=2)
+    got = [pre.next().clone() for _ in range(3)]
+    pre.finish()
+    for a, b in zip(got, ref):
+        assert a.shape == (6,) + tile and torch.equal(a, b)
+    assert torch.equal(torch.rand(4), after)          # the generator is where the reference leaves it
+    with pytest.raises(AssertionError):
+        pre.next()
+
+
+def test_gaussian_weights_are_scipys():
+    from scipy.ndimage import _filters
+
+    from cellulus_amd.detect import gaussian_weights
+
+    for sigma in (2.0, 0.7, 3.5):
+        w, r = gaussian_weights(sigma)
+        ref = _filters._gaussian_kernel1d(sigma, 0, int(4.0 * sigma + 0.5))
+        assert r == (len(ref) - 1) // 2
+        np.testing.assert_array_equal(w, ref[r:])
+        np.testing.assert_array_equal(ref[:r + 1][::-1], w)      # symmetric: scipy takes the symmetric branch
+
+
+def test_centre_grid_and_device_pair_table():
+    from cellulus_amd.datasets.zarr_dataset import DevicePairSampler, ZarrDataset
+    from cellulus_amd.utils.mean_shift import _center_grid
+
+    rng = np.random.default_rng(0)
+    for nd in (2, 3):
+        centers = rng.uniform(-20, 300, size=(200, nd))
+        order, cstart, origin, dims = _center_grid(centers, 15.0)
+        cells = np.floor((centers - origin) / 15.0).astype(int)
+        cid = cells[:, 0] + dims[0] * cells[:, 1] + (dims[0] * dims[1] * cells[:, 2] if nd == 3 else 0)
+        assert cstart[-1] == 200 and sorted(order.tolist()) == list(range(200))
+        for c in range(dims[0] * dims[1] * dims[2]):
+            assert set(order[cstart[c]:cstart[c + 1]].tolist()) == set(np.flatnonzero(cid == c).tolist())
+        ds = ZarrDataset.__new__(ZarrDataset)
+        ds.num_spatial_dims, ds.kappa, ds.density = nd, 5.0, 0.1
+        ds.output_shape = (40,) * nd
+        ds.unbiased_shape = (30,) * nd
+        s = DevicePairSampler(ds, torch.device("cpu"), seed=1)       # the table is host work; sample() needs HIP
+        table = {tuple(o) for o in s.offsets.numpy().tolist()}
+        np.random.seed(0)
+        ref = {tuple(o) for o in ds.sample_offsets_within_radius(5.0, 20000).tolist()}
+        assert ref <= table and len(table - ref) <= 2              # the reference's rejection loop fills the same set
+        assert (0,) * nd not in table and all(sum(v * v for v in o) < 25 for o in table)
+        assert s.lo == 5 and s.hi == [35] * nd
