@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256) void ms_assign_grid_kernel(
 }  // namespace
 
 static int prep_pairs() {      // pairs of pixels per thread: 8 (4096-pixel tiles, measured 0.74 vs 0.82 ms at
-  static const int kp = (getenv("CLX_MS_PREP_K") && atoi(getenv("CLX_MS_PREP_K")) == 4) ? 4 : 8;   // 8192^2) or 4
-  return kp;
+  static const int env = getenv("CLX_MS_PREP_K") ? atoi(getenv("CLX_MS_PREP_K")) : 8;             // 8192^2), 4 or 16
+  return env == 4 ? 4 : env == 16 ? 16 : 8;
 }
 
 extern "C" size_t clx_ms_prepare_workspace(long long npix) {
@@ -476,7 +476,7 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare: workspace must be 8-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare: too many pixels");
-  const int kp = prep_pairs();
+  const int kp = (ND == 3 && prep_pairs() == 16) ? 8 : prep_pairs();
   const int ntiles = (int)((npix + 512 * kp - 1) / (512 * kp));
   hipStream_t st = (hipStream_t)stream;
   unsigned int* ticket = (unsigned int*)workspace;
@@ -490,8 +490,8 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
 #define CLX_PREP(ND_, KP_)                                                                                   \
   ms_prepare_kernel<ND_, KP_><<<ntiles, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, \
                                                       desc, Xout, index, nfg_out)
-  if (ND == 2) { if (kp == 8) CLX_PREP(2, 8); else CLX_PREP(2, 4); }
-  else         { if (kp == 8) CLX_PREP(3, 8); else CLX_PREP(3, 4); }
+  if (ND == 2) { if (kp == 16) CLX_PREP(2, 16); else if (kp == 8) CLX_PREP(2, 8); else CLX_PREP(2, 4); }
+  else         { if (kp >= 8) CLX_PREP(3, 8); else CLX_PREP(3, 4); }
 #undef CLX_PREP
   CLX_CHECK_LAUNCH("clx_ms_prepare");
   return CLX_OK;

@@ -77,15 +77,26 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
   }
 }
 
+// A thread keeps the bin of its previous value and a count: images are smooth (the std channel of a
+// cell image is two plateaus), so consecutive values of a thread mostly share a bin and one LDS
+// atomic covers the run — with one atomic per value a two-valued image serialises 64 lanes on two
+// addresses.
 __device__ __forceinline__ void hist_one(double v, double first, double last, double denom, int nbins,
-                                         const double* __restrict__ edges, unsigned int* local) {
+                                         const double* __restrict__ edges, unsigned int* local, int& cur,
+                                         unsigned int& run) {
   if (!(v >= first) || !(v <= last)) return;
   const double f = ((v - first) / denom) * (double)nbins;
   int idx = (int)f;
   if (idx == nbins) idx -= 1;
   if (v < edges[idx]) idx -= 1;
   if (v >= edges[idx + 1] && idx != nbins - 1) idx += 1;
-  atomicAdd(&local[idx], 1u);
+  if (idx == cur) {
+    ++run;
+  } else {
+    if (run) atomicAdd(&local[cur], run);
+    cur = idx;
+    run = 1u;
+  }
 }
 
 // per-WAVE private histograms in LDS (4 copies) cut the LDS-atomic contention; the bin
@@ -104,13 +115,16 @@ __global__ __launch_bounds__(256) void histogram_kernel(const double* __restrict
   const double denom = last - first;
   const long long n2 = n >> 1;
   const f64x2* x2 = reinterpret_cast<const f64x2*>(x);
+  int cur = 0;
+  unsigned int run = 0u;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
        i += (long long)gridDim.x * blockDim.x) {
     const f64x2 v = x2[i];
-    hist_one(v[0], first, last, denom, nbins, eds, mine);
-    hist_one(v[1], first, last, denom, nbins, eds, mine);
+    hist_one(v[0], first, last, denom, nbins, eds, mine, cur, run);
+    hist_one(v[1], first, last, denom, nbins, eds, mine, cur, run);
   }
-  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) hist_one(x[n - 1], first, last, denom, nbins, eds, mine);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) hist_one(x[n - 1], first, last, denom, nbins, eds, mine, cur, run);
+  if (run) atomicAdd(&mine[cur], run);
   __syncthreads();
   for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
     const unsigned int c = local[k] + local[nbins + k] + local[2 * nbins + k] + local[3 * nbins + k];
