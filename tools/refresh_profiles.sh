@@ -23,6 +23,15 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train3d > /dev/null 2>&1
 python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train2d.json > $O/hbm_traffic_train2d.txt
 rm -rf $O/pmc_rd $O/pmc_wr
+# ... the 3-D workload ...
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline > /dev/null 2>&1
+python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train3d.json > $O/hbm_traffic_train3d.txt
+rm -rf $O/pmc_rd $O/pmc_wr
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --workload train3d --steps 2 --warmup 1 --no-infer --no-cpu-baseline > /dev/null 2>&1
+python3 tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels_3d.txt
+rm -rf $O/pmc
+CLX_BENCH_DETAIL=1 python bench.py --workload train3d --steps 6 --warmup 2 --no-infer --no-cpu-baseline > $O/per_layer_3d.txt 2>&1
 # ... and the streaming kernels of detect / segment (one 8192^2 image = 256 samples of 512^2 per launch)
 python tools/bench_stream.py 8192 > $O/streaming_kernels.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
