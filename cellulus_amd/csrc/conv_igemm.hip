@@ -46,6 +46,9 @@ struct ConvP {
   const float* mask;
   const float* zeros;   // 16 zero bytes in global memory (target of out-of-range loads)
   float* out;
+  unsigned int* gate_out;          // ReLU gates of `out` as bits (optional)
+  const unsigned int* mask_bits;   // gate bits read instead of `mask` (optional)
+  int ld_gate, ld_mask_bits;
   int relu, ld_mask, ld_out, accumulate;
   int nbm, nbn;
   long long bs_in, bs_w, bs_out;   // per-batch strides in floats (gridDim.y batches; 0 = none)
@@ -292,17 +295,38 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     const int idx = tid + 256 * it;
     const int row = idx / F4_PER_ROW, c4 = (idx % F4_PER_ROW) * 4;
     const int m = m0 + row, n = n0 + c4;
-    if (m >= p.M || n >= p.N) continue;
-    f32x4 val = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
+    const bool live = m < p.M && n < p.N;
+    f32x4 val = {0.f, 0.f, 0.f, 0.f};
     float* dst = p.out + blockIdx.y * p.bs_out + (size_t)m * p.ld_out + n;
-    if (p.accumulate) {       // out = act(conv + bias + out): n + 3 < ld_out always (ld_out % 4 == 0)
-      const f32x4 prev = *reinterpret_cast<const f32x4*>(dst);
-      val += prev;
-    }
-    if (p.relu) {
+    if (live) {
+      val = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
+      if (p.accumulate) {       // out = act(conv + bias + out): n + 3 < ld_out always (ld_out % 4 == 0)
+        const f32x4 prev = *reinterpret_cast<const f32x4*>(dst);
+        val += prev;
+      }
+      if (p.relu) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+        for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
+      }
+      if (p.mask_bits) {          // gate of the producer's ReLU, one bit per channel
+        const unsigned int w = p.mask_bits[(size_t)m * p.ld_mask_bits + (n >> 5)] >> (n & 31);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = ((w >> e) & 1u) ? val[e] : 0.f;
+      }
     }
+    if (p.gate_out) {
+      // eight consecutive lanes hold the 32 channels of one word (F4_PER_ROW is 16 or 32, so a group of
+      // eight never straddles a row): OR their nibbles together, the first lane of the group stores
+      unsigned int nib = 0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) nib |= (live && n + e < p.N && val[e] > 0.f) ? (1u << e) : 0u;
+      unsigned int word = nib << (4 * (lane & 7));
+      word |= __shfl_xor(word, 1, 64);
+      word |= __shfl_xor(word, 2, 64);
+      word |= __shfl_xor(word, 4, 64);
+      if ((lane & 7) == 0 && m < p.M && n < p.ld_out) p.gate_out[(size_t)m * p.ld_gate + (n >> 5)] = word;
+    }
+    if (!live) continue;
     if (n + 3 < p.N) {
       if (p.mask) {
         const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.ld_mask + n);
@@ -383,6 +407,7 @@ static void fill_params(const clx_conv_desc* d, ConvP& p) {
   p.Ktot = p.Ctot * d->KD * d->KH * d->KW;
   p.dOW = make_fastdiv(p.OW); p.dOH = make_fastdiv(p.OH); p.dOD = make_fastdiv(p.OD);
   p.wpack = d->wpack; p.bias = d->bias; p.mask = d->mask; p.out = d->out;
+  p.gate_out = d->gate_out; p.ld_gate = d->ld_gate; p.mask_bits = d->mask_bits; p.ld_mask_bits = d->ld_mask_bits;
   p.relu = d->relu; p.ld_mask = d->ld_mask; p.ld_out = d->ld_out;
   p.accumulate = d->accumulate;
   p.bs_in = p.bs_w = p.bs_out = 0;
@@ -399,6 +424,10 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
               "clx_conv_fwd: mask must be 16-byte aligned with ld_mask %% 4 == 0 and >= N");
   CLX_REQUIRE(d->ld_out % 4 == 0 && ((uintptr_t)d->out & 15) == 0,
               "clx_conv_fwd: out must be 16-byte aligned with ld_out %% 4 == 0");
+  CLX_REQUIRE(d->gate_out == nullptr || (d->relu && d->ld_out % 32 == 0 && d->ld_gate * 32 >= d->ld_out),
+              "clx_conv_fwd: gate_out needs relu, ld_out %% 32 == 0 and ld_gate >= ld_out / 32");
+  CLX_REQUIRE(d->mask_bits == nullptr || (d->mask == nullptr && d->ld_mask_bits * 32 >= d->N),
+              "clx_conv_fwd: mask_bits replaces mask and needs ld_mask_bits >= ceil(N / 32)");
   CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
               "clx_conv_fwd: bad algo");
   if (d->algo != CLX_ALGO_DIRECT) return clx_wino_fwd(d, (hipStream_t)stream);

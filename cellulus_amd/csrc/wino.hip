@@ -149,11 +149,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ bias, int relu,
                                                           const float* __restrict__ mask, int ld_mask,
                                                           float* __restrict__ out, int ld_out, int Nreal,
-                                                          int accumulate, long long total) {
+                                                          int accumulate, unsigned int* __restrict__ gate_out,
+                                                          int ld_gate, const unsigned int* __restrict__ mask_bits,
+                                                          int ld_mask_bits, long long total) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   const int N = N4 * 4;
   const long long plane = g.T * N;
+  // gate bits (N4 % 8 == 0, checked by the launcher): the 8 lanes i .. i + 7, i % 8 == 0, are the 32
+  // channels of one word of one tile, and they take every branch below together
+  const int sub = threadIdx.x & 7;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i % N4) * 4;
@@ -204,6 +209,21 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (mask_bits) {
+          const unsigned int wbits = mask_bits[m * ld_mask_bits + (n >> 5)] >> (n & 31);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ((wbits >> e) & 1u) ? v[e] : 0.f;
+        }
+        if (gate_out) {
+          unsigned int nib = 0u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) nib |= (n + e < Nreal && v[e] > 0.f) ? (1u << e) : 0u;
+          unsigned int word = nib << (4 * sub);
+          word |= __shfl_xor(word, 1, 64);
+          word |= __shfl_xor(word, 2, 64);
+          word |= __shfl_xor(word, 4, 64);
+          if (sub == 0) gate_out[m * ld_gate + (n >> 5)] = word;
         }
         if (n + 3 < Nreal) {
           if (mask) {
@@ -453,8 +473,14 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   const int rc = clx_igemm_launch(&gd, AA, gin.T * C, (long long)Np * d->KD * C, gout.T * Np, st);
   if (rc) return rc;
   const long long tot_out = gout.T * (Np / 4);
+  // the bit forms need whole words per lane group: channel count a multiple of 32
+  CLX_REQUIRE((d->gate_out == nullptr && d->mask_bits == nullptr) || Np % 32 == 0,
+              "clx_conv_fwd(winograd): gate_out / mask_bits need a channel count that is a multiple of 32");
+  CLX_REQUIRE(d->gate_out == nullptr || d->relu, "clx_conv_fwd(winograd): gate_out needs relu");
   wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, gout, d->bias, d->relu, d->mask,
-                                                                      d->ld_mask, d->out, d->ld_out, d->N, d->accumulate, tot_out);
+                                                                      d->ld_mask, d->out, d->ld_out, d->N, d->accumulate,
+                                                                      d->gate_out, d->ld_gate, d->mask_bits,
+                                                                      d->ld_mask_bits, tot_out);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }

@@ -401,6 +401,17 @@ class UNetPlan:
                     zs = sp["zshape"]
                     tiles = self.B * (zs[0] + sp["zk"][0] - 1) * -(-zs[1] // 4) * -(-zs[2] // 4)
                     sp["vcache"] = torch.empty(25 * tiles * sp["C1p"], dtype=torch.float32, device=self.device)
+        # ReLU gates as bits: written by the epilogue that produces a layer's output, read by the data
+        # gradient that passes through that ReLU — 1/32 of the float tensor it would otherwise read (the
+        # 64-channel 1x1 layers of the 3-D network are HBM-bound).  Whole words per pixel (channels %
+        # 32 == 0) and a producer that knows the bits (not the first-layer kernels); CLX_GATE_BITS=0 = off
+        self.gate = {}
+        if os.environ.get("CLX_GATE_BITS", "1") != "0":
+            for layer in t.convs:
+                if layer.relu and layer.param_index > 0 and pad4(layer.cout) % 32 == 0:
+                    n = self.B * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
+                    self.gate[layer.out] = torch.zeros((n, pad4(layer.cout) // 32), dtype=torch.int32,
+                                                       device=self.device)
         # forward and weight gradient of a Winograd layer transform the same input: keep V
         self.vcache = {}
         for layer in t.convs:
@@ -601,6 +612,8 @@ class UNetPlan:
         ds.accumulate = 1
         ds.out = out.data_ptr()
         ds.ld_out = sp["N"]
+        if layer.relu and self.keep:
+            self._set_gate_out(ds, layer.out)
         sp["_vskip_fresh"] = False
         if sp["wino_skip"]:
             self._use_workspace(ds, sp["wino_skip"])
@@ -697,8 +710,11 @@ class UNetPlan:
         dl.algo = 0
         dl.workspace = None
         dl.workspace_bytes = 0
-        dl.mask = self.buf[up_s.tensor].data_ptr()        # ReLU gate of the low-res tensor
-        dl.ld_mask = pad4(low_c)
+        if dzbuf is not None:
+            self._set_mask(dl, up_s.tensor)                 # ReLU gate of the low-res tensor
+        else:                                               # geometry-only query
+            dl.mask = self.buf[up_s.tensor].data_ptr()
+            dl.ld_mask = pad4(low_c)
         dl.out = self.gbuf[up_s.tensor].data_ptr() if dzbuf is not None else None
         dl.ld_out = pad4(low_c)
         return dl
@@ -729,6 +745,26 @@ class UNetPlan:
         # a raw image with 1-3 channels is stored padded to 4: tell the first-layer kernels
         d.c_real = layer.sources[0].channels if len(layer.sources) == 1 else 0
         return d
+
+    def _set_gate_out(self, d, name):
+        """forward epilogue of the layer producing buffer `name`: also emit the ReLU gates as bits"""
+        g = getattr(self, "gate", {}).get(name) if self._bwd_ready else None
+        if g is not None:
+            d.gate_out = g.data_ptr()
+            d.ld_gate = g.shape[1]
+
+    def _set_mask(self, d, name, relu=True):
+        """data-gradient epilogue: gate by the ReLU of the layer that produced buffer `name`"""
+        g = self.gate.get(name)
+        if not relu:
+            d.mask, d.ld_mask = None, 0
+        elif g is not None:
+            d.mask, d.ld_mask = None, 0
+            d.mask_bits = g.data_ptr()
+            d.ld_mask_bits = g.shape[1]
+        else:
+            d.mask = self.buf[name].data_ptr()
+            d.ld_mask = self.buf[name].shape[1]
 
     def _use_workspace(self, d, code):
         d.algo = code
@@ -835,6 +871,8 @@ class UNetPlan:
                 d.ld_mask = 0
                 d.out = self.buf[op.out].data_ptr()
                 d.ld_out = pad4(op.cout)
+                if op.relu and self.keep:
+                    self._set_gate_out(d, op.out)
                 if self.algo[op.name]["fwd"]:
                     self._use_workspace(d, self.algo[op.name]["fwd"])
                     if self.keep and self._bwd_ready and op.name in self.vcache:
@@ -969,8 +1007,7 @@ class UNetPlan:
                               pad4(pool.channels), *pool.factor, st)
                 else:
                     prev = by_out[s.tensor]
-                    dd.mask = self.buf[prev.out].data_ptr() if prev.relu else None
-                    dd.ld_mask = pad4(prev.cout)
+                    self._set_mask(dd, prev.out, relu=prev.relu)
                     dd.out = self.gbuf[prev.out].data_ptr()
                     dd.ld_out = pad4(prev.cout)
                     _clx.call("clx_conv_fwd", ctypes.byref(dd), st)

@@ -104,6 +104,15 @@ typedef struct clx_conv_desc {
    * padding of a 1-, 2- or 3-channel raw image up to 4).  Kernels may skip the padding; the weight
    * gradient then leaves the padded channels of dwpack untouched (clx_unpack_wgrad drops them). */
   int c_real;
+  /* ReLU gates as bits (optional, both may be NULL).  gate_out: with relu = 1, also write
+   * bit (n & 31) of word gate_out[m * ld_gate + (n >> 5)] = (out[m][n] > 0); requires ld_out % 32 == 0
+   * (whole words per pixel; bits of channels >= N are written as 0).  mask_bits: the same layout
+   * read INSTEAD of `mask` in the epilogue (out *= gate): 1/32 of the bytes of the float mask, which
+   * is what the data-gradient of a 1x1 layer — HBM-bound at 64 channels — otherwise reads in full. */
+  unsigned int* gate_out;
+  int ld_gate;
+  const unsigned int* mask_bits;
+  int ld_mask_bits;
 } clx_conv_desc;
 
 enum clx_conv_algo {
