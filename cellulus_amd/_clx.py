@@ -69,6 +69,7 @@ class ClxConvDesc(Structure):
         ("vcache", c_void_p),
         ("vcache_valid", c_int),
         ("c_real", c_int),
+        ("dy_vcache", c_void_p),
         ("gate_out", c_void_p),
         ("ld_gate", c_int),
         ("mask_bits", c_void_p),

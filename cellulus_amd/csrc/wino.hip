@@ -315,6 +315,112 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
 }
 
+// dY read ONCE for both of its Winograd transforms: the data gradient's input transform
+// V_d = B^T d B of the (K-1)-padded dY (tile t of the dX grid reads the A x A patch at MT t - P) and
+// the weight gradient's Mdy = A dy A^T of the MT x MT tile at MT t — which is rows / columns
+// P .. P + MT - 1 of that same patch.  gd: geometry of the data gradient's transform (over the dX
+// tiles), gw: the weight gradient's (over the dY tiles); dbias as in wino_dy_kernel.
+template <int MT, int R>
+__global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restrict__ dy, int ld_dy, int N4,
+                                                           Geom gd, Geom gw, float* __restrict__ Vd,
+                                                           float* __restrict__ Md, float* __restrict__ dbias,
+                                                           int Nreal, long long total) {
+  using W = WT<MT, R>;
+  constexpr int A = W::A;
+  constexpr int P = R - 1;
+  extern __shared__ float bacc[];
+  const int N = N4 * 4;
+  const long long plane_d = gd.T * N, plane_w = gw.T * N;
+  if (dbias) {
+    for (int k = threadIdx.x; k < N; k += blockDim.x) bacc[k] = 0.f;
+    __syncthreads();
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N4) * 4;
+    long long t = i / N4;
+    const int tx = (int)(t % gd.tw);
+    const long long q = t / gd.tw;
+    const int ty = (int)(q % gd.th);
+    const int b = (int)(q / gd.th);
+    f32x4 d[A][A];
+#pragma unroll
+    for (int r = 0; r < A; ++r) {
+      const int ly = MT * ty - P + r;
+#pragma unroll
+      for (int c = 0; c < A; ++c) {
+        const int lx = MT * tx - P + c;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)ly < (unsigned)gd.IH && (unsigned)lx < (unsigned)gd.IW)
+          v = ld4(dy + (((long long)b * gd.IH + ly) * gd.IW + lx) * ld_dy + n);
+        d[r][c] = v;
+      }
+    }
+    // ---- weight-gradient side first (it only needs the inner MT x MT block)
+    if (ty < gw.th && tx < gw.tw) {
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      f32x4 w[A][MT];
+#pragma unroll
+      for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int r = 0; r < A; ++r) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          bool first = true;
+#pragma unroll
+          for (int a = 0; a < MT; ++a) axpy(acc, first, W::AT[a][r], d[P + a][P + c]);
+          w[r][c] = acc;
+        }
+      if (dbias) {
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+          for (int c = 0; c < MT; ++c) sum += d[P + a][P + c];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&bacc[n + e], sum[e]);
+      }
+      float* dst = Md + (((long long)b * gw.th + ty) * gw.tw + tx) * N + n;
+#pragma unroll
+      for (int r = 0; r < A; ++r)
+#pragma unroll
+        for (int qq = 0; qq < A; ++qq) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          bool first = true;
+#pragma unroll
+          for (int c = 0; c < MT; ++c) axpy(acc, first, W::AT[c][qq], w[r][c]);
+          st4(dst + (r * A + qq) * plane_w, acc);
+        }
+    }
+    // ---- data-gradient side: V_d = B^T d B
+    f32x4 w2[A][A];
+#pragma unroll
+    for (int c = 0; c < A; ++c)
+#pragma unroll
+      for (int r = 0; r < A; ++r) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy(acc, first, W::BT[r][k], d[k][c]);
+        w2[r][c] = acc;
+      }
+    float* dstv = Vd + t * N + n;
+#pragma unroll
+    for (int r = 0; r < A; ++r)
+#pragma unroll
+      for (int qq = 0; qq < A; ++qq) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int k = 0; k < A; ++k) axpy(acc, first, W::BT[qq][k], w2[r][k]);
+        st4(dstv + (r * A + qq) * plane_d, acc);
+      }
+  }
+  if (dbias) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < Nreal; k += blockDim.x)
+      if (bacc[k] != 0.f) atomicAdd(dbias + k, bacc[k]);
+  }
+}
+
 // U[xi][n][c] = (G g G^T)[xi], computed in double
 // mode FWD:   g = w[n][c][:, :]            rows n < rows_pad (cout_pad), cols c < cin_pad
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
@@ -466,8 +572,10 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   const int C = S.C, Np = pad4(d->N);
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
   float* M = (float*)d->workspace + AA * gin.T * C;
-  const long long tot_in = gin.T * (C / 4);
-  wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
+  if (!(d->vcache && d->vcache_valid)) {     // (a weight-gradient call may have left V: dy_vcache)
+    const long long tot_in = gin.T * (C / 4);
+    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
+  }
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
   const int rc = clx_igemm_launch(&gd, AA, gin.T * C, (long long)Np * d->KD * C, gout.T * Np, st);
@@ -497,10 +605,26 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
     const long long tot_in = gin.T * (C / 4);
     wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
   }
-  const long long tot_dy = gout.T * (N / 4);
-  int blocks = grid_for(tot_dy, 256);
-  if (blocks > 2048) blocks = 2048;
-  wino_dy_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, gout, Md, dbias, N, tot_dy);
+  if (d->dy_vcache) {
+    // the data gradient of this layer follows: its input transform of dY comes out of the same pass
+    Geom gd = gout;                       // images = B x output planes, stored grid = the dY grid
+    gd.SH = gout.OH; gd.SW = gout.OW; gd.oy = gd.ox = 0;
+    gd.ID = gd.SD = out_planes(d); gd.oz = 0;
+    gd.IH = gout.OH; gd.IW = gout.OW; gd.P = R - 1;
+    gd.OH = gout.OH + R - 1; gd.OW = gout.OW + R - 1;
+    gd.th = (gd.OH + MT - 1) / MT; gd.tw = (gd.OW + MT - 1) / MT;
+    gd.T = (long long)gd.B * gd.th * gd.tw;
+    const long long tot = gd.T * (N / 4);
+    int blocks = grid_for(tot, 256);
+    if (dbias && blocks > 2048) blocks = 2048;
+    wino_dy_dual_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, gd, gout,
+                                                                               (float*)d->dy_vcache, Md, dbias, N, tot);
+  } else {
+    const long long tot_dy = gout.T * (N / 4);
+    int blocks = grid_for(tot_dy, 256);
+    if (blocks > 2048) blocks = 2048;
+    wino_dy_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, gout, Md, dbias, N, tot_dy);
+  }
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = N;
   const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, gin.T * C, gout.T * N,

@@ -412,6 +412,25 @@ class UNetPlan:
                     n = self.B * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
                     self.gate[layer.out] = torch.zeros((n, pad4(layer.cout) // 32), dtype=torch.int32,
                                                        device=self.device)
+        # a Winograd layer's weight gradient and data gradient both transform dY: one pass produces both
+        # (clx_conv_desc.dy_vcache); the buffer is shared by all layers (written and consumed back to back)
+        self.dycache = None
+        if os.environ.get("CLX_DY_DUAL", "1") != "0":
+            need = 0
+
+            def dual_floats(code, out_shape, k, chans):
+                a2, m = (WINO_TAPS[code], WINO_TILE[code]) if k == 3 else (25, 4)
+                return a2 * self.B * out_shape[0] * (-(-(out_shape[1] + k - 1) // m)) * (-(-(out_shape[2] + k - 1) // m)) * chans
+
+            for layer in t.convs:
+                a = self.algo[layer.name]
+                if a["wgrad"] and a["wgrad"] == a["dgrad"] and layer.name not in self.subpixel:
+                    need = max(need, dual_floats(a["wgrad"], layer.out_shape, 3, pad4(layer.cout)))
+            for name, sp in self.subpixel.items():
+                if sp["wino"]:
+                    need = max(need, dual_floats(2, sp["zshape"], 2, sp["P"] * sp["N"]))
+            if need:
+                self.dycache = torch.empty(need + 4, dtype=torch.float32, device=self.device)
         # forward and weight gradient of a Winograd layer transform the same input: keep V
         self.vcache = {}
         for layer in t.convs:
@@ -646,6 +665,8 @@ class UNetPlan:
             if sp.get("_v_fresh"):
                 dz.vcache = sp["vcache"].data_ptr()
                 dz.vcache_valid = 1
+            if self.dycache is not None:
+                dz.dy_vcache = self.dycache.data_ptr()
         _clx.call("clx_conv_wgrad", ctypes.byref(dz), _clx.ptr(dzbuf), PN, _clx.ptr(sp["dw_z"]), None, st)
         g_skip, g_z = sp["g_skip"], sp["g_z"]
         if sp["wino_skip"]:
@@ -680,6 +701,9 @@ class UNetPlan:
         dl.wpack = sp["wp_z_dgrad"].data_ptr()
         if sp["wino"]:
             self._use_workspace(dl, sp["wino"])
+            if self.dycache is not None:       # written by the weight-gradient call on dZ above
+                dl.vcache = self.dycache.data_ptr()
+                dl.vcache_valid = 1
         _clx.call("clx_conv_fwd", ctypes.byref(dl), st)
         return dskip
 
@@ -940,11 +964,15 @@ class UNetPlan:
             wino_w = self.algo[layer.name]["wgrad"]
             wtaps = wino_taps(wino_w, layer.kernel) if wino_w else layer.taps
             dwp = self.dwpack[off:off + wtaps * pad4(layer.cout) * layer.cin_pad]
+            dual = (self.dycache is not None and wino_w and layer.param_index > 0
+                    and self.algo[layer.name]["dgrad"] == wino_w)
             if wino_w:
                 self._use_workspace(d, wino_w)
                 if layer.name in self.vcache and layer.name in self._vcache_fresh:
                     d.vcache = self.vcache[layer.name].data_ptr()
                     d.vcache_valid = 1
+                if dual:
+                    d.dy_vcache = self.dycache.data_ptr()
             _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), pad4(layer.cout), _clx.ptr(dwp),
                       _clx.ptr(gb) if gb is not None else None, st)
             gw = grads[2 * layer.param_index]
@@ -969,6 +997,9 @@ class UNetPlan:
             dd.wpack = self.wpack_dgrad[layer.name].data_ptr()
             if self.algo[layer.name]["dgrad"]:
                 self._use_workspace(dd, self.algo[layer.name]["dgrad"])
+                if dual:                       # V of dY was written by the weight-gradient call above
+                    dd.vcache = self.dycache.data_ptr()
+                    dd.vcache_valid = 1
             if len(layer.sources) == 2:
                 info = r_by_conv0[layer.name]
                 cat = self.gbuf["cat%d" % info["level"]]

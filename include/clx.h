@@ -97,7 +97,8 @@ typedef struct clx_conv_desc {
   /* Winograd only, optional: a^2 * T * C floats (the head of the workspace layout) that hold the
    * transformed input V = B^T d B instead of the workspace.  clx_conv_fwd writes it; a later
    * clx_conv_wgrad of the same layer with vcache_valid = 1 reads it and skips its own input
-   * transform (the forward and the weight gradient transform the same tensor). */
+   * transform (the forward and the weight gradient transform the same tensor); clx_conv_fwd with
+   * vcache_valid = 1 takes V from it instead of transforming (see dy_vcache). */
   void* vcache;
   int vcache_valid;
   /* Hint, 0 = unknown: only the first c_real channels of src[0] can be non-zero (the rest is the
@@ -109,6 +110,12 @@ typedef struct clx_conv_desc {
    * (whole words per pixel; bits of channels >= N are written as 0).  mask_bits: the same layout
    * read INSTEAD of `mask` in the epilogue (out *= gate): 1/32 of the bytes of the float mask, which
    * is what the data-gradient of a 1x1 layer — HBM-bound at 64 channels — otherwise reads in full. */
+  /* Winograd, optional: clx_conv_wgrad also writes the input transform of dY that the data gradient
+   * of the same layer needs (zero padding K - 1) into this buffer — a^2 * T_d * N floats, T_d = B *
+   * output planes * ceil((OH + K - 1) / tile) * ceil((OW + K - 1) / tile) — reading dY once for both
+   * transforms; the following clx_conv_fwd (data-gradient form) then sets vcache = this buffer and
+   * vcache_valid = 1 and skips its own input transform.  dY must be dense (ld_dy == N). */
+  void* dy_vcache;
   unsigned int* gate_out;
   int ld_gate;
   const unsigned int* mask_bits;
