@@ -343,6 +343,49 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
     const long long q = t / gd.tw;
     const int ty = (int)(q % gd.th);
     const int b = (int)(q / gd.th);
+    // ---- weight-gradient side first, from its own loads of the inner MT x MT block: holding the whole
+    // A x A patch across both transforms costs 256 VGPRs (one wave per SIMD — measured 0.6 ms SLOWER per
+    // 3-D step); read twice, the second time the block comes out of the vector cache
+    if (ty < gw.th && tx < gw.tw) {
+      f32x4 dd[MT][MT];
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < MT; ++c) {
+          const int oy = MT * ty + a, ox = MT * tx + c;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
+          if (oy < gd.IH && ox < gd.IW) v = ld4(dy + (((long long)b * gd.IH + oy) * gd.IW + ox) * ld_dy + n);
+          dd[a][c] = v;
+          sum += v;
+        }
+      if (dbias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(&bacc[n + e], sum[e]);
+      }
+      f32x4 w[A][MT];
+#pragma unroll
+      for (int c = 0; c < MT; ++c)
+#pragma unroll
+        for (int r = 0; r < A; ++r) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          bool first = true;
+#pragma unroll
+          for (int a = 0; a < MT; ++a) axpy(acc, first, W::AT[a][r], dd[a][c]);
+          w[r][c] = acc;
+        }
+      float* dst = Md + (((long long)b * gw.th + ty) * gw.tw + tx) * N + n;
+#pragma unroll
+      for (int r = 0; r < A; ++r)
+#pragma unroll
+        for (int qq = 0; qq < A; ++qq) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+          bool first = true;
+#pragma unroll
+          for (int c = 0; c < MT; ++c) axpy(acc, first, W::AT[c][qq], w[r][c]);
+          st4(dst + (r * A + qq) * plane_w, acc);
+        }
+    }
     f32x4 d[A][A];
 #pragma unroll
     for (int r = 0; r < A; ++r) {
@@ -355,40 +398,6 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
           v = ld4(dy + (((long long)b * gd.IH + ly) * gd.IW + lx) * ld_dy + n);
         d[r][c] = v;
       }
-    }
-    // ---- weight-gradient side first (it only needs the inner MT x MT block)
-    if (ty < gw.th && tx < gw.tw) {
-      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-      f32x4 w[A][MT];
-#pragma unroll
-      for (int c = 0; c < MT; ++c)
-#pragma unroll
-        for (int r = 0; r < A; ++r) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          bool first = true;
-#pragma unroll
-          for (int a = 0; a < MT; ++a) axpy(acc, first, W::AT[a][r], d[P + a][P + c]);
-          w[r][c] = acc;
-        }
-      if (dbias) {
-#pragma unroll
-        for (int a = 0; a < MT; ++a)
-#pragma unroll
-          for (int c = 0; c < MT; ++c) sum += d[P + a][P + c];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) atomicAdd(&bacc[n + e], sum[e]);
-      }
-      float* dst = Md + (((long long)b * gw.th + ty) * gw.tw + tx) * N + n;
-#pragma unroll
-      for (int r = 0; r < A; ++r)
-#pragma unroll
-        for (int qq = 0; qq < A; ++qq) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-          bool first = true;
-#pragma unroll
-          for (int c = 0; c < MT; ++c) axpy(acc, first, W::AT[c][qq], w[r][c]);
-          st4(dst + (r * A + qq) * plane_w, acc);
-        }
     }
     // ---- data-gradient side: V_d = B^T d B
     f32x4 w2[A][A];
