@@ -66,53 +66,54 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restric
   }
 }
 
-__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                   const float* __restrict__ dyp, const float* __restrict__ dskip,
-                                   int ld_skip, int SD, int SH, int SW, int cz, int cy, int cx,
-                                   float* __restrict__ dxo, int D, int H, int W, int C4,
-                                   int fz, int fy, int fx, Dec dc, FastDiv dfz, FastDiv dfy, FastDiv dfx,
-                                   uint32_t total) {
+// max-pool backward + skip gradient + ReLU gate, one thread per WINDOW (x 4 channels): the window's values
+// are read once, the first maximum is found in registers (no pooled tensor, no re-reads of the earlier window positions),
+// the pooled gradient is read once per window instead of once per pixel
+__global__ void maxpool_bwd_window_kernel(const float* __restrict__ x, const float* __restrict__ dyp,
+                                          const float* __restrict__ dskip, int ld_skip, int SD, int SH, int SW,
+                                          int cz, int cy, int cx, float* __restrict__ dxo, int D, int H, int W,
+                                          int C4, int fz, int fy, int fx, Dec dcw, uint32_t total) {
   const int C = C4 * 4;
   const int OD = D / fz, OH = H / fy, OW = W / fx;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    uint32_t pixel;
-    int c4, px, py, pz, bi;
-    decode(i, dc, pixel, c4, px, py, pz, bi);
+    uint32_t win;
+    int c4, wx, wy, wz, bi;
+    decode(i, dcw, win, c4, wx, wy, wz, bi);         // decoded over the POOLED grid (OW, OH, OD)
     const int c = c4 * 4;
-    const long long b = bi;
-    const int wz = (int)fdiv((uint32_t)pz, dfz), wy = (int)fdiv((uint32_t)py, dfy), wx = (int)fdiv((uint32_t)px, dfx);
-    const f32x4 xv = ld4(x + (size_t)pixel * C + c);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    if (wz < OD && wy < OH && wx < OW) {
-      const long long win = ((b * OD + wz) * OH + wy) * OW + wx;
-      const f32x4 yv = ld4(y + win * C + c);
-      const f32x4 gv = ld4(dyp + win * C + c);
-      bool is_max[4], earlier[4] = {false, false, false, false};
+    const f32x4 gv = ld4(dyp + (size_t)win * C + c);
+    // pass 1: maximum and the scan position of its first occurrence (torch's rule), per channel
+    f32x4 best = {0.f, 0.f, 0.f, 0.f};
+    int arg[4] = {0, 0, 0, 0};
+    int k = 0;
+    for (int dz = 0; dz < fz; ++dz)
+      for (int dy = 0; dy < fy; ++dy)
+        for (int dx = 0; dx < fx; ++dx, ++k) {
+          const size_t pix = (((size_t)bi * D + wz * fz + dz) * H + wy * fy + dy) * W + wx * fx + dx;
+          const f32x4 v = ld4(x + pix * C + c);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) is_max[e] = (xv[e] == yv[e]);
-      // torch keeps the FIRST maximum in window scan order
-      const int rz = pz - wz * fz, ry = py - wy * fy, rx = px - wx * fx;
-      const int my = (rz * fy + ry) * fx + rx;
-      for (int k = 0; k < my; ++k) {
-        const int dx = k % fx, dy = (k / fx) % fy, dz = k / (fx * fy);
-        const long long pix = ((b * D + wz * fz + dz) * H + wy * fy + dy) * W + wx * fx + dx;
-        const f32x4 ov = ld4(x + pix * C + c);
+          for (int e = 0; e < 4; ++e)
+            if (k == 0 || v[e] > best[e]) { best[e] = v[e]; arg[e] = k; }
+        }
+    // pass 2 (the window is in cache): route the gradient, add the skip gradient, gate by the ReLU
+    k = 0;
+    for (int dz = 0; dz < fz; ++dz)
+      for (int dy = 0; dy < fy; ++dy)
+        for (int dx = 0; dx < fx; ++dx, ++k) {
+          const int pz = wz * fz + dz, py = wy * fy + dy, px = wx * fx + dx;
+          const size_t pix = (((size_t)bi * D + pz) * H + py) * W + px;
+          const f32x4 xv = ld4(x + pix * C + c);
+          f32x4 g;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) earlier[e] = earlier[e] || (ov[e] == yv[e]);
-      }
+          for (int e = 0; e < 4; ++e) g[e] = (arg[e] == k) ? gv[e] : 0.f;
+          if (dskip) {
+            const int sz = pz - cz, sy = py - cy, sx = px - cx;
+            if ((unsigned)sz < (unsigned)SD && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW)
+              g += ld4(dskip + ((((size_t)bi * SD + sz) * SH + sy) * SW + sx) * ld_skip + c);
+          }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] = (is_max[e] && !earlier[e]) ? gv[e] : 0.f;
-    }
-    if (dskip) {
-      const int sz = pz - cz, sy = py - cy, sx = px - cx;
-      if ((unsigned)sz < (unsigned)SD && (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW) {
-        const long long sp = ((b * SD + sz) * SH + sy) * SW + sx;
-        g += ld4(dskip + sp * ld_skip + c);
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) g[e] = (xv[e] > 0.f) ? g[e] : 0.f;
-    st4(dxo + (size_t)pixel * C + c, g);
+          for (int e = 0; e < 4; ++e) g[e] = (xv[e] > 0.f) ? g[e] : 0.f;
+          st4(dxo + pix * C + c, g);
+        }
   }
 }
 
@@ -254,10 +255,11 @@ extern "C" int clx_maxpool_bwd(const float* x, const float* y, const float* dy_p
   CLX_REQUIRE(dskip == nullptr || (ld_skip % 4 == 0 && ld_skip >= C), "clx_maxpool_bwd: bad ld_skip");
   const long long total = (long long)B * D * H * W * (C / 4);
   CLX_REQUIRE(total < (1ll << 31), "clx_maxpool_bwd: tensor too large");
-  maxpool_bwd_kernel<<<grid_for(total, 256), 256, 0, (hipStream_t)stream>>>(
-      x, y, dy_pool, dskip, ld_skip, SD, SH, SW, cz, cy, cx, dx, D, H, W, C / 4, fz, fy, fx,
-      make_dec(C / 4, W, H, D), make_fastdiv((uint32_t)fz), make_fastdiv((uint32_t)fy), make_fastdiv((uint32_t)fx),
-      (uint32_t)total);
+  // extents divide (checked above): every pixel belongs to exactly one window
+  const long long wtotal = total / ((long long)fz * fy * fx);
+  maxpool_bwd_window_kernel<<<grid_for(wtotal, 256), 256, 0, (hipStream_t)stream>>>(
+      x, dy_pool, dskip, ld_skip, SD, SH, SW, cz, cy, cx, dx, D, H, W, C / 4, fz, fy, fx,
+      make_dec(C / 4, W / fx, H / fy, D / fz), (uint32_t)wtotal);
   CLX_CHECK_LAUNCH("clx_maxpool_bwd");
   return CLX_OK;
 }
