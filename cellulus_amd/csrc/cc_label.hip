@@ -10,6 +10,7 @@
 // final root of a component is its smallest raster index.  Stale reads of the
 // parent array are harmless (parents only decrease along a chain; progress is
 // made by the values returned from the atomics).
+#include <stdlib.h>
 #include "clx_common.h"
 
 namespace {
@@ -130,6 +131,106 @@ __global__ __launch_bounds__(256) void cc_merge_runs(const int* __restrict__ seg
       if (b && !(left && a)) uf_union(L, (int)p.i, (int)r);
       if (a && !b && !left) uf_union(L, (int)p.i, (int)r - 1);
       if (c && !b && !right) uf_union(L, (int)p.i, (int)r + 1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-D fast path for passes 1 + 2: a wavefront walks a strip of STRIP_ROWS rows of its 64-pixel
+// column segment TOP-DOWN, carrying the previous row's values and labels in registers.  A run takes
+// the smallest label of the runs it touches in the row above (segmented min inside the wave), a run
+// that touches nothing starts a new label (its first pixel), and a global union is needed only when
+// a run touches two different labels — so inside a strip an object costs no atomic at all instead
+// of one per row.  What the strips do not see — the row above a strip, the column left of a
+// segment — is linked afterwards by cc_link_borders (1/32 + 1/64 of the pixels).
+// ---------------------------------------------------------------------------------------------
+constexpr int STRIP_ROWS = 32;
+
+__global__ __launch_bounds__(256) void cc_strip_kernel(const int* __restrict__ seg, int* L, int* __restrict__ size,
+                                                       int Y, int X, int nseg, int nstrips) {
+  const int lane = threadIdx.x & 63;
+  const long long nwaves = (long long)nstrips * nseg;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const int strip = (int)(w / nseg), sg = (int)(w - (long long)strip * nseg);
+    const int x = sg * 64 + lane;
+    const bool in_x = x < X;
+    const int y0 = strip * STRIP_ROWS, y1 = min(y0 + STRIP_ROWS, Y);
+    int pv = 0, pl = -1;
+    for (int y = y0; y < y1; ++y) {
+      const long long i = (long long)y * X + x;
+      const int v = in_x ? seg[i] : 0;
+      unsigned long long starts;
+      const int sl = run_start_lane(v, lane, &starts);
+      // smallest label among the (up to three) touching pixels of the row above
+      int cand = 0x7fffffff;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int src = min(max(lane + dx, 0), 63);
+        const int nv = __shfl(pv, src, 64), nl = __shfl(pl, src, 64);
+        if (v != 0 && nv == v && (lane + dx) == src) cand = min(cand, nl);
+      }
+      const int own = cand;
+      // segmented inclusive min-scan towards higher lanes, then everyone takes the run's last lane
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(cand, d, 64);
+        if (lane - d >= sl) cand = min(cand, t);
+      }
+      const unsigned long long above = (lane == 63) ? 0ull : (starts >> (lane + 1));
+      const int el = above ? lane + __builtin_ctzll(above) : 63;
+      const int runmin = __shfl(cand, el, 64);
+      int label = -1;
+      if (v != 0) {
+        label = (runmin == 0x7fffffff) ? (int)(i - lane + sl) : runmin;
+        if (runmin == 0x7fffffff && sl == lane) size[i] = 0;       // a new root
+        L[i] = label;
+      } else if (in_x) {
+        L[i] = -1;
+      }
+      // a run that touches several labels joins them (the L entries involved were written by this
+      // wavefront in earlier rows, or are being linked by others through atomics: both are safe)
+      const int left_own = __shfl_up(own, 1, 64);
+      if (v != 0 && own != 0x7fffffff && own != label && (lane == sl || left_own != own)) {
+        __threadfence();            // this wavefront's plain stores of L (earlier rows) before the finds / atomics
+        uf_union(L, own, label);
+      }
+      pv = v;
+      pl = label;
+    }
+  }
+}
+
+// links across the borders the strips ignore: for the first row of every strip the three pixels above,
+// for the first column of every segment the three pixels to the left
+__global__ void cc_link_borders(const int* __restrict__ seg, int* L, int Y, int X, int nseg, int nstrips) {
+  const long long n_rows = (long long)(nstrips - 1) * X;          // pixels of the strips' first rows (not strip 0)
+  const long long n_cols = (long long)(nseg - 1) * Y;             // pixels of the segments' first columns
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows + n_cols;
+       k += (long long)gridDim.x * blockDim.x) {
+    if (k < n_rows) {
+      const int y = (int)(k / X + 1) * STRIP_ROWS, x = (int)(k % X);
+      const long long i = (long long)y * X + x;
+      const int v = seg[i];
+      if (v == 0) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= X) continue;
+        const long long j = i - X + dx;
+        if (seg[j] == v) uf_union(L, (int)i, (int)j);
+      }
+    } else {
+      const long long kk = k - n_rows;
+      const int x = (int)(kk / Y + 1) * 64, y = (int)(kk % Y);
+      const long long i = (long long)y * X + x;
+      const int v = seg[i];
+      if (v == 0) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= Y) continue;
+        const long long j = (long long)yy * X + x - 1;
+        if (seg[j] == v) uf_union(L, (int)i, (int)j);
+      }
     }
   }
 }
@@ -280,8 +381,16 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
   const int nseg = (X + 63) / 64;
   const long long nwaves = (long long)Z * Y * nseg;
   const int wgrid = grid_for(nwaves * 64, 256);
-  cc_init_runs<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
-  cc_merge_runs<<<wgrid, 256, 0, st>>>(seg, L, Z, Y, X, nseg, nwaves);
+  static const bool strips = getenv("CLX_CC_STRIPS") == nullptr || atoi(getenv("CLX_CC_STRIPS")) != 0;
+  if (Z == 1 && strips) {
+    const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
+    cc_strip_kernel<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, L, size, Y, X, nseg, nstrips);
+    const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
+    if (nb > 0) cc_link_borders<<<grid_for(nb, 256), 256, 0, st>>>(seg, L, Y, X, nseg, nstrips);
+  } else {
+    cc_init_runs<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
+    cc_merge_runs<<<wgrid, 256, 0, st>>>(seg, L, Z, Y, X, nseg, nwaves);
+  }
   cc_flatten_count<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
   cc_count_roots<<<nblocks, 256, 0, st>>>(seg, L, size, min_size, npix, counts);
   cc_scan_counts<<<1, 1024, 0, st>>>(counts, nblocks, ncomp_out);
