@@ -162,15 +162,18 @@ __global__ __launch_bounds__(256) void cc_strip_kernel(const int* __restrict__ s
       const int v = in_x ? seg[i] : 0;
       unsigned long long starts;
       const int sl = run_start_lane(v, lane, &starts);
-      // smallest label among the (up to three) touching pixels of the row above
-      int cand = 0x7fffffff;
+      // labels of the (up to three) touching pixels of the row above.  If the pixel straight above
+      // matches, its two neighbours belong to the same run; otherwise up-left and up-right are two
+      // DIFFERENT runs (the pixel between them differs), and both labels count.
+      int c[3];
 #pragma unroll
       for (int dx = -1; dx <= 1; ++dx) {
         const int src = min(max(lane + dx, 0), 63);
         const int nv = __shfl(pv, src, 64), nl = __shfl(pl, src, 64);
-        if (v != 0 && nv == v && (lane + dx) == src) cand = min(cand, nl);
+        c[dx + 1] = (v != 0 && nv == v && (lane + dx) == src) ? nl : 0x7fffffff;
       }
-      const int own = cand;
+      if (c[1] != 0x7fffffff) c[0] = c[2] = 0x7fffffff;
+      int cand = min(c[0], min(c[1], c[2]));
       // segmented inclusive min-scan towards higher lanes, then everyone takes the run's last lane
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -188,12 +191,15 @@ __global__ __launch_bounds__(256) void cc_strip_kernel(const int* __restrict__ s
       } else if (in_x) {
         L[i] = -1;
       }
-      // a run that touches several labels joins them (the L entries involved were written by this
-      // wavefront in earlier rows, or are being linked by others through atomics: both are safe)
-      const int left_own = __shfl_up(own, 1, 64);
-      if (v != 0 && own != 0x7fffffff && own != label && (lane == sl || left_own != own)) {
-        __threadfence();            // this wavefront's plain stores of L (earlier rows) before the finds / atomics
-        uf_union(L, own, label);
+      // every other label the run touches is joined to the one it took (the L entries involved were
+      // written by this wavefront in earlier rows: fence; the links themselves are atomics)
+      const bool j0 = c[0] != 0x7fffffff && c[0] != label, j1 = c[1] != 0x7fffffff && c[1] != label,
+                 j2 = c[2] != 0x7fffffff && c[2] != label;
+      if (j0 || j1 || j2) {
+        __threadfence();
+        if (j0) uf_union(L, c[0], label);
+        if (j1) uf_union(L, c[1], label);
+        if (j2) uf_union(L, c[2], label);
       }
       pv = v;
       pl = label;
