@@ -101,6 +101,21 @@ def train(experiment_config):
     )
     model = model.to(device)
 
+    # the pair sampler draws coordinates for an output of extent crop_size - 16 (zarr_dataset.py:94): a
+    # network whose output is smaller (deeper, other factors) makes the reference fail in its first
+    # iteration with an IndexError out of select_and_add_coordinates — say so before any work is done
+    from .models.plan import build_topology
+
+    topo = build_topology(model.in_channels, model.out_channels, model.num_fmaps, model.fmap_inc_factor,
+                          model.features_in_last_layer, model.downsampling_factors, model.num_spatial_dims,
+                          tuple(train_config.crop_size))
+    out_extent = tuple(topo.out_shape[3 - model.num_spatial_dims:])
+    if any(o < d for o, d in zip(out_extent, train_dataset.output_shape)):
+        raise IndexError(
+            f"the network maps crop_size {tuple(train_config.crop_size)} to an output of extent {out_extent}, but "
+            f"the pair sampler draws coordinates for {train_dataset.output_shape} (crop_size - 16): choose a "
+            "model / crop_size whose output is crop_size - 16")
+
     # initialize model weights
     if model_config.initialize:
         for _name, layer in model.named_modules():

@@ -210,6 +210,39 @@ def test_second_backward_accumulates_like_torch(device):
         assert torch.allclose(p.grad, g, rtol=1e-4, atol=1e-5)
 
 
+def test_gate_bits_and_dual_dy_transform_change_nothing(device, monkeypatch):
+    """The byte-saving forms — ReLU gates as bits (clx_conv_desc.gate_out / mask_bits) and dY read once for
+    its two Winograd transforms (dy_vcache) — make the same decisions and run the same arithmetic in the
+    same order as the plain forms: the data-gradient chain is bit-identical, the weight gradients agree
+    to the atomics' summation order.  (Both are on by default; 64 / 96 channels: whole gate words.)"""
+    cfg = dict(in_channels=2, out_channels=2, num_fmaps=64, fmap_inc_factor=2, features_in_last_layer=64,
+               downsampling_factors=[[2, 2]], num_spatial_dims=2)
+    torch.manual_seed(4)
+    raw = torch.rand(2, 2, 76, 84, device=device)
+    results = {}
+    for gate, dual in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("CLX_GATE_BITS", gate)
+        monkeypatch.setenv("CLX_DY_DUAL", dual)
+        torch.manual_seed(5)
+        model = get_model(**cfg).to(device)
+        out = model(raw)
+        plan = next(iter(model._plans.values()))
+        assert bool(plan.gate) == (gate == "1") and (plan.dycache is not None) == (dual == "1")
+        assert sum(1 for a in plan.algo.values() if a["dgrad"] and a["wgrad"]) >= 2      # Winograd layers present
+        torch.manual_seed(6)
+        out.backward(torch.randn_like(out))
+        first = plan.topo.convs[1]                     # gradient w.r.t. the first layer's pre-activation:
+        results[gate, dual] = (out.detach().clone(), plan.gbuf[plan.topo.convs[0].out].clone(),   # end of the dgrad chain
+                               [p.grad.clone() for p in model.parameters()])
+        assert first.relu
+    ref = results["0", "0"]
+    for key, (out, g0, grads) in results.items():
+        assert torch.equal(out, ref[0]), key
+        assert torch.equal(g0, ref[1]), key            # every data gradient on the way is a pure function of these
+        for g, r in zip(grads, ref[2]):
+            assert torch.allclose(g, r, rtol=1e-4, atol=1e-5 * r.abs().max().item()), key
+
+
 def test_rejects_cpu_tensors():
     from cellulus_amd._clx import ClxError
 
