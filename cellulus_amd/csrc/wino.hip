@@ -587,6 +587,7 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   }
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
+  gd.precision = d->precision;
   const int rc = clx_igemm_launch(&gd, AA, gin.T * C, (long long)Np * d->KD * C, gout.T * Np, st);
   if (rc) return rc;
   const long long tot_out = gout.T * (Np / 4);

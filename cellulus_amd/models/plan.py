@@ -59,6 +59,17 @@ def wino_min_channels(kernel):
     return WINO_MIN_CHANNELS_3D if kernel[0] > 1 else WINO_MIN_CHANNELS
 
 
+def precision_code() -> int:
+    """clx_conv_precision for the forward / data-gradient GEMMs: 0 = float32 MFMA (default); CLX_PRECISION=
+    f32x3bf16 opts into the three-way bfloat16 split of the float32 operands (csrc/gemm_x3.hip)."""
+    name = os.environ.get("CLX_PRECISION", "f32")
+    if name in ("f32", ""):
+        return 0
+    if name == "f32x3bf16":
+        return 1
+    raise ValueError(f"CLX_PRECISION must be 'f32' or 'f32x3bf16', got {name!r}")
+
+
 def winograd_enabled() -> bool:
     return os.environ.get("CLX_WINOGRAD", "1") != "0"
 
@@ -251,6 +262,7 @@ class UNetPlan:
         self.B = int(batch)
         self.device = device
         self.keep = keep_activations
+        self.precision = precision_code()
         self.buf = {}
         self._alloc()
 
@@ -578,6 +590,7 @@ class UNetPlan:
         ds.KD, ds.KH, ds.KW = layer.kernel
         ds.PD = ds.PH = ds.PW = 0
         for d in (dz, ds):
+            d.precision = self.precision
             d.algo = 0
             d.accumulate = 0
             d.workspace = None
@@ -734,6 +747,7 @@ class UNetPlan:
         dl.algo = 0
         dl.workspace = None
         dl.workspace_bytes = 0
+        dl.precision = self.precision
         if dzbuf is not None:
             self._set_mask(dl, up_s.tensor)                 # ReLU gate of the low-res tensor
         else:                                               # geometry-only query
@@ -768,6 +782,7 @@ class UNetPlan:
         d.workspace_bytes = 0
         # a raw image with 1-3 channels is stored padded to 4: tell the first-layer kernels
         d.c_real = layer.sources[0].channels if len(layer.sources) == 1 else 0
+        d.precision = self.precision
         return d
 
     def _set_gate_out(self, d, name):
@@ -818,6 +833,7 @@ class UNetPlan:
         dd.algo = 0
         dd.workspace = None
         dd.workspace_bytes = 0
+        dd.precision = self.precision
         return dd
 
     def _expand_cin(self, layer, w):

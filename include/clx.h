@@ -49,7 +49,8 @@ int clx_device_count(void);
 enum clx_profile_kind {
   CLX_PROF_IGEMM_WIDE = 0,   /* conv_igemm_kernel<128,128> */
   CLX_PROF_IGEMM_NARROW = 1, /* conv_igemm_kernel<128,64>  */
-  CLX_PROF_WGRAD = 2         /* conv_wgrad_kernel<...>     */
+  CLX_PROF_WGRAD = 2,        /* conv_wgrad_kernel<...>     */
+  CLX_PROF_GEMM_X3 = 3       /* gemm_x3_kernel (opt-in precision f32x3bf16; FLOPs = f32-equivalent 2*M*N*K) */
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);
@@ -105,6 +106,12 @@ typedef struct clx_conv_desc {
    * padding of a 1-, 2- or 3-channel raw image up to 4).  Kernels may skip the padding; the weight
    * gradient then leaves the padded channels of dwpack untouched (clx_unpack_wgrad drops them). */
   int c_real;
+  /* clx_conv_precision: 0 = float32 MFMA (default, the reference's arithmetic).  1 = opt-in
+   * "f32x3bf16": where the convolution is a plain matrix product (1x1 layers, the batched GEMMs of
+   * the 2-D Winograd layers; N % 128 == 0, K % 32 == 0) every float32 operand is split exactly into
+   * three bfloat16 pieces and six exact products are accumulated in float32 on the bf16 matrix
+   * cores (error ~ one float32 rounding per product); everything else stays on the default path. */
+  int precision;
   /* ReLU gates as bits (optional, both may be NULL).  gate_out: with relu = 1, also write
    * bit (n & 31) of word gate_out[m * ld_gate + (n >> 5)] = (out[m][n] > 0); requires ld_out % 32 == 0
    * (whole words per pixel; bits of channels >= N are written as 0).  mask_bits: the same layout
@@ -142,6 +149,7 @@ enum clx_conv_algo {
   CLX_ALGO_WINOGRAD4 = 2
 };
 enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
+enum clx_conv_precision { CLX_PREC_F32 = 0, CLX_PREC_F32X3BF16 = 1 };
 /* Scratch bytes clx_conv_fwd (pass FWD; also the dgrad form) / clx_conv_wgrad (pass WGRAD)
  * need for descriptor `d` with algo = CLX_ALGO_WINOGRAD / _WINOGRAD4; 0 if Winograd does not apply to
  * the geometry (the caller must then use CLX_ALGO_DIRECT). */

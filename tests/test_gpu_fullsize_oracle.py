@@ -60,8 +60,9 @@ def _planar(plan, name, nd):
     return t[:, :, 0] if nd == 2 else t
 
 
-@pytest.mark.parametrize("name,cfg,crop", [("cfg2", CFG2, (256, 256)), ("cfg4", CFG4, (64, 64, 64))])
-def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, device):
+@pytest.mark.parametrize("name,cfg,crop,precision", [("cfg2", CFG2, (256, 256), "f32"), ("cfg4", CFG4, (64, 64, 64), "f32"),
+                                                    ("cfg2", CFG2, (256, 256), "f32x3bf16")])
+def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, precision, device, monkeypatch):
     """Forward: < 1e-4 against the float32 AND the float64 oracle.  Gradients: every parameter
     within 1e-4 (relative L2) of the float64 oracle run with the HIP forward pass's ReLU gates and
     pooling winners (oracle.unet_oracle.forced_decisions explains why: ~2e-6 of the 1.3e8 gate
@@ -70,6 +71,10 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, devic
     against the free-running float64 oracle no farther than the float32 CPU oracle is."""
     import torch.nn.functional as F
 
+    # "f32x3bf16": the opt-in precision (plain GEMMs on the bf16 matrix cores, float32 operands split
+    # exactly into three bfloat16 pieces, six exact products) is held to the SAME bars as the default
+    monkeypatch.setenv("CLX_PRECISION", precision)
+    name = f"{name}/{precision}"
     nd = len(crop)
     torch.manual_seed(0)
     oracle = O.OracleUNetModel(**cfg)
@@ -82,6 +87,7 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, devic
     # the default plan at this size is the one the benchmark runs
     got = model(raw.to(device))
     plan = next(iter(model._plans.values()))
+    assert plan.precision == (1 if precision == "f32x3bf16" else 0)
     assert sum(1 for a in plan.algo.values() if a["fwd"] == 2) >= 3, "Winograd F(4x4) expected on the wide layers"
     assert plan.subpixel, "the sub-pixel form of the upsample convolution is expected here"
     torch.manual_seed(2)

@@ -243,6 +243,47 @@ def test_gate_bits_and_dual_dy_transform_change_nothing(device, monkeypatch):
             assert torch.allclose(g, r, rtol=1e-4, atol=1e-5 * r.abs().max().item()), key
 
 
+def test_opt_in_precision_f32x3bf16_matches_the_oracle_and_is_used(device, monkeypatch):
+    """CLX_PRECISION=f32x3bf16: the plain GEMMs (1x1 layers, Winograd batched GEMMs; N % 128 == 0, K % 32 == 0)
+    run gemm_x3_kernel — seen through the in-library launch profile — and forward / gradients keep the
+    default path's bars against the float64 oracle; layers the kernel does not cover fall back to float32."""
+    import ctypes
+
+    from cellulus_amd import _clx
+
+    cfg = dict(in_channels=1, out_channels=2, num_fmaps=128, fmap_inc_factor=2, features_in_last_layer=64,
+               downsampling_factors=[[2, 2]], num_spatial_dims=2)
+    monkeypatch.setenv("CLX_PRECISION", "f32x3bf16")
+    torch.manual_seed(0)
+    oracle = OracleUNetModel(**cfg)
+    for _n, layer in oracle.named_modules():
+        if isinstance(layer, torch.nn.modules.conv._ConvNd):
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+    model = get_model(**cfg)
+    model.load_state_dict(oracle.state_dict(), strict=True)
+    model = model.to(device)
+    raw = torch.rand(2, 1, 92, 100)
+    _clx.call("clx_profile_enable", 2)
+    got = model(raw.to(device))
+    torch.manual_seed(2)
+    dout = torch.randn(got.shape)
+    got.backward(dout.to(device))
+    n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _clx.load().clx_profile_read(3, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+    _clx.call("clx_profile_enable", 0)
+    assert n_l.value >= 8, "gemm_x3_kernel was not launched"
+    o64 = oracle.double()
+    ref = o64(raw.double())
+    ref.backward(dout.double())
+    assert (got.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4
+    for (n, po), (_n2, pm) in zip(o64.named_parameters(), model.named_parameters()):
+        l2 = ((pm.grad.cpu().double() - po.grad).norm() / (po.grad.norm() + 1e-30)).item()
+        assert l2 < 1e-4, (n, l2)
+    monkeypatch.setenv("CLX_PRECISION", "fp8")
+    with pytest.raises(ValueError, match="CLX_PRECISION"):
+        get_model(**cfg).to(device)(raw.to(device))
+
+
 def test_rejects_cpu_tensors():
     from cellulus_amd._clx import ClxError
 
