@@ -106,6 +106,12 @@ typedef struct clx_conv_desc {
    * padding of a 1-, 2- or 3-channel raw image up to 4).  Kernels may skip the padding; the weight
    * gradient then leaves the padded channels of dwpack untouched (clx_unpack_wgrad drops them). */
   int c_real;
+  /* Winograd, optional: clx_conv_wgrad also writes the input transform of dY that the data gradient
+   * of the same layer needs (zero padding K - 1) into this buffer — a^2 * T_d * N floats, T_d = B *
+   * output planes * ceil((OH + K - 1) / tile) * ceil((OW + K - 1) / tile) — reading dY once for both
+   * transforms; the following clx_conv_fwd (data-gradient form) then sets vcache = this buffer and
+   * vcache_valid = 1 and skips its own input transform.  dY must be dense (ld_dy == N). */
+  void* dy_vcache;
   /* clx_conv_precision: 0 = float32 MFMA (default, the reference's arithmetic).  1 = opt-in
    * "f32x3bf16": where the convolution is a plain matrix product (1x1 layers, the batched GEMMs of
    * the 2-D Winograd layers; N % 128 == 0, K % 32 == 0) every float32 operand is split exactly into
@@ -117,12 +123,6 @@ typedef struct clx_conv_desc {
    * (whole words per pixel; bits of channels >= N are written as 0).  mask_bits: the same layout
    * read INSTEAD of `mask` in the epilogue (out *= gate): 1/32 of the bytes of the float mask, which
    * is what the data-gradient of a 1x1 layer — HBM-bound at 64 channels — otherwise reads in full. */
-  /* Winograd, optional: clx_conv_wgrad also writes the input transform of dY that the data gradient
-   * of the same layer needs (zero padding K - 1) into this buffer — a^2 * T_d * N floats, T_d = B *
-   * output planes * ceil((OH + K - 1) / tile) * ceil((OW + K - 1) / tile) — reading dY once for both
-   * transforms; the following clx_conv_fwd (data-gradient form) then sets vcache = this buffer and
-   * vcache_valid = 1 and skips its own input transform.  dY must be dense (ld_dy == N). */
-  void* dy_vcache;
   unsigned int* gate_out;
   int ld_gate;
   const unsigned int* mask_bits;

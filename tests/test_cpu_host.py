@@ -603,3 +603,24 @@ def test_centre_grid_and_device_pair_table():
         assert ref <= table and len(table - ref) <= 2              # the reference's rejection loop fills the same set
         assert (0,) * nd not in table and all(sum(v * v for v in o) < 25 for o in table)
         assert s.lo == 5 and s.hi == [35] * nd
+
+
+def test_ctypes_descriptor_layout_equals_the_c_struct(tmp_path):
+    """cellulus_amd/_clx.py::ClxConvDesc against include/clx.h::clx_conv_desc as gcc lays it out: size and
+    the offset of every field (a field inserted on one side only shifts pointers silently)."""
+    from cellulus_amd import _clx
+
+    fields = [name for name, _t in _clx.ClxConvDesc._fields_]
+    prog = ['#include <stddef.h>', '#include <stdio.h>', f'#include "{os.path.join(ROOT, "include", "clx.h")}"',
+            'int main(void) {', '  printf("%zu\\n", sizeof(clx_conv_desc));']
+    prog += [f'  printf("%zu\\n", offsetof(clx_conv_desc, {name}));' for name in fields]
+    prog += ['  printf("%zu\\n", sizeof(clx_src));', '  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(prog))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert vals[0] == ctypes.sizeof(_clx.ClxConvDesc)
+    for name, off in zip(fields, vals[1:1 + len(fields)]):
+        assert getattr(_clx.ClxConvDesc, name).offset == off, name
+    assert vals[-1] == ctypes.sizeof(_clx.ClxSrc)
