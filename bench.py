@@ -295,7 +295,7 @@ def run_workload(wl_key, args, rank, world, device):
 
     lib = _clx.load()
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-             3: "gemm_x3_kernel"}
+             3: "gemm_x3_kernel", 4: "wgrad_x3_kernel"}
     prof = {}
     for kind, kname in kinds.items():
         n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
@@ -342,7 +342,7 @@ def run_workload(wl_key, args, rank, world, device):
     # HIP-event durations (events recorded inside libclx around the kernel launch itself)
     dom_name, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    peak = BF16_MFMA_PEAK_TFLOPS / 6 if dom_name == "gemm_x3_kernel" else F32_MFMA_PEAK_TFLOPS
+    peak = BF16_MFMA_PEAK_TFLOPS / 6 if dom_name in ("gemm_x3_kernel", "wgrad_x3_kernel") else F32_MFMA_PEAK_TFLOPS
     mfma_ms = sum(v[1] for v in prof.values())
     mfma_fl = sum(v[2] for v in prof.values())
     plan_algo = getattr(plan, "algo", {})
@@ -504,12 +504,17 @@ def main():
     torch.cuda.set_device(device)
 
     res = run_workload(args.workload, args, rank, world, device)
-    res_x3 = None
+    res_x3 = infer_x3 = None
     if args.precision == "f32x3bf16":
         os.environ["CLX_PRECISION"] = "f32x3bf16"
         torch.cuda.empty_cache()
         try:
             res_x3 = run_workload(args.workload, args, rank, world, device)
+            if world == 1 and not args.no_infer:
+                from bench_infer import infer_bench
+
+                torch.cuda.empty_cache()
+                infer_x3 = infer_bench(device, with_cpu=False, with_e2e=False, with_streaming=False)
         finally:
             os.environ["CLX_PRECISION"] = "f32"
     res3d = None
@@ -543,6 +548,9 @@ def main():
             metric="train crops/sec with the OPT-IN precision f32x3bf16 (not the headline; dtype of the results is "
                    "still float32: six exact bf16 products per f32 product on the plain GEMMs, the rest unchanged)",
             steps=args.steps, warmup=args.warmup, **res_x3)
+    if infer_x3 is not None:
+        out["infer_f32x3bf16"] = dict(infer_x3, metric=infer_x3["metric"] + " with the OPT-IN precision f32x3bf16 "
+                                      "on the embedding network (not the headline)")
     if res3d is not None:
         out["train3d"] = dict(metric="train crops/sec, BASELINE configs[3]", steps=args.steps, warmup=args.warmup,
                               **res3d)

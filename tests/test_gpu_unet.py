@@ -270,7 +270,10 @@ def test_opt_in_precision_f32x3bf16_matches_the_oracle_and_is_used(device, monke
     got.backward(dout.to(device))
     n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
     _clx.load().clx_profile_read(3, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+    n_w = ctypes.c_double()
+    _clx.load().clx_profile_read(4, ctypes.byref(n_w), ctypes.byref(ms_l), ctypes.byref(fl_l))
     _clx.call("clx_profile_enable", 0)
+    assert n_w.value >= 4, "the weight gradients of the wide layers were expected on wgrad_x3_kernel"
     assert n_l.value >= 8, "gemm_x3_kernel was not launched"
     o64 = oracle.double()
     ref = o64(raw.double())
@@ -542,3 +545,47 @@ def test_winograd_entry_points_vs_f64_convolution(k, algo, kd, pad, device):
             err = (dw.cpu().double().reshape(N, C, kd, k, k) - wr.grad).abs().max().item()
             assert err < 2e-5 * wr.grad.abs().max().item(), (cached, err)
             assert (db.cpu().double() - dy.double().sum((0, 1, 2, 3))).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("N,C,M", [(128, 128, 5000), (256, 384, 33333), (128, 256, 31)])
+def test_opt_in_precision_weight_gradient_kernel_vs_f64(N, C, M, device):
+    """wgrad_x3_kernel (clx_conv_wgrad on a plain 1x1 product with precision = CLX_PREC_F32X3BF16): weight and bias
+    gradient against float64, ragged pixel counts (zero-filled last chunk, many slices), accumulation into a
+    non-zero buffer; the same call in the default precision for scale."""
+    import ctypes
+
+    from cellulus_amd import _clx
+    from cellulus_amd._clx import ClxConvDesc, ClxSrc
+
+    torch.manual_seed(N + C + M)
+    x = torch.relu(torch.randn(M, C))
+    dy = torch.randn(M, N)
+    ref = dy.double().t() @ x.double()
+    refb = dy.double().sum(0)
+    x_d, dy_d = x.to(device), dy.to(device)
+    errs = {}
+    for prec in (0, 1):
+        dw = torch.ones(N * C, device=device)
+        db = torch.ones(N, device=device)
+        d = ClxConvDesc()
+        d.nsrc = 1
+        s = ClxSrc()
+        s.ptr, s.C, s.ld = x_d.data_ptr(), C, C
+        s.D, s.H, s.W = 1, 1, M
+        s.fz = s.fy = s.fx = 1
+        d.src[0] = s
+        d.B, d.ID, d.IH, d.IW = 1, 1, 1, M
+        d.KD = d.KH = d.KW = 1
+        d.N = N
+        d.precision = prec
+        _clx.call("clx_profile_enable", 2)
+        _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy_d), N, _clx.ptr(dw), _clx.ptr(db), _clx.stream_ptr(device))
+        n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _clx.load().clx_profile_read(4, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+        _clx.call("clx_profile_enable", 0)
+        assert n_l.value == prec, "wgrad_x3_kernel runs exactly when the descriptor asks for the opt-in precision"
+        got = dw.view(N, C).cpu().double() - 1.0
+        errs[prec] = ((got - ref).norm() / ref.norm()).item()
+        assert errs[prec] < 2e-6, (prec, errs)
+        assert ((db.cpu().double() - 1.0 - refb).abs().max() / refb.abs().max()).item() < 1e-5
+    print(f"wgrad N={N} C={C} M={M}: rel L2 vs f64: f32 {errs[0]:.2e}, f32x3bf16 {errs[1]:.2e}")
