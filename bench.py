@@ -503,6 +503,7 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
+    env_precision = os.environ.get("CLX_PRECISION", "f32") or "f32"
     res = run_workload(args.workload, args, rank, world, device)
     res_x3 = infer_x3 = None
     if args.precision == "f32x3bf16":
@@ -516,7 +517,7 @@ def main():
                 torch.cuda.empty_cache()
                 infer_x3 = infer_bench(device, with_cpu=False, with_e2e=False, with_streaming=False)
         finally:
-            os.environ["CLX_PRECISION"] = "f32"
+            os.environ["CLX_PRECISION"] = env_precision
     res3d = None
     if args.workload == "train2d" and not args.no_train3d:
         torch.cuda.empty_cache()
@@ -543,6 +544,10 @@ def main():
         "data": "synthetic",
     }
     out.update({k: v for k, v in res.items() if k not in out})
+    if env_precision != "f32":
+        # (profiling runs of the opt-in precision set CLX_PRECISION outside; such a line is never the headline)
+        out["dtype"] = env_precision
+        out["note"] = f"CLX_PRECISION={env_precision} was set in the environment: every number of this line is the opt-in precision's"
     if res_x3 is not None:
         out["train2d_f32x3bf16"] = dict(
             metric="train crops/sec with the OPT-IN precision f32x3bf16 (not the headline; dtype of the results is "

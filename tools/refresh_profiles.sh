@@ -39,10 +39,16 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t 
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
 python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_streaming.json ms_ cc_ gs_ grow_shrink bucket_ histogram_kernel minmax_kernel noise_stats > $O/hbm_traffic_streaming.txt
 rm -rf $O/pmc_rd $O/pmc_wr
-for d in prof prof3d prof_stream; do
+# ... and the opt-in precision f32x3bf16 (its own bench object; kernel statistics and matrix-pipe busy of that step)
+python bench.py --precision f32x3bf16 > $O/bench_f32x3bf16.json 2> $O/bench_f32x3bf16.err
+CLX_PRECISION=f32x3bf16 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_x3 -o t -- python3 bench.py --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train3d > $O/bench_x3_under_rocprof.json 2>/dev/null
+CLX_PRECISION=f32x3bf16 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train3d > /dev/null 2>&1
+python3 tools/pmc_digest.py $O/pmc _x3 > $O/pmc_x3_kernels.txt
+rm -rf $O/pmc
+for d in prof prof3d prof_stream prof_x3; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
 done
-rm -rf $O/prof $O/prof3d $O/prof_stream
+rm -rf $O/prof $O/prof3d $O/prof_stream $O/prof_x3
 ls -la $O
 echo refresh done
