@@ -589,3 +589,71 @@ def test_opt_in_precision_weight_gradient_kernel_vs_f64(N, C, M, device):
         assert errs[prec] < 2e-6, (prec, errs)
         assert ((db.cpu().double() - 1.0 - refb).abs().max() / refb.abs().max()).item() < 1e-5
     print(f"wgrad N={N} C={C} M={M}: rel L2 vs f64: f32 {errs[0]:.2e}, f32x3bf16 {errs[1]:.2e}")
+
+
+@pytest.mark.parametrize("C,N,M", [(32, 128, 1000), (256, 256, 4099), (96, 128, 130)])
+def test_opt_in_precision_gemm_kernel_epilogues_vs_f64(C, N, M, device):
+    """gemm_x3_kernel straight through clx_conv_fwd (1x1 product, precision = CLX_PREC_F32X3BF16): plain,
+    bias + ReLU + gate bits, ReLU-gate mask as floats and as bits, accumulate — against float64, ragged row counts."""
+    import ctypes
+
+    from cellulus_amd import _clx
+    from cellulus_amd._clx import ClxConvDesc, ClxSrc
+
+    torch.manual_seed(C + N + M)
+    x = torch.randn(M, C)
+    w = torch.randn(N, C) * 0.2
+    bias = torch.randn(N)
+    ref = x.double() @ w.double().t()
+    x_d, w_d, b_d = x.to(device), w.to(device), bias.to(device)
+    gate = torch.randn(M, N)
+    gate_d = gate.to(device).contiguous()
+    packed = torch.zeros(M, N // 32, dtype=torch.int64)
+    for c in range(N):
+        packed[:, c // 32] |= (gate[:, c] > 0).long() << (c % 32)
+    bits = torch.where(packed >= (1 << 31), packed - (1 << 32), packed).to(torch.int32).to(device)
+    prev = torch.randn(M, N)
+    st = _clx.stream_ptr(device)
+    _clx.call("clx_profile_enable", 2)
+    for mode in ("plain", "bias_relu_gate", "mask", "mask_bits", "accumulate"):
+        out = prev.to(device).clone().contiguous() if mode == "accumulate" else torch.full((M, N), float("nan"), device=device)
+        d = ClxConvDesc()
+        d.nsrc = 1
+        s = ClxSrc()
+        s.ptr, s.C, s.ld = x_d.data_ptr(), C, C
+        s.D, s.H, s.W = 1, 1, M
+        s.fz = s.fy = s.fx = 1
+        d.src[0] = s
+        d.B, d.ID, d.IH, d.IW = 1, 1, 1, M
+        d.KD = d.KH = d.KW = 1
+        d.N = N
+        d.wpack = w_d.data_ptr()
+        d.out, d.ld_out = out.data_ptr(), N
+        d.precision = 1
+        want, gate_out = ref, None
+        if mode == "bias_relu_gate":
+            d.bias, d.relu = b_d.data_ptr(), 1
+            want = torch.relu(ref + bias.double())
+            gate_out = torch.zeros(M, N // 32, dtype=torch.int32, device=device)
+            d.gate_out, d.ld_gate = gate_out.data_ptr(), N // 32
+        elif mode == "mask":
+            d.mask, d.ld_mask = gate_d.data_ptr(), N
+            want = ref * (gate > 0)
+        elif mode == "mask_bits":
+            d.mask_bits, d.ld_mask_bits = bits.data_ptr(), N // 32
+            want = ref * (gate > 0)
+        elif mode == "accumulate":
+            d.accumulate = 1
+            want = ref + prev.double()
+        _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+        got = out.cpu().double()
+        assert torch.isfinite(got).all(), mode
+        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-6, mode
+        if gate_out is not None:
+            g = gate_out.cpu().long() & 0xFFFFFFFF
+            for c in range(0, N, 7):
+                assert torch.equal(((g[:, c // 32] >> (c % 32)) & 1).bool(), got[:, c] > 0), (mode, c)
+    n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _clx.load().clx_profile_read(3, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+    _clx.call("clx_profile_enable", 0)
+    assert n_l.value == 5, "gemm_x3_kernel was expected to run these products"
