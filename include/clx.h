@@ -115,9 +115,12 @@ typedef struct clx_conv_desc {
   void* dy_vcache;
   /* clx_conv_precision: 0 = float32 MFMA (default, the reference's arithmetic).  1 = opt-in
    * "f32x3bf16": where the convolution is a plain matrix product (1x1 layers, the batched GEMMs of
-   * the 2-D Winograd layers; N % 128 == 0, K % 32 == 0) every float32 operand is split exactly into
+   * the 2-D Winograd layers; clx_conv_fwd incl. its data-gradient form: N % 128 == 0, K % 32 == 0;
+   * clx_conv_wgrad: N % 128 == 0 and C % 128 == 0) every float32 operand is split exactly into
    * three bfloat16 pieces and six exact products are accumulated in float32 on the bf16 matrix
-   * cores (error ~ one float32 rounding per product); everything else stays on the default path. */
+   * cores, the accumulation bias of that instruction cancelled between two accumulators (error ~
+   * one float32 rounding per product, measured below the float32 MFMA's); everything else stays on
+   * the default path. */
   int precision;
   /* ReLU gates as bits (optional, both may be NULL).  gate_out: with relu = 1, also write
    * bit (n & 31) of word gate_out[m * ld_gate + (n >> 5)] = (out[m][n] > 0); requires ld_out % 32 == 0
