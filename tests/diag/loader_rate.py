@@ -1,6 +1,6 @@
 """Loader-inclusive training rate at the benchmark configuration: train() on a synthetic zarr (zarr
 reads, random crops, pair sampling in the loader processes — or on the device with CLX_DEVICE_PAIRS=1 —
-H2D, logging).  Usage: [CLX_DEVICE_PAIRS=1] python tests/diag/loader_rate.py [iterations] [workers]"""
+H2D, logging).  Usage: [CLX_DEVICE_PAIRS=1] python tests/diag/loader_rate.py [iterations] [workers] [elastic: 0|1]"""
 import contextlib
 import io
 import os
@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+elastic = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
 tmp = tempfile.mkdtemp(prefix="clx_lr_")
 os.chdir(tmp)
 from bench import synthetic_raw  # noqa: E402
@@ -28,7 +29,7 @@ from cellulus_amd.configs import ExperimentConfig  # noqa: E402
 
 cfg = ExperimentConfig(normalization_factor=1.0, model_config=dict(num_fmaps=256, fmap_inc_factor=3),
                        train_config=dict(crop_size=[256, 256], batch_size=8, max_iterations=iters, num_workers=workers,
-                                         elastic_deform=False, save_model_every=10 ** 6, save_best_model_every=10 ** 6,
+                                         elastic_deform=elastic, save_model_every=10 ** 6, save_best_model_every=10 ** 6,
                                          save_snapshot_every=10 ** 6,
                                          train_data_config=dict(container_path="data.zarr", dataset_name="train/raw")))
 stamps = []
@@ -47,7 +48,7 @@ with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.St
     T.train(cfg)
 dt = time.perf_counter() - t0
 steady = (stamps[-1] - stamps[50]) / (len(stamps) - 51)
-print(f"CLX_DEVICE_PAIRS={os.environ.get('CLX_DEVICE_PAIRS', '0')} workers={workers}: {iters} iterations in {dt:.1f} s "
+print(f"CLX_DEVICE_PAIRS={os.environ.get('CLX_DEVICE_PAIRS', '0')} workers={workers} elastic={int(elastic)}: {iters} iterations in {dt:.1f} s "
       f"({iters * 8 / dt:.1f} crops/s incl. start-up); steady state {steady * 1e3:.1f} ms per iteration = "
       f"{8 / steady:.1f} crops/s")
 shutil.rmtree(tmp, ignore_errors=True)
