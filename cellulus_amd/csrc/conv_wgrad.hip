@@ -255,16 +255,18 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
 // splits every value exactly into three bf16 pieces and stores, per channel and piece, the eight pixels as one
 // 16-byte LDS word — image [piece][pixel group][channel][8], the four channel words of a thread XOR-swizzled so
 // that the 8-lane groups of ds_write_b128 and the 16-lane groups of the fragment reads are conflict-free.
-// Threads 0-127 stage dy, 128-255 stage x.  k-steps alternate between a +dy and a -dy accumulator (the
-// accumulation bias of the bf16 MFMA cancels in their difference).  Slices, tail split and the float-atomic
-// combine are those of conv_wgrad_kernel.
+// Threads 0-127 stage dy, 128-255 stage x.  One accumulator set (164 VGPRs, three blocks per CU): the
+// accumulation bias of the bf16 MFMA, which gemm_x3.hip cancels between two accumulators because a weight
+// gradient sums its outputs coherently over the pixels, ends here in single weight-gradient elements that
+// nothing sums — 1e-7 of their size.  Slices, tail split and the float-atomic combine are those of
+// conv_wgrad_kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X3_BKP = 32;                       // pixels per chunk: two k-steps of 16
 constexpr int X3_PIECE = 4 * 128 * 8;            // bf16 elements per piece image (8 KB)
 
-__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradP p) {
+__global__ __launch_bounds__(256, 3) void wgrad_x3_kernel(const WgradP p) {
   __shared__ __attribute__((aligned(16))) unsigned short Ys[3 * X3_PIECE];
   __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * X3_PIECE];
 
@@ -291,7 +293,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradP p) {
   const long long ld = op == 0 ? p.ld_dy : p.src[0].ld;
   unsigned short* img = (op == 0 ? Ys : Xs) + (pg * 128 + 4 * cg) * 8;
   const int esw = (cg >> 1) & 3;
-  const unsigned int flip = (op == 0 && pg >= 2) ? 0x80008000u : 0u;     // second k-step: -dy
 
   const int chunk0 = slice * cps;
   int nchunks = (p.M + X3_BKP - 1) / X3_BKP - chunk0;
@@ -327,22 +328,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradP p) {
       for (int q = 0; q < 3; ++q) {
         u32x4 w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_perm(h[q][2 * k + 1], h[q][2 * k], 0x07060302u) ^ flip;
+        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_perm(h[q][2 * k + 1], h[q][2 * k], 0x07060302u);
         *reinterpret_cast<u32x4*>(img + q * X3_PIECE + (e ^ esw) * 8) = w;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  f32x16 acc[2][2][2];                           // [k-step parity][i][j]; parity 1 accumulates -(dy^T x)
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int q = 0; q < 2; ++q)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // fragment word of channel ch: slot 4 (ch >> 2) + ((ch & 3) ^ ((ch >> 3) & 3))
   int fa[2], fb[2];
@@ -374,14 +373,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradP p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[ks][i][j];
+          f32x16 c = acc[i][j];
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);    // smallest terms first
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-          acc[ks][i][j] = c;
+          acc[i][j] = c;
         }
     }
   }
@@ -396,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = tile_n * 128 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(dst + (size_t)n * p.Ctot + c, acc[0][i][j][r] - acc[1][i][j][r]);
+        atomicAdd(dst + (size_t)n * p.Ctot + c, acc[i][j][r]);
       }
     }
 
