@@ -69,7 +69,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const X3P p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
   const int m0 = (v / p.nbn) * XBM, n0 = (v % p.nbn) * XBN;
-  const int lr = t >> 3, lk = (t & 7) * 4;
+  // staging thread -> (row, 4 columns): the 16 contiguous lanes of a ds_write_b64 group take rows r and r + 4,
+  // 4 x 80 B = 16 banks apart, so their two 64-byte runs cover the 32 banks once (rows r and r + 1 overlap on 4
+  // banks: measured as SQ_LDS_BANK_CONFLICT = 1/3 of the kernel's LDS cycles)
+  const int lr = (t >> 6) * 8 + ((t >> 4) & 3) + 4 * ((t >> 3) & 1), lk = (t & 7) * 4;
   const float* Ab = p.A + blockIdx.y * p.bs_a;
   const float* ap[4];
 #pragma unroll
