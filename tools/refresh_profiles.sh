@@ -50,5 +50,10 @@ for d in prof prof3d prof_stream prof_x3; do
   [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
 done
 rm -rf $O/prof $O/prof3d $O/prof_stream $O/prof_x3
+# LDS bank conflicts / wait counters of the MFMA kernels, both precisions
+for prec in f32 f32x3bf16; do
+  CLX_PRECISION=$prec bash tools/pmc_issue_counters.sh > /dev/null 2>&1
+  cat gpurun_out/pmc_$prec/set1.txt gpurun_out/pmc_$prec/set1_f32.txt | grep -v "grey\|smallc" > $O/pmc_lds_conflicts_$prec.txt
+done
 ls -la $O
 echo refresh done
