@@ -65,7 +65,11 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
 
   // one LDS arena: A/B double buffers during the K loop, the C tile in the epilogue
-  constexpr int LDC = BN + 4;
+  // C tile rows: 16 lanes read one 64-float row of the narrow tile, and ds_read_b128 serves the lane groups
+  // {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31}: two consecutive rows must present complementary 16-byte slots,
+  // i.e. a row stride of a whole 256-byte line (with + 4 floats a tenth of this kernel's LDS cycles were
+  // conflicts of these reads); the 128-wide tile keeps a lane group inside one row, where the pad is harmless
+  constexpr int LDC = BN == 64 ? BN : BN + 4;
   constexpr int SMEM_AB = 2 * (BM + BN) * LDS_LD;
   constexpr int SMEM_C = BM * LDC;
   __shared__ float smem[SMEM_AB > SMEM_C ? SMEM_AB : SMEM_C];
