@@ -62,6 +62,64 @@ extern "C" long long clx_lz4_decompress(const unsigned char* src, long long src_
   return (long long)(op - dst);
 }
 
+// BloscLZ stream (c-blosc 1.x blosclz.c, a FastLZ descendant; codec 0 of a Blosc chunk): control bytes < 32 start
+// a run of ctrl + 1 literals; others are matches — length (ctrl >> 5) + 2, 255-extended when the field is 7;
+// distance ((ctrl & 31) << 8) + next byte + 1, or, when both fields are saturated, a 16-bit big-endian distance
+// beyond 8191.  The first control byte is masked to a literal run.  Returns the bytes written, or a negative
+// value on malformed / overflowing input.
+extern "C" long long clx_blosclz_decompress(const unsigned char* src, long long src_bytes, unsigned char* dst,
+                                            long long dst_capacity) {
+  if (!src || !dst || src_bytes < 0 || dst_capacity < 0) return -1;
+  if (src_bytes == 0) return 0;
+  const unsigned char* ip = src;
+  const unsigned char* const iend = src + src_bytes;
+  unsigned char* op = dst;
+  unsigned char* const oend = dst + dst_capacity;
+  unsigned ctrl = (*ip++) & 31u;
+  for (;;) {
+    if (ctrl >= 32) {
+      long long len = (long long)(ctrl >> 5) - 1;
+      long long ofs = (long long)(ctrl & 31u) << 8;
+      unsigned code;
+      if (len == 7 - 1) {
+        do {
+          if (ip + 1 >= iend) return -2;
+          code = *ip++;
+          len += code;
+        } while (code == 255);
+      } else if (ip + 1 >= iend) {
+        return -3;
+      }
+      code = *ip++;
+      len += 3;
+      long long dist = ofs + code;
+      if (code == 255 && ofs == (31ll << 8)) {
+        if (ip + 1 >= iend) return -4;
+        dist = ((long long)ip[0] << 8) + ip[1] + 8191;
+        ip += 2;
+      }
+      dist += 1;
+      if (len > oend - op) return -5;
+      if (dist > op - dst) return -6;
+      const bool last = ip >= iend;
+      if (!last) ctrl = *ip++;
+      const unsigned char* match = op - dist;
+      for (long long k = 0; k < len; ++k) op[k] = match[k];     // byte by byte: overlapping matches replicate
+      op += len;
+      if (last) break;
+    } else {
+      const long long run = (long long)ctrl + 1;
+      if (run > oend - op || run > iend - ip) return -7;
+      memcpy(op, ip, (size_t)run);
+      op += run;
+      ip += run;
+      if (ip >= iend) break;
+      ctrl = *ip++;
+    }
+  }
+  return (long long)(op - dst);
+}
+
 // Blosc byte shuffle, inverse: src holds `typesize` planes of n / typesize bytes (plane j = byte j
 // of every element), then the n % typesize left-over bytes verbatim.
 extern "C" int clx_unshuffle_bytes(const unsigned char* src, unsigned char* dst, long long n, int typesize) {

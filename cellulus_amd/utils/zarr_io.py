@@ -82,9 +82,9 @@ def blosc_decode(raw):
     byte-shuffled into planes of >= 128 bytes and the don't-split flag (0x10) is clear, else one
     stream; every stream is an int32 length followed by the codec's output (or the bytes
     themselves when the length equals the plain size); the last, shorter block is never split.
-    Codecs: LZ4 / LZ4HC (zarr's default, decoded by libclx's clx_lz4_decompress) and zlib;
-    byte shuffle is undone by clx_unshuffle_bytes.  blosclz, snappy, zstd and bit-shuffle are
-    not implemented and raise."""
+    Codecs: LZ4 / LZ4HC (zarr's default) and BloscLZ (decoded by libclx: clx_lz4_decompress,
+    clx_blosclz_decompress), zlib, and — when pyarrow is importable (its bundled codecs) — zstd and
+    snappy; byte shuffle is undone by clx_unshuffle_bytes, bit shuffle by `_bit_unshuffle`."""
     import ctypes
 
     from .. import _clx
@@ -100,17 +100,16 @@ def blosc_decode(raw):
         return b""
     if flags & 0x02:                                     # memcpyed
         return raw[16:16 + nbytes]
-    if flags & 0x04:
-        raise ZarrError("Blosc bit-shuffle is not supported by this reader (byte shuffle and no shuffle are)")
     codec = _BLOSC_CODECS.get(flags >> 5, "?")
-    if codec not in ("lz4", "zlib"):
-        raise ZarrError(f"Blosc codec {codec!r} is not supported by this reader (lz4, lz4hc and zlib are); "
-                        "re-save the array with Blosc(cname='lz4') (zarr's default) or an uncompressed / zlib compressor")
+    if codec not in ("lz4", "zlib", "zstd", "snappy", "blosclz"):
+        raise ZarrError(f"Blosc codec id {flags >> 5} is not known to this reader (blosclz, lz4, lz4hc, snappy, zlib and zstd are)")
+    arrow = _arrow_codec(codec) if codec in ("zstd", "snappy") else None
     if blocksize <= 0:
         raise ZarrError("corrupt Blosc header (block size)")
     nblocks = -(-nbytes // blocksize)
     leftover = nbytes % blocksize
-    shuffle = bool(flags & 0x01) and typesize > 1
+    bitshuffle = bool(flags & 0x04)
+    shuffle = (bool(flags & 0x01) and typesize > 1) or bitshuffle
     dont_split = bool(flags & 0x10)
     lib = _clx.load()
     src = np.frombuffer(raw, dtype=np.uint8)
@@ -133,21 +132,52 @@ def blosc_decode(raw):
                 raise ZarrError("corrupt Blosc block")
             if clen == neblock:
                 target[done:done + neblock] = src[pos:pos + neblock]
-            elif codec == "lz4":
-                n = lib.clx_lz4_decompress(u8p(src.ctypes.data + pos), clen, u8p(target.ctypes.data + done), neblock)
+            elif codec in ("lz4", "blosclz"):
+                fn = lib.clx_lz4_decompress if codec == "lz4" else lib.clx_blosclz_decompress
+                n = fn(u8p(src.ctypes.data + pos), clen, u8p(target.ctypes.data + done), neblock)
                 if n != neblock:
-                    raise ZarrError(f"LZ4 stream of a Blosc block decoded to {n} bytes, expected {neblock}")
+                    raise ZarrError(f"{codec} stream of a Blosc block decoded to {n} bytes, expected {neblock}")
             else:
-                piece = zlib.decompress(raw[pos:pos + clen])
+                if arrow is not None:
+                    piece = arrow.decompress(raw[pos:pos + clen], decompressed_size=neblock, asbytes=True)
+                else:
+                    piece = zlib.decompress(raw[pos:pos + clen])
                 if len(piece) != neblock:
-                    raise ZarrError("zlib stream of a Blosc block has the wrong length")
+                    raise ZarrError(f"{codec} stream of a Blosc block has the wrong length")
                 target[done:done + neblock] = np.frombuffer(piece, dtype=np.uint8)
             pos += clen
             done += neblock
-        if shuffle:
+        if bitshuffle:
+            out[b * blocksize:b * blocksize + bsize] = _bit_unshuffle(tmp[:bsize], typesize)
+        elif shuffle:
             dst = out[b * blocksize:]
             lib.clx_unshuffle_bytes(u8p(tmp.ctypes.data), u8p(dst.ctypes.data), bsize, typesize)
     return out.tobytes()
+
+
+def _bit_unshuffle(block, typesize):
+    """Inverse of c-blosc's bit shuffle of one block (c-blosc 1.x `bitshuffle()`): a block of n = 8 m elements is
+    stored as [byte of the element][bit][element / 8] (bit k of a stored byte belongs to element 8 j + k) with
+    any bytes past n * typesize copied; a block whose element count is not a multiple of 8 is stored unshuffled."""
+    n = len(block) // typesize
+    if n == 0 or n % 8:
+        return block
+    out = np.empty(len(block), dtype=np.uint8)
+    bits = np.unpackbits(block[:n * typesize].reshape(typesize, 8, n // 8), axis=-1, bitorder="little")
+    out[:n * typesize] = np.packbits(bits.transpose(2, 0, 1), axis=-1, bitorder="little").reshape(-1)
+    out[n * typesize:] = block[n * typesize:]
+    return out
+
+
+def _arrow_codec(name):
+    """zstd / snappy streams are decoded by the codecs bundled with pyarrow when it is importable."""
+    try:
+        import pyarrow
+    except ImportError as e:
+        raise ZarrError(f"reading {name}-compressed chunks needs pyarrow (its bundled {name} codec); not importable: {e}")
+    if not pyarrow.Codec.is_available(name):
+        raise ZarrError(f"this pyarrow build has no {name} codec")
+    return pyarrow.Codec(name)
 
 
 def _decode(raw, compressor):
@@ -160,7 +190,40 @@ def _decode(raw, compressor):
         return gzip.decompress(raw)
     if cid == "blosc":
         return blosc_decode(raw)
-    raise ZarrError(f"unsupported zarr compressor {cid!r} (null, zlib, gzip and blosc[lz4 | zlib] can be read here)")
+    if cid == "zstd":                                    # numcodecs.Zstd: one zstd frame with its content size
+        return _zstd_frame(bytes(raw))
+    if cid == "lz4":                                     # numcodecs.LZ4: int32 plain size + one LZ4 block
+        import ctypes
+
+        from .. import _clx
+        raw = bytes(raw)
+        n = int.from_bytes(raw[:4], "little")
+        out = np.empty(n, dtype=np.uint8)
+        src = np.frombuffer(raw, dtype=np.uint8)
+        got = _clx.load().clx_lz4_decompress(ctypes.c_void_p(src.ctypes.data + 4), len(raw) - 4,
+                                             ctypes.c_void_p(out.ctypes.data), n)
+        if got != n:
+            raise ZarrError(f"LZ4 chunk decoded to {got} bytes, expected {n}")
+        return out.tobytes()
+    if cid == "bz2":
+        import bz2
+        return bz2.decompress(raw)
+    raise ZarrError(f"unsupported zarr compressor {cid!r} (null, zlib, gzip, bz2, lz4, zstd and "
+                    "blosc[lz4 | lz4hc | zlib | zstd | snappy] can be read here)")
+
+
+def _zstd_frame(raw):
+    """A zstd frame whose header carries the content size (numcodecs.Zstd always writes it)."""
+    if raw[:4] != b"\x28\xb5\x2f\xfd":
+        raise ZarrError("not a zstd frame")
+    fhd = raw[4]
+    single, dict_flag, fcs_flag = (fhd >> 5) & 1, fhd & 3, fhd >> 6
+    pos = 5 + (0 if single else 1) + (0, 1, 2, 4)[dict_flag]
+    width = (1 if single else 0, 2, 4, 8)[fcs_flag]
+    if width == 0:
+        raise ZarrError("zstd frame without a content size")
+    size = int.from_bytes(raw[pos:pos + width], "little") + (256 if width == 2 else 0)
+    return _arrow_codec("zstd").decompress(raw, decompressed_size=size, asbytes=True)
 
 
 def _encode(raw, compressor):

@@ -507,6 +507,9 @@ int clx_joint_histogram(const int32_t* pred, const int32_t* gt, long long n,
 /* LZ4 block decoder on HOST buffers; returns the bytes written (<= dst_capacity) or < 0. */
 long long clx_lz4_decompress(const unsigned char* src, long long src_bytes, unsigned char* dst,
                              long long dst_capacity);
+/* BloscLZ stream decoder (codec 0 of a Blosc chunk) on HOST buffers; same return convention. */
+long long clx_blosclz_decompress(const unsigned char* src, long long src_bytes, unsigned char* dst,
+                                 long long dst_capacity);
 /* inverse of Blosc's byte shuffle for n bytes of elements of `typesize` bytes (HOST buffers) */
 int clx_unshuffle_bytes(const unsigned char* src, unsigned char* dst, long long n, int typesize);
 

@@ -30,6 +30,16 @@ cases = {
     "tiny": (np.arange(7, dtype=np.int32), dict(compressor="lz4", level=5, shuffle=1)),
     "i64_labels_lz4": (np.repeat(rng.integers(0, 5, size=300), 37).astype(np.int64).reshape(100, 111),
                        dict(compressor="lz4", level=5, shuffle=1)),
+    # (appended in round 2, after the cases above so that their random draws are unchanged)
+    "f32_zstd_shuffle": (blobs((1, 1, 64, 64)), dict(compressor="zstd", level=3, shuffle=1)),
+    "u16_zstd_noshuffle_multiblock": ((blobs((3, 50, 64)) * 60000).astype(np.uint16), dict(compressor="zstd", level=1, shuffle=0, blocksize=8192)),
+    "f32_lz4_bitshuffle": (blobs((1, 1, 64, 64)), dict(compressor="lz4", level=5, shuffle=2)),
+    "u8_zstd_bitshuffle_leftover": ((blobs((65, 67)) * 255).astype(np.uint8), dict(compressor="zstd", level=5, shuffle=2, blocksize=4096)),
+    "f64_lz4_bitshuffle_odd": (blobs((37, 41)).astype(np.float64), dict(compressor="lz4", level=5, shuffle=2)),
+    "f32_blosclz_shuffle": (blobs((1, 1, 64, 64)), dict(compressor="blosclz", level=5, shuffle=1)),
+    "i64_labels_blosclz": (np.repeat(rng.integers(0, 5, size=300), 37).astype(np.int64).reshape(100, 111),
+                           dict(compressor="blosclz", level=9, shuffle=1)),
+    "u8_blosclz_noshuffle": ((blobs((2, 1, 64, 80)) * 255).astype(np.uint8), dict(compressor="blosclz", level=5, shuffle=0)),
 }
 for name, (arr, kw) in cases.items():
     kw = dict(kw)

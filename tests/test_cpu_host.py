@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/clx.h but not exported"
     assert sorted(_clx.PROTOTYPES) == declared, "ctypes prototypes and clx.h disagree"
-    assert _clx.load().clx_abi_version() == 10
+    assert _clx.load().clx_abi_version() == 11
 
 
 def test_argument_validation_without_gpu():
@@ -507,16 +507,17 @@ def test_pair_sampler_matches_real_reference_golden(tag):
 # ------------------------------------------------------------------ Blosc input
 def test_blosc_chunks_written_by_the_real_c_blosc_decode(tmp_path):
     """g12: chunks compressed by the real c-blosc (tests/golden/make_golden_blosc.py, conda's
-    imagecodecs) — LZ4 / LZ4HC / zlib, byte shuffle on and off, split and unsplit blocks, several
-    blocks with a shorter last one, an incompressible (stored) chunk, a tiny one — decode to the
-    original arrays, directly and through a zarr array whose compressor is zarr's default Blosc."""
+    imagecodecs) — LZ4 / LZ4HC / zlib / zstd / BloscLZ, byte shuffle, bit shuffle (whole blocks and the
+    unshuffled odd ones) and none, split and unsplit blocks, several blocks with a shorter last one, an
+    incompressible (stored) chunk, a tiny one — decode to the original arrays, directly and through a zarr
+    array whose compressor is zarr's default Blosc; numcodecs' plain Zstd / LZ4 / BZ2 compressors too."""
     import json
 
     from cellulus_amd.utils import zarr_io
 
     g = np.load(os.path.join(G, "g12_blosc.npz"))
     names = sorted({k.split("/")[0] for k in g.files})
-    assert len(names) >= 9
+    assert len(names) >= 17
     for name in names:
         arr, chunk = g[f"{name}/array"], g[f"{name}/chunk"].tobytes()
         assert zarr_io.blosc_decode(chunk) == arr.tobytes(), name
@@ -537,9 +538,25 @@ def test_blosc_chunks_written_by_the_real_c_blosc_decode(tmp_path):
     np.testing.assert_array_equal(ds[1, 0, 10:20, 5:9], arr[1, 0, 10:20, 5:9])
     # corrupt / unsupported input fails loudly
     bad = bytearray(g["f32_lz4_shuffle/chunk"].tobytes())
-    bad[2] = (bad[2] & 0x1f) | (4 << 5)                   # claims zstd
-    with pytest.raises(zarr_io.ZarrError, match="zstd"):
+    bad[2] = (bad[2] & 0x1f) | (6 << 5)                   # a codec id c-blosc does not define
+    with pytest.raises(zarr_io.ZarrError, match="codec id 6"):
         zarr_io.blosc_decode(bytes(bad))
+    bad[2] = (bad[2] & 0x1f) | (4 << 5)                   # claims zstd: the LZ4 bytes are not a zstd frame
+    with pytest.raises(Exception):
+        zarr_io.blosc_decode(bytes(bad))
+    # numcodecs' stand-alone compressors: Zstd (a frame carrying its content size), LZ4 (int32 size + block), BZ2
+    import bz2
+
+    import pyarrow
+
+    payload = g["i64_labels_lz4/array"].tobytes()
+    frame = pyarrow.Codec("zstd").compress(payload, asbytes=True)
+    assert zarr_io._decode(frame, {"id": "zstd", "level": 1}) == payload
+    block = pyarrow.Codec("lz4_raw").compress(payload, asbytes=True)
+    assert zarr_io._decode(len(payload).to_bytes(4, "little") + block, {"id": "lz4", "acceleration": 1}) == payload
+    assert zarr_io._decode(bz2.compress(payload), {"id": "bz2", "level": 1}) == payload
+    with pytest.raises(zarr_io.ZarrError, match="lzma"):
+        zarr_io._decode(b"", {"id": "lzma"})
     with pytest.raises(zarr_io.ZarrError):
         zarr_io.blosc_decode(g["f32_lz4_shuffle/chunk"].tobytes()[:40] + b"\x00" * 100)
 
