@@ -139,6 +139,8 @@ PROTOTYPES = {
     "clx_inst_refine": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     "clx_lz4_decompress": (_LL, [_P, _LL, _P, _LL]),
     "clx_blosclz_decompress": (_LL, [_P, _LL, _P, _LL]),
+    "clx_blosc_compress_bound": (_LL, [_LL]),
+    "clx_blosc_compress_lz4": (_LL, [_P, _LL, _I, _I, _P, _LL]),
     "clx_unshuffle_bytes": (_I, [_P, _P, _LL, _I]),
     "clx_label_presence": (_I, [_P, _LL, _I, _P, _P, _P]),
     "clx_joint_histogram": (_I, [_P, _P, _LL, _P, _P, _I, _P, _P]),

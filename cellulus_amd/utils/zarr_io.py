@@ -226,7 +226,12 @@ def _zstd_frame(raw):
     return _arrow_codec("zstd").decompress(raw, decompressed_size=size, asbytes=True)
 
 
-def _encode(raw, compressor):
+# what zarr-python 2.x uses when no compressor is given (numcodecs.Blosc's defaults): the reference's stages
+# create their output datasets this way (cellulus/predict.py:103-110, detect.py:23-70, segment.py:24-33)
+DEFAULT_COMPRESSOR = {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}
+
+
+def _encode(raw, compressor, typesize=1):
     if compressor is None:
         return raw
     cid = compressor.get("id")
@@ -234,6 +239,24 @@ def _encode(raw, compressor):
         return zlib.compress(raw, compressor.get("level", 1))
     if cid == "gzip":
         return gzip.compress(raw, compressor.get("level", 1))
+    if cid == "blosc":
+        if compressor.get("cname", "lz4") != "lz4" or compressor.get("shuffle", 1) not in (0, 1, -1):
+            raise ZarrError("this writer produces Blosc chunks with LZ4 inside and byte shuffle or none "
+                            f"(asked for {compressor!r})")
+        import ctypes
+
+        from .. import _clx
+        lib = _clx.load()
+        src = np.frombuffer(raw, dtype=np.uint8)
+        cap = lib.clx_blosc_compress_bound(src.size)
+        out = np.empty(cap, dtype=np.uint8)
+        # numcodecs' AUTOSHUFFLE (-1): byte shuffle unless the items are single bytes
+        shuffle = 0 if compressor.get("shuffle", 1) == 0 or typesize == 1 else 1
+        src_p = ctypes.c_void_p(src.ctypes.data) if src.size else ctypes.c_void_p(out.ctypes.data)   # (never read)
+        n = lib.clx_blosc_compress_lz4(src_p, src.size, int(typesize), shuffle, ctypes.c_void_p(out.ctypes.data), cap)
+        if n < 0:
+            raise ZarrError(f"Blosc encoder failed ({n})")
+        return out[:n].tobytes()
     raise ZarrError(f"unsupported zarr compressor {cid!r}")
 
 
@@ -290,7 +313,7 @@ class Array:
         os.makedirs(os.path.dirname(p), exist_ok=True)
         tmp = p + ".tmp"
         with io.open(tmp, "wb") as f:
-            f.write(_encode(np.ascontiguousarray(data, dtype=self.dtype).tobytes(), self.compressor))
+            f.write(_encode(np.ascontiguousarray(data, dtype=self.dtype).tobytes(), self.compressor, self.dtype.itemsize))
         os.replace(tmp, p)
 
     def _normalize(self, key):
@@ -403,11 +426,17 @@ class Group:
             Group(cur, create=True)
         return os.path.join(cur, parts[-1])
 
-    def create_dataset(self, name, shape, dtype, chunks=None, compressor=None, fill_value=0,
+    def create_dataset(self, name, shape, dtype, chunks=None, compressor="default", fill_value=0,
                        overwrite=False):
         """zarr's ``Group.create_dataset``: raises when `name` exists unless ``overwrite=True``
         (zarr-python's ContainsArrayError; the reference's stages therefore refuse to clobber
-        an existing ``embeddings`` / ``detection`` / ``segmentation`` dataset)."""
+        an existing ``embeddings`` / ``detection`` / ``segmentation`` dataset).  As in zarr-python the
+        chunks are Blosc / LZ4 / byte-shuffle compressed unless ``compressor=None`` is passed."""
+        if isinstance(compressor, str):
+            if compressor != "default":
+                raise ZarrError(f"compressor must be 'default', None or a numcodecs-style dict, got {compressor!r}")
+            # (CLX_ZARR_COMPRESSOR=none: plain chunks, for measurements of the write path)
+            compressor = None if os.environ.get("CLX_ZARR_COMPRESSOR", "") == "none" else dict(DEFAULT_COMPRESSOR)
         p = self._make_parents(name)
         dtype = np.dtype(dtype)
         shape = tuple(int(s) for s in shape)

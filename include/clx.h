@@ -510,6 +510,12 @@ long long clx_lz4_decompress(const unsigned char* src, long long src_bytes, unsi
 /* BloscLZ stream decoder (codec 0 of a Blosc chunk) on HOST buffers; same return convention. */
 long long clx_blosclz_decompress(const unsigned char* src, long long src_bytes, unsigned char* dst,
                                  long long dst_capacity);
+/* Writer side (HOST buffers): one Blosc chunk, LZ4 inside, byte shuffle on / off — what zarr-python writes with
+ * its default compressor (zarr outputs of predict / detect / segment, cellulus/predict.py:103-110 etc.).
+ * dst must hold clx_blosc_compress_bound(nbytes) bytes; returns the chunk size or < 0. */
+long long clx_blosc_compress_bound(long long nbytes);
+long long clx_blosc_compress_lz4(const unsigned char* src, long long nbytes, int typesize, int shuffle,
+                                 unsigned char* dst, long long dst_capacity);
 /* inverse of Blosc's byte shuffle for n bytes of elements of `typesize` bytes (HOST buffers) */
 int clx_unshuffle_bytes(const unsigned char* src, unsigned char* dst, long long n, int typesize);
 

@@ -561,6 +561,66 @@ def test_blosc_chunks_written_by_the_real_c_blosc_decode(tmp_path):
         zarr_io.blosc_decode(g["f32_lz4_shuffle/chunk"].tobytes()[:40] + b"\x00" * 100)
 
 
+def test_blosc_writer_round_trips_and_is_read_by_the_real_c_blosc(tmp_path):
+    """clx_blosc_compress_lz4 (the writer behind zarr_io's default compressor — zarr-python's default, which the
+    reference's stages use for their outputs): smooth / label / random / tiny / empty arrays of several item sizes,
+    with and without byte shuffle, decode to the same bytes through zarr_io's reader (itself pinned by chunks from
+    the real c-blosc) and — where conda's imagecodecs is present — through the real c-blosc; create_dataset writes
+    zarr's default compressor into .zarray, compressor=None plain chunks."""
+    import json
+    import subprocess
+
+    from cellulus_amd.utils import zarr_io
+
+    rng = np.random.default_rng(0)
+    yy, xx = np.meshgrid(np.arange(300, dtype=np.float32), np.arange(400, dtype=np.float32), indexing="ij")
+    smooth = np.exp(-((yy - 150) ** 2 + (xx - 200) ** 2) / 5000).astype(np.float32)
+    cases = {
+        "f32": smooth, "f64": smooth.astype(np.float64), "u8": (smooth * 255).astype(np.uint8),
+        "u16": (smooth * 60000).astype(np.uint16), "i64_labels": np.repeat(rng.integers(0, 9, size=4000), 173).astype(np.int64),
+        "random_u8": rng.integers(0, 256, size=70001, dtype=np.uint8), "tiny": np.arange(5, dtype=np.int32),
+        "empty": np.zeros(0, np.float32), "odd_f32": smooth.reshape(-1)[:99991].copy(),
+        "big_f64": np.tile(smooth.astype(np.float64), (3, 1)),            # several 256-KB blocks + a shorter last one
+    }
+    comp = dict(zarr_io.DEFAULT_COMPRESSOR)
+    for name, arr in cases.items():
+        for shuffle in (1, 0):
+            chunk = zarr_io._encode(arr.tobytes(), dict(comp, shuffle=shuffle), arr.dtype.itemsize)
+            assert zarr_io._decode(chunk, comp) == arr.tobytes(), (name, shuffle)
+            if name in ("f32", "f64", "u16", "i64_labels", "u8", "big_f64"):
+                assert len(chunk) < (0.8 if shuffle else 0.95) * arr.nbytes, (name, shuffle, len(chunk))
+            if name == "random_u8":
+                assert chunk[2] & 0x02 and len(chunk) == arr.nbytes + 16            # stored verbatim
+            (tmp_path / f"{name}_{shuffle}.blosc").write_bytes(chunk)
+            np.save(tmp_path / f"{name}_{shuffle}.npy", arr)
+    with pytest.raises(zarr_io.ZarrError, match="LZ4"):
+        zarr_io._encode(b"abcd", dict(comp, cname="zstd"), 1)
+    conda = "/opt/conda/bin/python3.9"
+    if os.path.exists(conda):
+        script = ("import imagecodecs, numpy as np, glob\n"
+                  f"fs = sorted(glob.glob('{tmp_path}/*.blosc'))\n"
+                  "n = 0\n"
+                  "for f in fs:\n"
+                  "    a = np.load(f[:-6] + '.npy')\n"
+                  "    if a.size:\n"
+                  "        assert imagecodecs.blosc_decode(open(f, 'rb').read()) == a.tobytes(), f\n"
+                  "        n += 1\n"
+                  "print('decoded', n)\n")
+        res = subprocess.run([conda, "-c", script], capture_output=True, text=True)
+        if "No module named" not in res.stderr:
+            assert res.returncode == 0 and "decoded 18" in res.stdout, res.stderr[-2000:]
+    f = zarr_io.open(tmp_path / "w.zarr")
+    ds = f.create_dataset("a/b", shape=(2, 300, 400), dtype=np.float32)
+    ds[0], ds[1] = smooth, 2 * smooth
+    meta = json.loads((tmp_path / "w.zarr" / "a" / "b" / ".zarray").read_text())
+    assert meta["compressor"] == zarr_io.DEFAULT_COMPRESSOR and meta["chunks"] == [1, 300, 400]
+    assert os.path.getsize(tmp_path / "w.zarr" / "a" / "b" / "1.0.0") < 0.8 * smooth.nbytes
+    np.testing.assert_array_equal(zarr_io.open(tmp_path / "w.zarr", "r")["a/b"][1], 2 * smooth)
+    raw = f.create_dataset("plain", shape=(300, 400), dtype=np.float32, chunks=(300, 400), compressor=None)
+    raw[...] = smooth
+    assert (tmp_path / "w.zarr" / "plain" / "0.0").read_bytes() == smooth.tobytes()
+
+
 def test_corrupted_blosc_chunks_raise_or_decode_but_never_crash():
     """The chunk decoders read files: 1500 random corruptions (byte flips anywhere, truncations) of the golden
     chunks — every codec and shuffle mode — must end in an exception or in some bytes, never in a crash of the
