@@ -281,6 +281,11 @@ class Array:
         self.fill_value = m.get("fill_value")
         self.sep = m.get("dimension_separator", ".")
         self.attrs = Attributes(path)
+        # decoded chunks of a COMPRESSED array, most recently used last (random crops of a training image hit
+        # the same few chunks again and again; CLX_ZARR_CACHE_MB per array and process, 0 = off)
+        self._cache = {}
+        self._cache_bytes = 0
+        self._cache_cap = int(float(os.environ.get("CLX_ZARR_CACHE_MB", "64")) * (1 << 20))
 
     @property
     def ndim(self):
@@ -304,11 +309,36 @@ class Array:
         p = self._chunk_path(idx)
         if not os.path.exists(p):
             return np.full(self.chunks, self._fill(), dtype=self.dtype)
+        use_cache = self.compressor is not None and self._cache_cap > 0
+        if use_cache:
+            key = tuple(idx)
+            try:
+                stamp = os.stat(p).st_mtime_ns
+            except OSError:
+                stamp = None
+            hit = self._cache.get(key)
+            if hit is not None and hit[0] == stamp:
+                self._cache[key] = self._cache.pop(key)                  # most recently used
+                return hit[1]
         with io.open(p, "rb") as f:
             raw = _decode(f.read(), self.compressor)
-        return np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+        chunk = np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
+        if use_cache and chunk.nbytes <= self._cache_cap:
+            old = self._cache.pop(key, None)
+            if old is not None:
+                self._cache_bytes -= old[1].nbytes
+            self._cache[key] = (stamp, chunk)
+            self._cache_bytes += chunk.nbytes
+            while self._cache_bytes > self._cache_cap:
+                _k, (_s, gone) = next(iter(self._cache.items()))
+                del self._cache[_k]
+                self._cache_bytes -= gone.nbytes
+        return chunk
 
     def _write_chunk(self, idx, data):
+        old = self._cache.pop(tuple(idx), None)
+        if old is not None:
+            self._cache_bytes -= old[1].nbytes
         p = self._chunk_path(idx)
         os.makedirs(os.path.dirname(p), exist_ok=True)
         tmp = p + ".tmp"

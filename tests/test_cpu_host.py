@@ -621,6 +621,35 @@ def test_blosc_writer_round_trips_and_is_read_by_the_real_c_blosc(tmp_path):
     assert (tmp_path / "w.zarr" / "plain" / "0.0").read_bytes() == smooth.tobytes()
 
 
+def test_decoded_chunk_cache_serves_repeated_crops_and_sees_rewrites(tmp_path, monkeypatch):
+    """A compressed array decodes a chunk once for repeated crops (least recently used chunks leave when
+    CLX_ZARR_CACHE_MB is exceeded), its own writes and another handle's rewrite of the chunk file are seen."""
+    from cellulus_amd.utils import zarr_io
+
+    rng = np.random.default_rng(0)
+    data = rng.random((4, 1, 64, 64), dtype=np.float32)
+    f = zarr_io.open(tmp_path / "c.zarr")
+    f["raw"] = data
+    calls = []
+    real = zarr_io._decode
+    monkeypatch.setattr(zarr_io, "_decode", lambda raw, comp: (calls.append(1), real(raw, comp))[1])
+    monkeypatch.setenv("CLX_ZARR_CACHE_MB", str(2.5 * 64 * 64 * 4 / (1 << 20)))       # room for two chunks
+    a = zarr_io.open(tmp_path / "c.zarr", "r")["raw"]
+    for _ in range(5):
+        np.testing.assert_array_equal(a[1, 0, 10:30, 5:25], data[1, 0, 10:30, 5:25])
+    assert len(calls) == 1
+    a[2], a[1], a[3]
+    assert len(calls) == 3                      # 1 was still cached; 2 and 3 were decoded
+    a[2]
+    assert len(calls) == 4                      # ... and 2, the least recently used, had to leave for 3
+    b = zarr_io.open(tmp_path / "c.zarr")["raw"]
+    b[1] = data[1] + 1.0                        # another handle (another rank) rewrites the chunk file
+    np.testing.assert_array_equal(a[1], data[1] + 1.0)
+    a2 = zarr_io.open(tmp_path / "c.zarr")["raw"]
+    a2[0, 0, :8, :8] = 7.0                      # partial write through the handle that cached
+    assert a2[0, 0, 3, 3] == 7.0 and a2[0, 0, 20, 20] == data[0, 0, 20, 20]
+
+
 def test_corrupted_blosc_chunks_raise_or_decode_but_never_crash():
     """The chunk decoders read files: 1500 random corruptions (byte flips anywhere, truncations) of the golden
     chunks — every codec and shuffle mode — must end in an exception or in some bytes, never in a crash of the
