@@ -112,6 +112,7 @@ PROTOTYPES = {
     "clx_sample_pairs": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, POINTER(c_int), ctypes.c_ulonglong,
                               ctypes.c_ulonglong, _P]),
     "clx_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P]),
+    "clx_adam_step_guarded": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P, _P]),
     "clx_noise_stats": (_I, [_P, _P, _I, _I, _LL, _P]),
     "clx_ms_prepare_workspace": (c_size_t, [_LL]),
     "clx_ms_prepare": (_I, [_P, _P, _D, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -169,10 +169,13 @@ __global__ __launch_bounds__(256) void oce_pairs_fused_kernel(
 // torch.optim.Adam single-tensor step order (weight_decay coupled into grad):
 //   g += wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g*g;
 //   denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m / denom
+// `skip_if_positive` (optional): a device double — the bad-coordinate count of the loss kernel — that turns the
+// whole step into a no-op when it is > 0, so that the step can be enqueued before the host has looked at it.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, long long n,
                             float one_minus_b1, float b2, float one_minus_b2, float eps,
-                            float wd, float step_size, float bc2_sqrt) {
+                            float wd, float step_size, float bc2_sqrt, const double* __restrict__ skip_if_positive) {
+  if (skip_if_positive != nullptr && *skip_if_positive > 0.0) return;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     const float pv = p[i];
@@ -317,6 +320,14 @@ extern "C" int clx_oce_pairs_fused(const float* offsets, const long long* anchor
 extern "C" int clx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                              long long n, double lr, double beta1, double beta2, double eps,
                              double weight_decay, int step, clx_stream stream) {
+  return clx_adam_step_guarded(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step,
+                               nullptr, stream);
+}
+
+extern "C" int clx_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                                     long long n, double lr, double beta1, double beta2, double eps,
+                                     double weight_decay, int step, const double* skip_if_positive,
+                                     clx_stream stream) {
   CLX_REQUIRE(param && grad && exp_avg && exp_avg_sq, "clx_adam_step: null pointer");
   CLX_REQUIRE(n >= 0 && step >= 1, "clx_adam_step: bad n/step");
   if (n == 0) return CLX_OK;
@@ -327,7 +338,7 @@ extern "C" int clx_adam_step(float* param, const float* grad, float* exp_avg, fl
   const float bc2_sqrt = (float)sqrt(bc2);
   adam_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(
       param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
-      (float)(1.0 - beta2), (float)eps, (float)weight_decay, step_size, bc2_sqrt);
+      (float)(1.0 - beta2), (float)eps, (float)weight_decay, step_size, bc2_sqrt, skip_if_positive);
   CLX_CHECK_LAUNCH("clx_adam_step");
   return CLX_OK;
 }

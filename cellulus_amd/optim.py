@@ -52,11 +52,21 @@ class Adam(Optimizer):
             off += n
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, guard=None):
+        """`guard` (optional, not part of torch's signature): a one-element float64 device tensor; the update is
+        enqueued at once and does nothing if the value is > 0 when the kernel runs (train._fused_step passes
+        the loss kernel's bad-coordinate count, which the host reads only afterwards — `undo_step()` then takes
+        the step counters back)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        guard_ptr = None
+        if guard is not None:
+            if guard.dtype != torch.float64 or guard.numel() != 1:
+                raise TypeError("guard must be a one-element float64 device tensor")
+            _clx.require_device(guard, "guard")
+            guard_ptr = _clx.ptr(guard)
         for group in self.param_groups:
             if group.get("amsgrad") or group.get("maximize") or group.get("decoupled_weight_decay"):
                 raise NotImplementedError("cellulus_amd.optim.Adam: amsgrad/maximize/AdamW are not supported")
@@ -87,16 +97,26 @@ class Adam(Optimizer):
             if (len(steps) == 1 and self._consecutive(params) and self._consecutive(grads)
                     and self._consecutive(ms) and self._consecutive(vs)):
                 n = sum(p.numel() for p in params)
-                _clx.call("clx_adam_step", _clx.ptr(params[0]), _clx.ptr(grads[0]), _clx.ptr(ms[0]),
-                          _clx.ptr(vs[0]), n, *args, steps.pop(), stream)
+                _clx.call("clx_adam_step_guarded", _clx.ptr(params[0]), _clx.ptr(grads[0]), _clx.ptr(ms[0]),
+                          _clx.ptr(vs[0]), n, *args, steps.pop(), guard_ptr, stream)
             else:
                 for p, g, m, v in zip(params, grads, ms, vs):
                     if not (p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()):
                         raise RuntimeError("cellulus_amd.optim.Adam needs contiguous parameters and gradients")
-                    _clx.call("clx_adam_step", _clx.ptr(p), _clx.ptr(g), _clx.ptr(m), _clx.ptr(v),
-                              p.numel(), *args, int(self.state[p]["step"].item()), stream)
+                    _clx.call("clx_adam_step_guarded", _clx.ptr(p), _clx.ptr(g), _clx.ptr(m), _clx.ptr(v),
+                              p.numel(), *args, int(self.state[p]["step"].item()), guard_ptr, stream)
             # the kernels wrote behind torch's back: bump the autograd version counters so
             # cached packed weights (UNetModel) are refreshed
             for p in params:
                 p.detach()[:0].zero_()
         return loss
+
+    def undo_step(self):
+        """Takes back the step COUNTERS of the last `step(guard=...)` whose guard turned out positive: the
+        kernel left parameters and moments untouched, only the host-side counts had moved."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st and "step" in st:
+                    n = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
+                    st["step"] = torch.tensor(float(max(n - 1, 0)), dtype=torch.float32)

@@ -308,6 +308,14 @@ int clx_adam_step(float* param, const float* grad, float* exp_avg,
                   float* exp_avg_sq, long long n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step,
                   clx_stream stream);
+/* The same step, enqueued BEFORE the host has read the loss kernel's bad-coordinate count: the kernel does
+ * nothing when the device double *skip_if_positive is > 0 (NULL = unconditional).  cellulus/train.py:171-179
+ * raises IndexError from the coordinate indexing before optimizer.step(); here the step is already in the
+ * stream when the host looks, and is a no-op exactly in that case. */
+int clx_adam_step_guarded(float* param, const float* grad, float* exp_avg,
+                          float* exp_avg_sq, long long n, double lr, double beta1,
+                          double beta2, double eps, double weight_decay, int step,
+                          const double* skip_if_positive, clx_stream stream);
 
 /* ------------------------------------------------------------------------ */
 /* Inference statistics (cellulus/models/unet.py:90-98)                     */

@@ -152,9 +152,24 @@ def test_out_of_range_coordinates_raise_like_the_reference(device):
         train_iteration((raw, a, r), model, crit, opt, device)
     for p, q in zip(model.parameters(), before):
         assert torch.equal(p.detach(), q)
+    # (the update was already in the stream, guarded on the device by the bad-coordinate count: it did nothing,
+    # moments included, and the step counters were taken back)
+    for st in opt.state.values():
+        assert st["step"].item() == 0.0 and not st["exp_avg"].any() and not st["exp_avg_sq"].any()
     r[0, 1, 0] = 23
     loss, _, _ = train_iteration((raw, a, r), model, crit, opt, device)
     assert np.isfinite(loss)
+    assert all(st["step"].item() == 1.0 for st in opt.state.values())
+    assert any(not torch.equal(p.detach(), q) for p, q in zip(model.parameters(), before))
+    # after good steps a bad batch leaves the trained state where it was
+    train_iteration((raw, a, r), model, crit, opt, device)
+    trained = [p.detach().clone() for p in model.parameters()]
+    moments = [st["exp_avg"].clone() for st in opt.state.values()]
+    r[0, 1, 0] = 24
+    with pytest.raises(IndexError):
+        train_iteration((raw, a, r), model, crit, opt, device)
+    assert all(torch.equal(p.detach(), q) for p, q in zip(model.parameters(), trained))
+    assert all(torch.equal(st["exp_avg"], m) and st["step"].item() == 2.0 for st, m in zip(opt.state.values(), moments))
 
 
 def _pairs(rng, B, out_shape, kappa, n_anchor, n_ref):
