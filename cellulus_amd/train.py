@@ -306,6 +306,14 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
               _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
               float(criterion.temperature), float(criterion.regularization_weight),
               _clx.stream_ptr(device))
+    early = None
+    if parallel.world_size() == 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
+        # One process: the sums are final HERE, before the backward pass.  They leave on a side stream into
+        # pinned memory now, and the host reads them after it has enqueued backward, update and packing —
+        # by then the copy is 25 ms old, so train_iteration returns while the device still works and the
+        # next call's Python runs under this step's kernels.  (Several ranks: the sums are all-reduced with
+        # the gradients and read at the end, below.)
+        early = _early_readback(model, sums, device)
     if parallel.world_size() > 1 and parallel.bucket_bytes() > 0:
         # gradient buckets go out while the rest of the backward pass runs (parallel.GradientBuckets)
         buckets = parallel.GradientBuckets(model._flat_grad, grads)
@@ -329,7 +337,11 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         # walks back into the next call (0.27 + 0.3 ms per step at the benchmark configuration otherwise idle).
         optimizer.step(guard=sums[3:4])
         plan.pack_weights(params, model._param_version(), need_dgrad=True)
-        host = sums.cpu()
+        if early is not None:
+            early[1].synchronize()
+            host = early[0].clone()
+        else:
+            host = sums.cpu()
         bad = int(host[3].item())
         if bad:
             optimizer.undo_step()              # the kernel did nothing; take the step counters back too
@@ -340,6 +352,25 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         optimizer.step()
     host = host.to(torch.float32)
     return host[0].item(), host[1].item(), offsets
+
+
+def _early_readback(model, sums, device):
+    """sums (device, float64[4]) -> the model's pinned host buffer through a side stream that waits for the
+    loss kernel only; returns (host buffer, event recorded behind the copy)."""
+    cache = getattr(model, "_early_readback_cache", None)
+    if cache is None or cache[0] != device:
+        cache = (device, torch.empty(4, dtype=torch.float64).pin_memory(), torch.cuda.Stream(device=device))
+        model._early_readback_cache = cache
+    _dev, host, side = cache
+    produced = torch.cuda.Event()
+    produced.record(torch.cuda.current_stream(device))
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        side.wait_event(produced)
+        host.copy_(sums, non_blocking=True)
+        sums.record_stream(side)
+        done.record(side)
+    return host, done
 
 
 def save_model(state, iteration, is_lowest=False):
