@@ -326,6 +326,10 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         if parallel.world_size() > 1:
             parallel.all_reduce_sum_(model._flat_grad)
             parallel.all_reduce_sum_(sums)
+    if early is None and parallel.world_size() > 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
+        # several ranks: the reduced sums exist once the last bucket is in; the copy then runs beside the update
+        # and the packing, and the host returns while those still execute
+        early = _early_readback(model, sums, device)
     from .criterions.oce_loss import raise_on_bad_coordinates
     from .optim import Adam as ClxAdam
 
