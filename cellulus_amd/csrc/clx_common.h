@@ -1,6 +1,7 @@
 // Shared helpers for the libclx HIP sources (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -81,5 +82,7 @@ int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int
 
 // in-library kernel timing (clx_core.hip); kinds match enum clx_profile_kind in clx.h
 bool clx_prof_enabled();
-void clx_prof_begin(int kind, double flops, hipStream_t st);
-void clx_prof_end(hipStream_t st);
+void clx_prof_events(int kind, double flops, hipEvent_t* e0, hipEvent_t* e1);
+// kernel launch with the optional event pair of clx_prof_events (null events: a plain launch)
+#define CLX_LAUNCH_TIMED(kernel, grid, block, st, e0, e1, ...) \
+  hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, __VA_ARGS__)

@@ -23,7 +23,7 @@ extern "C" int clx_device_count(void) {
 
 // ---------------------------------------------------------------------------
 // Optional in-library kernel timing (bench.py roofline): when enabled, the MFMA kernel
-// launchers bracket their launch with HIP events on the launch stream and record the
+// launchers attach a HIP event pair to their launch (start / end of the kernel on its stream) and record the
 // FLOPs the launch executes.  Off by default; no cost when off.
 // ---------------------------------------------------------------------------
 #include <vector>
@@ -36,16 +36,16 @@ std::vector<ProfRec> g_prof;
 
 bool clx_prof_enabled() { return g_prof_on; }
 
-void clx_prof_begin(int kind, double flops, hipStream_t st) {
+// a launch's event pair: handed to hipExtLaunchKernelGGL, which stamps them with the kernel's own start and end
+// (no separate event packets in the stream: bracketing hipEventRecord calls cost the step ~5 us per launch)
+void clx_prof_events(int kind, double flops, hipEvent_t* e0, hipEvent_t* e1) {
+  *e0 = *e1 = nullptr;
   ProfRec r;
   r.kind = kind; r.flops = flops;
-  if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-  (void)hipEventRecord(r.e0, st);
+  if (hipEventCreate(&r.e0) != hipSuccess) return;
+  if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
   g_prof.push_back(r);
-}
-
-void clx_prof_end(hipStream_t st) {
-  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, st);
+  *e0 = r.e0; *e1 = r.e1;
 }
 
 extern "C" int clx_profile_enable(int on) {

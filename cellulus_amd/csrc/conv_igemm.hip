@@ -458,16 +458,15 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   p.bs_in = bs_in; p.bs_w = bs_w; p.bs_out = bs_out;
   // 128-wide N tiles unless padding N up to a multiple of 128 wastes > 20 % of the MFMAs
   const bool wide = d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2;
-  const bool prof = clx_prof_enabled();
-  if (prof) clx_prof_begin(wide ? CLX_PROF_IGEMM_WIDE : CLX_PROF_IGEMM_NARROW,
-                           2.0 * p.M * p.N * p.Ktot * batch, st);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (clx_prof_enabled())
+    clx_prof_events(wide ? CLX_PROF_IGEMM_WIDE : CLX_PROF_IGEMM_NARROW, 2.0 * p.M * p.N * p.Ktot * batch, &e0, &e1);
   if (wide) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
-    conv_igemm_kernel<128, 128, 2, 2><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
+    CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   } else {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
-    conv_igemm_kernel<128, 64, 4, 1><<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
+    CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   }
-  if (prof) clx_prof_end(st);
   return CLX_OK;
 }

@@ -534,19 +534,19 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   }
   p.n_main = T * p.nslices * p.batch_split;
   const dim3 grid(p.n_main + T * p.nslices_tail * (batch - p.batch_split)), block(256);
-  const bool prof = clx_prof_enabled();
-  if (prof) clx_prof_begin(x3 ? CLX_PROF_WGRAD_X3 : CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, st);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (clx_prof_enabled())
+    clx_prof_events(x3 ? CLX_PROF_WGRAD_X3 : CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, &e0, &e1);
   if (x3)
-    wgrad_x3_kernel<<<grid, block, 0, st>>>(p);
+    CLX_LAUNCH_TIMED(wgrad_x3_kernel, grid, block, st, e0, e1, p);
   else if (big_n && big_c)
-    conv_wgrad_kernel<128, 128, 2, 2><<<grid, block, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 128, 2, 2>), grid, block, st, e0, e1, p);
   else if (big_n)
-    conv_wgrad_kernel<128, 64, 4, 1><<<grid, block, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 64, 4, 1>), grid, block, st, e0, e1, p);
   else if (big_c)
-    conv_wgrad_kernel<64, 128, 1, 4><<<grid, block, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((conv_wgrad_kernel<64, 128, 1, 4>), grid, block, st, e0, e1, p);
   else
-    conv_wgrad_kernel<64, 64, 2, 2><<<grid, block, 0, st>>>(p);
-  if (prof) clx_prof_end(st);
+    CLX_LAUNCH_TIMED((conv_wgrad_kernel<64, 64, 2, 2>), grid, block, st, e0, e1, p);
   return CLX_OK;
 }
 

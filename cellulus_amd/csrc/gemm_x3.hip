@@ -236,9 +236,8 @@ int clx_x3_launch(const clx_conv_desc* d, int batch, long long bs_in, long long 
   p.ld_gate = d->ld_gate;
   p.bs_a = bs_in; p.bs_b = bs_w; p.bs_out = bs_out;
   p.nbm = cdiv(p.M, XBM); p.nbn = p.N / XBN;
-  const bool prof = clx_prof_enabled();
-  if (prof) clx_prof_begin(CLX_PROF_GEMM_X3, 2.0 * p.M * p.N * p.K * batch, st);
-  gemm_x3_kernel<<<dim3(p.nbm * p.nbn, batch), dim3(256), 0, st>>>(p);
-  if (prof) clx_prof_end(st);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (clx_prof_enabled()) clx_prof_events(CLX_PROF_GEMM_X3, 2.0 * p.M * p.N * p.K * batch, &e0, &e1);
+  CLX_LAUNCH_TIMED(gemm_x3_kernel, dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   return CLX_OK;
 }

@@ -1,0 +1,35 @@
+"""One infer_on_device() call (512^2 tile, 32 noisy forwards) for a kernel trace:
+rocprofv3 --kernel-trace --output-format csv -d OUT -o t -- python3 tools/infer_gaps.py ; then tools/infer_gaps.py --digest OUT"""
+import sys
+if len(sys.argv) > 2 and sys.argv[1] == "--digest":
+    import csv, glob, collections
+    f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "noise_stats" in r["Kernel_Name"]]
+    a, b = marks[-2], marks[-1]
+    seg = rows[a + 1:b + 1]
+    busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e3
+    span = (int(seg[-1]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e3
+    prev = int(rows[a]["End_Timestamp"]); gaps = []
+    for r in seg:
+        gaps.append(((int(r["Start_Timestamp"]) - prev) / 1e3, r["Kernel_Name"][:60])); prev = max(prev, int(r["End_Timestamp"]))
+    print(f"kernels {len(seg)}, busy {busy:.0f} us, span {span:.0f} us, idle {span - busy:.0f} us")
+    print(sorted(gaps, reverse=True)[:8])
+    sys.exit(0)
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+from cellulus_amd.models import get_model
+dev = torch.device("cuda:0")
+cfg = dict(in_channels=1, out_channels=2, num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64,
+           downsampling_factors=[[2, 2]], num_spatial_dims=2)
+torch.manual_seed(0)
+model = get_model(**cfg).to(dev)
+model.eval()
+model.set_infer(p_salt_pepper=0.01, num_infer_iterations=16, device=dev)
+model.max_infer_batch = 8
+raw = torch.rand(1, 1, 528, 528, device=dev)
+noise = torch.rand(1, 32, 1, 528, 528, device=dev)
+for _ in range(4):
+    model.infer_on_device(raw, noise=noise)
+torch.cuda.synchronize()
