@@ -7,7 +7,10 @@ restated: the raw image is reflect-padded by the network context
 the output tile, the last tile of every axis is shifted back inside the
 image (overlaps are overwritten by the later tile, as gunpowder's Scan does),
 and every tile is the (mean, std) of ``2 * num_infer_iterations`` salt/pepper
-noised forwards (``UNetModel.infer_on_device``).  Output: float64 zarr dataset
+noised forwards (``UNetModel.infer_on_device``).  The reference's dry-run forward on
+a zero tile (predict.py:32-39, run in infer mode, hence ``2 * num_infer_iterations``
+``torch.rand`` draws before the first tile) is replayed as draws, so that a seeded
+run sees the reference's noise.  Output: float64 zarr dataset
 ``(S, D+1, *spatial)`` with ``axis_names`` / ``resolution`` / ``offset``.
 
 Samples are independent units: under torch.distributed every rank predicts
@@ -42,13 +45,21 @@ class NoisePrefetcher:
     """The uniform random numbers of the infer-mode forward (unet.py:81: one ``torch.rand`` per noisy
     copy on the CPU generator), drawn by a background thread one tile ahead of the GPU.
 
-    The calls are the reference's, in the reference's order (tile after tile, copy after copy, each
-    ``torch.rand(1, C, *crop)``), so a seeded run reproduces the same numbers and leaves the generator
-    in the same state; what changes is WHEN they are drawn: while the previous tile's forwards run,
-    into pinned memory, so that neither the draw (tens of ms per 512^2 tile) nor the upload sits
-    between two tiles' kernels."""
+    The calls are the reference's, in the reference's order, so a seeded run reproduces the same
+    numbers and leaves the generator in the same state:
 
-    def __init__(self, num_tiles, copies, tile_shape, depth=2):
+    * first the ``dry_run`` draws.  The reference finds the output shape by calling the model on a
+      zero tile AFTER ``set_infer`` (predict.py:21-39), i.e. it runs the noise loop of unet.py:75-88
+      once before the scan: ``2 * num_infer_iterations`` calls of ``torch.rand(1, C, *crop)`` whose
+      numbers never reach an image.  Here the shape comes from the launch plan, so the draws are made
+      and discarded;
+    * then tile after tile, copy after copy, each ``torch.rand(1, C, *crop)``.
+
+    What changes is WHEN they are drawn: while the previous tile's forwards run, into pinned memory,
+    so that neither the draw (tens of ms per 512^2 tile) nor the upload sits between two tiles'
+    kernels."""
+
+    def __init__(self, num_tiles, copies, tile_shape, depth=2, dry_run=0):
         import queue
         import threading
 
@@ -58,6 +69,10 @@ class NoisePrefetcher:
 
         def work():
             try:
+                if dry_run:
+                    scratch = torch.empty(tuple(tile_shape), dtype=torch.float32)
+                    for _ in range(dry_run):
+                        torch.rand(*tile_shape, out=scratch)
                 for _ in range(num_tiles):
                     buf = torch.empty((copies,) + tuple(tile_shape), dtype=torch.float32, pin_memory=pin)
                     for t in range(copies):
@@ -110,10 +125,15 @@ class PredictScan:
         self.noise = None
 
     def start_noise(self, num_samples):
-        """Announce how many samples will be predicted: their noise is then drawn ahead of the GPU."""
+        """Announce how many samples will be predicted: their noise is then drawn ahead of the GPU.
+        Called once per ``predict()`` / ``infer()``, as the reference's dry-run forward is
+        (predict.py:32-39); its ``2 * num_infer_iterations`` draws come first.  With several ranks
+        every rank is a process of its own with its own generator and does what a reference process
+        restricted to that rank's block of samples would do: dry run, then its tiles.  World size 1
+        is the reference's sequence."""
         tile_shape = (1, self.model.in_channels) + self.crop
-        self.noise = NoisePrefetcher(num_samples * self.tiles_per_sample, 2 * int(self.model.num_infer_iterations),
-                                     tile_shape)
+        copies = 2 * int(self.model.num_infer_iterations)
+        self.noise = NoisePrefetcher(num_samples * self.tiles_per_sample, copies, tile_shape, dry_run=copies)
 
     def predict_sample(self, raw):
         raw = raw.astype(np.float32) * np.float32(self.factor)             # gp.Normalize

@@ -5,6 +5,9 @@ Follows:
   * cellulus/models/unet.py:24-63   (backbone arguments, 1x1 head)
   * cellulus/models/unet.py:69-100  (train / infer forward)
   * cellulus/models/unet.py:108-124 (select_and_add_coordinates)
+  * cellulus/predict.py:21-135      (predict_scan: set_infer, the dry-run forward on zeros that
+    fixes the output shape — and consumes 2 * num_infer_iterations torch.rand draws —, then the
+    tile scan; gunpowder's Scan order itself is restated, gunpowder is absent)
   * cellulus/criterions/oce_loss.py:45-63 (OCE loss)
   * funlib.learn.torch.models.UNet @ f36decaf (pyproject.toml:30) — NOT present
     under /root/reference; restated from its published architecture (ConvPass =
@@ -173,6 +176,61 @@ class OracleUNetModel(nn.Module):
             std = std.sum(dim=0, keepdim=True)
             embeddings.append(torch.cat((mean, std), dim=0))
         return torch.stack(embeddings, dim=0)
+
+
+def predict_scan(model, raw, crop_size, p_salt_pepper, num_infer_iterations, normalization_factor=1.0,
+                 literal_dry_run=True):
+    """cellulus/predict.py:9-135 for an in-memory raw array (S, C, *spatial) -> (S, D+1, *spatial)
+    float64, on the CPU generator of torch exactly as the reference uses it:
+
+    * predict.py:21-25  ``model.set_infer(...)`` FIRST;
+    * predict.py:32-39  ``output_shape = model(zeros(1, C, *crop)).shape`` — the model is already in
+      infer mode, so this dry run executes unet.py:75-88: 2 * num_infer_iterations forwards, each
+      behind one ``torch.rand(1, C, *crop)``.  ``literal_dry_run=False`` makes the same draws without
+      the forwards (same generator state, for sizes where 2N extra CPU forwards cost minutes);
+    * predict.py:114-135  Normalize, reflect Pad by the context, Scan: tiles of ``crop_size``, stride
+      = output tile, last tile of an axis shifted back inside (later tile overwrites), every tile
+      one infer-mode forward of a batch of one (unet.py:73-100)."""
+    import itertools
+
+    import numpy as np
+
+    model.set_infer(p_salt_pepper, num_infer_iterations)
+    crop = tuple(int(c) for c in crop_size)
+    S, C = raw.shape[0], raw.shape[1]
+    spatial = tuple(raw.shape[2:])
+    nd = len(spatial)
+    zeros = torch.zeros((1, C) + crop, dtype=torch.float32)
+    if literal_dry_run:
+        with torch.no_grad():
+            out_shape = tuple(model(zeros).shape)
+    else:
+        for val in [0.5, 1.0]:
+            for _ in range(num_infer_iterations):
+                torch.rand(*zeros.shape)
+        model.mode = "train"
+        with torch.no_grad():       # the shape without the noise loop (no draw in train mode)
+            out_shape = (1, nd + 1) + tuple(model(torch.zeros((1, C) + crop)).shape[2:])
+        model.mode = "infer"
+    out_tile = out_shape[2:]
+    context = tuple((c - o) // 2 for c, o in zip(crop, out_tile))
+    result = np.zeros((S, nd + 1) + spatial, dtype=np.float64)
+
+    def offsets(size, tile):
+        offs = list(range(0, size - tile + 1, tile))
+        if offs[-1] + tile < size:
+            offs.append(size - tile)
+        return offs
+
+    for s in range(S):
+        img = raw[s].astype(np.float32) * np.float32(normalization_factor)
+        img = np.pad(img, [(0, 0)] + [(c, c) for c in context], mode="reflect")
+        for off in itertools.product(*[offsets(sz, t) for sz, t in zip(spatial, out_tile)]):
+            sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, crop))
+            with torch.no_grad():
+                e = model(torch.from_numpy(np.ascontiguousarray(img[sl]))[None])[0].numpy()
+            result[(s, slice(None)) + tuple(slice(o, o + t) for o, t in zip(off, out_tile))] = e
+    return result
 
 
 def select_and_add_coordinates(outputs, coordinates):

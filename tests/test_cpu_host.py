@@ -678,16 +678,20 @@ def test_corrupted_blosc_chunks_raise_or_decode_but_never_crash():
 # ------------------------------------------------------- round-2 host pieces
 def test_noise_prefetcher_draws_the_reference_sequence():
     """predict.NoisePrefetcher: the background thread makes exactly the torch.rand calls of the
-    reference's infer-mode forward (unet.py:81: one per noisy copy, tile after tile) — same numbers,
-    same final generator state — only earlier."""
+    reference's predict(): FIRST the 2 * num_infer_iterations draws of the dry-run forward on a zero
+    tile (predict.py:32-39 calls the model after set_infer, so unet.py:75-88 runs once before the
+    scan), then one per noisy copy, tile after tile (unet.py:81) — same numbers, same final
+    generator state — only earlier."""
     from cellulus_amd.predict import NoisePrefetcher
 
     tile = (1, 1, 20, 24)
     torch.manual_seed(7)
+    for _ in range(6):                                # the dry run: drawn, never used
+        torch.rand(*tile)
     ref = [torch.stack([torch.rand(*tile) for _ in range(6)]) for _tile in range(3)]
     after = torch.rand(4)
     torch.manual_seed(7)
-    pre = NoisePrefetcher(num_tiles=3, copies=6, tile_shape=tile, depth=2)
+    pre = NoisePrefetcher(num_tiles=3, copies=6, tile_shape=tile, depth=2, dry_run=6)
     got = [pre.next().clone() for _ in range(3)]
     pre.finish()
     for a, b in zip(got, ref):
@@ -695,6 +699,60 @@ def test_noise_prefetcher_draws_the_reference_sequence():
     assert torch.equal(torch.rand(4), after)          # the generator is where the reference leaves it
     with pytest.raises(AssertionError):
         pre.next()
+    # a rank without samples (more ranks than samples) still makes the dry-run draws and stops
+    torch.manual_seed(7)
+    pre = NoisePrefetcher(num_tiles=0, copies=6, tile_shape=tile, dry_run=6)
+    pre.finish()
+    torch.manual_seed(7)
+    for _ in range(6):
+        torch.rand(*tile)
+    state = torch.get_rng_state()
+    torch.manual_seed(7)
+    pre = NoisePrefetcher(num_tiles=0, copies=6, tile_shape=tile, dry_run=6)
+    pre.finish()
+    assert torch.equal(torch.get_rng_state(), state)
+
+
+def test_oracle_scan_replays_the_reference_predict_call_sequence():
+    """oracle.unet_oracle.predict_scan against a LITERAL transcription of what the reference's
+    predict() makes the model do (cellulus/predict.py:21-39 + gp.torch.Predict per tile, the model
+    being cellulus/models/unet.py:73-100): set_infer, model(zeros) — a full infer-mode forward —,
+    then one model(tile) per scanned tile.  Both forms of the oracle's dry run (the forward itself /
+    its draws alone) give the same embeddings and leave the generator in the same state."""
+    import itertools
+
+    from oracle.unet_oracle import OracleUNetModel, predict_scan
+
+    torch.manual_seed(3)
+    model = OracleUNetModel(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=2,
+                            features_in_last_layer=8, downsampling_factors=[(2, 2)], num_spatial_dims=2)
+    raw = np.random.RandomState(0).rand(2, 1, 50, 64).astype(np.float32)
+    crop, n_it, p = (40, 40), 3, 0.1
+
+    torch.manual_seed(11)
+    model.set_infer(p, n_it)
+    with torch.no_grad():
+        out_shape = model(torch.zeros(1, 1, *crop)).shape          # predict.py:32-39
+    assert tuple(out_shape) == (1, 3, 24, 24)
+    expect = np.zeros((2, 3, 50, 64))
+    for s in range(2):
+        padded = np.pad(raw[s], [(0, 0), (8, 8), (8, 8)], mode="reflect")
+        for oy, ox in itertools.product([0, 24, 26], [0, 24, 40]):
+            with torch.no_grad():
+                e = model(torch.from_numpy(padded[:, oy:oy + 40, ox:ox + 40].copy())[None])[0].numpy()
+            expect[s, :, oy:oy + 24, ox:ox + 24] = e
+    state = torch.get_rng_state()
+
+    for literal in (True, False):
+        torch.manual_seed(11)
+        got = predict_scan(model, raw, crop, p, n_it, 1.0, literal_dry_run=literal)
+        np.testing.assert_array_equal(got, expect)
+        assert torch.equal(torch.get_rng_state(), state)
+    # without the dry run the first tile would have seen other numbers
+    torch.manual_seed(11)
+    with torch.no_grad():
+        first = model(torch.from_numpy(np.pad(raw[0], [(0, 0), (8, 8), (8, 8)], mode="reflect")[:, :40, :40].copy())[None])
+    assert np.abs(first[0].numpy() - expect[0, :, :24, :24]).max() > 0
 
 
 def test_gaussian_weights_are_scipys():

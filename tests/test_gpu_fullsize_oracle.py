@@ -16,7 +16,6 @@ gemm_convolutions; held against nn.ConvNd in tests/test_cpu_oracle_golden.py) â€
 float64 convolution would take minutes per crop at these sizes.
 """
 
-import itertools
 import os
 
 import numpy as np
@@ -295,17 +294,14 @@ def test_cfg5_predict_tile_at_256_feature_maps_matches_the_oracle_scan(device, t
     emb = zarr_io.open(container, "r")["embeddings"][...]
     assert emb.dtype == np.float64 and emb.shape == (1, 3, 512, 512)
 
-    oracle.set_infer(p, n_it)
+    # the oracle's scan with the reference's dry run (predict.py:32-39) as draws only: the 4 extra
+    # 528^2 CPU forwards of the literal form change no number (tests/test_cpu_host.py holds the two
+    # forms of the dry run together)
+    after_predict = torch.rand(3)
     torch.manual_seed(42)
-    padded = np.pad(raw[0], [(0, 0), (8, 8), (8, 8)], mode="reflect")
-    ref = np.zeros_like(emb)
-    offs = [tile_offsets(512, 512)] * 2
-    assert offs == [[0], [0]]
-    for off in itertools.product(*offs):
-        sl = (slice(None),) + tuple(slice(o, o + 528) for o in off)
-        with torch.no_grad():
-            e = oracle(torch.from_numpy(padded[sl][None]))[0].numpy()
-        ref[(0, slice(None)) + tuple(slice(o, o + 512) for o in off)] = e
+    assert tile_offsets(512, 512) == [0]
+    ref = O.predict_scan(oracle, raw, [528, 528], p, n_it, 1.0, literal_dry_run=False)
+    assert torch.equal(torch.rand(3), after_predict)
     err_mean = np.abs(emb[:, :2] - ref[:, :2]).max()
     err_std = np.abs(emb[:, 2] - ref[:, 2]).max()
     print(f"cfg-5: embedding range {np.abs(ref[:, :2]).max():.3f}, |mean - oracle| {err_mean:.2e}, "

@@ -246,7 +246,6 @@ def test_infer_pipeline_matches_oracle(nd, device, tmp_path, monkeypatch):
     """infer(): predict -> detect -> segment over zarr vs the oracle stage by stage."""
     from cellulus_amd.configs import ExperimentConfig
     from cellulus_amd.infer import infer
-    from cellulus_amd.predict import tile_offsets
     from cellulus_amd.utils import zarr_io
     from oracle.unet_oracle import OracleUNetModel
 
@@ -283,20 +282,15 @@ def test_infer_pipeline_matches_oracle(nd, device, tmp_path, monkeypatch):
     assert emb.dtype == np.float64 and emb.shape == (raw.shape[0], nd + 1) + spatial
     assert f["embeddings"].attrs["axis_names"] == ["s", "c"] + ["z", "y", "x"][-nd:]
 
-    # ---- oracle predict: same tiling, same torch.rand sequence
-    oracle.set_infer(0.05, n_it)
-    out_tile = tuple(c - 16 for c in crop)
+    # ---- oracle predict (cellulus/predict.py:21-135 restated, INCLUDING the dry-run forward on a
+    # zero tile that the reference runs in infer mode before the scan): same torch.rand sequence
+    after_infer = torch.rand(5)
     torch.manual_seed(42)
-    ref_emb = np.zeros_like(emb)
-    import itertools
-    for s in range(raw.shape[0]):
-        padded = np.pad(raw[s], [(0, 0)] + [(8, 8)] * nd, mode="reflect")
-        for off in itertools.product(*[tile_offsets(n, t) for n, t in zip(spatial, out_tile)]):
-            sl = (slice(None),) + tuple(slice(o, o + c) for o, c in zip(off, crop))
-            with torch.no_grad():
-                e = oracle(torch.from_numpy(padded[sl][None]))[0].numpy()
-            ref_emb[(s, slice(None)) + tuple(slice(o, o + t) for o, t in zip(off, out_tile))] = e
+    from oracle.unet_oracle import predict_scan
+    ref_emb = predict_scan(oracle, raw, crop, 0.05, n_it, 1.0, literal_dry_run=True)
     assert np.abs(emb - ref_emb).max() < 1e-4
+    # ... and the generator is where the reference leaves it
+    assert torch.equal(torch.rand(5), after_infer)
 
     # ---- detect + segment, stage by stage on the pipeline's own zarr data
     np.random.seed(42)
