@@ -435,7 +435,10 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
   CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
               "clx_conv_fwd: bad algo");
   if (d->algo != CLX_ALGO_DIRECT) return clx_wino_fwd(d, (hipStream_t)stream);
-  if (clx_smallc_applicable(d) && d->mask == nullptr) {
+  // the small-channel kernels know neither ReLU-gate form (float mask, gate bits in or out): a
+  // layer that asks for one — e.g. a NON-first layer with 4 input channels whose output feeds a
+  // bit-gated data gradient — stays on the implicit-GEMM kernel, which writes / applies them
+  if (clx_smallc_applicable(d) && d->mask == nullptr && d->mask_bits == nullptr && d->gate_out == nullptr) {
     clx_smallc_fwd(d, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_fwd(small-channel)");
     return CLX_OK;

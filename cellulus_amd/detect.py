@@ -113,13 +113,13 @@ def detect(inference_config: InferenceConfig) -> None:
     f = zarr_io.open(inference_config.detection_dataset_config.container_path)
     ds = f[inference_config.detection_dataset_config.secondary_dataset_name]
     spatial = tuple(meta.spatial_array)
-    if parallel.rank() == 0:
+    def create():
         _create(f, inference_config.detection_dataset_config.dataset_name,
                 (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
         _create(f, "binary-segmentation", (meta.num_samples, 1, *spatial), np.uint16, nd)
         _create(f, "centered-embeddings", (meta.num_samples, nd + 1, *spatial), float, nd)
-    if parallel.world_size() > 1:
-        torch.distributed.barrier()
+
+    parallel.rank0_first(create)
     ds_detection = f[inference_config.detection_dataset_config.dataset_name]
     ds_binary_segmentation = f["binary-segmentation"]
     ds_object_centered_embeddings = f["centered-embeddings"]

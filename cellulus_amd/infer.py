@@ -50,14 +50,14 @@ def fused_stages(model, inference_config, normalization_factor, device):
     names = dict(emb=inference_config.prediction_dataset_config.dataset_name,
                  det=inference_config.detection_dataset_config.dataset_name, bin="binary-segmentation",
                  cen="centered-embeddings", seg=inference_config.segmentation_dataset_config.dataset_name)
-    if parallel.rank() == 0:         # one creator (create_dataset refuses / replaces an existing dataset)
+    def create():                    # one creator (create_dataset refuses an existing dataset)
         _create(f, names["emb"], (meta.num_samples, nd + 1, *spatial), float, nd)
         _create(f, names["det"], (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
         _create(f, names["bin"], (meta.num_samples, 1, *spatial), np.uint16, nd)
         _create(f, names["cen"], (meta.num_samples, nd + 1, *spatial), float, nd)
         _create(f, names["seg"], (meta.num_samples, inference_config.num_bandwidths, *spatial), np.uint16, nd)
-    if parallel.world_size() > 1:
-        torch.distributed.barrier()
+
+    parallel.rank0_first(create)     # every rank raises with rank 0 instead of waiting at a barrier
     ds_emb, ds_det, ds_bin, ds_cen, ds_seg = (f[names[k]] for k in ("emb", "det", "bin", "cen", "seg"))
     # samples are independent units: every rank takes a contiguous block, no collective on the data path
     lo, hi = parallel.shard_range(meta.num_samples)

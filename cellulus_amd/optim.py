@@ -62,6 +62,7 @@ class Adam(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         guard_ptr = None
+        self._advanced = []                      # what undo_step() may take back
         if guard is not None:
             if guard.dtype != torch.float64 or guard.numel() != 1:
                 raise TypeError("guard must be a one-element float64 device tensor")
@@ -84,9 +85,14 @@ class Adam(Optimizer):
                 st = self.state[p]
                 # torch.optim.Adam keeps `step` as a CPU float tensor; checkpoints written by older
                 # torch versions hold a Python int — accept both, store back torch's layout
-                n = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
-                st["step"] = torch.tensor(float(n + 1), dtype=torch.float32)
-                steps.add(n + 1)
+                if torch.is_tensor(st["step"]) and st["step"].device.type == "cpu" and st["step"].dtype == torch.float32:
+                    st["step"] += 1                               # in place, as torch.optim.Adam does
+                    n = int(st["step"].item())
+                else:
+                    n = (int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])) + 1
+                    st["step"] = torch.tensor(float(n), dtype=torch.float32)
+                steps.add(n)
+            self._advanced.extend(params)
             b1, b2 = group["betas"]
             args = (float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                     float(group["weight_decay"]))
@@ -113,10 +119,10 @@ class Adam(Optimizer):
 
     def undo_step(self):
         """Takes back the step COUNTERS of the last `step(guard=...)` whose guard turned out positive: the
-        kernel left parameters and moments untouched, only the host-side counts had moved."""
-        for group in self.param_groups:
-            for p in group["params"]:
-                st = self.state.get(p)
-                if st and "step" in st:
-                    n = int(st["step"].item()) if torch.is_tensor(st["step"]) else int(st["step"])
-                    st["step"] = torch.tensor(float(max(n - 1, 0)), dtype=torch.float32)
+        kernel left parameters and moments untouched, only the host-side counts had moved — and only those of
+        the parameters that step advanced (a frozen or unused parameter, grad None, kept its count)."""
+        for p in getattr(self, "_advanced", []):
+            st = self.state[p]
+            if int(st["step"].item()) > 0:
+                st["step"] -= 1
+        self._advanced = []

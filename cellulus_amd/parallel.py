@@ -125,3 +125,24 @@ def shard_range(n, r=None, w=None):
     base, rem = divmod(n, w)
     lo = r * base + min(r, rem)
     return lo, lo + base + (1 if r < rem else 0)
+
+
+def rank0_first(fn):
+    """Runs ``fn`` on rank 0 only, then lets every rank continue — or makes every rank raise TOGETHER
+    if rank 0 failed (e.g. ``create_dataset`` over an existing dataset): a bare ``barrier()`` after a
+    rank-0-only step would leave the other ranks waiting until the collective times out."""
+    if world_size() == 1:
+        fn()
+        return
+    error = None
+    if rank() == 0:
+        try:
+            fn()
+        except BaseException as e:                       # noqa: B902 - re-raised below on every rank
+            error = e
+    box = [None if error is None else f"{type(error).__name__}: {error}"]
+    dist.broadcast_object_list(box, src=0)
+    if rank() == 0 and error is not None:
+        raise error
+    if box[0] is not None:
+        raise RuntimeError(f"rank 0 failed: {box[0]}")

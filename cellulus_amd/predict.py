@@ -165,16 +165,13 @@ def predict(model: torch.nn.Module, inference_config: InferenceConfig, normaliza
 
     raw_ds = zarr_io.open(dataset_config.container_path, "r")[dataset_config.dataset_name]
     f = zarr_io.open(inference_config.prediction_dataset_config.container_path)
-    # one creator: create_dataset replaces what is there, so a second rank calling it would delete
-    # chunks the first one has already written (detect.py / segment.py follow the same order)
-    if parallel.rank() == 0:
-        f.create_dataset(
-            inference_config.prediction_dataset_config.dataset_name,
-            shape=(meta.num_samples, nd + 1, *meta.spatial_array),
-            dtype=float,
-        )
-    if parallel.world_size() > 1:
-        torch.distributed.barrier()
+    # one creator (create_dataset refuses an existing dataset, as zarr's does; if rank 0 fails every
+    # rank raises with it instead of waiting at a barrier; detect.py / segment.py do the same)
+    parallel.rank0_first(lambda: f.create_dataset(
+        inference_config.prediction_dataset_config.dataset_name,
+        shape=(meta.num_samples, nd + 1, *meta.spatial_array),
+        dtype=float,
+    ))
     ds = f[inference_config.prediction_dataset_config.dataset_name]
 
     scan = PredictScan(model, inference_config, meta, normalization_factor, raw_ds.dtype, device)

@@ -148,7 +148,7 @@ def segment(inference_config: InferenceConfig) -> None:
 
     f = zarr_io.open(inference_config.segmentation_dataset_config.container_path)
     ds = f[inference_config.segmentation_dataset_config.secondary_dataset_name]
-    if parallel.rank() == 0:
+    def create():
         ds_new = f.create_dataset(
             inference_config.segmentation_dataset_config.dataset_name,
             shape=(meta.num_samples, inference_config.num_bandwidths, *meta.spatial_array),
@@ -156,8 +156,8 @@ def segment(inference_config: InferenceConfig) -> None:
         ds_new.attrs["axis_names"] = ["s", "c"] + ["t", "z", "y", "x"][-nd:]
         ds_new.attrs["resolution"] = (1,) * nd
         ds_new.attrs["offset"] = (0,) * nd
-    if parallel.world_size() > 1:
-        torch.distributed.barrier()
+
+    parallel.rank0_first(create)
     ds_segmented = f[inference_config.segmentation_dataset_config.dataset_name]
 
     lo, hi = parallel.shard_range(meta.num_samples)

@@ -73,7 +73,7 @@ class Attributes:
 _BLOSC_CODECS = {0: "blosclz", 1: "lz4", 2: "snappy", 3: "zlib", 4: "zstd"}
 
 
-def blosc_decode(raw):
+def blosc_decode(raw, expected=None):
     """One Blosc (format 2, c-blosc 1.x — what numcodecs.Blosc writes) chunk -> bytes.
 
     Layout: 16-byte header (version, versionlz, flags, typesize, nbytes, blocksize, cbytes), then —
@@ -84,7 +84,9 @@ def blosc_decode(raw):
     themselves when the length equals the plain size); the last, shorter block is never split.
     Codecs: LZ4 / LZ4HC (zarr's default) and BloscLZ (decoded by libclx: clx_lz4_decompress,
     clx_blosclz_decompress), zlib, and — when pyarrow is importable (its bundled codecs) — zstd and
-    snappy; byte shuffle is undone by clx_unshuffle_bytes, bit shuffle by `_bit_unshuffle`."""
+    snappy; byte shuffle is undone by clx_unshuffle_bytes, bit shuffle by `_bit_unshuffle`.
+    ``expected`` (the chunk's byte count, prod(chunks) * itemsize): a header announcing anything
+    else is rejected BEFORE a buffer of the announced size is allocated."""
     import ctypes
 
     from .. import _clx
@@ -96,6 +98,8 @@ def blosc_decode(raw):
     nbytes, blocksize, cbytes = (int.from_bytes(raw[o:o + 4], "little") for o in (4, 8, 12))
     if cbytes > len(raw) or typesize < 1:
         raise ZarrError("corrupt Blosc header")
+    if expected is not None and nbytes != expected:
+        raise ZarrError(f"Blosc chunk announces {nbytes} bytes, the array's chunks hold {expected}")
     if nbytes == 0:
         return b""
     if flags & 0x02:                                     # memcpyed
@@ -104,9 +108,11 @@ def blosc_decode(raw):
     if codec not in ("lz4", "zlib", "zstd", "snappy", "blosclz"):
         raise ZarrError(f"Blosc codec id {flags >> 5} is not known to this reader (blosclz, lz4, lz4hc, snappy, zlib and zstd are)")
     arrow = _arrow_codec(codec) if codec in ("zstd", "snappy") else None
-    if blocksize <= 0:
+    if blocksize <= 0 or blocksize > nbytes:
         raise ZarrError("corrupt Blosc header (block size)")
     nblocks = -(-nbytes // blocksize)
+    if 16 + 4 * nblocks > len(raw):
+        raise ZarrError("corrupt Blosc header (block table longer than the chunk)")
     leftover = nbytes % blocksize
     bitshuffle = bool(flags & 0x04)
     shuffle = (bool(flags & 0x01) and typesize > 1) or bitshuffle
@@ -120,6 +126,8 @@ def blosc_decode(raw):
         bsize = leftover if (b == nblocks - 1 and leftover) else blocksize
         is_leftover = b == nblocks - 1 and leftover > 0
         pos = int.from_bytes(raw[16 + 4 * b:20 + 4 * b], "little")
+        if pos < 16 + 4 * nblocks or pos + 4 > len(raw):
+            raise ZarrError("corrupt Blosc block offset")
         nsplits = typesize if (not dont_split and typesize <= 16 and blocksize // typesize >= 128
                                and not is_leftover) else 1
         neblock = bsize // nsplits
@@ -180,7 +188,9 @@ def _arrow_codec(name):
     return pyarrow.Codec(name)
 
 
-def _decode(raw, compressor):
+def _decode(raw, compressor, expected=None):
+    """Chunk bytes -> array bytes.  ``expected`` = prod(chunks) * itemsize when the caller knows it:
+    size fields of untrusted chunk headers are checked against it before anything is allocated."""
     if compressor is None:
         return raw
     cid = compressor.get("id")
@@ -189,7 +199,7 @@ def _decode(raw, compressor):
     if cid == "gzip":
         return gzip.decompress(raw)
     if cid == "blosc":
-        return blosc_decode(raw)
+        return blosc_decode(raw, expected)
     if cid == "zstd":                                    # numcodecs.Zstd: one zstd frame with its content size
         return _zstd_frame(bytes(raw))
     if cid == "lz4":                                     # numcodecs.LZ4: int32 plain size + one LZ4 block
@@ -197,7 +207,11 @@ def _decode(raw, compressor):
 
         from .. import _clx
         raw = bytes(raw)
+        if len(raw) < 4:
+            raise ZarrError("LZ4 chunk shorter than its size field")
         n = int.from_bytes(raw[:4], "little")
+        if expected is not None and n != expected:
+            raise ZarrError(f"LZ4 chunk announces {n} bytes, the array's chunks hold {expected}")
         out = np.empty(n, dtype=np.uint8)
         src = np.frombuffer(raw, dtype=np.uint8)
         got = _clx.load().clx_lz4_decompress(ctypes.c_void_p(src.ctypes.data + 4), len(raw) - 4,
@@ -321,7 +335,7 @@ class Array:
                 self._cache[key] = self._cache.pop(key)                  # most recently used
                 return hit[1]
         with io.open(p, "rb") as f:
-            raw = _decode(f.read(), self.compressor)
+            raw = _decode(f.read(), self.compressor, int(np.prod(self.chunks)) * self.dtype.itemsize)
         chunk = np.frombuffer(raw, dtype=self.dtype).reshape(self.chunks)
         if use_cache and chunk.nbytes <= self._cache_cap:
             old = self._cache.pop(key, None)

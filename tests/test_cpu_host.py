@@ -376,9 +376,87 @@ for i in reversed(range(len(sizes))):
 assert gb0.issued == []
 gb0.finish()
 assert gb0.issued == [(0, 122)] and torch.equal(flat, torch.arange(float(sum(sizes))) * 6)
+# a rank-0-only step that fails makes EVERY rank raise (nobody is left waiting at a barrier)
+def boom():
+    raise FileExistsError("dataset exists")
+try:
+    parallel.rank0_first(boom)
+    raise SystemExit("rank0_first swallowed the error")
+except FileExistsError:
+    assert rank == 0
+except RuntimeError as e:
+    assert rank != 0 and "FileExistsError: dataset exists" in str(e)
+ran = []
+parallel.rank0_first(lambda: ran.append(rank))
+assert ran == ([0] if rank == 0 else [])
 dist.barrier()
 print("rank", rank, "ok")
 """
+
+_DDP8_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from cellulus_amd import parallel
+rank, world, _ = parallel.init_from_env(backend="gloo")
+assert world == 8 and parallel.world_size() == 8 and parallel.rank() == rank
+# 5 independent samples on 8 ranks: three ranks get nothing, the others one each, no overlap
+lo, hi = parallel.shard_range(5)
+assert (lo, hi) == ((rank, rank + 1) if rank < 5 else (5, 5))
+mine = torch.zeros(5); mine[lo:hi] = 1
+parallel.all_reduce_sum_(mine)
+assert torch.equal(mine, torch.ones(5))
+# SUM, never a mean: eight ranks' gradients of a summed loss
+g = torch.full((1000,), float(rank + 1))
+parallel.all_reduce_sum_(g)
+assert torch.equal(g, torch.full((1000,), 36.0))
+# the bucket sequence depends on the plan only: every rank issues the same ranges in the same order
+sizes = [3, 300, 17, 1024, 64, 5, 2048, 9]
+flat = torch.ones(sum(sizes)) * (rank + 1)
+views, off = [], 0
+for n in sizes:
+    views.append(flat[off:off + n]); off += n
+gb = parallel.GradientBuckets(flat, views, min_bytes=1024 * 4)
+for i in (7, 6, 4, 5, 3, 1, 2, 0):
+    gb.params_done(i)
+gb.finish()
+assert torch.equal(flat, torch.full((sum(sizes),), 36.0))
+issued = [None] * world
+dist.all_gather_object(issued, gb.issued)
+assert all(i == issued[0] for i in issued) and issued[0][0] == (1413, 3470), issued[0]
+def boom():
+    raise FileExistsError("dataset exists")
+try:
+    parallel.rank0_first(boom)
+    raise SystemExit("rank0_first swallowed the error")
+except FileExistsError:
+    assert rank == 0
+except RuntimeError as e:
+    assert rank != 0 and "FileExistsError" in str(e)
+dist.barrier()
+print("rank", rank, "ok")
+"""
+
+
+def _run_ranks(script_text, world, tmp_path):
+    script = tmp_path / f"ddp{world}.py"
+    script.write_text(script_text)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world),
+               OMP_NUM_THREADS="1")
+    procs = []
+    for r in range(world):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert f"rank {r} ok" in o
+
+
+def test_data_parallel_wiring_gloo_world8(tmp_path):
+    """Eight ranks (the node size of BASELINE configs[2]): ranks without samples, SUM semantics, one
+    bucket sequence on every rank, a failing rank-0-only step raising everywhere."""
+    _run_ranks(_DDP8_SCRIPT, 8, tmp_path)
 
 
 def test_data_parallel_wiring_gloo_world2(tmp_path):
@@ -632,7 +710,7 @@ def test_decoded_chunk_cache_serves_repeated_crops_and_sees_rewrites(tmp_path, m
     f["raw"] = data
     calls = []
     real = zarr_io._decode
-    monkeypatch.setattr(zarr_io, "_decode", lambda raw, comp: (calls.append(1), real(raw, comp))[1])
+    monkeypatch.setattr(zarr_io, "_decode", lambda raw, comp, n=None: (calls.append(1), real(raw, comp, n))[1])
     monkeypatch.setenv("CLX_ZARR_CACHE_MB", str(2.5 * 64 * 64 * 4 / (1 << 20)))       # room for two chunks
     a = zarr_io.open(tmp_path / "c.zarr", "r")["raw"]
     for _ in range(5):
@@ -648,6 +726,31 @@ def test_decoded_chunk_cache_serves_repeated_crops_and_sees_rewrites(tmp_path, m
     a2 = zarr_io.open(tmp_path / "c.zarr")["raw"]
     a2[0, 0, :8, :8] = 7.0                      # partial write through the handle that cached
     assert a2[0, 0, 3, 3] == 7.0 and a2[0, 0, 20, 20] == data[0, 0, 20, 20]
+
+
+def test_chunk_headers_are_checked_against_the_array_before_allocating():
+    """A corrupt or foreign chunk whose header announces another size than prod(chunks) * itemsize
+    is rejected up front (no multi-GiB allocation from an untrusted field)."""
+    from cellulus_amd.utils import zarr_io
+
+    g = np.load(os.path.join(GOLDEN, "g12_blosc.npz"))
+    chunk = g["f32_lz4_shuffle/chunk"].tobytes()
+    nbytes = int.from_bytes(chunk[4:8], "little")
+    assert len(zarr_io._decode(chunk, {"id": "blosc"}, nbytes)) == nbytes
+    with pytest.raises(zarr_io.ZarrError, match="announces"):
+        zarr_io._decode(chunk, {"id": "blosc"}, nbytes + 4)
+    huge = bytearray(chunk)
+    huge[4:8] = (0xFFFFFFF0).to_bytes(4, "little")
+    with pytest.raises(zarr_io.ZarrError, match="announces"):
+        zarr_io._decode(bytes(huge), {"id": "blosc"}, nbytes)
+    with pytest.raises(zarr_io.ZarrError):                       # block size larger than the chunk
+        bad = bytearray(chunk)
+        bad[8:12] = (nbytes * 2).to_bytes(4, "little")
+        zarr_io.blosc_decode(bytes(bad))
+    with pytest.raises(zarr_io.ZarrError, match="announces"):
+        zarr_io._decode((1 << 31).to_bytes(4, "little") + b"\x00" * 8, {"id": "lz4"}, 64)
+    with pytest.raises(zarr_io.ZarrError):
+        zarr_io._decode(b"\x01", {"id": "lz4"}, 64)
 
 
 def test_corrupted_blosc_chunks_raise_or_decode_but_never_crash():

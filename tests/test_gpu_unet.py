@@ -37,6 +37,15 @@ CONFIGS = {
     "3d_four_fmaps": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=4, fmap_inc_factor=2,
                                    features_in_last_layer=8, downsampling_factors=[[2, 2, 2]],
                                    num_spatial_dims=3), spatial=(20, 20, 24), batch=2),
+    # a NON-first layer with 4 input channels, more than one tap and 32 output channels (level-1
+    # conv 4 -> 32): its output's ReLU gate is kept as bits, which the small-channel kernel cannot
+    # write — the dispatch must leave it to the implicit-GEMM kernel (round-2 advisor finding)
+    "2d_four_to_32": dict(cfg=dict(in_channels=1, out_channels=2, num_fmaps=4, fmap_inc_factor=8,
+                                   features_in_last_layer=32, downsampling_factors=[[2, 2]],
+                                   num_spatial_dims=2), spatial=(36, 40), batch=2),
+    "3d_four_to_32": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=4, fmap_inc_factor=8,
+                                   features_in_last_layer=32, downsampling_factors=[[2, 2, 2]],
+                                   num_spatial_dims=3), spatial=(20, 20, 24), batch=1),
     "3d_small": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=8, fmap_inc_factor=2,
                               features_in_last_layer=16, downsampling_factors=[[2, 2, 2]],
                               num_spatial_dims=3), spatial=(28, 24, 32), batch=2),
