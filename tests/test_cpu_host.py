@@ -733,7 +733,7 @@ def test_chunk_headers_are_checked_against_the_array_before_allocating():
     is rejected up front (no multi-GiB allocation from an untrusted field)."""
     from cellulus_amd.utils import zarr_io
 
-    g = np.load(os.path.join(GOLDEN, "g12_blosc.npz"))
+    g = np.load(os.path.join(G, "g12_blosc.npz"))
     chunk = g["f32_lz4_shuffle/chunk"].tobytes()
     nbytes = int.from_bytes(chunk[4:8], "little")
     assert len(zarr_io._decode(chunk, {"id": "blosc"}, nbytes)) == nbytes
