@@ -122,6 +122,37 @@ def test_adam_matches_torch(device):
     assert all(torch.is_tensor(st["step"]) and st["step"].item() == 6.0 for st in opt.state.values())
 
 
+def test_adam_undo_takes_back_only_what_the_guarded_step_advanced(device):
+    """step(guard=...) with a positive guard leaves parameters and moments alone; undo_step() then
+    takes back the counters of exactly the parameters that step advanced — one without a gradient
+    (frozen / unused) keeps its count, so the counters never drift apart (round-2 advisor finding)."""
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(6, device=device))
+    b = torch.nn.Parameter(torch.randn(4, device=device))
+    opt = Adam([a, b], lr=1e-2, weight_decay=0.01)
+    a.grad, b.grad = torch.randn(6, device=device), torch.randn(4, device=device)
+    opt.step()
+    opt.step()
+    step_tensor = opt.state[a]["step"]
+    assert opt.state[a]["step"].item() == opt.state[b]["step"].item() == 2.0
+    b.grad = None                                     # frozen from here on
+    before = a.detach().clone()
+    guard = torch.ones(1, dtype=torch.float64, device=device)
+    opt.step(guard=guard)                             # guarded off on the device
+    torch.cuda.synchronize()
+    assert torch.equal(a.detach(), before)
+    assert opt.state[a]["step"].item() == 3.0 and opt.state[b]["step"].item() == 2.0
+    opt.undo_step()
+    assert opt.state[a]["step"].item() == 2.0 and opt.state[b]["step"].item() == 2.0
+    assert opt.state[a]["step"] is step_tensor         # updated in place, as torch.optim.Adam does
+    opt.undo_step()                                   # a second undo has nothing to take back
+    assert opt.state[a]["step"].item() == 2.0
+    guard.zero_()
+    opt.step(guard=guard)
+    torch.cuda.synchronize()
+    assert not torch.equal(a.detach(), before) and opt.state[a]["step"].item() == 3.0
+
+
 def test_out_of_range_coordinates_raise_like_the_reference(device):
     """unet.py:113-118 indexes outputs[b, :, y, x]: torch wraps -n..-1 and raises IndexError beyond;
     the kernels must never dereference such a row (they used to)."""
