@@ -21,6 +21,8 @@ Extra objects on that line:
   train3d      — BASELINE.json configs[3] (3-D 64^3, 64 fmaps) timed the same way,
                  with its own roofline object.
   infer        — inference throughput (embed + mean-shift + CC) in Mpixels/s (1 GPU).
+  train_e2e    — the real train() (zarr -> loader processes with the default augmentation and the
+                 np.random pair stream -> H2D -> step -> logging), steady-state crops/s (1 GPU).
   cpu_baseline — the oracle's CPU train step (plain PyTorch, host cores) on
                  a bounded sample of the same workload; baseline only (1 GPU).
   ranks_seen, per_rank_ms_per_step, allreduce_ms_exposed — what the data-parallel run saw.
@@ -393,8 +395,93 @@ def run_workload(wl_key, args, rank, world, device):
         out["per_rank_ms_per_step"] = [round(t / args.steps * 1e3, 3) for t in per_rank]
         out["allreduce_ms_exposed"] = round(exposed, 3)
         out["backend"] = torch.distributed.get_backend()
+        # what one step puts on the wire per rank: the flat f32 gradient (+ 4 float64 loss sums), in the
+        # ranges parallel.GradientBuckets issued (suffixes of the flat buffer, in backward order)
+        ranges = getattr(model, "_last_bucket_ranges", None) or [(0, model._flat_grad.numel())]
+        out["allreduce_bytes"] = int(model._flat_grad.numel() * 4 + 4 * 8)
+        out["allreduce_bucket_bytes"] = [int((hi - lo) * 4) for lo, hi in ranges]
+        out["grad_bucket_mb"] = float(os.environ.get("CLX_GRAD_BUCKET_MB", "4"))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    # the timed steps read HBM-resident inputs: no loader process runs beside them (train_e2e has the loader)
+    out["host_cores_per_rank"] = max(1, cores // world)
+    out["loader_procs"] = 0
     del model, optimizer, plan
     return out
+
+
+def train_e2e(wl_key, device, iterations=140, settle=40, workers=8):
+    """The REAL ``cellulus_amd.train.train()`` at the benchmark configuration over a synthetic zarr: zarr
+    reads, random crops, the reference's default elastic augmentation (train_config.py:124), the reference's
+    np.random pair stream in the loader processes (train.py:38-44: DataLoader(num_workers=8)), H2D of every
+    batch (train.py:161-166), loss logging — everything ``value`` leaves out.  Steady-state crops/s between
+    iteration ``settle`` and the end (the start-up — loader processes, plan build — is reported beside it)."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+
+    import numpy as np
+    import torch
+
+    import cellulus_amd.train as T
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.utils import zarr_io
+
+    wl = WORKLOADS[wl_key]
+    crop = list(wl["crop"])
+    nd = len(crop)
+    tmp = tempfile.mkdtemp(prefix="clx_e2e_")
+    cwd = os.getcwd()
+    stamps, mem = [], []
+    real = T.train_iteration
+
+    def spy(*a, **k):
+        out = real(*a, **k)
+        stamps.append(time.perf_counter())
+        mem.append(torch.cuda.memory_allocated(device))
+        return out
+
+    try:
+        os.chdir(tmp)
+        f = zarr_io.open("data.zarr")
+        # images larger than the crop, as the augmentation needs (zarr_dataset.py:123-132)
+        big = tuple(int(c * 1.5) for c in crop)
+        f["train/raw"] = np.concatenate([synthetic_raw(1, big, s).numpy() for s in range(16)])
+        f["train/raw"].attrs["axis_names"] = ["s", "c"] + ["z", "y", "x"][-nd:]
+        m = wl["model"]
+        cfg = ExperimentConfig(
+            normalization_factor=1.0, object_size=30,
+            model_config=dict(num_fmaps=m["num_fmaps"], fmap_inc_factor=m["fmap_inc_factor"],
+                              features_in_last_layer=m["features_in_last_layer"],
+                              downsampling_factors=[list(x) for x in m["downsampling_factors"]]),
+            train_config=dict(crop_size=crop, batch_size=wl["batch"], max_iterations=iterations, num_workers=workers,
+                              kappa=wl["kappa"], density=wl["density"], device=str(device),
+                              save_model_every=10 ** 6, save_best_model_every=10 ** 6, save_snapshot_every=10 ** 6,
+                              train_data_config=dict(container_path="data.zarr", dataset_name="train/raw")))
+        policy = T.loader_policy(1, cfg.train_config.num_workers)
+        T.train_iteration = spy
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            T.train(cfg)
+        total = time.perf_counter() - t0
+    finally:
+        T.train_iteration = real
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+    steady = (stamps[-1] - stamps[settle]) / (len(stamps) - 1 - settle)
+    return dict(
+        value=round(wl["batch"] / steady, 3), unit="crops/s", ms_per_iteration=round(steady * 1e3, 3),
+        iterations=iterations, steady_from_iteration=settle, seconds_total=round(total, 2),
+        loader_procs=policy["loader_procs"], pair_sampler="device" if policy["device_pairs"] else "np.random in the loader processes (reference stream)",
+        elastic_deform=bool(cfg.train_config.elastic_deform), host_cores=policy["host_cores_per_rank"],
+        # (a reading may or may not include the prefetched next batch, 40 MB: compare window maxima)
+        device_mem_growth_mb=round((max(mem[-20:]) - max(mem[settle:settle + 20])) / 2 ** 20, 3),
+        what="cellulus_amd.train.train(): synthetic zarr (16 images 1.5x the crop) -> loader processes (random crop, "
+             "elastic augmentation, pair sampling) -> pinned H2D prefetch -> train_iteration -> loss.csv; "
+             "checkpoints / snapshots at cadences beyond the run")
 
 
 def cpu_baseline(workload, device, seed, budget_s=90.0):
@@ -425,8 +512,9 @@ def cpu_baseline(workload, device, seed, budget_s=90.0):
             torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
     state0 = {k: v.clone() for k, v in model.state_dict().items()}
     opt = torch.optim.Adam(model.parameters(), lr=4e-5, weight_decay=0.01)
-    raw = synthetic_raw(2, workload["crop"], seed)
-    anchor, reference = sample_pairs(2, workload["crop"], workload["kappa"], workload["density"], seed)
+    full = int(workload["batch"])
+    raw = synthetic_raw(full, workload["crop"], seed)
+    anchor, reference = sample_pairs(full, workload["crop"], workload["kappa"], workload["density"], seed)
 
     t_begin = time.perf_counter()
     # thread count: one forward per candidate (after one untimed forward that pays the start-up)
@@ -449,8 +537,10 @@ def cpu_baseline(workload, device, seed, budget_s=90.0):
     t0 = time.perf_counter()
     l_cpu, _o, _off = O.train_step(model, opt, raw[:1], anchor[:1], reference[:1], 10.0, 1e-5)
     t_warm = time.perf_counter() - t0
-    # timed: a second step; two crops if the budget allows
-    nb = 2 if (time.perf_counter() - t_begin) + 2.2 * t_warm < budget_s else 1
+    # timed: a second step — on the workload's full batch if the budget allows (a warm step costs about as
+    # much per crop as the warm-up step did), else on two crops, else on one
+    left = budget_s - (time.perf_counter() - t_begin)
+    nb = full if 1.1 * full * t_warm < left else 2 if 2.2 * t_warm < left else 1
     t0 = time.perf_counter()
     O.train_step(model, opt, raw[:nb], anchor[:nb], reference[:nb], 10.0, 1e-5)
     dt = time.perf_counter() - t0
@@ -465,7 +555,7 @@ def cpu_baseline(workload, device, seed, budget_s=90.0):
     l_gpu, _o, _off = train_iteration((raw[:1], anchor[:1], reference[:1]), gm, crit, gopt, device)
     return dict(value=round(nb / dt, 4), unit="crops/s", cores=threads, kind="port",
                 sample=f"PyTorch-CPU oracle (the reference's own CPU ops), 1 warm-up train step ({t_warm:.1f} s, "
-                       f"1 crop) then 1 timed train step on {nb} crop(s) of the same workload ({dt:.1f} s), "
+                       f"1 crop) then 1 timed train step on {nb} crop(s) of the same workload — batch {full} — ({dt:.1f} s), "
                        f"torch threads = {threads} (forward probe s: "
                        + ", ".join(f"{c}: {probe[c]:.2f}" for c in probe) + f"; host has {logical} logical cores)",
                 loss_cpu=round(float(l_cpu), 4), loss_hip=round(float(l_gpu), 4),
@@ -482,6 +572,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-train3d", action="store_true")
+    ap.add_argument("--no-train-e2e", action="store_true")
     ap.add_argument("--precision", default="f32", choices=["f32", "f32x3bf16"],
                     help="f32 (default, the headline): float32 MFMA.  f32x3bf16: ALSO time the 2-D workload with the "
                          "opt-in precision (plain GEMMs on the bf16 matrix cores, three-way exact split of the float32 "
@@ -567,6 +658,12 @@ def main():
             out["infer"] = infer_bench(device)
         except Exception as e:  # the train line must survive an inference-side failure
             out["infer"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_train_e2e and args.workload in ("train2d", "train3d"):
+        try:
+            torch.cuda.empty_cache()
+            out["train_e2e"] = train_e2e(args.workload, device)
+        except Exception as e:
+            out["train_e2e"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], device, seed=0)

@@ -42,6 +42,37 @@ def _require_hip_device(device_str):
     return device
 
 
+def loader_policy(world, num_workers):
+    """How the input pipeline of ONE rank uses the host (the reference is one process with
+    ``num_workers`` loader processes, train.py:38-44).
+
+    * One rank: the reference's behaviour — ``num_workers`` loader processes, pair coordinates from the
+      ``np.random`` stream inside them.  ``CLX_DEVICE_PAIRS=1`` opts into the device sampler.
+    * Several ranks share one host: each gets ``cores // world`` cores.  The loader processes are capped to
+      that share minus one (the rank's own Python), and the pair coordinates are drawn on the device by
+      default (``CLX_DEVICE_PAIRS=0`` keeps the np.random stream): at 8 ranks x 8 crops x 5 steps/s the
+      np.random stream alone needs 8 cores PER RANK, the device sampler 2.5 for crops + augmentation."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    per_rank = max(1, cores // max(world, 1))
+    env = os.environ.get("CLX_DEVICE_PAIRS")
+    procs = int(num_workers)
+    if world > 1:
+        device_pairs = env != "0"
+        cap = max(1, per_rank - 1)
+        why = f"{world} ranks share {cores} cores"
+        if procs > cap:
+            why += f": num_workers {procs} capped to {cap}"
+            procs = cap
+        why += "; CLX_DEVICE_PAIRS=0 keeps np.random pairs" if device_pairs and env is None else ""
+    else:
+        device_pairs = env == "1"
+        why = "single process: the reference's loader" + (" + CLX_DEVICE_PAIRS=1" if device_pairs else "")
+    return dict(loader_procs=procs, host_cores_per_rank=per_rank, device_pairs=device_pairs, why=why)
+
+
 def train(experiment_config):
     print(experiment_config)
     rank, world, local_rank = parallel.init_from_env()
@@ -71,12 +102,19 @@ def train(experiment_config):
         normalization_factor=experiment_config.normalization_factor,
     )
 
-    # opt-in: pair coordinates drawn on the device instead of in the loader processes (same distribution,
-    # another random stream): 2 x B x 150 040 x 2 int64 = 38 MB per step less to sample, pickle and upload
+    # the input pipeline's share of the host: every loader process draws the np.random pair stream of its
+    # crops (27 ms of one core per 256^2 crop) next to the zarr reads and the augmentation
+    policy = loader_policy(world, train_config.num_workers)
+    if is_main:
+        print(f"[cellulus_amd] input pipeline: {policy['loader_procs']} loader processes per rank "
+              f"({policy['host_cores_per_rank']} host cores per rank, world size {world}), pair coordinates "
+              f"drawn {'on the device (clx_sample_pairs)' if policy['device_pairs'] else 'in the loader processes (np.random, the reference stream)'}"
+              f" [{policy['why']}]")
     pair_sampler = None
-    if os.environ.get("CLX_DEVICE_PAIRS", "0") == "1":
+    if policy["device_pairs"]:
         from .datasets.zarr_dataset import DevicePairSampler
 
+        # 2 x B x 150 040 x 2 int64 = 38 MB per step less to sample, pickle and upload
         train_dataset.skip_pairs = True
         pair_sampler = DevicePairSampler(train_dataset, device, seed=torch.initial_seed() + 7919 * rank)
 
@@ -85,7 +123,7 @@ def train(experiment_config):
         dataset=train_dataset,
         batch_size=train_config.batch_size,
         drop_last=True,
-        num_workers=train_config.num_workers,
+        num_workers=policy["loader_procs"],
         pin_memory=True,
     )
 
@@ -321,11 +359,13 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
         plan.backward(doffsets, params, grads, on_layer_done=lambda i: buckets.params_done(2 * i, 2 * i + 1),
                       flat_grad=model._flat_grad)
         buckets.finish()
+        model._last_bucket_ranges = list(buckets.issued)      # (lo, hi) element ranges, in issue order
     else:
         plan.backward(doffsets, params, grads, flat_grad=model._flat_grad)
         if parallel.world_size() > 1:
             parallel.all_reduce_sum_(model._flat_grad)
             parallel.all_reduce_sum_(sums)
+            model._last_bucket_ranges = [(0, model._flat_grad.numel())]
     if early is None and parallel.world_size() > 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
         # several ranks: the reduced sums exist once the last bucket is in; the copy then runs beside the update
         # and the packing, and the host returns while those still execute

@@ -459,6 +459,25 @@ def test_data_parallel_wiring_gloo_world8(tmp_path):
     _run_ranks(_DDP8_SCRIPT, 8, tmp_path)
 
 
+def test_multi_rank_train_defaults_to_device_pairs_and_caps_the_loaders(monkeypatch):
+    """train()'s input-pipeline policy (host side only): one rank = the reference's loader; several ranks
+    share the host — loader processes capped to the rank's share of the cores, pairs drawn on the device
+    unless CLX_DEVICE_PAIRS=0."""
+    from cellulus_amd.train import loader_policy
+
+    monkeypatch.delenv("CLX_DEVICE_PAIRS", raising=False)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(64)))
+    one = loader_policy(1, 8)
+    assert one["loader_procs"] == 8 and not one["device_pairs"] and one["host_cores_per_rank"] == 64
+    eight = loader_policy(8, 8)
+    assert eight["loader_procs"] == 7 and eight["device_pairs"] and eight["host_cores_per_rank"] == 8
+    assert loader_policy(8, 4)["loader_procs"] == 4
+    monkeypatch.setenv("CLX_DEVICE_PAIRS", "0")
+    assert not loader_policy(8, 8)["device_pairs"]
+    monkeypatch.setenv("CLX_DEVICE_PAIRS", "1")
+    assert loader_policy(1, 8)["device_pairs"]
+
+
 def test_data_parallel_wiring_gloo_world2(tmp_path):
     script = tmp_path / "ddp.py"
     script.write_text(_DDP_SCRIPT)

@@ -35,15 +35,26 @@ parallel.broadcast_(flat, src=0)                    # ... made identical by the 
 crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=2, device=dev)
 opt = Adam(model.parameters(), lr=1e-3, weight_decay=0.01)
 data = np.load(sys.argv[2])
+per = data["raw0"].shape[0] // world                # crops per rank
 losses = []
 for step in range(2):
-    raw = torch.from_numpy(data[f"raw{step}"][rank * 2:(rank + 1) * 2])
-    a = torch.from_numpy(data[f"a{step}"][rank * 2:(rank + 1) * 2])
-    r = torch.from_numpy(data[f"r{step}"][rank * 2:(rank + 1) * 2])
+    raw = torch.from_numpy(data[f"raw{step}"][rank * per:(rank + 1) * per])
+    a = torch.from_numpy(data[f"a{step}"][rank * per:(rank + 1) * per])
+    r = torch.from_numpy(data[f"r{step}"][rank * per:(rank + 1) * per])
     loss, _, _ = train_iteration((raw, a, r), model, crit, opt, dev)
     losses.append(loss)
+# every rank issued the same gradient ranges in the same order (they depend on the plan only) ...
+ranges = [None] * world
+torch.distributed.all_gather_object(ranges, model._last_bucket_ranges)
+assert all(r == ranges[0] for r in ranges), ranges
+assert ranges[0][-1][0] == 0 and ranges[0][0][1] == model._flat_grad.numel()
+assert all(a[0] == b[1] for a, b in zip(ranges[0], ranges[0][1:]))        # a partition of the flat buffer
+# ... and ends with the same parameters
+mine = model._flat.clone()
+parallel.broadcast_(mine, src=0)
+assert torch.equal(mine, model._flat), "ranks diverged"
 if rank == 0:
-    np.savez(sys.argv[3], flat=model._flat.cpu().numpy(), losses=np.array(losses))
+    np.savez(sys.argv[3], flat=model._flat.cpu().numpy(), losses=np.array(losses), nbuckets=len(ranges[0]))
 torch.distributed.barrier()
 """
 
@@ -68,10 +79,12 @@ def _launch(script, args, env_extra, nproc=2, port=None):
     return outs
 
 
-@pytest.mark.parametrize("bucket_mb", ["4", "0.002", "0"])
-def test_two_ranks_equal_one_process_at_global_batch(tmp_path, device, bucket_mb):
+@pytest.mark.parametrize("world,bucket_mb", [(2, "4"), (2, "0.002"), (2, "0"), (8, "4"), (8, "0.002")])
+def test_ranks_equal_one_process_at_global_batch(tmp_path, device, world, bucket_mb):
     """bucket_mb: default (one bucket at this model size), 2 KB buckets (every layer goes out on its own
-    while the backward pass continues), 0 (single all-reduce after the backward pass)."""
+    while the backward pass continues), 0 (single all-reduce after the backward pass).  world 8 = the
+    node size of BASELINE configs[2] (one crop per rank here): same bucket sequence on every rank, same
+    parameters on every rank, and those of one process at the global batch."""
     from cellulus_amd.criterions import get_loss
     from cellulus_amd.models import get_model
     from cellulus_amd.optim import Adam
@@ -79,19 +92,21 @@ def test_two_ranks_equal_one_process_at_global_batch(tmp_path, device, bucket_mb
 
     rng = np.random.default_rng(0)
     data = {}
+    G = 4 if world == 2 else 8                             # global batch
     for step in range(2):
-        data[f"raw{step}"] = rng.random((4, 1, 44, 52)).astype(np.float32)
-        a = np.repeat(rng.integers(3, 25, size=(4, 40, 2)), 5, axis=1)
+        data[f"raw{step}"] = rng.random((G, 1, 44, 52)).astype(np.float32)
+        a = np.repeat(rng.integers(3, 25, size=(G, 40, 2)), 5, axis=1)
         data[f"a{step}"] = a.astype(np.int64)
         data[f"r{step}"] = (a + rng.integers(1, 3, size=a.shape)).astype(np.int64)
     np.savez(tmp_path / "data.npz", **data)
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
     _launch(str(script), [ROOT, str(tmp_path / "data.npz"), str(tmp_path / "out.npz")],
-            {"CLX_GRAD_BUCKET_MB": bucket_mb})
+            {"CLX_GRAD_BUCKET_MB": bucket_mb}, nproc=world)
     got = np.load(tmp_path / "out.npz")
+    assert got["nbuckets"] == 1 if bucket_mb != "0.002" else got["nbuckets"] > 4
 
-    # single process, global batch 4, same initial weights (rank 0's seed)
+    # single process at the global batch, same initial weights (rank 0's seed)
     cfg = dict(in_channels=1, out_channels=2, num_fmaps=8, fmap_inc_factor=3, features_in_last_layer=16,
                downsampling_factors=[[2, 2]], num_spatial_dims=2)
     torch.manual_seed(100)
@@ -106,6 +121,25 @@ def test_two_ranks_equal_one_process_at_global_batch(tmp_path, device, bucket_mb
     # the loss is a SUM over pairs: the all-reduced loss equals the global-batch loss
     np.testing.assert_allclose(got["losses"], losses, rtol=1e-5)
     np.testing.assert_allclose(got["flat"], model._flat.cpu().numpy(), atol=2e-5)
+
+
+def test_bench_starts_eight_ranks(tmp_path):
+    """`python bench.py --gpus 8` as the driver's scaling run issues it (no rank environment): eight
+    fresh children, one JSON line from rank 0 with what the backend saw and what went over the wire."""
+    env = dict(os.environ, CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--workload", "tiny"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["ranks_seen"] == 8 and len(rec["per_rank_ms_per_step"]) == 8
+    assert rec["config"]["global_batch"] == 16 and rec["config"]["parallelism"] == "dp8" and rec["scaling"] == "weak"
+    # the gradient exchange: the whole flat f32 gradient (+ the four float64 loss sums), as buckets
+    assert sum(rec["allreduce_bucket_bytes"]) + 32 == rec["allreduce_bytes"] and rec["allreduce_bytes"] > 4 * 100000
+    assert rec["loader_procs"] == 0 and rec["host_cores_per_rank"] >= 1
 
 
 def test_bench_multi_rank_control_flow(tmp_path):
@@ -222,8 +256,8 @@ infer(cfg)
 """
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
-def test_two_rank_inference_shards_samples_and_writes_one_dataset(tmp_path, device, fused):
+@pytest.mark.parametrize("fused,nproc", [("1", 2), ("0", 2), ("1", 8), ("0", 8)])
+def test_multi_rank_inference_shards_samples_and_writes_one_dataset(tmp_path, device, fused, nproc):
     """infer() under two ranks (samples sharded, no collective on the data path; ADVICE r1: every rank
     used to create — i.e. replace — the prediction dataset): rank 0 creates each dataset once, both
     ranks fill their samples, nothing a faster rank wrote is lost.  The post-processing of each
@@ -234,7 +268,7 @@ def test_two_rank_inference_shards_samples_and_writes_one_dataset(tmp_path, devi
 
     container = str(tmp_path / "data.zarr")
     rng = np.random.default_rng(0)
-    raw = rng.random((5, 1, 72, 80)).astype(np.float32)          # 5 samples: ranks get 3 + 2
+    raw = rng.random((5, 1, 72, 80)).astype(np.float32)   # 5 samples: 3 + 2 on two ranks; of eight, three get none
     f = zarr_io.open(container)
     f["test/raw"] = raw
     f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
@@ -280,7 +314,8 @@ secondary_dataset_name = "detection"
     script.write_text(_INFER_SCRIPT)
     # fused = "1": predict -> detect -> segment per sample in device memory on each rank's samples;
     # "0": the reference's dataset-by-dataset order (three sharded passes over the zarr container)
-    _launch(str(script), [ROOT, str(tmp_path), str(tmp_path / "infer.toml")], {"CLX_FUSED_INFER": fused})
+    _launch(str(script), [ROOT, str(tmp_path), str(tmp_path / "infer.toml")], {"CLX_FUSED_INFER": fused},
+            nproc=nproc)
     g = zarr_io.open(container, "r")
     emb, det, seg = g["embeddings"][...], g["detection"][...], g["segmentation"][...]
     assert emb.shape == (5, 3, 72, 80) and det.shape == seg.shape == (5, 1, 72, 80)
