@@ -92,6 +92,8 @@ PROTOTYPES = {
     "clx_profile_read": (_I, [_I, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "clx_conv_fwd": (_I, [POINTER(ClxConvDesc), _P]),
     "clx_conv_wgrad": (_I, [POINTER(ClxConvDesc), _P, _I, _P, _P, _P]),
+    "clx_chain64_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
+    "clx_chain64_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "clx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

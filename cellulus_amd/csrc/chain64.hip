@@ -1,0 +1,420 @@
+// Two consecutive 1x1 convolutions over 64 channels in ONE pass over the pixels (gfx950).
+//
+// The U-Net of the reference (funlib ConvPass as called from cellulus/models/unet.py:24-51)
+// follows every 3x3 convolution by two 1x1 convolutions + ReLU, and the head is two more
+// (unet.py:52-63).  Where those layers are 64 channels wide — the whole 3-D benchmark network's
+// top level, the last level and the head of the 2-D one — each of them is HBM-bound as a launch
+// of its own (K = 64: 0.3 of the matrix pipe, 3.5 TB/s): the intermediate tensor is written by
+// one launch and read back by the next, and in the backward pass it is read FOUR times (two data
+// gradients, two weight gradients) and its gradient written and read once more.
+//
+//   forward   y1 = relu(x W1^T + b1),  y2 = [relu](y1 W2^T + b2)        read x, write y1, y2
+//   backward  dP1 = (dP2 W2) * (y1 > 0),  dP0 = (dP1 W1) * (x > 0)      read dP2, y1, x; write dP0
+//             dW2 += dP2^T y1, db2 += sum dP2, dW1 += dP1^T x, db1 += sum dP1
+//             (dP1 never exists in HBM)
+//
+// Formulation: every product is computed TRANSPOSED, Y^T = W X^T, with the weights as the MFMA's
+// A operand (LDS-resident for the whole kernel, fragment order, one ds_read_b128 per four
+// v_mfma_f32_32x32x2_f32) and the activations as its B operand straight from the registers the
+// global loads filled: lane (pixel i, half h) holds channels {8q + 4h + j} of its pixel, which is
+// (a) 16-byte runs of a pixel-major row in HBM, (b) the k order the A fragments are stored in and
+// (c) exactly the accumulator layout of the transposed product (row n = 8g + 4h + j of lane
+// (i, h), register 4g + j) — so layer 1's result, after bias + ReLU in registers, IS layer 2's B
+// operand: no LDS round trip, no barrier, no transpose between the layers.  Only the weight
+// gradients (contraction over pixels) need the tile in LDS: a block's four waves stage their 32
+// pixels each, and each wave accumulates one 32x32 quarter of dW over all 128.
+#include "clx_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int LDW = 68;                 // floats per staged pixel row: 64 + 4 (ds_write_b128 of 8 lanes: 8 x 4 banks apart)
+
+// [rows][k] row-major matrix (k contiguous, leading dimension ld) -> LDS in A-fragment order:
+// the float4 (row 32 rt + i, k = 8q + 4h .. + 3) goes to slot ((rt * 8 + q) * 64 + h * 32 + i);
+// rows >= nrows and k >= ncols are zero.  rt < RT.
+template <int RT>
+__device__ __forceinline__ void load_matrix(float* lds, const float* __restrict__ w, int nrows, int ncols, int ld) {
+  for (int idx = threadIdx.x; idx < RT * 512; idx += blockDim.x) {
+    const int row = idx >> 4, c4 = idx & 15;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nrows && 4 * c4 < ncols) v = *reinterpret_cast<const f32x4*>(w + (size_t)row * ld + 4 * c4);
+    const int rt = row >> 5, i = row & 31, q = c4 >> 1, h = c4 & 1;
+    *reinterpret_cast<f32x4*>(lds + ((((rt * 8 + q) * 64) + h * 32 + i) << 2)) = v;
+  }
+}
+
+struct ChainFwdP {
+  const float* x; int ld_x; int M;
+  const float* w1; const float* b1; float* y1; int ld_y1; unsigned int* gate1; int ld_gate1;
+  const float* w2; const float* b2; int N2; int relu2; float* y2; int ld_y2; unsigned int* gate2; int ld_gate2;
+  int ntiles;
+};
+
+// NT2: 32-row tiles of layer 2's output channels — 2 (64 channels) or 1 (N2 <= 32, the head's last layer)
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) {
+  __shared__ __attribute__((aligned(16))) float W1s[2 * 2048];
+  __shared__ __attribute__((aligned(16))) float W2s[NT2 * 2048];
+  __shared__ __attribute__((aligned(16))) float B1s[64];
+  __shared__ __attribute__((aligned(16))) float B2s[64];
+  load_matrix<2>(W1s, p.w1, 64, 64, 64);
+  load_matrix<NT2>(W2s, p.w2, p.N2, 64, 64);
+  if (threadIdx.x < 64) {
+    B1s[threadIdx.x] = p.b1 ? p.b1[threadIdx.x] : 0.f;
+    B2s[threadIdx.x] = (p.b2 && (int)threadIdx.x < p.N2) ? p.b2[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int n2p = (p.N2 + 3) & ~3;
+  const int stride = gridDim.x * 4;
+  // the rows of tile t for this lane, clamped into the tensor (loads are unconditional, stores predicated)
+  auto load_rows = [&](int tile, f32x4* dst) {
+    int row = tile * 32 + i;
+    row = row < p.M ? row : p.M - 1;
+    const float* xr = p.x + (size_t)row * p.ld_x + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xr + 8 * q);
+  };
+  f32x4 xb[8], xn[8];
+  int tile = blockIdx.x * 4 + wid;
+  if (tile < p.ntiles) load_rows(tile, xb);
+  for (; tile < p.ntiles; tile += stride) {
+    // the weights stay in LDS (a hoisted copy would be 128 VGPRs): nothing moves across this point
+    asm volatile("" ::: "memory");
+    load_rows(tile + stride < p.ntiles ? tile + stride : tile, xn);      // next tile's rows, in flight during this one
+    const int row = tile * 32 + i;
+    const bool ok = row < p.M;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W1s + (((t * 8 + q) * 64 + lane) << 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], xb[q][j], acc[t], 0, 0, 0);
+      }
+    // ---- layer 1 epilogue: bias + ReLU in registers; y[4t + g][j] = channel 32t + 8g + 4h + j
+    f32x4 y[8];
+    unsigned int bits[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(B1s + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = fmaxf(acc[t][4 * g + j] + b[j], 0.f);
+          y[4 * t + g][j] = v;
+          bits[t] |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + j);
+        }
+      }
+    if (p.y1 != nullptr && ok) {
+      float* yr = p.y1 + (size_t)row * p.ld_y1 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(yr + 8 * q) = y[q];
+    }
+    if (p.gate1 != nullptr) {
+      const unsigned int w0 = bits[0] | (unsigned int)__shfl_xor((int)bits[0], 32, 64);
+      const unsigned int w1 = bits[1] | (unsigned int)__shfl_xor((int)bits[1], 32, 64);
+      if (ok) p.gate1[(size_t)row * p.ld_gate1 + h] = h ? w1 : w0;
+    }
+    // ---- layer 2: its B operand is y as it stands
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int t = 0; t < NT2; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W2s + (((t * 8 + q) * 64 + lane) << 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], y[q][j], acc2[t], 0, 0, 0);
+      }
+    unsigned int bits2[NT2];
+#pragma unroll
+    for (int t = 0; t < NT2; ++t) {
+      bits2[t] = 0u;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = 32 * t + 8 * g + 4 * h;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(B2s + c0);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float u = acc2[t][4 * g + j] + b[j];
+          if (p.relu2) u = fmaxf(u, 0.f);
+          v[j] = u;
+          bits2[t] |= (u > 0.f ? 1u : 0u) << (8 * g + 4 * h + j);
+        }
+        if (ok && c0 < n2p) *reinterpret_cast<f32x4*>(p.y2 + (size_t)row * p.ld_y2 + c0) = v;
+      }
+    }
+    if (p.gate2 != nullptr) {
+      if constexpr (NT2 == 2) {
+        const unsigned int w0 = bits2[0] | (unsigned int)__shfl_xor((int)bits2[0], 32, 64);
+        const unsigned int w1 = bits2[1] | (unsigned int)__shfl_xor((int)bits2[1], 32, 64);
+        if (ok) p.gate2[(size_t)row * p.ld_gate2 + h] = h ? w1 : w0;
+      } else {
+        const unsigned int w0 = bits2[0] | (unsigned int)__shfl_xor((int)bits2[0], 32, 64);
+        if (ok && h == 0) p.gate2[(size_t)row * p.ld_gate2] = w0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xb[q] = xn[q];
+  }
+}
+
+struct ChainBwdP {
+  const float* dp2; int ld_dp2; int N2;
+  const float* y1; int ld_y1;
+  const float* x; int ld_x; int gate_x;
+  int M;
+  const float* w2t; const float* w1t;
+  float* dp0; int ld_dp0;
+  float* dw2; float* db2; float* dw1; float* db1;
+  int ntiles;          // tiles of 128 pixels
+};
+
+// KQ2: k-steps of 8 over layer 2's output channels — 8 (64 channels) or 1 (N2 <= 8, the head's last layer)
+// One block per CU (the two staged tiles + both weight matrices are 100 KB of LDS): the next tile's rows are
+// loaded into a second register set while the current tile computes, which is what a second block would give.
+template <int KQ2>
+__global__ __launch_bounds__(256, 1) void chain64_bwd_kernel(const ChainBwdP p) {
+  __shared__ __attribute__((aligned(16))) float W2Ts[2 * 2048];
+  __shared__ __attribute__((aligned(16))) float W1Ts[2 * 2048];
+  __shared__ __attribute__((aligned(16))) float bufA[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float bufB[128 * LDW];
+  const int n2p = (p.N2 + 3) & ~3;
+  load_matrix<2>(W2Ts, p.w2t, 64, n2p, n2p);
+  load_matrix<2>(W1Ts, p.w1t, 64, 64, 64);
+  __syncthreads();
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int nt = wid >> 1, ct = wid & 1;          // this wave's 32x32 quarter of dW (rows n, columns c)
+  const bool w2_rows = 32 * nt < n2p;             // does the quarter hold rows of dW2 at all?
+  const int bch = tid & 63;                       // bias sums: channel bch over this wave's 32 staged rows
+  f32x16 accW2, accW1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { accW2[r] = 0.f; accW1[r] = 0.f; }
+  float bsum2 = 0.f, bsum1 = 0.f;
+  const int srow = wid * 32 + i;                  // this lane's staged row
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_rows = [&](int tile, f32x4* g2d, f32x4* yd, f32x4* xd) {
+    int row = tile * 128 + srow;
+    row = row < p.M ? row : p.M - 1;
+#pragma unroll
+    for (int q = 0; q < KQ2; ++q) {
+      const int c0 = 8 * q + 4 * h;
+      g2d[q] = *reinterpret_cast<const f32x4*>(p.dp2 + (size_t)row * p.ld_dp2 + (c0 < n2p ? c0 : 0));
+    }
+    const float* yr = p.y1 + (size_t)row * p.ld_y1 + 4 * h;
+    const float* xr = p.x + (size_t)row * p.ld_x + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      yd[q] = *reinterpret_cast<const f32x4*>(yr + 8 * q);
+      xd[q] = *reinterpret_cast<const f32x4*>(xr + 8 * q);
+    }
+  };
+  f32x4 g2[KQ2], yv[8], xv[8], g2n[KQ2], yn[8], xn[8];
+  int tile = blockIdx.x;
+  if (tile < p.ntiles) load_rows(tile, g2, yv, xv);
+  for (; tile < p.ntiles; tile += gridDim.x) {
+    load_rows(tile + (int)gridDim.x < p.ntiles ? tile + (int)gridDim.x : tile, g2n, yn, xn);
+    const int row = tile * 128 + srow;
+    const bool ok = row < p.M;
+    // rows beyond the tensor (clamped loads) and channels beyond N2 contribute nothing
+#pragma unroll
+    for (int q = 0; q < KQ2; ++q)
+      if (!(ok && 8 * q + 4 * h < n2p)) g2[q] = zero4;
+    if (!ok) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { yv[q] = zero4; xv[q] = zero4; }
+    }
+    // ---- stage A: dP2 and y1 rows into LDS (the previous tile's phase-B reads ended at the loop-end barrier)
+#pragma unroll
+    for (int q = 0; q < KQ2; ++q) *reinterpret_cast<f32x4*>(bufA + srow * LDW + 8 * q + 4 * h) = g2[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(bufB + srow * LDW + 8 * q + 4 * h) = yv[q];
+    // ---- data gradient through layer 2: dP1^T = W2^T dP2^T, gated by y1 > 0
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < KQ2; ++q)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(W2Ts + (((t * 8 + q) * 64 + lane) << 2));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], g2[q][j], acc[t], 0, 0, 0);
+      }
+    f32x4 g1[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g1[4 * t + g][j] = yv[4 * t + g][j] > 0.f ? acc[t][4 * g + j] : 0.f;
+    __syncthreads();
+    // ---- weight gradient of layer 2: dW2[n][c] += sum_p dP2[p][n] y1[p][c], one 32x32 quarter per wave
+    if (w2_rows) {
+      const float* ap = bufA + h * LDW + 32 * nt + i;
+      const float* bp = bufB + h * LDW + 32 * ct + i;
+#pragma unroll 8
+      for (int s = 0; s < 64; ++s)
+        accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * LDW], bp[2 * s * LDW], accW2, 0, 0, 0);
+    }
+    if (p.db2 != nullptr && bch < n2p) {
+      const float* cp = bufA + wid * 32 * LDW + bch;
+      float s2 = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s2 += cp[r * LDW];
+      bsum2 += s2;
+    }
+    // ---- data gradient through layer 1: dP0^T = W1^T dP1^T, gated by x > 0 (x is the previous layer's ReLU output)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    if (p.dp0 != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(W1Ts + (((t * 8 + q) * 64 + lane) << 2));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], g1[q][j], acc[t], 0, 0, 0);
+        }
+      if (ok) {
+        float* orow = p.dp0 + (size_t)row * p.ld_dp0 + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              v[j] = (!p.gate_x || xv[4 * t + g][j] > 0.f) ? acc[t][4 * g + j] : 0.f;
+            *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g) = v;
+          }
+      }
+    }
+    __syncthreads();                               // phase-A reads done
+    // ---- stage B: dP1 and x rows
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      *reinterpret_cast<f32x4*>(bufA + srow * LDW + 8 * q + 4 * h) = g1[q];
+      *reinterpret_cast<f32x4*>(bufB + srow * LDW + 8 * q + 4 * h) = xv[q];
+    }
+    __syncthreads();
+    {
+      const float* ap = bufA + h * LDW + 32 * nt + i;
+      const float* bp = bufB + h * LDW + 32 * ct + i;
+#pragma unroll 8
+      for (int s = 0; s < 64; ++s)
+        accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * LDW], bp[2 * s * LDW], accW1, 0, 0, 0);
+    }
+    if (p.db1 != nullptr) {
+      const float* cp = bufA + wid * 32 * LDW + bch;
+      float s1 = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s1 += cp[r * LDW];
+      bsum1 += s1;
+    }
+    __syncthreads();                               // before the next tile's stage A
+#pragma unroll
+    for (int q = 0; q < KQ2; ++q) g2[q] = g2n[q];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { yv[q] = yn[q]; xv[q] = xn[q]; }
+  }
+
+  // ---- flush: one atomic per weight-gradient element and block
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int c = 32 * ct + i;
+    if (n < n2p) atomicAdd(p.dw2 + (size_t)n * 64 + c, accW2[r]);
+    atomicAdd(p.dw1 + (size_t)n * 64 + c, accW1[r]);
+  }
+  if (p.db2 != nullptr && bch < p.N2) atomicAdd(p.db2 + bch, bsum2);
+  if (p.db1 != nullptr) atomicAdd(p.db1 + bch, bsum1);
+}
+
+int chain_grid(const void* fn, int work_items) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  int g = cus * per_cu;
+  if (g > work_items) g = work_items;
+  return g < 1 ? 1 : g;
+}
+
+}  // namespace
+
+extern "C" int clx_chain64_fwd(const float* x, int ld_x, long long M, const float* w1, const float* b1, float* y1,
+                               int ld_y1, unsigned int* gate1, int ld_gate1, const float* w2, const float* b2,
+                               int N2, int relu2, float* y2, int ld_y2, unsigned int* gate2, int ld_gate2,
+                               clx_stream stream) {
+  CLX_REQUIRE(x && w1 && w2 && y2, "clx_chain64_fwd: null pointer");
+  CLX_REQUIRE(M > 0 && M < (1ll << 31) - 256, "clx_chain64_fwd: bad pixel count %lld", M);
+  CLX_REQUIRE(N2 >= 1 && N2 <= 64 && (N2 == 64 || N2 <= 32), "clx_chain64_fwd: N2 must be 64 or <= 32 (got %d)", N2);
+  const int n2p = (N2 + 3) & ~3;
+  CLX_REQUIRE(ld_x >= 64 && ld_x % 4 == 0 && ld_y2 >= n2p && ld_y2 % 4 == 0 && (y1 == nullptr || (ld_y1 >= 64 && ld_y1 % 4 == 0)),
+              "clx_chain64_fwd: leading dimensions must be multiples of 4 and cover the channels");
+  CLX_REQUIRE((((uintptr_t)x | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)y1 | (uintptr_t)y2) & 15) == 0,
+              "clx_chain64_fwd: pointers must be 16-byte aligned");
+  CLX_REQUIRE(gate1 == nullptr || ld_gate1 >= 2, "clx_chain64_fwd: gate1 needs two words per pixel");
+  CLX_REQUIRE(gate2 == nullptr || (relu2 && ld_gate2 >= (n2p + 31) / 32), "clx_chain64_fwd: gate2 needs relu2 and whole words");
+  ChainFwdP p{x, ld_x, (int)M, w1, b1, y1, ld_y1, gate1, ld_gate1, w2, b2, N2, relu2, y2, ld_y2, gate2, ld_gate2,
+              (int)((M + 31) / 32)};
+  hipStream_t st = (hipStream_t)stream;
+  if (N2 == 64) {
+    const int g = chain_grid((const void*)chain64_fwd_kernel<2>, (p.ntiles + 3) / 4);
+    chain64_fwd_kernel<2><<<g, 256, 0, st>>>(p);
+  } else {
+    const int g = chain_grid((const void*)chain64_fwd_kernel<1>, (p.ntiles + 3) / 4);
+    chain64_fwd_kernel<1><<<g, 256, 0, st>>>(p);
+  }
+  CLX_CHECK_LAUNCH("clx_chain64_fwd");
+  return CLX_OK;
+}
+
+extern "C" int clx_chain64_bwd(const float* dp2, int ld_dp2, int N2, const float* y1, int ld_y1, const float* x,
+                               int ld_x, int gate_x, long long M, const float* w2t, const float* w1t, float* dp0,
+                               int ld_dp0, float* dw2, float* db2, float* dw1, float* db1, clx_stream stream) {
+  CLX_REQUIRE(dp2 && y1 && x && w2t && w1t && dw2 && dw1, "clx_chain64_bwd: null pointer");
+  CLX_REQUIRE(M > 0 && M < (1ll << 31) - 256, "clx_chain64_bwd: bad pixel count %lld", M);
+  CLX_REQUIRE(N2 == 64 || (N2 >= 1 && N2 <= 8), "clx_chain64_bwd: N2 must be 64 or <= 8 (got %d)", N2);
+  const int n2p = (N2 + 3) & ~3;
+  CLX_REQUIRE(ld_dp2 >= n2p && ld_dp2 % 4 == 0 && ld_y1 >= 64 && ld_y1 % 4 == 0 && ld_x >= 64 && ld_x % 4 == 0 &&
+                  (dp0 == nullptr || (ld_dp0 >= 64 && ld_dp0 % 4 == 0)),
+              "clx_chain64_bwd: leading dimensions must be multiples of 4 and cover the channels");
+  CLX_REQUIRE((((uintptr_t)dp2 | (uintptr_t)y1 | (uintptr_t)x | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)dp0) & 15) == 0,
+              "clx_chain64_bwd: pointers must be 16-byte aligned");
+  ChainBwdP p{dp2, ld_dp2, N2, y1, ld_y1, x, ld_x, gate_x, (int)M, w2t, w1t, dp0, ld_dp0, dw2, db2, dw1, db1,
+              (int)((M + 127) / 128)};
+  hipStream_t st = (hipStream_t)stream;
+  if (N2 == 64) {
+    const int g = chain_grid((const void*)chain64_bwd_kernel<8>, p.ntiles);
+    chain64_bwd_kernel<8><<<g, 256, 0, st>>>(p);
+  } else {
+    const int g = chain_grid((const void*)chain64_bwd_kernel<1>, p.ntiles);
+    chain64_bwd_kernel<1><<<g, 256, 0, st>>>(p);
+  }
+  CLX_CHECK_LAUNCH("clx_chain64_bwd");
+  return CLX_OK;
+}

@@ -375,6 +375,34 @@ class UNetPlan:
         self._bwd_ready = False
         self.vcache = {}
         self._vcache_fresh = set()
+        self._find_chains()
+
+    def _find_chains(self):
+        """Pairs of consecutive 64-channel 1x1 layers (conv_pass.2 -> conv_pass.4 of a level, head.0 ->
+        head.2) that run as ONE launch each way (csrc/chain64.hip: the intermediate tensor is written once
+        and never read back, its gradient never exists in HBM).  CLX_CHAIN64=0 keeps the layer-by-layer path."""
+        t = self.topo
+        self.chains, self.chain_second = {}, {}
+        if os.environ.get("CLX_CHAIN64", "1") == "0" or self.precision != 0:
+            return
+        produced_by_conv = {layer.out: layer for layer in t.convs}
+        one = (1, 1, 1)
+        plain = lambda s: tuple(s.crop) == (0, 0, 0) and tuple(s.factor) == (1, 1, 1)       # noqa: E731
+        i = 0
+        while i + 1 < len(t.convs):
+            a, b = t.convs[i], t.convs[i + 1]
+            ok = (tuple(a.kernel) == one and tuple(b.kernel) == one and len(a.sources) == 1 and len(b.sources) == 1
+                  and plain(a.sources[0]) and plain(b.sources[0]) and b.sources[0].tensor == a.out
+                  and a.sources[0].tensor in produced_by_conv and a.sources[0].channels == 64 and a.cout == 64
+                  and a.relu and (b.cout == 64 or b.cout <= 8)
+                  and not self.algo[a.name]["fwd"] and not self.algo[b.name]["fwd"]
+                  and self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2] < (1 << 31) - 256)
+            if ok:
+                self.chains[a.name] = (a, b)
+                self.chain_second[b.name] = (a, b)
+                i += 2
+            else:
+                i += 1
 
     def _alloc_backward(self):
         t = self.topo
@@ -418,8 +446,12 @@ class UNetPlan:
         # 64-channel 1x1 layers of the 3-D network are HBM-bound).  Whole words per pixel (channels %
         # 32 == 0) and a producer that knows the bits (not the first-layer kernels); CLX_GATE_BITS=0 = off
         self.gate = {}
+        # (the fused 1x1 pairs gate by the float tensors they read anyway: no bits for their input and middle)
+        chain_gated = {a.out for a, _b in self.chains.values()} | {a.sources[0].tensor for a, _b in self.chains.values()}
         if os.environ.get("CLX_GATE_BITS", "1") != "0":
             for layer in t.convs:
+                if layer.out in chain_gated:
+                    continue
                 if layer.relu and layer.param_index > 0 and pad4(layer.cout) % 32 == 0:
                     n = self.B * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
                     self.gate[layer.out] = torch.zeros((n, pad4(layer.cout) // 32), dtype=torch.int32,
@@ -859,6 +891,39 @@ class UNetPlan:
             c0 += pad4(s.channels)
         return torch.cat(parts, dim=1)
 
+    def _chain_forward(self, a, b, params, st):
+        """y1 = relu(x w1^T + b1), y2 = act(y1 w2^T + b2) in one launch (clx_chain64_fwd)."""
+        M = self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2]
+        x = self.buf[a.sources[0].tensor]
+        y1, y2 = self.buf[a.out], self.buf[b.out]
+        g1 = g2 = None
+        if self.keep and self._bwd_ready:
+            g1 = self.gate.get(a.out)
+            g2 = self.gate.get(b.out) if b.relu else None
+        b1, b2 = params[2 * a.param_index + 1], params[2 * b.param_index + 1]
+        _clx.call("clx_chain64_fwd", _clx.ptr(x), x.shape[1], M, _clx.ptr(self.wpack_fwd[a.name]), _clx.ptr(b1),
+                  _clx.ptr(y1) if self.keep else None, y1.shape[1], _clx.ptr(g1), g1.shape[1] if g1 is not None else 0,
+                  _clx.ptr(self.wpack_fwd[b.name]), _clx.ptr(b2), b.cout, 1 if b.relu else 0, _clx.ptr(y2),
+                  y2.shape[1], _clx.ptr(g2), g2.shape[1] if g2 is not None else 0, st)
+
+    def _chain_backward(self, a, b, prev, grads, st):
+        """Both data gradients, both weight gradients and both bias gradients of the pair in one launch
+        (clx_chain64_bwd); the gradient w.r.t. the middle tensor is never written."""
+        M = self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2]
+        dp2 = self.gbuf[b.out]
+        x, y1 = self.buf[a.sources[0].tensor], self.buf[a.out]
+        dp0 = self.gbuf[prev.out]
+        n2p = pad4(b.cout)
+        dw2 = self.dwpack[self.dw_off[b.name]:self.dw_off[b.name] + n2p * 64]
+        dw1 = self.dwpack[self.dw_off[a.name]:self.dw_off[a.name] + 64 * 64]
+        _clx.call("clx_chain64_bwd", _clx.ptr(dp2), dp2.shape[1], b.cout, _clx.ptr(y1), y1.shape[1], _clx.ptr(x),
+                  x.shape[1], 1 if prev.relu else 0, M, _clx.ptr(self.wpack_dgrad[b.name]),
+                  _clx.ptr(self.wpack_dgrad[a.name]), _clx.ptr(dp0), dp0.shape[1], _clx.ptr(dw2),
+                  _clx.ptr(grads[2 * b.param_index + 1]), _clx.ptr(dw1), _clx.ptr(grads[2 * a.param_index + 1]), st)
+        for layer, dwp in ((b, dw2), (a, dw1)):
+            _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(grads[2 * layer.param_index]), layer.cout, layer.cin,
+                      1, pad4(layer.cout), layer.cin_pad, st)
+
     def pack_weights(self, params, version, need_dgrad):
         """(Re)pack weights when the parameters changed (version = tuple of tensor versions)."""
         if need_dgrad and not self._bwd_ready:
@@ -898,7 +963,11 @@ class UNetPlan:
         _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
                   t.in_channels, npix_in, pad4(t.in_channels), st)
         for op in t.fwd_order:
-            if isinstance(op, ConvLayer) and op.name in self.subpixel:
+            if isinstance(op, ConvLayer) and op.name in self.chain_second:
+                continue                                    # computed with its predecessor
+            if isinstance(op, ConvLayer) and op.name in self.chains:
+                self._chain_forward(*self.chains[op.name], params, st)
+            elif isinstance(op, ConvLayer) and op.name in self.subpixel:
                 self._sp_forward(op, self.subpixel[op.name], params[2 * op.param_index + 1], st)
             elif isinstance(op, ConvLayer):
                 d = self._desc(op)
@@ -964,6 +1033,15 @@ class UNetPlan:
                 continue  # handled when its consumer's data gradient is produced
             layer = op
             dy = self.gbuf[layer.out]
+            if layer.name in self.chains:
+                continue                                    # done with its successor
+            if layer.name in self.chain_second:
+                a, b = self.chain_second[layer.name]
+                self._chain_backward(a, b, by_out[a.sources[0].tensor], grads, st)
+                if on_layer_done is not None:
+                    on_layer_done(b.param_index)
+                    on_layer_done(a.param_index)
+                continue
             if layer.name in self.subpixel:
                 sp = self.subpixel[layer.name]
                 dskip = self._sp_backward(layer, sp, dy, grads[2 * layer.param_index],

@@ -164,6 +164,30 @@ size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass);
  * (PD = K-1, weights packed with CLX_PACK_DGRAD). */
 int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream);
 
+/* Two consecutive 1x1 convolutions over 64 channels in one pass over the pixels — the
+ * `conv_pass.2 -> conv_pass.4` pair of every funlib ConvPass the reference builds
+ * (cellulus/models/unet.py:24-51: kernel sizes [3, 1, 1, 3]) and the head
+ * `head.0 -> head.2` (unet.py:52-63), where the level is 64 channels wide (HBM-bound layers):
+ *   y1 = relu(x w1^T + b1)           [M][ld_y1]  (y1 may be NULL: inference keeps nothing)
+ *   y2 = act(y1 w2^T + b2)           [M][ld_y2], N2 = 64 or <= 32 channels, act = ReLU if relu2
+ * w1 / w2: forward packs of clx_pack_weights (CLX_PACK_FWD, one tap): [64][64] and [pad4(N2)][64].
+ * gate1 / gate2: optional ReLU gates as bits (layout of clx_conv_desc.gate_out).
+ * Same arithmetic as two clx_conv_fwd calls (f32 MFMA, f32 accumulation over the 64 channels). */
+int clx_chain64_fwd(const float* x, int ld_x, long long M, const float* w1, const float* b1, float* y1,
+                    int ld_y1, unsigned int* gate1, int ld_gate1, const float* w2, const float* b2, int N2,
+                    int relu2, float* y2, int ld_y2, unsigned int* gate2, int ld_gate2, clx_stream stream);
+/* Backward of that pair in one pass (autograd of the two convolutions in cellulus/train.py:178):
+ *   dP1 = (dp2 w2) * (y1 > 0)   — never written —   dp0 = (dP1 w1) * (x > 0 if gate_x)
+ *   dw2[n][c] += sum_p dp2[p][n] y1[p][c],  db2[n] += sum_p dp2[p][n]      ([pad4(N2)][64], [N2])
+ *   dw1[n][c] += sum_p dP1[p][n] x[p][c],   db1[n] += sum_p dP1[p][n]      ([64][64], [64])
+ * dp2: gradient w.r.t. layer 2's PRE-activation, [M][ld_dp2], N2 = 64 or <= 8 channels;
+ * w2t / w1t: data-gradient packs (CLX_PACK_DGRAD, one tap): [64][pad4(N2)] and [64][64];
+ * dw*: the dwpack layout of clx_conv_wgrad (one tap), accumulated with float atomics;
+ * dp0 may be NULL (no data gradient wanted), db* may be NULL. */
+int clx_chain64_bwd(const float* dp2, int ld_dp2, int N2, const float* y1, int ld_y1, const float* x,
+                    int ld_x, int gate_x, long long M, const float* w2t, const float* w1t, float* dp0,
+                    int ld_dp0, float* dw2, float* db2, float* dw1, float* db1, clx_stream stream);
+
 /* Weight gradient of the convolution described by `d` (d->out/bias/relu/mask/
  * wpack ignored): dwpack[tap][n][c] += sum_p dy[p][n] * in[p (+) tap][c],
  * dbias[n] += sum_p dy[p][n]  (dbias may be NULL).  Both outputs are

@@ -46,6 +46,14 @@ CONFIGS = {
     "3d_four_to_32": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=4, fmap_inc_factor=8,
                                    features_in_last_layer=32, downsampling_factors=[[2, 2, 2]],
                                    num_spatial_dims=3), spatial=(20, 20, 24), batch=1),
+    # 64 channels at the top level and in the head: the fused 1x1 pairs (csrc/chain64.hip) on every
+    # conv_pass.2 -> conv_pass.4 of level 0, of the right path, and on head.0 -> head.2
+    "2d_chain64": dict(cfg=dict(in_channels=1, out_channels=2, num_fmaps=64, fmap_inc_factor=2,
+                                features_in_last_layer=64, downsampling_factors=[[2, 2]],
+                                num_spatial_dims=2), spatial=(44, 52), batch=3),
+    "3d_chain64": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=64, fmap_inc_factor=2,
+                                features_in_last_layer=64, downsampling_factors=[[2, 2, 2]],
+                                num_spatial_dims=3), spatial=(24, 20, 20), batch=1),
     "3d_small": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=8, fmap_inc_factor=2,
                               features_in_last_layer=16, downsampling_factors=[[2, 2, 2]],
                               num_spatial_dims=3), spatial=(28, 24, 32), batch=2),
@@ -97,6 +105,34 @@ def test_backward_matches_oracle(name, device):
         l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-12)).item()
         assert err < 1e-3, f"{name}: grad of {n}: max rel err {err} (scale {scale})"
         assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
+
+
+@pytest.mark.parametrize("name", ["2d_chain64", "3d_chain64"])
+def test_fused_1x1_pairs_are_used_and_equal_the_layer_by_layer_path(name, device, monkeypatch):
+    """The plan fuses three pairs at these widths; CLX_CHAIN64=0 runs the same layers one by one — same
+    outputs and gradients to rounding (the two paths differ in summation order only), in training and in
+    inference (where the pair keeps nothing of its first layer)."""
+    oracle, model, raw = _make(name, device, seed=4)
+    x = raw.to(device)
+    got = model(x)
+    plan = next(iter(model._plans.values()))
+    assert sorted(plan.chains) == ["backbone.l_conv.0.conv_pass.2", "backbone.r_conv.0.0.conv_pass.2", "head.0"]
+    torch.manual_seed(9)
+    dout = torch.randn_like(got)
+    got.backward(dout)
+    grads = [p.grad.clone() for p in model.parameters()]
+    with torch.no_grad():
+        inf = model(x).clone()
+    assert torch.allclose(inf, got.detach(), atol=1e-6)
+    monkeypatch.setenv("CLX_CHAIN64", "0")
+    _o, plain, _r = _make(name, device, seed=4)
+    ref = plain(x)
+    assert not next(iter(plain._plans.values())).chains
+    ref.backward(dout)
+    assert (ref - got).abs().max().item() < 1e-5
+    for (n, p), g in zip(plain.named_parameters(), grads):
+        l2 = ((p.grad - g).norm() / (p.grad.norm() + 1e-30)).item()
+        assert l2 < 1e-5, (n, l2)
 
 
 def test_forward_is_deterministic_and_repacks_after_weight_change(device):
