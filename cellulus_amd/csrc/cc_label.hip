@@ -356,6 +356,244 @@ __global__ void cc_write(const int* __restrict__ seg, const int* __restrict__ L,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2-D path, round 3: four byte-moving passes instead of nine.  The union-find parent array IS the
+// output image (entries = parent index + 1, background 0 — so background pixels are written once
+// and never touched again), and everything between the strip pass and the final rewrite works on
+// the (few thousand) strip-local LABELS instead of on pixels:
+//   1. cc_strip1   seg -> out (label + 1 | 0); every run adds its length to its provisional label's
+//                  size; the labels a row creates are recorded as one 64-bit mask per (row, segment)
+//   2. cc_link1    unions across strip / segment borders
+//   3. cc_fold     per label: root = find(label); size[root] += size[label]; out[label] = root + 1
+//   4. cc_mark     per label: surviving roots set their bit in a pixel bitmap + count per chunk (>= 2048 pixels)
+//   5. cc_scan_counts over the (<= 8192) chunks
+//   6. cc_rank     per label: id of its root = roots before it in raster order (chunk prefix + popcounts of
+//                  the chunk's bitmap words) + 1, 0 if removed; stored in size[label]
+//   7. cc_rewrite  out[i] = out[i] ? size[out[i] - 1] : 0, in place, 16 bytes per lane, untouched quads not written
+// Bytes per pixel: 4 read + 4 written (1), 4 read + 4 written at foreground pixels only (7); passes 2-6
+// touch borders and labels (3-6: a few microseconds each).  Round 2 read or wrote every pixel nine times
+// (36 B per pixel).
+// ---------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int uf1_find(const int* L, int a) {
+  int p = L[a] - 1;
+  while (p != a) { a = p; p = L[a] - 1; }
+  return a;
+}
+__device__ __forceinline__ int uf1_find_halve(int* L, int a) {
+  int p = L[a] - 1;
+  while (p != a) {
+    const int gp = L[p] - 1;
+    if (gp != p) L[a] = gp + 1;
+    a = p;
+    p = gp;
+  }
+  return a;
+}
+__device__ __forceinline__ void uf1_union(int* L, int a, int b) {
+  bool done;
+  do {
+    a = uf1_find_halve(L, a);
+    b = uf1_find_halve(L, b);
+    if (a < b) {
+      const int old = atomicMin(&L[b], a + 1) - 1;
+      done = (old == b);
+      b = old;
+    } else if (b < a) {
+      const int old = atomicMin(&L[a], b + 1) - 1;
+      done = (old == a);
+      a = old;
+    } else {
+      done = true;
+    }
+  } while (!done);
+}
+
+// whole-wave shifts by one lane as DPP moves (no LDS crossbar trip): lane i takes lane i -/+ 1, the end lane `fill`
+__device__ __forceinline__ int wave_shr1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, int* L, int* size,
+                                                 unsigned long long* __restrict__ labelmask, int Y, int X, int nseg,
+                                                 int nstrips) {
+  __shared__ int runlab[4][64];
+  const int lane = threadIdx.x & 63;
+  int* rl = runlab[threadIdx.x >> 6];
+  constexpr int INF = 0x7fffffff;
+  const long long nwaves = (long long)nstrips * nseg;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const int strip = (int)(w / nseg), sg = (int)(w - (long long)strip * nseg);
+    const int x = sg * 64 + lane;
+    const bool in_x = x < X;
+    const int y0 = strip * STRIP_ROWS, y1 = min(y0 + STRIP_ROWS, Y);
+    int pv = 0, pl = -1;
+    for (int yb = y0; yb < y1; yb += 4) {
+      int vv[4];                                            // four rows in flight
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vv[k] = (in_x && yb + k < y1) ? seg[(long long)(yb + k) * X + x] : 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int y = yb + k;
+        if (y >= y1) break;
+        const long long i = (long long)y * X + x;
+        const int v = vv[k];
+        // runs of equal non-zero values inside the segment (background lanes: runs of their own)
+        // (every DPP move is issued with all lanes active, before any lane-dependent condition: a move under a
+        //  partial EXEC mask treats the inactive source lanes as out of range)
+        const int v_left = wave_shr1(v, 0);
+        const int pv_left = wave_shr1(pv, 0), pl_left = wave_shr1(pl, INF);
+        const int pv_right = wave_shl1(pv, 0), pl_right = wave_shl1(pl, INF);
+        const bool same_left = v != 0 && v_left == v;
+        const unsigned long long starts = __ballot(!same_left);
+        const int sl = 63 - __builtin_clzll(starts & ((2ull << lane) - 1ull));
+        // labels of the (up to three) touching pixels of the row above.  If the pixel straight above
+        // matches, its two neighbours belong to the same run; otherwise up-left and up-right are two
+        // DIFFERENT runs (the pixel between them differs), and both labels count.
+        int c0 = (v != 0 && pv_left == v) ? pl_left : INF;
+        const int c1 = (v != 0 && pv == v) ? pl : INF;
+        int c2 = (v != 0 && pv_right == v) ? pl_right : INF;
+        if (c1 != INF) c0 = c2 = INF;
+        const int cand = min(c0, min(c1, c2));
+        // the run's smallest candidate through one LDS word per run (the wave's LDS operations execute in order):
+        // the start lane resets it, touching lanes atomic-min into it, everyone reads it back
+        if (sl == lane) rl[lane] = INF;
+        if (cand != INF) atomicMin(&rl[sl], cand);
+        const int runmin = rl[sl];
+        const unsigned long long above = (lane == 63) ? 0ull : (starts >> (lane + 1));
+        const int el = above ? lane + __builtin_ctzll(above) : 63;
+        int label = -1;
+        if (v != 0) {
+          const bool fresh = runmin == INF;
+          label = fresh ? (int)(i - lane + sl) : runmin;
+          L[i] = label + 1;
+          if (sl == lane) {                                 // once per run: its length goes to its label
+            const int len = el - lane + 1;
+            if (fresh) atomicExch(&size[label], len);       // creates the label (no zero-filled array needed)
+            else atomicAdd(&size[label], len);
+          }
+        } else if (in_x) {
+          L[i] = 0;
+        }
+        // the labels this row created, one 64-bit word per (row, segment): what the label passes iterate over
+        // (a single global list would serialise its appends on one counter: 162 us of a 4096^2 image)
+        const unsigned long long created = __ballot(v != 0 && runmin == INF && sl == lane);
+        if (lane == 0) labelmask[(long long)y * nseg + sg] = created;
+        const bool j0 = c0 != INF && c0 != label, j1 = c1 != INF && c1 != label, j2 = c2 != INF && c2 != label;
+        if (j0 || j1 || j2) {
+          __threadfence();
+          if (j0) uf1_union(L, c0, label);
+          if (j1) uf1_union(L, c1, label);
+          if (j2) uf1_union(L, c2, label);
+        }
+        pv = v;
+        pl = label;
+      }
+    }
+  }
+}
+
+__global__ void cc_link1(const int* __restrict__ seg, int* L, int Y, int X, int nseg, int nstrips) {
+  const long long n_rows = (long long)(nstrips - 1) * X;
+  const long long n_cols = (long long)(nseg - 1) * Y;
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows + n_cols;
+       k += (long long)gridDim.x * blockDim.x) {
+    if (k < n_rows) {
+      const int y = (int)(k / X + 1) * STRIP_ROWS, x = (int)(k % X);
+      const long long i = (long long)y * X + x;
+      const int v = seg[i];
+      if (v == 0) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int xx = x + dx;
+        if (xx < 0 || xx >= X) continue;
+        const long long j = i - X + dx;
+        if (seg[j] == v) uf1_union(L, (int)i, (int)j);
+      }
+    } else {
+      const long long kk = k - n_rows;
+      const int x = (int)(kk / Y + 1) * 64, y = (int)(kk % Y);
+      const long long i = (long long)y * X + x;
+      const int v = seg[i];
+      if (v == 0) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= Y) continue;
+        const long long j = (long long)yy * X + x - 1;
+        if (seg[j] == v) uf1_union(L, (int)i, (int)j);
+      }
+    }
+  }
+}
+
+// the label passes: one thread per (row, segment) word of labelmask, one iteration per label in it
+#define CC_FOR_EACH_LABEL(l)                                                                        \
+  for (long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x; wd < nwords;                \
+       wd += (long long)gridDim.x * blockDim.x)                                                     \
+    for (unsigned long long m_ = labelmask[wd]; m_ != 0ull; m_ &= m_ - 1ull)                        \
+      if (const int l = (int)((wd / nseg) * X + (wd % nseg) * 64 + __builtin_ctzll(m_)); true)
+
+// (Measured and not kept: the three label passes as ONE launch with two software grid barriers —
+// 137 us instead of 3 x 5 us + gaps: every block's agent-scope fence writes back / invalidates its
+// XCD's L2; and the bitmap / counter zeroing folded into the strip pass — 67 -> 84 us for the strip
+// kernel against a 3-us fill.)
+constexpr int MAX_RANK_CHUNKS = 8192;
+
+__global__ void cc_fold(int* L, int* size, const unsigned long long* __restrict__ labelmask, long long nwords,
+                        int nseg, int X) {
+  CC_FOR_EACH_LABEL(l) {
+    const int r = uf1_find(L, l);
+    if (r != l) {
+      atomicAdd(&size[r], size[l]);     // size[l] is final (written by the strip pass only)
+      L[l] = r + 1;                     // any ancestor is a valid parent; the root is the best one
+    }
+  }
+}
+
+__global__ void cc_mark(const int* __restrict__ L, const int* __restrict__ size,
+                        const unsigned long long* __restrict__ labelmask, long long nwords, int nseg, int X,
+                        int min_size, unsigned int* bitmap, int* chunk_count, int rank_chunk) {
+  CC_FOR_EACH_LABEL(l) {
+    if (L[l] == l + 1 && size[l] >= min_size) {
+      atomicOr(&bitmap[l >> 5], 1u << (l & 31));
+      atomicAdd(&chunk_count[l / rank_chunk], 1);
+    }
+  }
+}
+
+__global__ void cc_rank(const int* __restrict__ L, int* size, const unsigned long long* __restrict__ labelmask,
+                        long long nwords, int nseg, int X, const unsigned int* __restrict__ bitmap,
+                        const int* __restrict__ chunk_prefix, int rank_chunk) {
+  CC_FOR_EACH_LABEL(l) {
+    const int r = L[l] - 1;             // cc_fold left the root here
+    int id = 0;
+    const unsigned int word = bitmap[r >> 5];
+    if ((word >> (r & 31)) & 1u) {
+      const int c = r / rank_chunk;
+      id = chunk_prefix[c] + 1 + __popc(word & ((1u << (r & 31)) - 1u));
+      for (int wd2 = (int)(((long long)c * rank_chunk) >> 5); wd2 < (r >> 5); ++wd2) id += __popc(bitmap[wd2]);
+    }
+    size[l] = id;
+  }
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void cc_rewrite(int* out, const int* __restrict__ size, long long npix) {
+  const long long nquads = npix >> 2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long long)gridDim.x * blockDim.x) {
+    i32x4 v = *reinterpret_cast<const i32x4*>(out + 4 * q);
+    if ((v[0] | v[1] | v[2] | v[3]) == 0) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] ? size[v[e] - 1] : 0;
+    *reinterpret_cast<i32x4*>(out + 4 * q) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {        // the last 1-3 pixels
+    const long long i = (nquads << 2) + threadIdx.x;
+    const int p = out[i];
+    if (p) out[i] = size[p - 1];
+  }
+}
+
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
   if (g > 8192) g = 8192;
@@ -366,8 +604,10 @@ inline int grid_for(long long total, int block) {
 }  // namespace
 
 extern "C" size_t clx_cc_workspace(long long npix) {
+  // the larger of the two layouts: [L | size | block counts] (3-D) and
+  // [size | label masks (one 64-bit word per row and 64-pixel segment, <= npix / 32 + 2 Y ints) | bitmap | chunk counts] (2-D)
   const long long nblocks = (npix + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  return (size_t)(2 * npix + nblocks + 1) * sizeof(int);
+  return (size_t)(3 * npix + npix / 32 + MAX_RANK_CHUNKS + nblocks + 64) * sizeof(int);
 }
 
 extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X, int min_size,
@@ -388,6 +628,36 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
   const long long nwaves = (long long)Z * Y * nseg;
   const int wgrid = grid_for(nwaves * 64, 256);
   static const bool strips = getenv("CLX_CC_STRIPS") == nullptr || atoi(getenv("CLX_CC_STRIPS")) != 0;
+  static const bool labels = getenv("CLX_CC_LABELS") == nullptr || atoi(getenv("CLX_CC_LABELS")) != 0;
+  if (Z == 1 && strips && labels && ((uintptr_t)out & 15) == 0) {
+    // label-list path: `out` is the parent array
+    int* sz = (int*)workspace;
+    unsigned long long* labelmask = (unsigned long long*)(sz + npix + (npix & 1));
+    const long long nmask = (long long)Y * nseg;
+    unsigned int* bitmap = (unsigned int*)(labelmask + nmask);
+    const long long nwords = (npix + 31) / 32;
+    // rank chunks: >= 2048 pixels, a multiple of 32, at most MAX_RANK_CHUNKS of them
+    long long rank_chunk = (npix + MAX_RANK_CHUNKS - 1) / MAX_RANK_CHUNKS;
+    rank_chunk = ((rank_chunk < 2048 ? 2048 : rank_chunk) + 31) / 32 * 32;
+    const int nchunks = (int)((npix + rank_chunk - 1) / rank_chunk);
+    int* chunk = (int*)(bitmap + nwords);
+    if (hipMemsetAsync(bitmap, 0, (size_t)(nwords + nchunks) * sizeof(int), st) != hipSuccess) {
+      clx_set_error("clx_cc_label_filter: memset failed");
+      return CLX_ERR_LAUNCH;
+    }
+    const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
+    cc_strip1<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, out, sz, labelmask, Y, X, nseg, nstrips);
+    const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
+    if (nb > 0) cc_link1<<<grid_for(nb, 256), 256, 0, st>>>(seg, out, Y, X, nseg, nstrips);
+    const int lgrid = grid_for(nmask, 256);
+    cc_fold<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X);
+    cc_mark<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X, min_size, bitmap, chunk, (int)rank_chunk);
+    cc_scan_counts<<<1, 1024, 0, st>>>(chunk, nchunks, ncomp_out);
+    cc_rank<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X, bitmap, chunk, (int)rank_chunk);
+    cc_rewrite<<<grid_for(npix / 4 + 1, 256), 256, 0, st>>>(out, sz, npix);
+    CLX_CHECK_LAUNCH("clx_cc_label_filter");
+    return CLX_OK;
+  }
   if (Z == 1 && strips) {
     const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
     cc_strip_kernel<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, L, size, Y, X, nseg, nstrips);
