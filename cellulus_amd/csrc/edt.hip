@@ -382,7 +382,11 @@ __global__ __launch_bounds__(256) void gs_rows_kernel(int* __restrict__ seg, con
     const u128 nonexp = ~expanded & inimg;
     const bool interior = lane >= H && lane < H + rows_per_wave && row_in;
     const unsigned long long ne_mid = (unsigned long long)(nonexp >> 32);
-    if (__any(interior && ne_mid != 0) && lane == 0) atomicOr(flag_nonexp, 1);
+    // (one flag for the whole image: raise it only while it is still down — thousands of wavefronts would
+    //  otherwise queue their atomics on one address: 71 us of a 4096^2 image)
+    if (__any(interior && ne_mid != 0) && lane == 0 &&
+        __hip_atomic_load(flag_nonexp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+      atomicOr(flag_nonexp, 1);
     // ---- cleared = non-expanded set dilated by the disc of `shrink` (middle word only)
     unsigned long long clear = 0;
     {

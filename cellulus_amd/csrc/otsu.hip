@@ -15,23 +15,13 @@ inline int grid_for(long long total, int block) {
   return (int)g;
 }
 
+// gfx950 has float64 min / max atomics in hardware (global_atomic_min_f64 / max_f64): fire-and-forget, where a
+// compare-and-swap loop made the 2048 blocks of a launch queue up on two addresses (15 of 57 us at 4096^2)
 __device__ __forceinline__ void atomic_min_f64(double* addr, double v) {
-  unsigned long long* a = (unsigned long long*)addr;
-  unsigned long long old = *a;
-  while (v < __longlong_as_double((long long)old)) {
-    const unsigned long long assumed = old;
-    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    if (old == assumed) break;
-  }
+  __builtin_amdgcn_global_atomic_fmin_f64(addr, v);
 }
 __device__ __forceinline__ void atomic_max_f64(double* addr, double v) {
-  unsigned long long* a = (unsigned long long*)addr;
-  unsigned long long old = *a;
-  while (v > __longlong_as_double((long long)old)) {
-    const unsigned long long assumed = old;
-    old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    if (old == assumed) break;
-  }
+  __builtin_amdgcn_global_atomic_fmax_f64(addr, v);
 }
 
 __global__ void minmax_init(double* mm) {
