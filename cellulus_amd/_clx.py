@@ -75,6 +75,7 @@ class ClxConvDesc(Structure):
         ("ld_gate", c_int),
         ("mask_bits", c_void_p),
         ("ld_mask_bits", c_int),
+        ("det_turns", c_void_p),
     ]
 
 
@@ -110,6 +111,11 @@ PROTOTYPES = {
     "clx_gather_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "clx_gather_add_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "clx_oce_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _LL, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P]),
+    "clx_conv_wgrad_turns_bytes": (c_size_t, [POINTER(ClxConvDesc)]),
+    "clx_colsum_scratch_bytes": (c_size_t, [_I]),
+    "clx_colsum_ordered": (_I, [_P, _I, _LL, _I, _P, _P, _P]),
+    "clx_oce_pairs_det_scratch_bytes": (c_size_t, [_I, _I, _LL]),
+    "clx_oce_pairs_fused_det": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P, _P]),
     "clx_oce_pairs_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, ctypes.c_float, ctypes.c_float, _P]),
     "clx_sample_pairs": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, POINTER(c_int), ctypes.c_ulonglong,
                               ctypes.c_ulonglong, _P]),

@@ -49,6 +49,9 @@ struct WgradP {
   // co-resident blocks — cut into `nslices_tail` >= nslices shorter slices so that the partial
   // round fills the chip and ends early instead of holding a few CUs for a whole block time
   int n_main, batch_split, nslices_tail, chunks_per_slice_tail;
+  // reproducible mode: one counter per (batch, output tile); slice s adds its partial sums when the counter
+  // reads s and then advances it — the float additions of a tile happen in slice order
+  int* turns;
 };
 
 template <int BMN, int BNC, int WAVES_M, int WAVES_N>
@@ -67,7 +70,11 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   const bool tail = (int)blockIdx.x >= p.n_main;
   const int ns = tail ? p.nslices_tail : p.nslices;
   const int cps = tail ? p.chunks_per_slice_tail : p.chunks_per_slice;
-  const int u = tail ? xcd_remap((int)blockIdx.x - p.n_main, (int)gridDim.x - p.n_main) : xcd_remap((int)blockIdx.x, p.n_main);
+  // (reproducible mode: blocks keep their dispatch order, so that the slice a block waits for — a lower block
+  //  index — is always already running; the XCD remap could put it behind the waiting block)
+  const int u = p.turns != nullptr ? (tail ? (int)blockIdx.x - p.n_main : (int)blockIdx.x)
+                : tail             ? xcd_remap((int)blockIdx.x - p.n_main, (int)gridDim.x - p.n_main)
+                                   : xcd_remap((int)blockIdx.x, p.n_main);
   const int per_batch = T * ns;
   const int batch = u / per_batch + (tail ? p.batch_split : 0);
   const int v = u % per_batch;
@@ -215,6 +222,14 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
 
   // ---- combine: float atomics into dwpack[tap][n][c]
   float* dst = p.dwp + batch * p.bs_out + (size_t)tap * p.N * p.Ctot;
+  int* my_turn = nullptr;
+  if (p.turns != nullptr) {
+    // lower slices of a tile have lower block indices: they were dispatched no later than this block
+    my_turn = p.turns + (size_t)batch * T + (v - slice * T);
+    if (tid == 0)
+      while (__hip_atomic_load(my_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != slice) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
@@ -243,6 +258,11 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
       const int n = tile_n * BMN + tid;
       if (n < p.N) atomicAdd(p.dbias + n, sum);
     }
+  }
+  if (my_turn != nullptr) {
+    __threadfence();                                   // this block's additions are performed ...
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(my_turn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... next slice
   }
 }
 
@@ -451,9 +471,17 @@ static bool wgrad_x3_applicable(const clx_conv_desc* d) {
   return d->N % 128 == 0 && S.C % 128 == 0;
 }
 
+// tiles of one batch element of the weight-gradient launch (n tiles x c tiles x taps)
+static int wgrad_tiles(const clx_conv_desc* d) {
+  auto wide = [](int n) { return n > 64 && (double)(cdiv(n, 128) * 128) / n <= 1.15; };
+  const int Ctot = d->src[0].C + (d->nsrc == 2 ? d->src[1].C : 0);
+  return cdiv(d->N, wide(d->N) ? 128 : 64) * cdiv(Ctot, wide(Ctot) ? 128 : 64) * d->KD * d->KH * d->KW;
+}
+
 int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
                      int batch, long long bs_x, long long bs_dy, long long bs_out, hipStream_t st) {
   WgradP p;
+  p.turns = d->det_turns;
   p.nsrc = d->nsrc;
   for (int s = 0; s < 2; ++s) {
     const clx_src& S = d->src[s < d->nsrc ? s : 0];
@@ -487,7 +515,11 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   p.tiles_c = cdiv(p.Ctot, bnc);
   const int T = p.tiles_n * p.tiles_c * p.taps;
   const int Tall = T * batch;
-  const bool x3 = wgrad_x3_applicable(d);
+  const bool x3 = wgrad_x3_applicable(d) && d->det_turns == nullptr;
+  if (p.turns != nullptr && hipMemsetAsync(p.turns, 0, (size_t)Tall * sizeof(int), st) != hipSuccess) {
+    clx_set_error("clx_conv_wgrad: clearing the turn counters failed");
+    return CLX_ERR_LAUNCH;
+  }
   const int BKP = x3 ? X3_BKP : big_n && big_c ? bkp<128, 128>() : 32;
   const int total_chunks = cdiv(p.M, BKP);
   // Split-K so that the grid is a whole number of "rounds" of co-resident blocks: a grid of
@@ -570,7 +602,7 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
               "clx_conv_wgrad: bad algo");
   if (d->algo != CLX_ALGO_DIRECT) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
-  if (clx_smallc_applicable(d)) {
+  if (clx_smallc_applicable(d) && d->det_turns == nullptr) {
     clx_smallc_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_wgrad(small-channel)");
     return CLX_OK;
@@ -579,4 +611,15 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_conv_wgrad");
   return CLX_OK;
+}
+
+// Winograd layers launch a^2 batched products (xi), the sub-pixel / direct layers one: an upper bound over the
+// forms clx_conv_wgrad can take for this descriptor
+extern "C" size_t clx_conv_wgrad_turns_bytes(const clx_conv_desc* d) {
+  if (d == nullptr) return 0;
+  clx_conv_desc one = *d;
+  one.KD = one.KH = one.KW = 1;
+  const size_t direct = (size_t)wgrad_tiles(d), per_xi = (size_t)wgrad_tiles(&one) * d->KD;
+  const size_t most = direct > 36 * per_xi ? direct : 36 * per_xi;
+  return (most + 64) * sizeof(int);
 }

@@ -45,7 +45,8 @@ __global__ void edt_pass_x(const unsigned char* __restrict__ in, int* __restrict
     }
     g[i] = best;
   }
-  if (__any(seen) && (threadIdx.x & 63) == 0) atomicOr(any_zero, 1);
+  if (__any(seen) && (threadIdx.x & 63) == 0 && __hip_atomic_load(any_zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    atomicOr(any_zero, 1);
 }
 
 // min over the axis with stride `stride` and extent `n` (axis index = (i / stride) % n).
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void grow_shrink_tile_kernel(int* __restrict__
   if (!__syncthreads_or(any_fg)) {
     // no foreground within reach: nothing is expanded, nothing can be cleared; every pixel of
     // the (never empty) tile is a zero of the second transform
-    if (tid == 0) atomicOr(flag_nonexp, 1);
+    if (tid == 0 && __hip_atomic_load(flag_nonexp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicOr(flag_nonexp, 1);
     return;
   }
   // ---- d1 < grow^2: x pass (rows of region 0, columns of region 1), y pass, z pass
@@ -255,7 +256,8 @@ __global__ __launch_bounds__(256) void grow_shrink_tile_kernel(int* __restrict__
                           cz >= s1 * hz && cz < s1 * hz + T::TZ;
     any |= (v && interior) ? 1 : 0;
   }
-  if (__any(any) && (tid & 63) == 0) atomicOr(flag_nonexp, 1);
+  if (__any(any) && (tid & 63) == 0 && __hip_atomic_load(flag_nonexp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+    atomicOr(flag_nonexp, 1);
   __syncthreads();
   // ---- d2 < shrink^2 on the tile
   gs_row_pass(ne, X1, pa, T::TX, Z1 * Y1, shrink, tid);

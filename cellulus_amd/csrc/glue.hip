@@ -320,3 +320,76 @@ extern "C" int clx_space_to_depth(const float* hi, int ld_hi, float* lo, int ld_
   return subpixel_launch(false, hi, lo, ld_lo, ld_hi, B, D, H, W, N, fz, fy, fx, (hipStream_t)stream,
                          "clx_space_to_depth");
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Reproducible column sums (the bias gradient of a convolution, db[n] = sum_m dY[m][n]) — the
+// fused forms accumulate it with LDS and global float atomics, whose order changes from run to run.
+// Stage 1: block b sums a contiguous range of rows (lane = 4 channels, the block's rows strided
+// over its 256 / (N/4) row groups, combined through LDS in a fixed loop) into partial[b][N];
+// stage 2: one block adds the partials in block order.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int COLSUM_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int ld, long long M, int N4,
+                                                             float* __restrict__ partial) {
+  extern __shared__ float cs_red[];                 // [groups][N4 * 4]
+  const int groups = 256 / N4 > 0 ? 256 / N4 : 1;   // row groups per block (N4 <= 256)
+  const int g = threadIdx.x / N4, c4 = threadIdx.x % N4;
+  const long long rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (g < groups)
+    for (long long r = r0 + g; r < r1; r += groups) acc += *reinterpret_cast<const f32x4*>(x + r * ld + 4 * c4);
+  if (g < groups) *reinterpret_cast<f32x4*>(cs_red + ((size_t)g * N4 + c4) * 4) = acc;
+  __syncthreads();
+  for (int n = threadIdx.x; n < N4 * 4; n += blockDim.x) {
+    float sum = 0.f;
+    for (int k = 0; k < groups; ++k) sum += cs_red[(size_t)k * N4 * 4 + n];
+    partial[(size_t)blockIdx.x * N4 * 4 + n] = sum;
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int Np, int N, float* __restrict__ out) {
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    float sum = 0.f;
+    for (int b = 0; b < nblocks; ++b) sum += partial[(size_t)b * Np + n];
+    out[n] = sum;
+  }
+}
+}  // namespace
+
+extern "C" size_t clx_colsum_scratch_bytes(int N) {
+  return (size_t)COLSUM_BLOCKS * (size_t)((N + 3) / 4 * 4) * sizeof(float);
+}
+
+extern "C" int clx_colsum_ordered(const float* x, int ld, long long M, int N, float* out, void* scratch,
+                                  clx_stream stream) {
+  CLX_REQUIRE(x && out && scratch, "clx_colsum_ordered: null pointer");
+  CLX_REQUIRE(M > 0 && N > 0, "clx_colsum_ordered: bad extents");
+  const int N4 = (N + 3) / 4;
+  CLX_REQUIRE(N4 <= 256 * 4, "clx_colsum_ordered: more than 4096 channels are not supported");
+  CLX_REQUIRE(ld % 4 == 0 && ld >= N4 * 4 && ((uintptr_t)x & 15) == 0, "clx_colsum_ordered: x must be 16-byte aligned with ld %% 4 == 0 covering pad4(N)");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)((M + 255) / 256);
+  if (blocks > COLSUM_BLOCKS) blocks = COLSUM_BLOCKS;
+  float* partial = (float*)scratch;
+  if (N4 <= 256) {
+    const int groups = 256 / N4;
+    colsum_partial_kernel<<<blocks, 256, (size_t)groups * N4 * 4 * sizeof(float), st>>>(x, ld, M, N4, partial);
+    colsum_final_kernel<<<(N + 255) / 256, 256, 0, st>>>(partial, blocks, N4 * 4, N, out);
+  } else {
+    // wide tensors: 1024 channels at a time
+    for (int c0 = 0; c0 < N4; c0 += 256) {
+      const int n4 = N4 - c0 < 256 ? N4 - c0 : 256;
+      const int groups = 256 / n4;
+      colsum_partial_kernel<<<blocks, 256, (size_t)groups * n4 * 4 * sizeof(float), st>>>(x + 4 * c0, ld, M, n4, partial);
+      const int nreal = N - 4 * c0 < n4 * 4 ? N - 4 * c0 : n4 * 4;
+      colsum_final_kernel<<<(nreal + 255) / 256, 256, 0, st>>>(partial, blocks, n4 * 4, nreal, out + 4 * c0);
+    }
+  }
+  CLX_CHECK_LAUNCH("clx_colsum_ordered");
+  return CLX_OK;
+}

@@ -6,9 +6,10 @@
 
 namespace {
 
+// (every block ends with three float64 atomics on the SAME three addresses: few, fat blocks)
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
-  if (g > 4096) g = 4096;
+  if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -164,6 +165,68 @@ __global__ __launch_bounds__(256) void oce_pairs_fused_kernel(
   }
   if (bad) atomicAdd(sums + 3, (double)bad);
   block_accumulate(oce_acc, reg_acc, sums);
+}
+
+// Reproducible form of oce_pairs_fused_kernel: the anchor gradients are scattered as 2^-40 fixed-point
+// integers (64-bit integer atomics: associative, so the order of arrival does not matter), the loss sums
+// leave each block as one partial that oce_pairs_det_finish adds in block order.
+constexpr double DET_SCALE = 1099511627776.0;        // 2^40: |g| < 2^22 per pair, millions of pairs per pixel fit
+constexpr int DET_BLOCKS = 1024;
+
+template <int ND>
+__global__ __launch_bounds__(256) void oce_pairs_det_kernel(
+    const float* __restrict__ offsets, const long long* __restrict__ anchor,
+    const long long* __restrict__ reference, unsigned long long* __restrict__ acc, double* __restrict__ partial,
+    int P, int Z, int Y, int X, long long npix, long long total, float T, float w) {
+  __shared__ double red[3][4];
+  double oce_acc = 0., reg_acc = 0., bad = 0.;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / P;
+    const long long* ca = anchor + i * ND;
+    const long long* cr = reference + i * ND;
+    const long long ia = coord_index(ca, ND, Z, Y, X), ir = coord_index(cr, ND, Z, Y, X);
+    if (ia < 0 || ir < 0) { bad += 1.; continue; }
+    const float* ob = offsets + b * ND * npix;
+    float av[ND], rv[ND], g[ND], oce, reg;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+      av[c] = ob[(long long)c * npix + ia] + (float)ca[c];
+      rv[c] = ob[(long long)c * npix + ir] + (float)cr[c];
+    }
+    oce_pair<ND>(av, rv, T, w, oce, reg, g);
+    oce_acc += oce; reg_acc += reg;
+    unsigned long long* gb = acc + b * ND * npix + ia;
+#pragma unroll
+    for (int c = 0; c < ND; ++c)
+      atomicAdd(gb + (long long)c * npix, (unsigned long long)__double2ll_rn((double)g[c] * DET_SCALE));
+  }
+  // fixed-shape reduction: wave shuffles, then the four waves in order
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    oce_acc += __shfl_down(oce_acc, o, 64);
+    reg_acc += __shfl_down(reg_acc, o, 64);
+    bad += __shfl_down(bad, o, 64);
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wid] = oce_acc; red[1][wid] = reg_acc; red[2][wid] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double o = 0., r = 0., bd = 0.;
+    for (int k = 0; k < 4; ++k) { o += red[0][k]; r += red[1][k]; bd += red[2][k]; }
+    partial[4 * blockIdx.x + 0] = o; partial[4 * blockIdx.x + 1] = r; partial[4 * blockIdx.x + 2] = bd;
+  }
+}
+
+__global__ void oce_pairs_det_finish(const unsigned long long* __restrict__ acc, float* __restrict__ doffsets,
+                                     long long n, const double* __restrict__ partial, int nblocks, double* sums) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    doffsets[i] = (float)((double)(long long)acc[i] * (1.0 / DET_SCALE));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double o = 0., r = 0., bd = 0.;
+    for (int k = 0; k < nblocks; ++k) { o += partial[4 * k]; r += partial[4 * k + 1]; bd += partial[4 * k + 2]; }
+    sums[0] = o + r; sums[1] = o; sums[2] = r; sums[3] = bd;
+  }
 }
 
 // torch.optim.Adam single-tensor step order (weight_decay coupled into grad):
@@ -340,5 +403,39 @@ extern "C" int clx_adam_step_guarded(float* param, const float* grad, float* exp
       param, grad, exp_avg, exp_avg_sq, n, (float)(1.0 - beta1), (float)beta2,
       (float)(1.0 - beta2), (float)eps, (float)weight_decay, step_size, bc2_sqrt, skip_if_positive);
   CLX_CHECK_LAUNCH("clx_adam_step");
+  return CLX_OK;
+}
+
+extern "C" size_t clx_oce_pairs_det_scratch_bytes(int B, int ND, long long npix) {
+  return (size_t)B * ND * npix * sizeof(unsigned long long) + (size_t)DET_BLOCKS * 4 * sizeof(double);
+}
+
+extern "C" int clx_oce_pairs_fused_det(const float* offsets, const long long* anchor, const long long* reference,
+                                       float* doffsets, double* sums, int B, int P, int ND, int Z, int Y, int X,
+                                       float temperature, float reg_weight, void* scratch, clx_stream stream) {
+  CLX_REQUIRE(offsets && anchor && reference && doffsets && sums && scratch, "clx_oce_pairs_fused_det: null pointer");
+  CLX_REQUIRE(B > 0 && P >= 0 && (ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0 && (ND == 3 || Z == 1),
+              "clx_oce_pairs_fused_det: bad extents");
+  CLX_REQUIRE(temperature > 0.f, "clx_oce_pairs_fused_det: temperature must be positive");
+  CLX_REQUIRE(((uintptr_t)scratch & 7) == 0, "clx_oce_pairs_fused_det: scratch must be 8-byte aligned");
+  const long long npix = (long long)Z * Y * X, total = (long long)B * P, n = (long long)B * ND * npix;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* acc = (unsigned long long*)scratch;
+  double* partial = (double*)(acc + n);
+  if (hipMemsetAsync(acc, 0, (size_t)n * sizeof(unsigned long long), st) != hipSuccess) {
+    clx_set_error("clx_oce_pairs_fused_det: memset failed");
+    return CLX_ERR_LAUNCH;
+  }
+  long long g = (total + 255) / 256;
+  const int grid = (int)(g < 1 ? 1 : g > DET_BLOCKS ? DET_BLOCKS : g);
+  if (ND == 2)
+    oce_pairs_det_kernel<2><<<grid, 256, 0, st>>>(offsets, anchor, reference, acc, partial, P, Z, Y, X, npix, total,
+                                                  temperature, reg_weight);
+  else
+    oce_pairs_det_kernel<3><<<grid, 256, 0, st>>>(offsets, anchor, reference, acc, partial, P, Z, Y, X, npix, total,
+                                                  temperature, reg_weight);
+  long long gf = (n + 255) / 256;
+  oce_pairs_det_finish<<<(int)(gf > 2048 ? 2048 : gf), 256, 0, st>>>(acc, doffsets, n, partial, grid, sums);
+  CLX_CHECK_LAUNCH("clx_oce_pairs_fused_det");
   return CLX_OK;
 }

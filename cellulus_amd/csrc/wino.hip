@@ -638,6 +638,7 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = N;
   gd.precision = d->precision;
+  gd.det_turns = d->det_turns;            // reproducible mode: the xi products add their slices in order
   const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, gin.T * C, gout.T * N,
                                   (long long)d->KD * N * C, st);
   if (rc) return rc;

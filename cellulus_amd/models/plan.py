@@ -263,6 +263,13 @@ class UNetPlan:
         self.device = device
         self.keep = keep_activations
         self.precision = precision_code()
+        # opt-in: run-to-run reproducible training (CLX_DETERMINISTIC=1; the reference's CPU autograd is
+        # deterministic, cellulus/train.py:177-179).  Weight-gradient slices add in a fixed order, bias
+        # gradients come from ordered column sums, the first layer takes the generic kernel and the fused
+        # 1x1 pairs are off (their block sums meet in float atomics); train._fused_step switches the loss.
+        self.deterministic = os.environ.get("CLX_DETERMINISTIC", "0") == "1"
+        if self.deterministic and self.precision != 0:
+            raise ValueError("CLX_DETERMINISTIC=1 is implemented for the default precision (float32 MFMA) only")
         self.buf = {}
         self._alloc()
 
@@ -383,7 +390,7 @@ class UNetPlan:
         and never read back, its gradient never exists in HBM).  CLX_CHAIN64=0 keeps the layer-by-layer path."""
         t = self.topo
         self.chains, self.chain_second = {}, {}
-        if os.environ.get("CLX_CHAIN64", "1") == "0" or self.precision != 0:
+        if os.environ.get("CLX_CHAIN64", "1") == "0" or self.precision != 0 or self.deterministic:
             return
         produced_by_conv = {layer.out: layer for layer in t.convs}
         one = (1, 1, 1)
@@ -501,6 +508,12 @@ class UNetPlan:
             sp_off[name] = (total, total + sp["_dw_skip_n"])
             total += sp["_dw_skip_n"] + sp["_dw_z_n"]
         self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
+        if self.deterministic:
+            lib = _clx.load()
+            width = max(pad4(layer.cout) for layer in t.convs)
+            self._det_turns = torch.zeros(1 << 20, dtype=torch.int32, device=self.device)     # 4 MB of turn counters
+            self._det_colsum = torch.empty(int(lib.clx_colsum_scratch_bytes(width)) // 4, dtype=torch.float32,
+                                           device=self.device)
         for name, sp in self.subpixel.items():
             a, b = sp_off[name]
             sp["dw_skip"] = self.dwpack[a:b]
@@ -703,8 +716,7 @@ class UNetPlan:
             if sp.get("_vskip_fresh"):
                 ds.vcache = sp["vcache_skip"].data_ptr()
                 ds.vcache_valid = 1
-        _clx.call("clx_conv_wgrad", ctypes.byref(ds), _clx.ptr(dy), sp["N"], _clx.ptr(sp["dw_skip"]),
-                  _clx.ptr(gb) if gb is not None else None, st)
+        self._wgrad(ds, dy, sp["N"], sp["dw_skip"], gb, layer.cout, st)
         if sp["wino"]:
             self._use_workspace(dz, sp["wino"])
             if sp.get("_v_fresh"):
@@ -712,7 +724,7 @@ class UNetPlan:
                 dz.vcache_valid = 1
             if self.dycache is not None:
                 dz.dy_vcache = self.dycache.data_ptr()
-        _clx.call("clx_conv_wgrad", ctypes.byref(dz), _clx.ptr(dzbuf), PN, _clx.ptr(sp["dw_z"]), None, st)
+        self._wgrad(dz, dzbuf, PN, sp["dw_z"], None, 0, st)
         g_skip, g_z = sp["g_skip"], sp["g_z"]
         if sp["wino_skip"]:
             _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
@@ -891,6 +903,22 @@ class UNetPlan:
             c0 += pad4(s.channels)
         return torch.cat(parts, dim=1)
 
+    def _wgrad(self, d, dy, ld_dy, dwp, gb, nbias, st):
+        """clx_conv_wgrad; in reproducible mode with ordered slices and the bias gradient from ordered column
+        sums of dy (rows = output pixels of the layer, `nbias` real channels)."""
+        if not self.deterministic:
+            _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), ld_dy, _clx.ptr(dwp),
+                      _clx.ptr(gb) if gb is not None else None, st)
+            return
+        need = int(_clx.load().clx_conv_wgrad_turns_bytes(ctypes.byref(d)))
+        if need > self._det_turns.numel() * 4:
+            self._det_turns = torch.zeros(need // 4 + 1, dtype=torch.int32, device=self.device)
+        d.det_turns = self._det_turns.data_ptr()
+        _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), ld_dy, _clx.ptr(dwp), None, st)
+        if gb is not None:
+            _clx.call("clx_colsum_ordered", _clx.ptr(dy), ld_dy, dy.shape[0], nbias, _clx.ptr(gb),
+                      _clx.ptr(self._det_colsum), st)
+
     def _chain_forward(self, a, b, params, st):
         """y1 = relu(x w1^T + b1), y2 = act(y1 w2^T + b2) in one launch (clx_chain64_fwd)."""
         M = self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2]
@@ -1067,8 +1095,7 @@ class UNetPlan:
                     d.vcache_valid = 1
                 if dual:
                     d.dy_vcache = self.dycache.data_ptr()
-            _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), pad4(layer.cout), _clx.ptr(dwp),
-                      _clx.ptr(gb) if gb is not None else None, st)
+            self._wgrad(d, dy, pad4(layer.cout), dwp, gb, layer.cout, st)
             gw = grads[2 * layer.param_index]
             if wino_w:
                 _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,

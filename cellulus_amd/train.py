@@ -339,11 +339,23 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
                          f"{tuple(reference.shape)}")
     Z, Y, X = (1, offsets.shape[2], offsets.shape[3]) if ND == 2 else tuple(offsets.shape[2:])
     sums = torch.zeros(4, dtype=torch.float64, device=device)     # loss, oce, reg, bad-coordinate count
-    doffsets = torch.zeros_like(offsets)
-    _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
-              _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
-              float(criterion.temperature), float(criterion.regularization_weight),
-              _clx.stream_ptr(device))
+    if plan.deterministic:
+        # CLX_DETERMINISTIC=1: fixed-point scatter of the anchor gradients, loss sums in block order
+        doffsets = torch.empty_like(offsets)
+        need = int(_clx.load().clx_oce_pairs_det_scratch_bytes(B, ND, Z * Y * X))
+        scratch = getattr(model, "_det_loss_scratch", None)
+        if scratch is None or scratch.numel() < need or scratch.device != device:
+            scratch = model._det_loss_scratch = torch.empty(need, dtype=torch.uint8, device=device)
+        _clx.call("clx_oce_pairs_fused_det", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
+                  _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
+                  float(criterion.temperature), float(criterion.regularization_weight), _clx.ptr(scratch),
+                  _clx.stream_ptr(device))
+    else:
+        doffsets = torch.zeros_like(offsets)
+        _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
+                  _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
+                  float(criterion.temperature), float(criterion.regularization_weight),
+                  _clx.stream_ptr(device))
     early = None
     if parallel.world_size() == 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
         # One process: the sums are final HERE, before the backward pass.  They leave on a side stream into

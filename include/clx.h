@@ -131,6 +131,14 @@ typedef struct clx_conv_desc {
   int ld_gate;
   const unsigned int* mask_bits;
   int ld_mask_bits;
+  /* clx_conv_wgrad only, optional: run-to-run REPRODUCIBLE weight gradients (the reference's CPU
+   * autograd, cellulus/train.py:177-179, is deterministic; the default split-K combine is not:
+   * float atomics arrive in any order).  With det_turns != NULL (clx_conv_wgrad_turns_bytes(d)
+   * bytes of device scratch) the pixel slices of an output tile add their partial sums in slice
+   * order — each block waits for its predecessor's turn counter — and the first-layer kernels
+   * (whose block sums meet in LDS atomics) are not used.  Pass dbias = NULL with it and take the
+   * bias gradient from clx_colsum_ordered. */
+  int* det_turns;
 } clx_conv_desc;
 
 enum clx_conv_algo {
@@ -163,6 +171,14 @@ size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass);
  * N = output channels, K = taps x channels). Also used for the data gradient
  * (PD = K-1, weights packed with CLX_PACK_DGRAD). */
 int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream);
+
+/* Bytes of device scratch clx_conv_desc.det_turns needs for this layer (0 if d is NULL). */
+size_t clx_conv_wgrad_turns_bytes(const clx_conv_desc* d);
+/* out[n] = sum_m x[m][n] in a FIXED order (block partials over contiguous row ranges, then one pass
+ * over the partials in block order): the reproducible bias gradient, db = column sums of dY
+ * (autograd of nn.ConvNd's bias, cellulus/train.py:178).  scratch: clx_colsum_scratch_bytes(N). */
+size_t clx_colsum_scratch_bytes(int N);
+int clx_colsum_ordered(const float* x, int ld, long long M, int N, float* out, void* scratch, clx_stream stream);
 
 /* Two consecutive 1x1 convolutions over 64 channels in one pass over the pixels — the
  * `conv_pass.2 -> conv_pass.4` pair of every funlib ConvPass the reference builds
@@ -316,6 +332,15 @@ int clx_oce_pairs_fused(const float* offsets, const long long* anchor,
                         const long long* reference, float* doffsets, double* sums,
                         int B, int P, int ND, int Z, int Y, int X,
                         float temperature, float reg_weight, clx_stream stream);
+/* The same with REPRODUCIBLE results: the scatter-add of the anchor gradients (every anchor pixel occurs
+ * ~31 times) accumulates 2^-40 fixed-point integers — integer addition is associative, so the sum
+ * does not depend on the order the atomics arrive in — and the loss sums are block partials reduced in
+ * block order.  scratch: clx_oce_pairs_det_scratch_bytes(B, ND, Z * Y * X), need not be zeroed. */
+size_t clx_oce_pairs_det_scratch_bytes(int B, int ND, long long npix);
+int clx_oce_pairs_fused_det(const float* offsets, const long long* anchor, const long long* reference,
+                            float* doffsets, double* sums, int B, int P, int ND, int Z, int Y, int X,
+                            float temperature, float reg_weight, void* scratch, clx_stream stream);
+
 /* Optional on-device pair sampler with the distribution of ZarrDataset.sample_coordinates
  * (cellulus/datasets/zarr_dataset.py:177-242) — NOT its random stream: anchor column d uniform on
  * the integers [lo, hi[d]] (hi: HOST array of ND ints), each anchor repeated num_refs times,

@@ -365,3 +365,85 @@ def test_device_pair_sampler_has_the_reference_distribution(nd, device):
         a4, r4 = sq.sample(2, step=0)
         loss, _, _ = train_iteration((torch.rand(2, 1, 56, 56), a4, r4), model, crit, opt, device)
         assert np.isfinite(loss)
+
+
+@pytest.mark.parametrize("nd", [2, 3])
+def test_deterministic_mode_is_bit_reproducible(nd, device, monkeypatch):
+    """CLX_DETERMINISTIC=1 (opt-in): two runs of ten fused train steps from the same weights on the same
+    batches end with bit-identical losses, gradients and parameters — as the reference's CPU path does
+    (cellulus/train.py:177-179).  Weight-gradient slices add in slice order, bias gradients are ordered
+    column sums, the pair-gradient scatter is fixed-point.  The result equals the default mode's to
+    rounding (same arithmetic, another summation order).  Wide enough for Winograd layers, the sub-pixel
+    upsample convolution and split-K slices."""
+    cfg = dict(in_channels=1, out_channels=nd, num_fmaps=64 if nd == 2 else 32, fmap_inc_factor=2,
+               features_in_last_layer=64, downsampling_factors=[[2] * nd], num_spatial_dims=nd)
+    spatial = (76, 84) if nd == 2 else (28, 28, 32)
+    out_shape = tuple(s - 16 for s in spatial)
+    rng = np.random.default_rng(5)
+    B = 3
+    raw = torch.rand(B, 1, *spatial)
+    anchor, reference = _pairs(rng, B, out_shape, 4, 150, 20)
+
+    def run(det):
+        monkeypatch.setenv("CLX_DETERMINISTIC", "1" if det else "0")
+        torch.manual_seed(11)
+        model = get_model(**cfg).to(device)
+        for layer in model.modules():
+            if isinstance(layer, torch.nn.modules.conv._ConvNd):
+                torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+        crit = get_loss(temperature=10.0, regularizer_weight=1e-5, density=0.1, num_spatial_dims=nd, device=device)
+        opt = Adam(model.parameters(), lr=4e-5, weight_decay=0.01)       # train_config.py's default rate
+        losses = [train_iteration((raw, anchor, reference), model, crit, opt, device)[0] for _ in range(10)]
+        plan = next(iter(model._plans.values()))
+        assert plan.deterministic == det and (not plan.chains if det else True)
+        torch.cuda.synchronize()
+        return losses, model._flat.detach().clone(), model._flat_grad.detach().clone()
+
+    l1, p1, g1 = run(True)
+    l2, p2, g2 = run(True)
+    assert l1 == l2
+    assert torch.equal(g1, g2) and torch.equal(p1, p2)
+    l0, p0, _g0 = run(False)
+    np.testing.assert_allclose(l1, l0, rtol=2e-4)
+    assert (p1 - p0).abs().max().item() < 2e-4          # ten Adam steps of 4e-5 move a weight by <= 4e-4
+
+
+def test_ordered_column_sums_and_fixed_point_scatter_through_the_c_abi(device):
+    """clx_colsum_ordered / clx_oce_pairs_fused_det: same values as the float64 reference, and identical bits
+    from call to call."""
+    from cellulus_amd import _clx
+
+    st = _clx.stream_ptr(device)
+    lib = _clx.load()
+    torch.manual_seed(0)
+    for M, N, ld in ((1000, 64, 64), (70001, 3, 4), (513, 768, 768), (40000, 1100, 1100)):
+        x = torch.randn(M, ld, device=device)
+        scratch = torch.empty(int(lib.clx_colsum_scratch_bytes(N)), dtype=torch.uint8, device=device)
+        outs = []
+        for _ in range(2):
+            out = torch.full((N,), float("nan"), device=device)
+            _clx.call("clx_colsum_ordered", _clx.ptr(x), ld, M, N, _clx.ptr(out), _clx.ptr(scratch), st)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        ref = x[:, :N].double().sum(0)
+        assert ((outs[0].double() - ref).abs() / (ref.abs() + M ** 0.5)).max().item() < 1e-5
+    # the pair loss: against the atomic-float kernel and the oracle
+    B, ND, Y, X = 2, 2, 40, 44
+    rng = np.random.default_rng(1)
+    offsets = torch.randn(B, ND, Y, X, device=device)
+    anchor, reference = _pairs(rng, B, (Y, X), 4, 60, 31)
+    a_d, r_d = anchor.to(device), reference.to(device)
+    scratch = torch.empty(int(lib.clx_oce_pairs_det_scratch_bytes(B, ND, Y * X)), dtype=torch.uint8, device=device)
+    res = []
+    for _ in range(2):
+        d = torch.full_like(offsets, float("nan"))
+        sums = torch.zeros(4, dtype=torch.float64, device=device)
+        _clx.call("clx_oce_pairs_fused_det", _clx.ptr(offsets), _clx.ptr(a_d), _clx.ptr(r_d), _clx.ptr(d),
+                  _clx.ptr(sums), B, anchor.shape[1], ND, 1, Y, X, 10.0, 1e-5, _clx.ptr(scratch), st)
+        res.append((d, sums.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    d0 = torch.zeros_like(offsets)
+    s0 = torch.zeros(4, dtype=torch.float64, device=device)
+    _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(a_d), _clx.ptr(r_d), _clx.ptr(d0), _clx.ptr(s0),
+              B, anchor.shape[1], ND, 1, Y, X, 10.0, 1e-5, st)
+    assert torch.allclose(res[0][0], d0, atol=1e-5) and torch.allclose(res[0][1], s0, rtol=1e-9)
