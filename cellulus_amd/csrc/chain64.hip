@@ -382,12 +382,14 @@ extern "C" int clx_chain64_fwd(const float* x, int ld_x, long long M, const floa
   ChainFwdP p{x, ld_x, (int)M, w1, b1, y1, ld_y1, gate1, ld_gate1, w2, b2, N2, relu2, y2, ld_y2, gate2, ld_gate2,
               (int)((M + 31) / 32)};
   hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (clx_prof_enabled()) clx_prof_events(CLX_PROF_CHAIN64, 2.0 * M * 64 * (64 + N2), &e0, &e1);
   if (N2 == 64) {
     const int g = chain_grid((const void*)chain64_fwd_kernel<2>, (p.ntiles + 3) / 4);
-    chain64_fwd_kernel<2><<<g, 256, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((chain64_fwd_kernel<2>), dim3(g), dim3(256), st, e0, e1, p);
   } else {
     const int g = chain_grid((const void*)chain64_fwd_kernel<1>, (p.ntiles + 3) / 4);
-    chain64_fwd_kernel<1><<<g, 256, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((chain64_fwd_kernel<1>), dim3(g), dim3(256), st, e0, e1, p);
   }
   CLX_CHECK_LAUNCH("clx_chain64_fwd");
   return CLX_OK;
@@ -408,12 +410,15 @@ extern "C" int clx_chain64_bwd(const float* dp2, int ld_dp2, int N2, const float
   ChainBwdP p{dp2, ld_dp2, N2, y1, ld_y1, x, ld_x, gate_x, (int)M, w2t, w1t, dp0, ld_dp0, dw2, db2, dw1, db1,
               (int)((M + 127) / 128)};
   hipStream_t st = (hipStream_t)stream;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  // two data-gradient and two weight-gradient products
+  if (clx_prof_enabled()) clx_prof_events(CLX_PROF_CHAIN64, 2.0 * M * 64 * (64 + N2) * (dp0 ? 2.0 : 1.5), &e0, &e1);
   if (N2 == 64) {
     const int g = chain_grid((const void*)chain64_bwd_kernel<8>, p.ntiles);
-    chain64_bwd_kernel<8><<<g, 256, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((chain64_bwd_kernel<8>), dim3(g), dim3(256), st, e0, e1, p);
   } else {
     const int g = chain_grid((const void*)chain64_bwd_kernel<1>, p.ntiles);
-    chain64_bwd_kernel<1><<<g, 256, 0, st>>>(p);
+    CLX_LAUNCH_TIMED((chain64_bwd_kernel<1>), dim3(g), dim3(256), st, e0, e1, p);
   }
   CLX_CHECK_LAUNCH("clx_chain64_bwd");
   return CLX_OK;

@@ -51,7 +51,9 @@ enum clx_profile_kind {
   CLX_PROF_IGEMM_NARROW = 1, /* conv_igemm_kernel<128,64>  */
   CLX_PROF_WGRAD = 2,        /* conv_wgrad_kernel<...>     */
   CLX_PROF_GEMM_X3 = 3,      /* gemm_x3_kernel (opt-in precision f32x3bf16; FLOPs = f32-equivalent 2*M*N*K) */
-  CLX_PROF_WGRAD_X3 = 4      /* wgrad_x3_kernel (weight gradient of the opt-in precision) */
+  CLX_PROF_WGRAD_X3 = 4,     /* wgrad_x3_kernel (weight gradient of the opt-in precision) */
+  CLX_PROF_GEMM_T = 5,       /* gemm_t_kernel (plain products, weights as the MFMA's A operand) */
+  CLX_PROF_CHAIN64 = 6       /* chain64_fwd / _bwd kernels (fused pairs of 64-channel 1x1 layers) */
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);

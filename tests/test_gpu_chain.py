@@ -3,6 +3,8 @@ the C ABI against float64 autograd of the same two layers (funlib ConvPass's ker
 and the head of cellulus/models/unet.py:52-63), incl. ragged pixel counts, the head's narrow last
 layer, the ReLU gate bits and a padded leading dimension."""
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -118,3 +120,109 @@ def test_chain_rejects_what_it_cannot_do(device):
     with pytest.raises(_clx.ClxError):
         _clx.call("clx_chain64_bwd", _clx.ptr(x), 64, 16, _clx.ptr(x), 64, _clx.ptr(x), 64, 1, 64, _clx.ptr(x),
                   _clx.ptr(x), None, 0, _clx.ptr(x), None, _clx.ptr(x), None, st)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (517, 768, 96), (129, 132, 36), (4100, 100, 260), (300, 260, 68),
+                                   (128 * 9, 128, 32), (50, 65, 8)])
+def test_plain_products_with_weights_as_the_a_operand(M, N, K, device, monkeypatch):
+    """gemm_t_kernel (the 1x1 convolutions and the Winograd-domain products with more than 64 output channels)
+    through clx_conv_fwd: every epilogue of the implicit-GEMM kernel it replaces — plain, bias + ReLU with gate
+    bits out, float ReLU-gate mask, gate bits in, accumulate — on pixel counts, channel counts and contraction
+    lengths that are not multiples of the tile, against float64; and bit-identical gate semantics."""
+    import ctypes
+    import subprocess
+    import sys
+
+    from cellulus_amd._clx import ClxConvDesc, ClxSrc
+
+    # the kernel is opt-in (CLX_GEMMT=1, read once per process): run this very test in a child that has it set
+    if os.environ.get("CLX_GEMMT") != "1":
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                            f"plain_products and {M}-{N}-{K}"], env=dict(os.environ, CLX_GEMMT="1"),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "1 passed" in r.stdout, (r.stdout + r.stderr)[-3000:]
+        return
+
+    torch.manual_seed(M + N + K)
+    st = _clx.stream_ptr(device)
+    ldx = K + 4                                        # a padded leading dimension
+    x = torch.randn(M, K)
+    xd = torch.zeros(M, ldx, device=device)
+    xd[:, :K] = x.to(device)
+    w = torch.randn(N, K) / K ** 0.5
+    wd = w.to(device).contiguous()
+    bias = torch.randn(N)
+    ldo = (N + 31) // 32 * 32
+    ref = x.double() @ w.double().t()
+
+    def desc(out):
+        d = ClxConvDesc()
+        d.nsrc = 1
+        s = ClxSrc()
+        s.ptr, s.C, s.ld = xd.data_ptr(), K, ldx
+        s.D, s.H, s.W = 1, 1, M
+        s.oz = s.oy = s.ox = 0
+        s.fz = s.fy = s.fx = 1
+        d.src[0] = s
+        d.B = 1
+        d.ID, d.IH, d.IW = 1, 1, M
+        d.KD = d.KH = d.KW = 1
+        d.PD = d.PH = d.PW = 0
+        d.N = N
+        d.wpack = wd.data_ptr()
+        d.out, d.ld_out = out.data_ptr(), ldo
+        return d
+
+    def run(setup):
+        out = torch.full((M, ldo), 7.0, device=device)
+        d = desc(out)
+        keep = setup(d, out)
+        _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+        torch.cuda.synchronize()
+        return out, keep
+
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    out, _ = run(lambda d, o: None)
+    assert (out[:, :N].cpu().double() - ref).abs().max().item() < tol
+    assert (out[:, N:] == 7.0).all()                   # nothing written beyond N
+
+    b_d = bias.to(device)
+    gate = torch.zeros((M, ldo // 32), dtype=torch.int32, device=device)
+
+    def bias_relu(d, o):
+        d.bias, d.relu = b_d.data_ptr(), 1
+        d.gate_out, d.ld_gate = gate.data_ptr(), ldo // 32
+    out, _ = run(bias_relu)
+    want = torch.relu(ref + bias.double())
+    assert (out[:, :N].cpu().double() - want).abs().max().item() < tol
+    bits = ((gate.cpu().numpy().astype(np.uint32)[:, :, None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)
+    bits = bits.reshape(M, -1)
+    np.testing.assert_array_equal(bits[:, :N], (out[:, :N] > 0).cpu().numpy())
+    assert not bits[:, N:].any()
+
+    mask = torch.randn(M, ldo, device=device)
+    def float_mask(d, o):
+        d.mask, d.ld_mask = mask.data_ptr(), ldo
+    out, _ = run(float_mask)
+    assert (out[:, :N].cpu().double() - ref * (mask[:, :N] > 0).cpu()).abs().max().item() < tol
+
+    def bit_mask(d, o):                                # the gates written above, read back as the mask
+        d.mask_bits, d.ld_mask_bits = gate.data_ptr(), ldo // 32
+    out, _ = run(bit_mask)
+    assert (out[:, :N].cpu().double() - ref * torch.from_numpy(bits[:, :N])).abs().max().item() < tol
+
+    prev = torch.randn(M, ldo, device=device)
+    def accumulate(d, o):
+        o.copy_(prev)
+        d.accumulate, d.bias, d.relu = 1, b_d.data_ptr(), 1
+    out, _ = run(accumulate)
+    want = torch.relu(ref + bias.double() + prev[:, :N].cpu().double())
+    assert (out[:, :N].cpu().double() - want).abs().max().item() < tol
+
+    # (the launch profile proves which kernel ran)
+    _clx.call("clx_profile_enable", 2)
+    run(lambda d, o: None)
+    n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _clx.load().clx_profile_read(5, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+    _clx.call("clx_profile_enable", 0)
+    assert n_l.value == 1 and fl_l.value == 2.0 * M * N * K
