@@ -334,7 +334,10 @@ __global__ __launch_bounds__(256) void ms_assign_kernel(const double* __restrict
 //   scatter: arrival-order slot inside the cell (atomic cursor)
 //   order:   one wavefront per cell ranks the cell's points by original index (rank sort:
 //            n^2 / 64 comparisons per cell, cells hold tens to a few thousand points) and writes
-//            the point into its final slot
+//            the point into its final slot.  Embeddings collapse onto object centres, so a
+//            degenerate prediction can put 1e5 - 1e6 points into ONE cell: cells above
+//            BUCKET_BIG points are ranked by one THREAD per point instead (bucket_order_big_kernel:
+//            the same n^2 comparisons spread over the whole chip rather than one wavefront)
 // ---------------------------------------------------------------------------------------------
 template <int ND>
 __global__ void bucket_count_kernel(const double* __restrict__ fit, int n, double ox, double oy, double oz,
@@ -385,14 +388,20 @@ __global__ void bucket_scatter_kernel(const int* __restrict__ cid, int n, const 
   }
 }
 
+constexpr int BUCKET_BIG = 2048;
+
 template <int ND>
 __global__ __launch_bounds__(256) void bucket_order_kernel(const double* __restrict__ fit,
                                                            const int* __restrict__ start, int ncells,
                                                            const int* __restrict__ slot_idx,
-                                                           double* __restrict__ fit_sorted) {
+                                                           double* __restrict__ fit_sorted, int* __restrict__ any_big) {
   const int lane = threadIdx.x & 63;
   for (int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < ncells; c += (gridDim.x * blockDim.x) >> 6) {
     const int lo = start[c], hi = start[c + 1];
+    if (hi - lo > BUCKET_BIG) {          // left to bucket_order_big_kernel
+      if (lane == 0) *any_big = 1;
+      continue;
+    }
     for (int j = lo + lane; j < hi; j += 64) {
       const int me = slot_idx[j];
       int rank = 0;
@@ -400,6 +409,29 @@ __global__ __launch_bounds__(256) void bucket_order_kernel(const double* __restr
 #pragma unroll
       for (int d = 0; d < ND; ++d) fit_sorted[(long long)(lo + rank) * ND + d] = fit[(long long)me * ND + d];
     }
+  }
+}
+
+// cells with more than BUCKET_BIG points: one thread per point of such a cell counts the cell's smaller indices
+// (every thread of a cell reads the same sequence: broadcast loads out of the caches); returns at once if the
+// wavefront kernel saw no such cell
+template <int ND>
+__global__ __launch_bounds__(256) void bucket_order_big_kernel(const double* __restrict__ fit, int n,
+                                                               const int* __restrict__ cid,
+                                                               const int* __restrict__ start,
+                                                               const int* __restrict__ slot_idx,
+                                                               double* __restrict__ fit_sorted,
+                                                               const int* __restrict__ any_big) {
+  if (*any_big == 0) return;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int me = slot_idx[j];
+    const int c = cid[me];
+    const int lo = start[c], hi = start[c + 1];
+    if (hi - lo <= BUCKET_BIG) continue;
+    int rank = 0;
+    for (int k = lo; k < hi; ++k) rank += (slot_idx[k] < me) ? 1 : 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) fit_sorted[(long long)(lo + rank) * ND + d] = fit[(long long)me * ND + d];
   }
 }
 
@@ -593,7 +625,8 @@ extern "C" int clx_ms_bucket(const double* fit, int n, int ND, const double* ori
   int* cid = (int*)workspace;
   int* slot_idx = cid + n;
   int* counts = slot_idx + n;
-  if (hipMemsetAsync(counts, 0, (size_t)ncells * sizeof(int), st) != hipSuccess) {
+  int* any_big = counts + ncells;           // one flag behind the counters, cleared with them
+  if (hipMemsetAsync(counts, 0, (size_t)(ncells + 1) * sizeof(int), st) != hipSuccess) {
     clx_set_error("clx_ms_bucket: memset failed");
     return CLX_ERR_LAUNCH;
   }
@@ -610,10 +643,14 @@ extern "C" int clx_ms_bucket(const double* fit, int n, int ND, const double* ori
     bucket_scatter_kernel<<<grid, 256, 0, st>>>(cid, n, cell_start, counts, slot_idx);
     long long waves = ncells < 65536 ? ncells : 65536;
     const int ogrid = (int)((waves * 64 + 255) / 256);
-    if (ND == 2)
-      bucket_order_kernel<2><<<ogrid, 256, 0, st>>>(fit, cell_start, (int)ncells, slot_idx, fit_sorted);
-    else
-      bucket_order_kernel<3><<<ogrid, 256, 0, st>>>(fit, cell_start, (int)ncells, slot_idx, fit_sorted);
+    const int bgrid = grid < 8192 ? grid : 8192;
+    if (ND == 2) {
+      bucket_order_kernel<2><<<ogrid, 256, 0, st>>>(fit, cell_start, (int)ncells, slot_idx, fit_sorted, any_big);
+      bucket_order_big_kernel<2><<<bgrid, 256, 0, st>>>(fit, n, cid, cell_start, slot_idx, fit_sorted, any_big);
+    } else {
+      bucket_order_kernel<3><<<ogrid, 256, 0, st>>>(fit, cell_start, (int)ncells, slot_idx, fit_sorted, any_big);
+      bucket_order_big_kernel<3><<<bgrid, 256, 0, st>>>(fit, n, cid, cell_start, slot_idx, fit_sorted, any_big);
+    }
   }
   CLX_CHECK_LAUNCH("clx_ms_bucket");
   return CLX_OK;

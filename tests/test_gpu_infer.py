@@ -400,6 +400,15 @@ def test_bucket_kernel_is_a_stable_sort_by_cell(nd, device):
     ref_start = np.concatenate([[0], np.cumsum(np.bincount(cid, minlength=nx * ny * nz))])
     np.testing.assert_array_equal(cell_start.cpu().numpy(), ref_start)
     np.testing.assert_array_equal(origin, pts.min(axis=0))
+    # a degenerate prediction: (almost) every embedding lands in ONE cell — the cell is ranked by one thread per
+    # point instead of one wavefront (round-2 advisor finding), the order is still the stable one
+    heap = np.concatenate([rng.uniform(100.0, 100.0 + 0.9 * bw, size=(30000, nd)), rng.uniform(0, 300, size=(50, nd))])
+    heap = heap[rng.permutation(len(heap))]
+    fs, cell_start, _origin, cell, (nx, ny, nz) = MS._bucket(torch.from_numpy(heap).to(device), bw)
+    coords = np.floor((heap - heap.min(axis=0)) / cell).astype(np.int64)
+    cid = coords[:, 0] + nx * coords[:, 1] + (nx * ny * coords[:, 2] if nd == 3 else 0)
+    assert np.bincount(cid).max() > 20000
+    np.testing.assert_array_equal(fs.cpu().numpy(), heap[np.argsort(cid, kind="stable")])
 
 
 @pytest.mark.parametrize("nd", [2, 3])

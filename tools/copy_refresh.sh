@@ -24,3 +24,7 @@ cp $R/hbm_traffic_streaming.txt profiles/${P}_hbm_traffic_streaming.txt
 cp $R/hbm_traffic_train2d.json $R/hbm_traffic_train3d.json $R/hbm_traffic_streaming.json profiles/
 cp $R/pmc_lds_conflicts_f32.txt profiles/${P}_pmc_lds_conflicts_f32.txt
 cp $R/pmc_lds_conflicts_f32x3bf16.txt profiles/${P}_pmc_lds_conflicts_f32x3bf16.txt
+[ -f $R/streaming_kernels_4096.txt ] && cp $R/streaming_kernels_4096.txt profiles/${P}_streaming_kernels_4096.txt
+[ -f $R/prof_stream4k_kernel_stats.csv ] && cp $R/prof_stream4k_kernel_stats.csv profiles/${P}_streaming_4096_kernel_stats.csv
+[ -f $R/bench_deterministic.json ] && cp $R/bench_deterministic.json profiles/${P}_bench_deterministic.json
+true
