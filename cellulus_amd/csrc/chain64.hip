@@ -21,8 +21,10 @@
 // (c) exactly the accumulator layout of the transposed product (row n = 8g + 4h + j of lane
 // (i, h), register 4g + j) — so layer 1's result, after bias + ReLU in registers, IS layer 2's B
 // operand: no LDS round trip, no barrier, no transpose between the layers.  Only the weight
-// gradients (contraction over pixels) need the tile in LDS: a block's four waves stage their 32
-// pixels each, and each wave accumulates one 32x32 quarter of dW over all 128.
+// gradients (contraction over pixels) need the tile in LDS, pixel-major as it arrives: every wave
+// stages its own 32 pixels and accumulates the whole of dW2 and dW1 over them (128 accumulator
+// registers — one wave per SIMD has them), so the tile loop has no block barrier at all; the
+// waves' sums meet once, at the end of the kernel.
 #include "clx_common.h"
 
 #include <stdlib.h>
@@ -53,12 +55,20 @@ struct ChainFwdP {
 };
 
 // NT2: 32-row tiles of layer 2's output channels — 2 (64 channels) or 1 (N2 <= 32, the head's last layer)
+//
+// Global memory is touched in FULL LINES only: a wave instruction reads / writes four whole 256-byte pixel rows
+// (lane l: row 4j + l / 16, 16-byte piece l % 16), and the wave's private LDS tile [32][LDW] turns that into the
+// fragment layout of the transposed products and back.  (The first version loaded and stored fragment-shaped —
+// 32 rows x 32 bytes per instruction — which keeps the texture addresser busy several times longer for the same
+// bytes: DESIGN.md 8b.)  The LDS operations of ONE wave execute in order, so its write -> read hand-offs through
+// the tile need no barrier.
 template <int NT2>
 __global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) {
   __shared__ __attribute__((aligned(16))) float W1s[2 * 2048];
   __shared__ __attribute__((aligned(16))) float W2s[NT2 * 2048];
   __shared__ __attribute__((aligned(16))) float B1s[64];
   __shared__ __attribute__((aligned(16))) float B2s[64];
+  __shared__ __attribute__((aligned(16))) float Stage[4][32 * LDW];
   load_matrix<2>(W1s, p.w1, 64, 64, 64);
   load_matrix<NT2>(W2s, p.w2, p.N2, 64, 64);
   if (threadIdx.x < 64) {
@@ -69,25 +79,48 @@ __global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) 
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
+  const int lr = lane >> 4, lp = lane & 15;            // full-line role: row 4j + lr of the tile, piece lp
+  float* stg = Stage[wid];
   const int n2p = (p.N2 + 3) & ~3;
   const int stride = gridDim.x * 4;
-  // the rows of tile t for this lane, clamped into the tensor (loads are unconditional, stores predicated)
-  auto load_rows = [&](int tile, f32x4* dst) {
-    int row = tile * 32 + i;
-    row = row < p.M ? row : p.M - 1;
-    const float* xr = p.x + (size_t)row * p.ld_x + 4 * h;
+  auto load_rows = [&](int tile, f32x4* dst) {         // clamped into the tensor (stores are predicated)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xr + 8 * q);
+    for (int j = 0; j < 8; ++j) {
+      int row = tile * 32 + 4 * j + lr;
+      row = row < p.M ? row : p.M - 1;
+      dst[j] = *reinterpret_cast<const f32x4*>(p.x + (size_t)row * p.ld_x + 4 * lp);
+    }
   };
-  f32x4 xb[8], xn[8];
+  // fragment layout (lane = pixel i, half h: channels 8q + 4h ..) -> full lines, through the wave's tile
+  auto store_rows = [&](const f32x4* frag, float* dst, int ld, int tile) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(stg + i * LDW + 8 * q + 4 * h) = frag[q];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (4 * j + lr) * LDW + 4 * lp);
+      const int row = tile * 32 + 4 * j + lr;
+      if (row < p.M) *reinterpret_cast<f32x4*>(dst + (size_t)row * ld + 4 * lp) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  f32x4 xl[8], xn[8];
   int tile = blockIdx.x * 4 + wid;
-  if (tile < p.ntiles) load_rows(tile, xb);
+  if (tile < p.ntiles) load_rows(tile, xl);
   for (; tile < p.ntiles; tile += stride) {
     // the weights stay in LDS (a hoisted copy would be 128 VGPRs): nothing moves across this point
     asm volatile("" ::: "memory");
     load_rows(tile + stride < p.ntiles ? tile + stride : tile, xn);      // next tile's rows, in flight during this one
     const int row = tile * 32 + i;
     const bool ok = row < p.M;
+    // full lines -> fragments
+    f32x4 xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(stg + (4 * j + lr) * LDW + 4 * lp) = xl[j];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) xb[q] = *reinterpret_cast<const f32x4*>(stg + i * LDW + 8 * q + 4 * h);
+    __builtin_amdgcn_wave_barrier();
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -116,11 +149,7 @@ __global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) 
           bits[t] |= (v > 0.f ? 1u : 0u) << (8 * g + 4 * h + j);
         }
       }
-    if (p.y1 != nullptr && ok) {
-      float* yr = p.y1 + (size_t)row * p.ld_y1 + 4 * h;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(yr + 8 * q) = y[q];
-    }
+    if (p.y1 != nullptr) store_rows(y, p.y1, p.ld_y1, tile);
     if (p.gate1 != nullptr) {
       const unsigned int w0 = bits[0] | (unsigned int)__shfl_xor((int)bits[0], 32, 64);
       const unsigned int w1 = bits[1] | (unsigned int)__shfl_xor((int)bits[1], 32, 64);
@@ -141,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) 
         for (int j = 0; j < 4; ++j) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], y[q][j], acc2[t], 0, 0, 0);
       }
     unsigned int bits2[NT2];
+    f32x4 y2[4 * NT2];
 #pragma unroll
     for (int t = 0; t < NT2; ++t) {
       bits2[t] = 0u;
@@ -156,9 +186,12 @@ __global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) 
           v[j] = u;
           bits2[t] |= (u > 0.f ? 1u : 0u) << (8 * g + 4 * h + j);
         }
-        if (ok && c0 < n2p) *reinterpret_cast<f32x4*>(p.y2 + (size_t)row * p.ld_y2 + c0) = v;
+        y2[4 * t + g] = v;
+        // the head's narrow last layer (a few channels per pixel) stores straight from the registers
+        if (NT2 == 1 && ok && c0 < n2p) *reinterpret_cast<f32x4*>(p.y2 + (size_t)row * p.ld_y2 + c0) = v;
       }
     }
+    if constexpr (NT2 == 2) store_rows(y2, p.y2, p.ld_y2, tile);
     if (p.gate2 != nullptr) {
       if constexpr (NT2 == 2) {
         const unsigned int w0 = bits2[0] | (unsigned int)__shfl_xor((int)bits2[0], 32, 64);
@@ -170,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void chain64_fwd_kernel(const ChainFwdP p) 
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) xb[q] = xn[q];
+    for (int q = 0; q < 8; ++q) xl[q] = xn[q];
   }
 }
 
@@ -186,14 +219,19 @@ struct ChainBwdP {
 };
 
 // KQ2: k-steps of 8 over layer 2's output channels — 8 (64 channels) or 1 (N2 <= 8, the head's last layer)
-// One block per CU (the two staged tiles + both weight matrices are 100 KB of LDS): the next tile's rows are
-// loaded into a second register set while the current tile computes, which is what a second block would give.
+// One block per CU: three staged tiles (dP2 then dP1 | y1 then dP0 | x) + both weight matrices are 134 KB of LDS.
+// Global memory is touched in full lines only (see the forward kernel): the rows a wave loads go to LDS as they
+// are, the fragments of the data-gradient products are read back from there — which the weight gradients need in
+// LDS anyway — and dP0 leaves through the y1 tile once the layer-2 weight gradient has read it.  The next tile's
+// rows are loaded right after the current tile's registers have been written to LDS: one register set, in flight
+// for the whole tile.
 template <int KQ2>
 __global__ __launch_bounds__(256, 1) void chain64_bwd_kernel(const ChainBwdP p) {
   __shared__ __attribute__((aligned(16))) float W2Ts[2 * 2048];
   __shared__ __attribute__((aligned(16))) float W1Ts[2 * 2048];
-  __shared__ __attribute__((aligned(16))) float bufA[128 * LDW];
-  __shared__ __attribute__((aligned(16))) float bufB[128 * LDW];
+  __shared__ __attribute__((aligned(16))) float bufA[128 * LDW];      // dP2 rows, later dP1 rows
+  __shared__ __attribute__((aligned(16))) float bufB[128 * LDW];      // y1 rows, later dP0 rows on their way out
+  __shared__ __attribute__((aligned(16))) float bufC[128 * LDW];      // x rows
   const int n2p = (p.N2 + 3) & ~3;
   load_matrix<2>(W2Ts, p.w2t, 64, n2p, n2p);
   load_matrix<2>(W1Ts, p.w1t, 64, 64, 64);
@@ -201,52 +239,82 @@ __global__ __launch_bounds__(256, 1) void chain64_bwd_kernel(const ChainBwdP p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int nt = wid >> 1, ct = wid & 1;          // this wave's 32x32 quarter of dW (rows n, columns c)
-  const bool w2_rows = 32 * nt < n2p;             // does the quarter hold rows of dW2 at all?
+  const int lr = lane >> 4, lp = lane & 15;       // full-line role: row 4j + lr of the wave's 32, piece lp
+  constexpr int NT2W = KQ2 == 8 ? 2 : 1;          // 32-row tiles of dW2 that hold rows at all
   const int bch = tid & 63;                       // bias sums: channel bch over this wave's 32 staged rows
-  f32x16 accW2, accW1;
+  // every wave accumulates the WHOLE of dW2 and dW1 over its own 32 pixels of a tile (128 accumulator registers:
+  // one wave per SIMD has them): no hand-off between waves, hence no block barrier anywhere in the tile loop
+  f32x16 accW2[NT2W][2], accW1[2][2];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { accW2[r] = 0.f; accW1[r] = 0.f; }
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        accW1[a][b][r] = 0.f;
+        if (a < NT2W) accW2[a][b][r] = 0.f;
+      }
   float bsum2 = 0.f, bsum1 = 0.f;
-  const int srow = wid * 32 + i;                  // this lane's staged row
-
+  const int srow = wid * 32 + i;                  // this lane's pixel among the block's 128
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto load_rows = [&](int tile, f32x4* g2d, f32x4* yd, f32x4* xd) {
-    int row = tile * 128 + srow;
-    row = row < p.M ? row : p.M - 1;
+
+  // rows of tile t in the full-line layout; rows beyond the tensor are loaded clamped and zeroed
+  // (dP2 of the head's narrow last layer is 16 or 32 bytes per pixel: a lane takes its pixel's half)
+  f32x4 l2[KQ2 == 8 ? 8 : 1], ly[8], lx[8];
+  auto load_rows = [&](int tile) {
+    if (KQ2 == 8) {
 #pragma unroll
-    for (int q = 0; q < KQ2; ++q) {
-      const int c0 = 8 * q + 4 * h;
-      g2d[q] = *reinterpret_cast<const f32x4*>(p.dp2 + (size_t)row * p.ld_dp2 + (c0 < n2p ? c0 : 0));
+      for (int j = 0; j < 8; ++j) {
+        const int row = tile * 128 + wid * 32 + 4 * j + lr;
+        const bool in = row < p.M;
+        l2[j] = *reinterpret_cast<const f32x4*>(p.dp2 + (size_t)(in ? row : p.M - 1) * p.ld_dp2 + 4 * lp);
+        if (!in) l2[j] = zero4;
+      }
+    } else {
+      const int row = tile * 128 + srow;
+      const bool in = row < p.M;
+      const bool have = 4 * h < n2p;                 // N2 <= 4: lanes h = 1 hold zeros; 5..8: channels 4-7
+      l2[0] = *reinterpret_cast<const f32x4*>(p.dp2 + (size_t)(in ? row : p.M - 1) * p.ld_dp2 + (have ? 4 * h : 0));
+      if (!in || !have) l2[0] = zero4;
     }
-    const float* yr = p.y1 + (size_t)row * p.ld_y1 + 4 * h;
-    const float* xr = p.x + (size_t)row * p.ld_x + 4 * h;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      yd[q] = *reinterpret_cast<const f32x4*>(yr + 8 * q);
-      xd[q] = *reinterpret_cast<const f32x4*>(xr + 8 * q);
+    for (int j = 0; j < 8; ++j) {
+      const int row = tile * 128 + wid * 32 + 4 * j + lr;
+      const bool in = row < p.M;
+      const size_t rc = (size_t)(in ? row : p.M - 1);
+      ly[j] = *reinterpret_cast<const f32x4*>(p.y1 + rc * p.ld_y1 + 4 * lp);
+      lx[j] = *reinterpret_cast<const f32x4*>(p.x + rc * p.ld_x + 4 * lp);
+      if (!in) { ly[j] = zero4; lx[j] = zero4; }
     }
   };
-  f32x4 g2[KQ2], yv[8], xv[8], g2n[KQ2], yn[8], xn[8];
+  float* rowsA = bufA + wid * 32 * LDW;
+  float* rowsB = bufB + wid * 32 * LDW;
+  float* rowsC = bufC + wid * 32 * LDW;
+
   int tile = blockIdx.x;
-  if (tile < p.ntiles) load_rows(tile, g2, yv, xv);
+  if (tile < p.ntiles) load_rows(tile);
   for (; tile < p.ntiles; tile += gridDim.x) {
-    load_rows(tile + (int)gridDim.x < p.ntiles ? tile + (int)gridDim.x : tile, g2n, yn, xn);
-    const int row = tile * 128 + srow;
-    const bool ok = row < p.M;
-    // rows beyond the tensor (clamped loads) and channels beyond N2 contribute nothing
+    // ---- the tile's rows into LDS (the previous tile's last readers passed the loop-end barrier)
+    if (KQ2 == 8) {
 #pragma unroll
-    for (int q = 0; q < KQ2; ++q)
-      if (!(ok && 8 * q + 4 * h < n2p)) g2[q] = zero4;
-    if (!ok) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { yv[q] = zero4; xv[q] = zero4; }
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(rowsA + (4 * j + lr) * LDW + 4 * lp) = l2[j];
+    } else {
+      // 8 columns: the pixel's 4 channels (lanes h = 0) and 4 zeros (lanes h = 1)
+      *reinterpret_cast<f32x4*>(rowsA + i * LDW + 4 * h) = l2[0];
     }
-    // ---- stage A: dP2 and y1 rows into LDS (the previous tile's phase-B reads ended at the loop-end barrier)
 #pragma unroll
-    for (int q = 0; q < KQ2; ++q) *reinterpret_cast<f32x4*>(bufA + srow * LDW + 8 * q + 4 * h) = g2[q];
+    for (int j = 0; j < 8; ++j) {
+      *reinterpret_cast<f32x4*>(rowsB + (4 * j + lr) * LDW + 4 * lp) = ly[j];
+      *reinterpret_cast<f32x4*>(rowsC + (4 * j + lr) * LDW + 4 * lp) = lx[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    load_rows(tile + (int)gridDim.x < p.ntiles ? tile + (int)gridDim.x : tile);     // in flight during this tile
+    // ---- this wave's fragments (its own rows: the wave's LDS operations execute in order)
+    f32x4 g2[KQ2], yv[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(bufB + srow * LDW + 8 * q + 4 * h) = yv[q];
+    for (int q = 0; q < KQ2; ++q) g2[q] = *reinterpret_cast<const f32x4*>(rowsA + i * LDW + 8 * q + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) yv[q] = *reinterpret_cast<const f32x4*>(rowsB + i * LDW + 8 * q + 4 * h);
     // ---- data gradient through layer 2: dP1^T = W2^T dP2^T, gated by y1 > 0
     f32x16 acc[2];
 #pragma unroll
@@ -268,28 +336,35 @@ __global__ __launch_bounds__(256, 1) void chain64_bwd_kernel(const ChainBwdP p) 
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) g1[4 * t + g][j] = yv[4 * t + g][j] > 0.f ? acc[t][4 * g + j] : 0.f;
-    __syncthreads();
-    // ---- weight gradient of layer 2: dW2[n][c] += sum_p dP2[p][n] y1[p][c], one 32x32 quarter per wave
-    if (w2_rows) {
-      const float* ap = bufA + h * LDW + 32 * nt + i;
-      const float* bp = bufB + h * LDW + 32 * ct + i;
-#pragma unroll 8
-      for (int s = 0; s < 64; ++s)
-        accW2 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * LDW], bp[2 * s * LDW], accW2, 0, 0, 0);
+    // ---- weight gradient of layer 2 over this wave's pixels: dW2[n][c] += sum_p dP2[p][n] y1[p][c]
+    {
+      const float* ap = rowsA + h * LDW + i;
+      const float* bp = rowsB + h * LDW + i;
+#pragma unroll 4
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float b0 = bp[2 * s2 * LDW], b1 = bp[2 * s2 * LDW + 32];
+#pragma unroll
+        for (int a = 0; a < NT2W; ++a) {
+          const float av = ap[2 * s2 * LDW + 32 * a];
+          accW2[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, accW2[a][0], 0, 0, 0);
+          accW2[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, accW2[a][1], 0, 0, 0);
+        }
+      }
     }
     if (p.db2 != nullptr && bch < n2p) {
-      const float* cp = bufA + wid * 32 * LDW + bch;
-      float s2 = 0.f;
+      const float* cp = rowsA + bch;
+      float t2 = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) s2 += cp[r * LDW];
-      bsum2 += s2;
+      for (int r = 0; r < 32; ++r) t2 += cp[r * LDW];
+      bsum2 += t2;
     }
     // ---- data gradient through layer 1: dP0^T = W1^T dP1^T, gated by x > 0 (x is the previous layer's ReLU output)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    f32x4 d0[8];
     if (p.dp0 != nullptr) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q)
 #pragma unroll
@@ -298,56 +373,75 @@ __global__ __launch_bounds__(256, 1) void chain64_bwd_kernel(const ChainBwdP p) 
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], g1[q][j], acc[t], 0, 0, 0);
         }
-      if (ok) {
-        float* orow = p.dp0 + (size_t)row * p.ld_dp0 + 4 * h;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4 v;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(rowsC + i * LDW + 32 * t + 8 * g + 4 * h);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-              v[j] = (!p.gate_x || xv[4 * t + g][j] > 0.f) ? acc[t][4 * g + j] : 0.f;
-            *reinterpret_cast<f32x4*>(orow + 32 * t + 8 * g) = v;
-          }
+          for (int j = 0; j < 4; ++j) d0[4 * t + g][j] = (!p.gate_x || xv[j] > 0.f) ? acc[t][4 * g + j] : 0.f;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- dP1 rows for the layer-1 weight gradient; dP0 out through the y1 tile, in full lines
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(rowsA + i * LDW + 8 * q + 4 * h) = g1[q];
+    if (p.dp0 != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(rowsB + i * LDW + 8 * q + 4 * h) = d0[q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rowsB + (4 * j + lr) * LDW + 4 * lp);
+        const int row = tile * 128 + wid * 32 + 4 * j + lr;
+        if (row < p.M) *reinterpret_cast<f32x4*>(p.dp0 + (size_t)row * p.ld_dp0 + 4 * lp) = v;
       }
     }
-    __syncthreads();                               // phase-A reads done
-    // ---- stage B: dP1 and x rows
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      *reinterpret_cast<f32x4*>(bufA + srow * LDW + 8 * q + 4 * h) = g1[q];
-      *reinterpret_cast<f32x4*>(bufB + srow * LDW + 8 * q + 4 * h) = xv[q];
-    }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     {
-      const float* ap = bufA + h * LDW + 32 * nt + i;
-      const float* bp = bufB + h * LDW + 32 * ct + i;
-#pragma unroll 8
-      for (int s = 0; s < 64; ++s)
-        accW1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s * LDW], bp[2 * s * LDW], accW1, 0, 0, 0);
+      const float* ap = rowsA + h * LDW + i;
+      const float* bp = rowsC + h * LDW + i;
+#pragma unroll 4
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const float b0 = bp[2 * s2 * LDW], b1 = bp[2 * s2 * LDW + 32];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float av = ap[2 * s2 * LDW + 32 * a];
+          accW1[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, accW1[a][0], 0, 0, 0);
+          accW1[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, accW1[a][1], 0, 0, 0);
+        }
+      }
     }
     if (p.db1 != nullptr) {
-      const float* cp = bufA + wid * 32 * LDW + bch;
-      float s1 = 0.f;
+      const float* cp = rowsA + bch;
+      float t1 = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) s1 += cp[r * LDW];
-      bsum1 += s1;
+      for (int r = 0; r < 32; ++r) t1 += cp[r * LDW];
+      bsum1 += t1;
     }
-    __syncthreads();                               // before the next tile's stage A
-#pragma unroll
-    for (int q = 0; q < KQ2; ++q) g2[q] = g2n[q];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { yv[q] = yn[q]; xv[q] = xn[q]; }
+    __builtin_amdgcn_wave_barrier();               // (the wave's own reads precede its next tile's writes in program order)
   }
 
-  // ---- flush: one atomic per weight-gradient element and block
+  // ---- flush: the four waves' sums meet in LDS (the x tile is free now), then one atomic per element and block
+  __syncthreads();
+  float* red = bufC;                               // [dW2 64 x 64 | dW1 64 x 64]
+  for (int k = tid; k < 2 * 4096; k += 256) red[k] = 0.f;
+  __syncthreads();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h;
-    const int c = 32 * ct + i;
-    if (n < n2p) atomicAdd(p.dw2 + (size_t)n * 64 + c, accW2[r]);
-    atomicAdd(p.dw1 + (size_t)n * 64 + c, accW1[r]);
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int c = 32 * b + i;
+        if (a < NT2W) atomicAdd(&red[n * 64 + c], accW2[a < NT2W ? a : 0][b][r]);
+        atomicAdd(&red[4096 + n * 64 + c], accW1[a][b][r]);
+      }
+  __syncthreads();
+  for (int k = tid; k < 4096; k += 256) {
+    if ((k >> 6) < n2p) atomicAdd(p.dw2 + k, red[k]);
+    atomicAdd(p.dw1 + k, red[4096 + k]);
   }
   if (p.db2 != nullptr && bch < p.N2) atomicAdd(p.db2 + bch, bsum2);
   if (p.db1 != nullptr) atomicAdd(p.db1 + bch, bsum1);

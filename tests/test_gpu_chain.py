@@ -33,7 +33,7 @@ def _bits(gate, M, C):
 
 
 @pytest.mark.parametrize("M,N2,relu2,ld_x", [(1000, 64, 1, 64), (128 * 7 + 5, 64, 1, 72), (33, 64, 0, 64),
-                                             (4099, 3, 0, 64), (257, 2, 0, 64), (128 * 40, 64, 1, 64)])
+                                             (4099, 3, 0, 64), (257, 2, 0, 64), (128 * 40, 64, 1, 64), (777, 7, 0, 68)])
 def test_chain_forward_and_backward_match_float64_autograd(M, N2, relu2, ld_x, device):
     torch.manual_seed(M + N2)
     n2p = (N2 + 3) // 4 * 4

@@ -405,7 +405,9 @@ def test_deterministic_mode_is_bit_reproducible(nd, device, monkeypatch):
     assert torch.equal(g1, g2) and torch.equal(p1, p2)
     l0, p0, _g0 = run(False)
     np.testing.assert_allclose(l1, l0, rtol=2e-4)
-    assert (p1 - p0).abs().max().item() < 2e-4          # ten Adam steps of 4e-5 move a weight by <= 4e-4
+    # (an element whose gradient is rounding noise moves by +-lr per Adam step in either mode: 2 x 10 x 4e-5 apart at most)
+    assert (p1 - p0).abs().max().item() < 1e-3
+    assert (p1 - p0).abs().mean().item() < 2e-5
 
 
 def test_ordered_column_sums_and_fixed_point_scatter_through_the_c_abi(device):
