@@ -407,7 +407,7 @@ def test_bucket_kernel_is_a_stable_sort_by_cell(nd, device):
     fs, cell_start, _origin, cell, (nx, ny, nz) = MS._bucket(torch.from_numpy(heap).to(device), bw)
     coords = np.floor((heap - heap.min(axis=0)) / cell).astype(np.int64)
     cid = coords[:, 0] + nx * coords[:, 1] + (nx * ny * coords[:, 2] if nd == 3 else 0)
-    assert np.bincount(cid).max() > 20000
+    assert np.bincount(cid).max() > 5000              # far beyond what one wavefront ranks
     np.testing.assert_array_equal(fs.cpu().numpy(), heap[np.argsort(cid, kind="stable")])
 
 
