@@ -38,6 +38,13 @@ class ClxSrc(Structure):
     ]
 
 
+class ClxPackJob(Structure):
+    """``clx_pack_job`` (include/clx.h)."""
+
+    _fields_ = [("w", c_void_p), ("wp", c_void_p), ("cout", c_int), ("cin", c_int), ("taps", c_int),
+                ("cin_pad", c_int), ("cout_pad", c_int), ("mode", c_int)]
+
+
 class ClxConvDesc(Structure):
     """``clx_conv_desc`` (include/clx.h)."""
 
@@ -96,6 +103,7 @@ PROTOTYPES = {
     "clx_chain64_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),
     "clx_chain64_bwd": (_I, [_P, _I, _I, _P, _I, _P, _I, _I, _LL, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "clx_pack_weights": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_pack_weights_batch": (_I, [_P, _I, _LL, _P]),
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),

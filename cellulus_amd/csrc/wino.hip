@@ -434,14 +434,14 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
 // mode FWD:   g = w[n][c][:, :]            rows n < rows_pad (cout_pad), cols c < cin_pad
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
 template <int MT, int R>
-__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
-                                   int cin, int rows, int cols, int kdt, int dgrad, long long total) {
+__device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, float* __restrict__ U, int cout, int cin,
+                                                 int rows, int cols, int kdt, int dgrad, long long total,
+                                                 long long first, long long step) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   // U[xi][row][dz][col]: the batched GEMM sees kdt "taps" along z (1 for 2-D layers)
   const long long plane = (long long)rows * kdt * cols;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
+  for (long long i = first; i < total; i += step) {
     const int col = (int)(i % cols);
     const long long q = i / cols;
     const int dz = (int)(q % kdt), row = (int)(q / kdt);
@@ -479,6 +479,47 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
         U[(r * A + qq) * plane + i] = (float)acc;
       }
   }
+}
+
+template <int MT, int R>
+__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
+                                   int cin, int rows, int cols, int kdt, int dgrad, long long total) {
+  wino_filter_body<MT, R>(w, U, cout, cin, rows, cols, kdt, dgrad, total,
+                          (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// every packing of a step in one launch: blockIdx.y = job (clx_pack_weights_batch)
+__global__ __launch_bounds__(256) void pack_batch_kernel(const clx_pack_job* __restrict__ jobs) {
+  const clx_pack_job j = jobs[blockIdx.y];
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+  if (j.mode == CLX_PACK_FWD || j.mode == CLX_PACK_DGRAD) {
+    const long long total = j.mode == CLX_PACK_FWD ? (long long)j.cout * j.taps * j.cin_pad
+                                                   : (long long)j.cin_pad * j.taps * j.cout_pad;
+    for (long long i = first; i < total; i += step) {
+      float v = 0.f;
+      if (j.mode == CLX_PACK_FWD) {
+        const int c = (int)(i % j.cin_pad);
+        const long long t = i / j.cin_pad;
+        const int tap = (int)(t % j.taps), n = (int)(t / j.taps);
+        if (c < j.cin) v = j.w[((long long)n * j.cin + c) * j.taps + tap];
+      } else {
+        const int n = (int)(i % j.cout_pad);
+        const long long t = i / j.cout_pad;
+        const int tap = (int)(t % j.taps), c = (int)(t / j.taps);
+        if (n < j.cout && c < j.cin) v = j.w[((long long)n * j.cin + c) * j.taps + (j.taps - 1 - tap)];
+      }
+      j.wp[i] = v;
+    }
+    return;
+  }
+  const bool four = j.mode == CLX_PACK_WINO4_FWD || j.mode == CLX_PACK_WINO4_DGRAD;
+  const int dgrad = (j.mode == CLX_PACK_WINO_DGRAD || j.mode == CLX_PACK_WINO4_DGRAD) ? 1 : 0;
+  const int ksize = (j.taps == 9 || j.taps == 27) ? 3 : 2, kd = (j.taps == 27 || j.taps == 8) ? ksize : 1;
+  const int rows = dgrad ? j.cin_pad : j.cout_pad, cols = dgrad ? j.cout_pad : j.cin_pad;
+  const long long total = (long long)rows * kd * cols;
+  if (ksize == 2) wino_filter_body<4, 2>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step);
+  else if (four) wino_filter_body<4, 3>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step);
+  else wino_filter_body<2, 3>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step);
 }
 
 // dw[n][c][R x R] = G^T dU G
@@ -691,6 +732,16 @@ int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int
   if (ksize == 2) wino_filter_kernel<4, 2><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
   else if (tile == 4) wino_filter_kernel<4, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
   else wino_filter_kernel<2, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
+  return CLX_OK;
+}
+
+extern "C" int clx_pack_weights_batch(const clx_pack_job* jobs, int njobs, long long max_total, clx_stream stream) {
+  CLX_REQUIRE(jobs != nullptr && njobs > 0 && njobs < 65536 && max_total > 0, "clx_pack_weights_batch: bad arguments");
+  CLX_REQUIRE(((uintptr_t)jobs & 7) == 0, "clx_pack_weights_batch: the job table must be 8-byte aligned");
+  long long gx = (max_total + 255) / 256;
+  if (gx > 512) gx = 512;                     // (the large jobs loop: 20 jobs x 512 blocks already cover the chip several times)
+  pack_batch_kernel<<<dim3((unsigned)gx, (unsigned)njobs), 256, 0, (hipStream_t)stream>>>(jobs);
+  CLX_CHECK_LAUNCH("clx_pack_weights_batch");
   return CLX_OK;
 }
 

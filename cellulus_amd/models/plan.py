@@ -952,6 +952,84 @@ class UNetPlan:
             _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(grads[2 * layer.param_index]), layer.cout, layer.cin,
                       1, pad4(layer.cout), layer.cin_pad, st)
 
+    def _pack_layer(self, layer, w, need_dgrad, st):
+        wv = w.detach().reshape(layer.cout, layer.cin, layer.taps)
+        if not wv.is_contiguous():
+            wv = wv.contiguous()
+        wv, cin_eff = self._expand_cin(layer, wv)
+        algo = self.algo[layer.name]
+        _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_fwd[layer.name]),
+                  layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
+                  WINO_PACK_FWD.get(algo["fwd"], 0), st)
+        if need_dgrad and layer.name in self.wpack_dgrad:
+            _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_dgrad[layer.name]),
+                      layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
+                      WINO_PACK_DGRAD.get(algo["dgrad"], 1), st)
+
+    def _pack_batched(self, params, need_dgrad, st):
+        """Every packing of the step in ONE launch (clx_pack_weights_batch): the job table — the arguments of
+        the ~40 clx_pack_weights calls — is built once per plan and lives on the device; it is rebuilt when a
+        parameter's storage moves.  The sub-pixel layers' weight split runs first (its outputs are sources of
+        jobs); layers whose weights need a gapped copy (odd channel counts in a concatenation) keep their calls."""
+        from .._clx import ClxPackJob
+
+        sig = (bool(need_dgrad),) + tuple(params[2 * layer.param_index].data_ptr() for layer in self.topo.convs)
+        cache = getattr(self, "_pack_table", None)
+        if cache is None or cache["sig"] != sig:
+            jobs, singles = [], []
+
+            def job(src, dst, cout, cin, taps, cin_pad, cout_pad, mode):
+                jobs.append(ClxPackJob(src.data_ptr(), dst.data_ptr(), cout, cin, taps, cin_pad, cout_pad, mode))
+                if mode in (0, 1):
+                    return (cout if mode == 0 else cin_pad) * taps * (cin_pad if mode == 0 else cout_pad)
+                rows, cols = (cin_pad, cout_pad) if mode in (3, 5) else (cout_pad, cin_pad)
+                return rows * (3 if taps == 27 else 2 if taps == 8 else 1) * cols
+
+            biggest = 1
+            for layer in self.topo.convs:
+                w = params[2 * layer.param_index]
+                if layer.name in self.subpixel:
+                    sp = self.subpixel[layer.name]
+                    PN = sp["P"] * sp["N"]
+                    biggest = max(biggest, job(sp["w_skip"], sp["wp_skip_fwd"], layer.cout, sp["C0"], layer.taps,
+                                               sp["C0p"], sp["N"], 4 if sp["wino_skip"] else 0),
+                                  job(sp["weff"], sp["wp_z_fwd"], PN, sp["C1"], sp["ztaps"], sp["C1p"], PN,
+                                      4 if sp["wino"] else 0))
+                    if need_dgrad:
+                        biggest = max(biggest, job(sp["w_skip"], sp["wp_skip_dgrad"], layer.cout, sp["C0"], layer.taps,
+                                                   sp["C0p"], sp["N"], 5 if sp["wino_skip_dgrad"] else 1),
+                                      job(sp["weff"], sp["wp_z_dgrad"], PN, sp["C1"], sp["ztaps"], sp["C1p"], PN,
+                                          5 if sp["wino"] else 1))
+                    continue
+                gapped = len(layer.sources) > 1 and not all(s.channels % 4 == 0 for s in layer.sources[:-1])
+                if gapped or not w.is_contiguous():
+                    singles.append(layer)
+                    continue
+                algo = self.algo[layer.name]
+                biggest = max(biggest, job(w, self.wpack_fwd[layer.name], layer.cout, layer.cin, layer.taps,
+                                           layer.cin_pad, pad4(layer.cout), WINO_PACK_FWD.get(algo["fwd"], 0)))
+                if need_dgrad and layer.name in self.wpack_dgrad:
+                    biggest = max(biggest, job(w, self.wpack_dgrad[layer.name], layer.cout, layer.cin, layer.taps,
+                                               layer.cin_pad, pad4(layer.cout), WINO_PACK_DGRAD.get(algo["dgrad"], 1)))
+            table = None
+            if jobs:
+                arr = (ClxPackJob * len(jobs))(*jobs)
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                table = host.to(self.device)
+            cache = self._pack_table = dict(sig=sig, table=table, njobs=len(jobs), biggest=int(biggest), singles=singles)
+        for layer in self.topo.convs:
+            if layer.name in self.subpixel:
+                sp = self.subpixel[layer.name]
+                wv = params[2 * layer.param_index].detach()
+                if not wv.is_contiguous():
+                    wv = wv.contiguous()
+                _clx.call("clx_subpixel_split_weights", _clx.ptr(wv), _clx.ptr(sp["w_skip"]), _clx.ptr(sp["weff"]),
+                          layer.cout, layer.cin, sp["C0"], sp["N"], *layer.kernel, *sp["fac"], st)
+        if cache["table"] is not None:
+            _clx.call("clx_pack_weights_batch", _clx.ptr(cache["table"]), cache["njobs"], cache["biggest"], st)
+        for layer in cache["singles"]:
+            self._pack_layer(layer, params[2 * layer.param_index], need_dgrad, st)
+
     def pack_weights(self, params, version, need_dgrad):
         """(Re)pack weights when the parameters changed (version = tuple of tensor versions)."""
         if need_dgrad and not self._bwd_ready:
@@ -961,23 +1039,16 @@ class UNetPlan:
                 (self._packed_version[1] or not need_dgrad):
             return
         st = _clx.stream_ptr(self.device)
+        if os.environ.get("CLX_PACK_BATCH", "1") != "0":
+            self._pack_batched(params, need_dgrad, st)
+            self._packed_version = key
+            return
         for layer in self.topo.convs:
             w = params[2 * layer.param_index]
             if layer.name in self.subpixel:
                 self._sp_pack(layer, self.subpixel[layer.name], w, need_dgrad, st)
                 continue
-            wv = w.detach().reshape(layer.cout, layer.cin, layer.taps)
-            if not wv.is_contiguous():
-                wv = wv.contiguous()
-            wv, cin_eff = self._expand_cin(layer, wv)
-            algo = self.algo[layer.name]
-            _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_fwd[layer.name]),
-                      layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
-                      WINO_PACK_FWD.get(algo["fwd"], 0), st)
-            if need_dgrad and layer.name in self.wpack_dgrad:
-                _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_dgrad[layer.name]),
-                          layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
-                          WINO_PACK_DGRAD.get(algo["dgrad"], 1), st)
+            self._pack_layer(layer, w, need_dgrad, st)
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward

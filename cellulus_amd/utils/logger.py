@@ -2,8 +2,12 @@
 ``<title>.png``; cellulus/utils/logger.py:7-35) but appends instead of
 rewriting the whole history every iteration, and draws the plot only every
 ``plot_every`` calls: at GPU step rates the reference's per-iteration
-CSV + PNG rewrite would dominate the step."""
+CSV + PNG rewrite would dominate the step.  The PNG is rendered by a
+background thread from a snapshot of the data (matplotlib needs 0.1-0.2 s per figure: in
+the training thread that is four steps at the benchmark configuration; the thread mostly
+waits for the device with the GIL released, so the render overlaps)."""
 
+import threading
 from typing import Dict, List
 
 
@@ -16,6 +20,8 @@ class Logger:
         self._written = 0
         self._plots = 0
         self._window = None
+        self._plot_thread = None
+        self._plot_lock = threading.Lock()
         print(f"Created logger with keys: {keys}")
 
     def add(self, key, value):
@@ -40,18 +46,31 @@ class Logger:
         self._plots += 1
         if not force and self._plots % self.plot_every != 1 and self.plot_every != 1:
             return
+        worker = getattr(self, "_plot_thread", None)
+        if worker is not None and worker.is_alive():
+            if not force:
+                return                      # a render is still running: the next due plot shows these points too
+            worker.join()
+        snapshot = {k: list(v) for k, v in self.data.items()}
+        if force:
+            self._render(snapshot)
+            return
+        self._plot_thread = threading.Thread(target=self._render, args=(snapshot,), name="clx-plot", daemon=True)
+        self._plot_thread.start()
+
+    def _render(self, data):
         import matplotlib
 
         matplotlib.use("Agg", force=False)
         import matplotlib.pyplot as plt
 
-        if self._window is None:
-            self._window = plt.subplots()
-        fig, ax = self._window
-        ax.cla()
-        for key in self.data:
-            data = self.data[key]
-            ax.plot(range(len(data)), data, marker=".")
-        ax.set_xlabel("Iteration")
-        ax.set_ylabel(self.title)
-        fig.savefig(self.title + ".png")
+        with self._plot_lock:
+            if self._window is None:
+                self._window = plt.subplots()
+            fig, ax = self._window
+            ax.cla()
+            for key, values in data.items():
+                ax.plot(range(len(values)), values, marker=".")
+            ax.set_xlabel("Iteration")
+            ax.set_ylabel(self.title)
+            fig.savefig(self.title + ".png")

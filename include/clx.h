@@ -229,6 +229,16 @@ enum clx_pack_mode {
  * DGRAD: wp is [cin_pad][taps][cout_pad] with the taps reversed. */
 int clx_pack_weights(const float* w, float* wp, int cout, int cin, int taps,
                      int cin_pad, int cout_pad, int mode, clx_stream stream);
+/* All the weight packings of a step in ONE launch (a step packs ~20 small layers, forward and data-gradient
+ * form each: as separate launches they are latency-bound).  `jobs`: DEVICE array of njobs descriptors, each
+ * exactly the arguments of one clx_pack_weights call; max_total: the largest element count of a job's packed
+ * output (sizes the grid).  Same results as the single calls. */
+typedef struct clx_pack_job {
+  const float* w;
+  float* wp;
+  int cout, cin, taps, cin_pad, cout_pad, mode;
+} clx_pack_job;
+int clx_pack_weights_batch(const clx_pack_job* jobs, int njobs, long long max_total, clx_stream stream);
 /* dw[n][c][tap] = dwpack[tap][n][c] for n < cout, c < cin  (wgrad output ->
  * torch layout). dwpack is [taps][rows][cin_pad], rows >= cout. */
 int clx_unpack_wgrad(const float* dwpack, float* dw, int cout, int cin, int taps,
