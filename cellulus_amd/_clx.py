@@ -83,6 +83,7 @@ class ClxConvDesc(Structure):
         ("mask_bits", c_void_p),
         ("ld_mask_bits", c_int),
         ("det_turns", c_void_p),
+        ("adjoint", c_int),
     ]
 
 

@@ -161,6 +161,12 @@ extern "C" int clx_pack_weights(const float* w, float* wp, int cout, int cin, in
   CLX_REQUIRE(cout > 0 && cin > 0 && taps > 0, "clx_pack_weights: bad extents");
   CLX_REQUIRE(cin_pad >= cin && cout_pad >= cout && cin_pad % 4 == 0 && cout_pad % 4 == 0,
               "clx_pack_weights: padded extents must be >= real and multiples of 4");
+  if (mode == CLX_PACK_WINO4_ADJOINT) {
+    CLX_REQUIRE(taps == 9, "clx_pack_weights: the adjoint form exists for 2-D 3x3 kernels");
+    clx_wino_pack(w, wp, cout, cin, cin_pad, cout_pad, 2, 4, 3, 1, (hipStream_t)stream);
+    CLX_CHECK_LAUNCH("clx_pack_weights(winograd adjoint)");
+    return CLX_OK;
+  }
   if (mode == CLX_PACK_WINO_FWD || mode == CLX_PACK_WINO_DGRAD || mode == CLX_PACK_WINO4_FWD ||
       mode == CLX_PACK_WINO4_DGRAD) {
     const bool four = mode == CLX_PACK_WINO4_FWD || mode == CLX_PACK_WINO4_DGRAD;

@@ -244,6 +244,126 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
   }
 }
 
+// ADJOINT data gradient of F(4x4, 3x3): the forward is Y = A^T [U (B^T d B)] A per tile, so
+//   d(input patch) = B [U^T (A dY A^T)] B^T        (A x A = 6 x 6, one per tile)
+// and dX is the overlap-add of the patches (stride MT = 4, overlap 2).  P[xi][t][c] = (U^T Mdy)[xi] comes from the
+// batched GEMM; this kernel is output-stationary: one thread per 4 x 4 block of dX and 4 channels gathers the
+// (up to four) tiles whose patches cover it — tile (by, bx) with patch rows / columns 0-3, its upper / left
+// neighbours with rows / columns 4-5 — so nothing is added in memory.  Epilogue: the ReLU gate of the tensor
+// whose gradient this is (float mask or bits).
+__global__ __launch_bounds__(256) void wino_adjoint_output_kernel(const float* __restrict__ Pm, int C4, int Bn, int th,
+                                                                  int tw, int IH, int IW, const float* __restrict__ mask,
+                                                                  int ld_mask, const unsigned int* __restrict__ mask_bits,
+                                                                  int ld_mask_bits, float* __restrict__ out, int ld_out,
+                                                                  int Creal, long long total) {
+  using W = WT<4, 3>;
+  constexpr int A = 6;
+  const int C = C4 * 4;
+  const int bh = (IH + 3) / 4, bw = (IW + 3) / 4;
+  const long long plane = (long long)Bn * th * tw * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long t = i / C4;
+    const int bx = (int)(t % bw);
+    const long long q = t / bw;
+    const int by = (int)(q % bh);
+    const int b = (int)(q / bh);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[a][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int uy = 0; uy < 2; ++uy) {
+      const int ty = by - uy;
+      if (ty < 0 || ty >= th) continue;
+#pragma unroll
+      for (int ux = 0; ux < 2; ++ux) {
+        const int tx = bx - ux;
+        if (tx < 0 || tx >= tw) continue;
+        const float* src = Pm + (((long long)b * th + ty) * tw + tx) * C + c;
+        // patch rows a0 .. a0 + na - 1 and columns b0 .. of this tile land on the block: rows 0-3 of its own tile,
+        // rows 4-5 of the tile above (block rows 0-1); the same for columns
+        const int a0 = uy ? 4 : 0, na = uy ? 2 : 4, b0 = ux ? 4 : 0, nb = ux ? 2 : 4;
+        // columns first: w[a][s] = sum_r B[a][r] P[r][s] = sum_r BT[r][a] P[r][s]
+        f32x4 w[4][A];
+#pragma unroll
+        for (int s2 = 0; s2 < A; ++s2) {
+          f32x4 pcol[A];
+#pragma unroll
+          for (int r = 0; r < A; ++r) pcol[r] = ld4(src + (r * A + s2) * plane);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a < na) {
+              bool first = true;
+              if (uy) {
+#pragma unroll
+                for (int r = 0; r < A; ++r) axpy(v, first, W::BT[r][(a & 1) + 4], pcol[r]);
+              } else {
+#pragma unroll
+                for (int r = 0; r < A; ++r) axpy(v, first, W::BT[r][a], pcol[r]);
+              }
+            }
+            w[a][s2] = v;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          if (a >= na) continue;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (e >= nb) continue;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            bool first = true;
+            if (ux) {
+#pragma unroll
+              for (int s2 = 0; s2 < A; ++s2) axpy(v, first, W::BT[s2][(e & 1) + 4], w[a][s2]);
+            } else {
+#pragma unroll
+              for (int s2 = 0; s2 < A; ++s2) axpy(v, first, W::BT[s2][e], w[a][s2]);
+            }
+            acc[a][e] += v;
+          }
+        }
+        (void)a0; (void)b0;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int y = 4 * by + a;
+      if (y >= IH) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = 4 * bx + e;
+        if (x >= IW) continue;
+        f32x4 v = acc[a][e];
+        const long long m = ((long long)b * IH + y) * IW + x;
+        if (mask_bits) {
+          const unsigned int wbits = mask_bits[m * ld_mask_bits + (c >> 5)] >> (c & 31);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = ((wbits >> k) & 1u) ? v[k] : 0.f;
+        }
+        if (c + 3 < Creal) {
+          if (mask) {
+            const f32x4 mk = ld4(mask + m * ld_mask + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (mk[k] > 0.f) ? v[k] : 0.f;
+          }
+          st4(out + m * ld_out + c, v);
+        } else {
+          for (int k = 0; k < 4 && c + k < Creal; ++k) {
+            float xv = v[k];
+            if (mask) xv = (mask[m * ld_mask + c + k] > 0.f) ? xv : 0.f;
+            out[m * ld_out + c + k] = xv;
+          }
+        }
+      }
+    }
+  }
+}
+
 // Mdy[xi][t][n] = (A dy A^T)[xi] with A = (A^T)^T (A x MT); dbias[n] += sum of dy
 // (block-private LDS accumulator, then one global atomic per channel per block)
 template <int MT, int R>
@@ -433,6 +553,7 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
 // U[xi][n][c] = (G g G^T)[xi], computed in double
 // mode FWD:   g = w[n][c][:, :]            rows n < rows_pad (cout_pad), cols c < cin_pad
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
+// mode 2 (adjoint form): g = w[n][c] as it is, transposed roles: U[xi][c][n] = the forward transform, transposed
 template <int MT, int R>
 __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, float* __restrict__ U, int cout, int cin,
                                                  int rows, int cols, int kdt, int dgrad, long long total,
@@ -445,8 +566,9 @@ __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, fl
     const int col = (int)(i % cols);
     const long long q = i / cols;
     const int dz = (int)(q % kdt), row = (int)(q / kdt);
+    const bool flip = dgrad == 1;            // dgrad 2 (adjoint form): transposed roles, filter as it is
     const int n = dgrad ? col : row, c = dgrad ? row : col;
-    const int wz = dgrad ? kdt - 1 - dz : dz;
+    const int wz = flip ? kdt - 1 - dz : dz;
     double g[R][R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -454,7 +576,7 @@ __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, fl
       for (int s2 = 0; s2 < R; ++s2) {
         double v = 0.0;
         if (n < cout && c < cin) {
-          const int rr = dgrad ? R - 1 - r : r, ss = dgrad ? R - 1 - s2 : s2;
+          const int rr = flip ? R - 1 - r : r, ss = flip ? R - 1 - s2 : s2;
           v = (double)w[(((long long)n * cin + c) * kdt + wz) * (R * R) + rr * R + ss];
         }
         g[r][s2] = v;
@@ -512,8 +634,9 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const clx_pack_job* __r
     }
     return;
   }
-  const bool four = j.mode == CLX_PACK_WINO4_FWD || j.mode == CLX_PACK_WINO4_DGRAD;
-  const int dgrad = (j.mode == CLX_PACK_WINO_DGRAD || j.mode == CLX_PACK_WINO4_DGRAD) ? 1 : 0;
+  const bool four = j.mode == CLX_PACK_WINO4_FWD || j.mode == CLX_PACK_WINO4_DGRAD || j.mode == CLX_PACK_WINO4_ADJOINT;
+  const int dgrad = (j.mode == CLX_PACK_WINO_DGRAD || j.mode == CLX_PACK_WINO4_DGRAD) ? 1
+                    : j.mode == CLX_PACK_WINO4_ADJOINT                               ? 2 : 0;
   const int ksize = (j.taps == 9 || j.taps == 27) ? 3 : 2, kd = (j.taps == 27 || j.taps == 8) ? ksize : 1;
   const int rows = dgrad ? j.cin_pad : j.cout_pad, cols = dgrad ? j.cout_pad : j.cin_pad;
   const long long total = (long long)rows * kd * cols;
@@ -699,7 +822,49 @@ extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
   return (size_t)(a * a * (gin.T * C + gout.T * N)) * sizeof(float);
 }
 
+// the adjoint data gradient (clx_conv_desc.adjoint): d is the data-gradient descriptor — source dY (C = the layer's
+// padded output channels, extent = the forward output), padding 2, N = the layer's padded input channels
+static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
+  CLX_REQUIRE(d->algo == CLX_ALGO_WINOGRAD4 && d->KD == 1 && d->KH == 3 && d->KW == 3 && d->PH == 2 && d->PW == 2 &&
+                  d->ID == 1 && d->nsrc == 1,
+              "clx_conv_fwd(adjoint): a 2-D 3x3 layer in its data-gradient form (padding 2) with CLX_ALGO_WINOGRAD4 only");
+  CLX_REQUIRE(d->bias == nullptr && !d->relu && !d->accumulate && d->gate_out == nullptr,
+              "clx_conv_fwd(adjoint): only the ReLU-gate epilogues (mask / mask_bits) exist");
+  CLX_REQUIRE(d->N % 4 == 0 && d->src[0].C % 4 == 0, "clx_conv_fwd(adjoint): channel counts must be multiples of 4");
+  const int OHf = d->IH, OWf = d->IW;                  // the forward layer's output extent = extent of dY
+  const int th = (OHf + 3) / 4, tw = (OWf + 3) / 4;
+  const long long T = (long long)d->B * th * tw;
+  const int Nf = d->src[0].C, Cp = d->N;
+  const size_t need = (size_t)36 * T * (Cp + Nf) * sizeof(float);
+  CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0,
+              "clx_conv_fwd(adjoint): needs the %zu workspace bytes of the layer's weight gradient (%zu given)", need,
+              d->workspace_bytes);
+  CLX_REQUIRE(d->mask_bits == nullptr || Cp % 32 == 0, "clx_conv_fwd(adjoint): mask_bits needs whole words per pixel");
+  float* P = (float*)d->workspace;                     // [36][T][Cp], over what was the weight gradient's V region
+  float* Mdy = P + (size_t)36 * T * Cp;                // [36][T][Nf]: left there by clx_conv_wgrad
+  clx_conv_desc gd = {};
+  gd.nsrc = 1;
+  gd.src[0].ptr = Mdy; gd.src[0].C = Nf; gd.src[0].ld = Nf;
+  gd.src[0].D = 1; gd.src[0].H = 1; gd.src[0].W = th * tw;
+  gd.src[0].fz = gd.src[0].fy = gd.src[0].fx = 1;
+  gd.B = d->B; gd.ID = 1; gd.IH = 1; gd.IW = th * tw;
+  gd.KD = gd.KH = gd.KW = 1;
+  gd.N = Cp; gd.wpack = d->wpack; gd.out = P; gd.ld_out = Cp;
+  gd.precision = d->precision;
+  const int rc = clx_igemm_launch(&gd, 36, (long long)th * tw * d->B * Nf, (long long)Cp * Nf,
+                                  (long long)th * tw * d->B * Cp, st);
+  if (rc) return rc;
+  const int IH = OHf + 2, IW = OWf + 2;
+  const long long total = (long long)d->B * ((IH + 3) / 4) * ((IW + 3) / 4) * (Cp / 4);
+  wino_adjoint_output_kernel<<<grid_for(total, 256), 256, 0, st>>>(P, Cp / 4, d->B, th, tw, IH, IW, d->mask, d->ld_mask,
+                                                                   d->mask_bits, d->ld_mask_bits, d->out, d->ld_out, Cp,
+                                                                   total);
+  CLX_CHECK_LAUNCH("clx_conv_fwd(winograd adjoint)");
+  return CLX_OK;
+}
+
 int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st) {
+  if (d->adjoint) return wino_adjoint(d, st);
   CLX_REQUIRE(applicable(d), "clx_conv_fwd: Winograd does not apply to this geometry");
   const size_t need = clx_conv_workspace_bytes(d, CLX_PASS_FWD);
   CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && need > 0,

@@ -463,6 +463,17 @@ class UNetPlan:
                     n = self.B * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
                     self.gate[layer.out] = torch.zeros((n, pad4(layer.cout) // 32), dtype=torch.int32,
                                                        device=self.device)
+        # 2-D F(4x4, 3x3) layers whose weight AND data gradient are Winograd: the data gradient in its ADJOINT form,
+        # dX = sum over tiles of B [U^T (A dY A^T)] B^T — its operand A dY A^T is what the weight gradient has just left
+        # in the workspace, so dY is transformed once and the (K-1)-padded input transform of dY is never written
+        # (clx_conv_desc.adjoint; CLX_WINO_ADJOINT=0 = the two-transform form)
+        self.adjoint = set()
+        if os.environ.get("CLX_WINO_ADJOINT", "1") != "0":
+            for layer in t.convs:
+                a = self.algo[layer.name]
+                if (a["wgrad"] == 2 and a["dgrad"] == 2 and tuple(layer.kernel) == (1, 3, 3) and layer.param_index > 0
+                        and layer.name not in self.subpixel and len(layer.sources) == 1):
+                    self.adjoint.add(layer.name)
         # a Winograd layer's weight gradient and data gradient both transform dY: one pass produces both
         # (clx_conv_desc.dy_vcache); the buffer is shared by all layers (written and consumed back to back)
         self.dycache = None
@@ -475,7 +486,7 @@ class UNetPlan:
 
             for layer in t.convs:
                 a = self.algo[layer.name]
-                if a["wgrad"] and a["wgrad"] == a["dgrad"] and layer.name not in self.subpixel:
+                if a["wgrad"] and a["wgrad"] == a["dgrad"] and layer.name not in self.subpixel and layer.name not in self.adjoint:
                     need = max(need, dual_floats(a["wgrad"], layer.out_shape, 3, pad4(layer.cout)))
             for name, sp in self.subpixel.items():
                 if sp["wino"]:
@@ -964,7 +975,7 @@ class UNetPlan:
         if need_dgrad and layer.name in self.wpack_dgrad:
             _clx.call("clx_pack_weights", _clx.ptr(wv), _clx.ptr(self.wpack_dgrad[layer.name]),
                       layer.cout, cin_eff, layer.taps, layer.cin_pad, pad4(layer.cout),
-                      WINO_PACK_DGRAD.get(algo["dgrad"], 1), st)
+                      6 if layer.name in self.adjoint else WINO_PACK_DGRAD.get(algo["dgrad"], 1), st)
 
     def _pack_batched(self, params, need_dgrad, st):
         """Every packing of the step in ONE launch (clx_pack_weights_batch): the job table — the arguments of
@@ -982,7 +993,7 @@ class UNetPlan:
                 jobs.append(ClxPackJob(src.data_ptr(), dst.data_ptr(), cout, cin, taps, cin_pad, cout_pad, mode))
                 if mode in (0, 1):
                     return (cout if mode == 0 else cin_pad) * taps * (cin_pad if mode == 0 else cout_pad)
-                rows, cols = (cin_pad, cout_pad) if mode in (3, 5) else (cout_pad, cin_pad)
+                rows, cols = (cin_pad, cout_pad) if mode in (3, 5, 6) else (cout_pad, cin_pad)
                 return rows * (3 if taps == 27 else 2 if taps == 8 else 1) * cols
 
             biggest = 1
@@ -1010,7 +1021,8 @@ class UNetPlan:
                                            layer.cin_pad, pad4(layer.cout), WINO_PACK_FWD.get(algo["fwd"], 0)))
                 if need_dgrad and layer.name in self.wpack_dgrad:
                     biggest = max(biggest, job(w, self.wpack_dgrad[layer.name], layer.cout, layer.cin, layer.taps,
-                                               layer.cin_pad, pad4(layer.cout), WINO_PACK_DGRAD.get(algo["dgrad"], 1)))
+                                               layer.cin_pad, pad4(layer.cout),
+                                               6 if layer.name in self.adjoint else WINO_PACK_DGRAD.get(algo["dgrad"], 1)))
             table = None
             if jobs:
                 arr = (ClxPackJob * len(jobs))(*jobs)
@@ -1157,8 +1169,9 @@ class UNetPlan:
             wino_w = self.algo[layer.name]["wgrad"]
             wtaps = wino_taps(wino_w, layer.kernel) if wino_w else layer.taps
             dwp = self.dwpack[off:off + wtaps * pad4(layer.cout) * layer.cin_pad]
+            adjoint = layer.name in self.adjoint
             dual = (self.dycache is not None and wino_w and layer.param_index > 0
-                    and self.algo[layer.name]["dgrad"] == wino_w)
+                    and self.algo[layer.name]["dgrad"] == wino_w and not adjoint)
             if wino_w:
                 self._use_workspace(d, wino_w)
                 if layer.name in self.vcache and layer.name in self._vcache_fresh:
@@ -1189,7 +1202,9 @@ class UNetPlan:
             dd.wpack = self.wpack_dgrad[layer.name].data_ptr()
             if self.algo[layer.name]["dgrad"]:
                 self._use_workspace(dd, self.algo[layer.name]["dgrad"])
-                if dual:                       # V of dY was written by the weight-gradient call above
+                if adjoint:                    # A dY A^T was left in the workspace by the weight-gradient call above
+                    dd.adjoint = 1
+                elif dual:                     # V of dY was written by the weight-gradient call above
                     dd.vcache = self.dycache.data_ptr()
                     dd.vcache_valid = 1
             if len(layer.sources) == 2:
