@@ -162,8 +162,8 @@ extern "C" int clx_pack_weights(const float* w, float* wp, int cout, int cin, in
   CLX_REQUIRE(cin_pad >= cin && cout_pad >= cout && cin_pad % 4 == 0 && cout_pad % 4 == 0,
               "clx_pack_weights: padded extents must be >= real and multiples of 4");
   if (mode == CLX_PACK_WINO4_ADJOINT) {
-    CLX_REQUIRE(taps == 9, "clx_pack_weights: the adjoint form exists for 2-D 3x3 kernels");
-    clx_wino_pack(w, wp, cout, cin, cin_pad, cout_pad, 2, 4, 3, 1, (hipStream_t)stream);
+    CLX_REQUIRE(taps == 9 || taps == 27, "clx_pack_weights: the adjoint form exists for 3x3 and 3x3x3 kernels");
+    clx_wino_pack(w, wp, cout, cin, cin_pad, cout_pad, 2, 4, 3, taps == 27 ? 3 : 1, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_pack_weights(winograd adjoint)");
     return CLX_OK;
   }

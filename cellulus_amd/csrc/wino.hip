@@ -566,9 +566,12 @@ __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, fl
     const int col = (int)(i % cols);
     const long long q = i / cols;
     const int dz = (int)(q % kdt), row = (int)(q / kdt);
-    const bool flip = dgrad == 1;            // dgrad 2 (adjoint form): transposed roles, filter as it is
+    // dgrad 1: the flipped filter (data gradient as a convolution); dgrad 2 (adjoint form): transposed roles and
+    // reversed z taps — the z taps stay an ordinary contraction, i.e. a transposed convolution along z — but the
+    // (y, x) filter as it is: its transform is the forward's, used transposed
+    const bool flip = dgrad == 1;
     const int n = dgrad ? col : row, c = dgrad ? row : col;
-    const int wz = flip ? kdt - 1 - dz : dz;
+    const int wz = dgrad ? kdt - 1 - dz : dz;
     double g[R][R];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -825,40 +828,42 @@ extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
 // the adjoint data gradient (clx_conv_desc.adjoint): d is the data-gradient descriptor — source dY (C = the layer's
 // padded output channels, extent = the forward output), padding 2, N = the layer's padded input channels
 static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
-  CLX_REQUIRE(d->algo == CLX_ALGO_WINOGRAD4 && d->KD == 1 && d->KH == 3 && d->KW == 3 && d->PH == 2 && d->PW == 2 &&
-                  d->ID == 1 && d->nsrc == 1,
-              "clx_conv_fwd(adjoint): a 2-D 3x3 layer in its data-gradient form (padding 2) with CLX_ALGO_WINOGRAD4 only");
+  CLX_REQUIRE(d->algo == CLX_ALGO_WINOGRAD4 && d->KH == 3 && d->KW == 3 && d->PH == 2 && d->PW == 2 && d->nsrc == 1 &&
+                  ((d->KD == 1 && d->ID == 1 && d->PD == 0) || (d->KD == 3 && d->PD == 2)),
+              "clx_conv_fwd(adjoint): a 3x3 (2-D) or 3x3x3 layer in its data-gradient form (padding 2) with "
+              "CLX_ALGO_WINOGRAD4 only");
   CLX_REQUIRE(d->bias == nullptr && !d->relu && !d->accumulate && d->gate_out == nullptr,
               "clx_conv_fwd(adjoint): only the ReLU-gate epilogues (mask / mask_bits) exist");
   CLX_REQUIRE(d->N % 4 == 0 && d->src[0].C % 4 == 0, "clx_conv_fwd(adjoint): channel counts must be multiples of 4");
   const int OHf = d->IH, OWf = d->IW;                  // the forward layer's output extent = extent of dY
   const int th = (OHf + 3) / 4, tw = (OWf + 3) / 4;
-  const long long T = (long long)d->B * th * tw;
+  const int planes_dy = d->ID, planes_dx = d->ID + 2 * d->PD - (d->KD - 1);      // z planes of dY / of dX
+  const long long Tdy = (long long)d->B * planes_dy * th * tw, Tdx = (long long)d->B * planes_dx * th * tw;
   const int Nf = d->src[0].C, Cp = d->N;
-  const size_t need = (size_t)36 * T * (Cp + Nf) * sizeof(float);
+  const size_t need = (size_t)36 * (Tdx * Cp + Tdy * Nf) * sizeof(float);
   CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0,
               "clx_conv_fwd(adjoint): needs the %zu workspace bytes of the layer's weight gradient (%zu given)", need,
               d->workspace_bytes);
   CLX_REQUIRE(d->mask_bits == nullptr || Cp % 32 == 0, "clx_conv_fwd(adjoint): mask_bits needs whole words per pixel");
-  float* P = (float*)d->workspace;                     // [36][T][Cp], over what was the weight gradient's V region
-  float* Mdy = P + (size_t)36 * T * Cp;                // [36][T][Nf]: left there by clx_conv_wgrad
+  float* P = (float*)d->workspace;                     // [36][Tdx][Cp], over what was the weight gradient's V region
+  float* Mdy = P + (size_t)36 * Tdx * Cp;              // [36][Tdy][Nf]: left there by clx_conv_wgrad
+  // the batched product as a (KD, 1, 1) transposed convolution along z over the tiles
   clx_conv_desc gd = {};
   gd.nsrc = 1;
   gd.src[0].ptr = Mdy; gd.src[0].C = Nf; gd.src[0].ld = Nf;
-  gd.src[0].D = 1; gd.src[0].H = 1; gd.src[0].W = th * tw;
+  gd.src[0].D = planes_dy; gd.src[0].H = 1; gd.src[0].W = th * tw;
   gd.src[0].fz = gd.src[0].fy = gd.src[0].fx = 1;
-  gd.B = d->B; gd.ID = 1; gd.IH = 1; gd.IW = th * tw;
-  gd.KD = gd.KH = gd.KW = 1;
+  gd.B = d->B; gd.ID = planes_dy; gd.IH = 1; gd.IW = th * tw;
+  gd.KD = d->KD; gd.KH = gd.KW = 1; gd.PD = d->PD;
   gd.N = Cp; gd.wpack = d->wpack; gd.out = P; gd.ld_out = Cp;
   gd.precision = d->precision;
-  const int rc = clx_igemm_launch(&gd, 36, (long long)th * tw * d->B * Nf, (long long)Cp * Nf,
-                                  (long long)th * tw * d->B * Cp, st);
+  const int rc = clx_igemm_launch(&gd, 36, Tdy * Nf, (long long)Cp * d->KD * Nf, Tdx * Cp, st);
   if (rc) return rc;
   const int IH = OHf + 2, IW = OWf + 2;
-  const long long total = (long long)d->B * ((IH + 3) / 4) * ((IW + 3) / 4) * (Cp / 4);
-  wino_adjoint_output_kernel<<<grid_for(total, 256), 256, 0, st>>>(P, Cp / 4, d->B, th, tw, IH, IW, d->mask, d->ld_mask,
-                                                                   d->mask_bits, d->ld_mask_bits, d->out, d->ld_out, Cp,
-                                                                   total);
+  const long long total = (long long)d->B * planes_dx * ((IH + 3) / 4) * ((IW + 3) / 4) * (Cp / 4);
+  wino_adjoint_output_kernel<<<grid_for(total, 256), 256, 0, st>>>(P, Cp / 4, d->B * planes_dx, th, tw, IH, IW, d->mask,
+                                                                   d->ld_mask, d->mask_bits, d->ld_mask_bits, d->out,
+                                                                   d->ld_out, Cp, total);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd adjoint)");
   return CLX_OK;
 }

@@ -463,7 +463,7 @@ class UNetPlan:
                     n = self.B * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
                     self.gate[layer.out] = torch.zeros((n, pad4(layer.cout) // 32), dtype=torch.int32,
                                                        device=self.device)
-        # 2-D F(4x4, 3x3) layers whose weight AND data gradient are Winograd: the data gradient in its ADJOINT form,
+        # F(4x4, 3x3[x3]) layers whose weight AND data gradient are Winograd: the data gradient in its ADJOINT form,
         # dX = sum over tiles of B [U^T (A dY A^T)] B^T — its operand A dY A^T is what the weight gradient has just left
         # in the workspace, so dY is transformed once and the (K-1)-padded input transform of dY is never written
         # (clx_conv_desc.adjoint; CLX_WINO_ADJOINT=0 = the two-transform form)
@@ -471,7 +471,7 @@ class UNetPlan:
         if os.environ.get("CLX_WINO_ADJOINT", "1") != "0":
             for layer in t.convs:
                 a = self.algo[layer.name]
-                if (a["wgrad"] == 2 and a["dgrad"] == 2 and tuple(layer.kernel) == (1, 3, 3) and layer.param_index > 0
+                if (a["wgrad"] == 2 and a["dgrad"] == 2 and tuple(layer.kernel) in ((1, 3, 3), (3, 3, 3)) and layer.param_index > 0
                         and layer.name not in self.subpixel and len(layer.sources) == 1):
                     self.adjoint.add(layer.name)
         # a Winograd layer's weight gradient and data gradient both transform dY: one pass produces both

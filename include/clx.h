@@ -141,7 +141,7 @@ typedef struct clx_conv_desc {
    * (whose block sums meet in LDS atomics) are not used.  Pass dbias = NULL with it and take the
    * bias gradient from clx_colsum_ordered. */
   int* det_turns;
-  /* clx_conv_fwd in its data-gradient form, CLX_ALGO_WINOGRAD4 with a 3x3 kernel on a 2-D layer only: ADJOINT
+  /* clx_conv_fwd in its data-gradient form, CLX_ALGO_WINOGRAD4 with a 3x3 (2-D) or 3x3x3 kernel only: ADJOINT
    * form.  The call must directly follow the clx_conv_wgrad of the same layer with the same workspace: the
    * weight gradient's A dY A^T (left in the workspace) is the operand — dX = sum over tiles of
    * B [U^T (A dY A^T)] B^T — so dY is not transformed a second time (src[0].ptr is not read).  wpack must come
@@ -228,8 +228,8 @@ enum clx_pack_mode {
   CLX_PACK_WINO4_FWD = 4,  /* F(4x4): taps 9 -> U[36][cout_pad][cin_pad], taps 4 (2x2) -> U[25][..],
                             * taps 27 / 8 (3-D) -> U[36 | 25][cout_pad][kd][cin_pad]            */
   CLX_PACK_WINO4_DGRAD = 5, /* the same for the flipped filter: U[a*a][cin_pad][kd][cout_pad]    */
-  CLX_PACK_WINO4_ADJOINT = 6 /* F(4x4, 3x3), 2-D: the FORWARD filter transform stored transposed,
-                              * U[36][cin_pad][cout_pad] (clx_conv_desc.adjoint) */
+  CLX_PACK_WINO4_ADJOINT = 6 /* F(4x4, 3x3[x3]): the FORWARD filter transform stored transposed (z taps reversed),
+                              * U[36][cin_pad][kd][cout_pad] (clx_conv_desc.adjoint) */
 };
 /* Repack torch-layout conv weights w (Cout, Cin, taps) for clx_conv_fwd.
  * cin_pad/cout_pad >= real extents (multiples of 4), padding is zero-filled.
