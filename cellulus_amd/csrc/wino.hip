@@ -247,10 +247,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 // ADJOINT data gradient of F(4x4, 3x3): the forward is Y = A^T [U (B^T d B)] A per tile, so
 //   d(input patch) = B [U^T (A dY A^T)] B^T        (A x A = 6 x 6, one per tile)
 // and dX is the overlap-add of the patches (stride MT = 4, overlap 2).  P[xi][t][c] = (U^T Mdy)[xi] comes from the
-// batched GEMM; this kernel is output-stationary: one thread per 4 x 4 block of dX and 4 channels gathers the
-// (up to four) tiles whose patches cover it — tile (by, bx) with patch rows / columns 0-3, its upper / left
-// neighbours with rows / columns 4-5 — so nothing is added in memory.  Epilogue: the ReLU gate of the tensor
-// whose gradient this is (float mask or bits).
+// batched GEMM; this kernel is output-stationary, so nothing is added in memory: a thread owns one column of 4 x 4
+// blocks of dX (ADJ_SEG of them, 4 channels) and walks DOWN the tiles — per tile row it transforms tile (ty, bx)
+// (patch columns 0-3) and its left neighbour (patch columns 4-5 = block columns 0-1), stores the block with the two
+// rows carried over from the tile above, and carries its own rows 4-5 on.  2 (+ 1/ADJ_SEG) tile reads per block
+// where a block-by-block gather reads 4 (344 -> ... us on the benchmark's layers).  Epilogue: the ReLU gate of the
+// tensor whose gradient this is (float mask or bits).
+constexpr int ADJ_SEG = 8;
+
 __global__ __launch_bounds__(256) void wino_adjoint_output_kernel(const float* __restrict__ Pm, int C4, int Bn, int th,
                                                                   int tw, int IH, int IW, const float* __restrict__ mask,
                                                                   int ld_mask, const unsigned int* __restrict__ mask_bits,
@@ -260,106 +264,101 @@ __global__ __launch_bounds__(256) void wino_adjoint_output_kernel(const float* _
   constexpr int A = 6;
   const int C = C4 * 4;
   const int bh = (IH + 3) / 4, bw = (IW + 3) / 4;
+  const int nseg = (bh + ADJ_SEG - 1) / ADJ_SEG;
   const long long plane = (long long)Bn * th * tw * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     long long t = i / C4;
     const int bx = (int)(t % bw);
-    const long long q = t / bw;
-    const int by = (int)(q % bh);
-    const int b = (int)(q / bh);
-    f32x4 acc[4][4];
+    long long q = t / bw;
+    const int sg = (int)(q % nseg);
+    const int b = (int)(q / nseg);
+    const int by0 = sg * ADJ_SEG, by1 = min(by0 + ADJ_SEG, bh);
+    f32x4 carry[2][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[a][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 4; ++e) carry[a][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // tiles ty = by0 - 1 (only for what it carries into block by0) .. by1 - 1; block by = th (if it exists) has no
+    // tile of its own and consists of the carry alone
+    for (int ty = by0 - 1; ty < by1; ++ty) {
+      f32x4 d[A][4];
 #pragma unroll
-    for (int uy = 0; uy < 2; ++uy) {
-      const int ty = by - uy;
-      if (ty < 0 || ty >= th) continue;
+      for (int a = 0; a < A; ++a)
 #pragma unroll
-      for (int ux = 0; ux < 2; ++ux) {
-        const int tx = bx - ux;
-        if (tx < 0 || tx >= tw) continue;
-        const float* src = Pm + (((long long)b * th + ty) * tw + tx) * C + c;
-        // patch rows a0 .. a0 + na - 1 and columns b0 .. of this tile land on the block: rows 0-3 of its own tile,
-        // rows 4-5 of the tile above (block rows 0-1); the same for columns
-        const int a0 = uy ? 4 : 0, na = uy ? 2 : 4, b0 = ux ? 4 : 0, nb = ux ? 2 : 4;
-        // columns first: w[a][s] = sum_r B[a][r] P[r][s] = sum_r BT[r][a] P[r][s]
-        f32x4 w[4][A];
+        for (int e = 0; e < 4; ++e) d[a][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ty >= 0 && ty < th) {
 #pragma unroll
-        for (int s2 = 0; s2 < A; ++s2) {
-          f32x4 pcol[A];
+        for (int ux = 0; ux < 2; ++ux) {
+          const int tx = bx - ux;
+          if (tx < 0 || tx >= tw) continue;
+          const float* src = Pm + (((long long)b * th + ty) * tw + tx) * C + c;
 #pragma unroll
-          for (int r = 0; r < A; ++r) pcol[r] = ld4(src + (r * A + s2) * plane);
+          for (int s2 = 0; s2 < A; ++s2) {
+            f32x4 pcol[A], wcol[A];
 #pragma unroll
-          for (int a = 0; a < 4; ++a) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a < na) {
+            for (int r = 0; r < A; ++r) pcol[r] = ld4(src + (r * A + s2) * plane);
+            // wcol[a] = sum_r B[a][r] P[r][s2] = sum_r BT[r][a] P[r][s2]
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+              f32x4 v = {0.f, 0.f, 0.f, 0.f};
               bool first = true;
-              if (uy) {
 #pragma unroll
-                for (int r = 0; r < A; ++r) axpy(v, first, W::BT[r][(a & 1) + 4], pcol[r]);
-              } else {
+              for (int r = 0; r < A; ++r) axpy(v, first, W::BT[r][a], pcol[r]);
+              wcol[a] = v;
+            }
+            // d[a][e] += wcol[a] * B[col][s2], col = e (own tile) or 4 + e, e < 2 (left neighbour)
 #pragma unroll
-                for (int r = 0; r < A; ++r) axpy(v, first, W::BT[r][a], pcol[r]);
+            for (int e = 0; e < 4; ++e) {
+              if (ux && e >= 2) continue;
+              const float coef = ux ? W::BT[s2][4 + (e & 1)] : W::BT[s2][e];
+#pragma unroll
+              for (int a = 0; a < A; ++a) {
+                bool first = false;
+                axpy(d[a][e], first, coef, wcol[a]);
               }
             }
-            w[a][s2] = v;
           }
         }
+      }
+      if (ty >= by0) {
+        // block by = ty: rows 0-3 of this tile row, plus rows 4-5 of the one above on its rows 0-1
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          if (a >= na) continue;
+          const int y = 4 * ty + a;
+          if (y >= IH) continue;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            if (e >= nb) continue;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            bool first = true;
-            if (ux) {
+            const int x = 4 * bx + e;
+            if (x >= IW) continue;
+            f32x4 v = d[a][e];
+            if (a < 2) v += carry[a][e];
+            const long long m = ((long long)b * IH + y) * IW + x;
+            if (mask_bits) {
+              const unsigned int wbits = mask_bits[m * ld_mask_bits + (c >> 5)] >> (c & 31);
 #pragma unroll
-              for (int s2 = 0; s2 < A; ++s2) axpy(v, first, W::BT[s2][(e & 1) + 4], w[a][s2]);
-            } else {
-#pragma unroll
-              for (int s2 = 0; s2 < A; ++s2) axpy(v, first, W::BT[s2][e], w[a][s2]);
+              for (int k = 0; k < 4; ++k) v[k] = ((wbits >> k) & 1u) ? v[k] : 0.f;
             }
-            acc[a][e] += v;
-          }
-        }
-        (void)a0; (void)b0;
-      }
-    }
+            if (c + 3 < Creal) {
+              if (mask) {
+                const f32x4 mk = ld4(mask + m * ld_mask + c);
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int y = 4 * by + a;
-      if (y >= IH) continue;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int x = 4 * bx + e;
-        if (x >= IW) continue;
-        f32x4 v = acc[a][e];
-        const long long m = ((long long)b * IH + y) * IW + x;
-        if (mask_bits) {
-          const unsigned int wbits = mask_bits[m * ld_mask_bits + (c >> 5)] >> (c & 31);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = ((wbits >> k) & 1u) ? v[k] : 0.f;
-        }
-        if (c + 3 < Creal) {
-          if (mask) {
-            const f32x4 mk = ld4(mask + m * ld_mask + c);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (mk[k] > 0.f) ? v[k] : 0.f;
-          }
-          st4(out + m * ld_out + c, v);
-        } else {
-          for (int k = 0; k < 4 && c + k < Creal; ++k) {
-            float xv = v[k];
-            if (mask) xv = (mask[m * ld_mask + c + k] > 0.f) ? xv : 0.f;
-            out[m * ld_out + c + k] = xv;
+                for (int k = 0; k < 4; ++k) v[k] = (mk[k] > 0.f) ? v[k] : 0.f;
+              }
+              st4(out + m * ld_out + c, v);
+            } else {
+              for (int k = 0; k < 4 && c + k < Creal; ++k) {
+                float xv = v[k];
+                if (mask) xv = (mask[m * ld_mask + c + k] > 0.f) ? xv : 0.f;
+                out[m * ld_out + c + k] = xv;
+              }
+            }
           }
         }
       }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { carry[0][e] = d[4][e]; carry[1][e] = d[5][e]; }
     }
   }
 }
@@ -860,7 +859,8 @@ static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
   const int rc = clx_igemm_launch(&gd, 36, Tdy * Nf, (long long)Cp * d->KD * Nf, Tdx * Cp, st);
   if (rc) return rc;
   const int IH = OHf + 2, IW = OWf + 2;
-  const long long total = (long long)d->B * planes_dx * ((IH + 3) / 4) * ((IW + 3) / 4) * (Cp / 4);
+  const int nseg = ((IH + 3) / 4 + ADJ_SEG - 1) / ADJ_SEG;
+  const long long total = (long long)d->B * planes_dx * nseg * ((IW + 3) / 4) * (Cp / 4);
   wino_adjoint_output_kernel<<<grid_for(total, 256), 256, 0, st>>>(P, Cp / 4, d->B * planes_dx, th, tw, IH, IW, d->mask,
                                                                    d->ld_mask, d->mask_bits, d->ld_mask_bits, d->out,
                                                                    d->ld_out, Cp, total);
