@@ -592,6 +592,107 @@ def test_winograd_entry_points_vs_f64_convolution(k, algo, kd, pad, device):
             assert (db.cpu().double() - dy.double().sum((0, 1, 2, 3))).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("kd,mask_kind", [(1, "none"), (1, "float"), (1, "bits"), (3, "none"), (3, "float")])
+def test_adjoint_winograd_data_gradient_through_the_c_abi(kd, mask_kind, device):
+    """clx_conv_desc.adjoint: after clx_conv_wgrad of a F(4x4, 3x3[x3]) layer, the data gradient from the A dY A^T that
+    call left in the workspace — against float64 autograd of the convolution, on extents that are not multiples of
+    the tile, with the ReLU-gate epilogues; and the batched packing (clx_pack_weights_batch) bit-identical to the
+    single calls it replaces."""
+    import ctypes
+
+    import torch.nn.functional as F
+
+    from cellulus_amd import _clx
+    from cellulus_amd._clx import ClxConvDesc, ClxPackJob, ClxSrc
+
+    torch.manual_seed(7 * kd + len(mask_kind))
+    B, D, H, W, C, N = 2, (6 if kd > 1 else 1), 23, 18, 32, 40
+    OD, OH, OW = D - kd + 1, H - 2, W - 2
+    x = torch.randn(B, D, H, W, C)
+    w = torch.randn(N, C, kd, 3, 3) * 0.2
+    dy = torch.randn(B, OD, OH, OW, N)
+    xr = x.permute(0, 4, 1, 2, 3).double().requires_grad_(True)
+    (F.conv3d(xr, w.double()) * dy.permute(0, 4, 1, 2, 3).double()).sum().backward()
+    ref = xr.grad.permute(0, 2, 3, 4, 1)                        # (B, D, H, W, C)
+    st = _clx.stream_ptr(device)
+    lib = _clx.load()
+    x_d, dy_d = x.to(device).contiguous(), dy.to(device).contiguous()
+    w_d = w.reshape(N, C, kd * 9).to(device).contiguous()
+    taps = kd * 9
+
+    # ---- packings: three single calls and one batch of the same three jobs
+    sizes = {4: 36 * N * kd * C, 5: 36 * C * kd * N, 6: 36 * C * kd * N}
+    single = {m: torch.full((n,), float("nan"), device=device) for m, n in sizes.items()}
+    for m, buf in single.items():
+        _clx.call("clx_pack_weights", _clx.ptr(w_d), _clx.ptr(buf), N, C, taps, C, N, m, st)
+    batch = {m: torch.full((n,), float("nan"), device=device) for m, n in sizes.items()}
+    jobs = (ClxPackJob * 3)(*[ClxPackJob(w_d.data_ptr(), batch[m].data_ptr(), N, C, taps, C, N, m) for m in (4, 5, 6)])
+    table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+    _clx.call("clx_pack_weights_batch", _clx.ptr(table), 3, max(sizes.values()) // 36, st)
+    for m in sizes:
+        assert torch.equal(single[m], batch[m]), m
+    assert not torch.equal(single[5], single[6])                 # the adjoint pack is NOT the flipped-filter pack
+
+    def fwd_desc():
+        d = ClxConvDesc()
+        d.nsrc = 1
+        s = ClxSrc()
+        s.ptr, s.C, s.ld = x_d.data_ptr(), C, C
+        s.D, s.H, s.W = D, H, W
+        s.fz = s.fy = s.fx = 1
+        d.src[0] = s
+        d.B, d.ID, d.IH, d.IW = B, D, H, W
+        d.KD, d.KH, d.KW = kd, 3, 3
+        d.N = N
+        d.algo = 2
+        return d
+
+    d = fwd_desc()
+    need = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 1))
+    ws = torch.empty(need // 4 + 4, device=device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    dwp = torch.zeros(36 * kd * N * C, device=device)
+    _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy_d), N, _clx.ptr(dwp), None, st)
+
+    dd = ClxConvDesc()                                          # the data-gradient descriptor: dY, padding 2
+    dd.nsrc = 1
+    s = ClxSrc()
+    s.ptr, s.C, s.ld = dy_d.data_ptr(), N, N
+    s.D, s.H, s.W = OD, OH, OW
+    s.fz = s.fy = s.fx = 1
+    dd.src[0] = s
+    dd.B, dd.ID, dd.IH, dd.IW = B, OD, OH, OW
+    dd.KD, dd.KH, dd.KW = kd, 3, 3
+    dd.PD, dd.PH, dd.PW = kd - 1, 2, 2
+    dd.N = C
+    dd.algo = 2
+    dd.adjoint = 1
+    dd.wpack = single[6].data_ptr()
+    dd.workspace, dd.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    out = torch.full((B, D, H, W, C), float("nan"), device=device)
+    dd.out, dd.ld_out = out.data_ptr(), C
+    gate = torch.randn(B, D, H, W, C)
+    want = ref
+    keep = None
+    if mask_kind == "float":
+        keep = gate.to(device).contiguous()
+        dd.mask, dd.ld_mask = keep.data_ptr(), C
+        want = ref * (gate > 0)
+    elif mask_kind == "bits":
+        bits = (gate > 0).numpy().reshape(-1, C)                 # C = 32: one word per pixel
+        words = (bits.astype(np.uint32) << np.arange(32, dtype=np.uint32)).sum(axis=1).astype(np.uint32)
+        keep = torch.from_numpy(words.view(np.int32).copy()).to(device)
+        dd.mask_bits, dd.ld_mask_bits = keep.data_ptr(), 1
+        want = ref * (gate > 0)
+    _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+    err = (out.cpu().double() - want).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
+    # what it cannot do is refused
+    dd.relu = 1
+    with pytest.raises(_clx.ClxError):
+        _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
+
+
 @pytest.mark.parametrize("N,C,M", [(128, 128, 5000), (256, 384, 33333), (128, 256, 31)])
 def test_opt_in_precision_weight_gradient_kernel_vs_f64(N, C, M, device):
     """wgrad_x3_kernel (clx_conv_wgrad on a plain 1x1 product with precision = CLX_PREC_F32X3BF16): weight and bias
