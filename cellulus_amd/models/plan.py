@@ -384,6 +384,16 @@ class UNetPlan:
         self._vcache_fresh = set()
         self._find_chains()
 
+    def share_from(self, other):
+        """Use `other`'s packed weights and gradient accumulators (same topology, batch size and switches): this
+        plan then never packs, and its weight-gradient kernels add into the accumulators `other` unpacks."""
+        assert other._bwd_ready and self._bwd_ready and other.B == self.B and other.algo == self.algo
+        assert other.dw_off == self.dw_off and other.dwpack.numel() == self.dwpack.numel()
+        self.wpack_fwd, self.wpack_dgrad, self.dwpack = other.wpack_fwd, other.wpack_dgrad, other.dwpack
+        for name, sp in self.subpixel.items():
+            for key in ("w_skip", "weff", "wp_skip_fwd", "wp_z_fwd", "wp_skip_dgrad", "wp_z_dgrad", "dw_skip", "dw_z"):
+                sp[key] = other.subpixel[name][key]
+
     def _find_chains(self):
         """Pairs of consecutive 64-channel 1x1 layers (conv_pass.2 -> conv_pass.4 of a level, head.0 ->
         head.2) that run as ONE launch each way (csrc/chain64.hip: the intermediate tensor is written once
@@ -710,10 +720,9 @@ class UNetPlan:
                 sp["_vskip_fresh"] = True
         _clx.call("clx_conv_fwd", ctypes.byref(ds), st)
 
-    def _sp_backward(self, layer, sp, dy, gw, gb, st):
-        """weight/bias gradient and both data gradients of a sub-pixel layer; returns the skip
-        gradient buffer (pre-gate, full skip-crop grid)."""
-        t = self.topo
+    def _sp_wgrad(self, layer, sp, dy, gw, gb, st):
+        """weight/bias gradient of a sub-pixel layer (added into the layer's slices of self.dwpack); returns
+        unpack(stream), which unpacks both halves and folds them into `gw`."""
         dz, ds = self._sp_descs(layer, sp)
         zs, PN = sp["zshape"], sp["P"] * sp["N"]
         # dZ = space_to_depth(dY)
@@ -737,21 +746,29 @@ class UNetPlan:
                 dz.dy_vcache = self.dycache.data_ptr()
         self._wgrad(dz, dzbuf, PN, sp["dw_z"], None, 0, st)
         g_skip, g_z = sp["g_skip"], sp["g_z"]
-        if sp["wino_skip"]:
-            _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
-                      sp["N"], sp["C0p"], 4, 3, layer.kernel[0], st)
-        else:
-            _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
-                      layer.taps, sp["N"], sp["C0p"], st)
-        if sp["wino"]:
-            _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], PN, sp["C1p"],
-                      4, 2, sp["zk"][0], st)
-        else:
-            _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
-                      sp["C1p"], st)
-        # adjoint of the weight split (one launch; _fold_phase_grads states the same in torch ops)
-        _clx.call("clx_subpixel_fold_grads", _clx.ptr(g_skip), _clx.ptr(g_z), _clx.ptr(gw), layer.cout, layer.cin,
-                  sp["C0"], sp["N"], *layer.kernel, *sp["fac"], st)
+
+        def unpack(st):
+            if sp["wino_skip"]:
+                _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
+                          sp["N"], sp["C0p"], 4, 3, layer.kernel[0], st)
+            else:
+                _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_skip"]), _clx.ptr(g_skip), layer.cout, sp["C0"],
+                          layer.taps, sp["N"], sp["C0p"], st)
+            if sp["wino"]:
+                _clx.call("clx_unpack_wgrad_wino", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], PN, sp["C1p"],
+                          4, 2, sp["zk"][0], st)
+            else:
+                _clx.call("clx_unpack_wgrad", _clx.ptr(sp["dw_z"]), _clx.ptr(g_z), PN, sp["C1"], sp["ztaps"], PN,
+                          sp["C1p"], st)
+            # adjoint of the weight split (one launch; _fold_phase_grads states the same in torch ops)
+            _clx.call("clx_subpixel_fold_grads", _clx.ptr(g_skip), _clx.ptr(g_z), _clx.ptr(gw), layer.cout, layer.cin,
+                      sp["C0"], sp["N"], *layer.kernel, *sp["fac"], st)
+        return unpack
+
+    def _sp_dgrad(self, layer, sp, dy, st):
+        """both data gradients of a sub-pixel layer (after _sp_wgrad: it reads the transformed dZ that call left
+        in self.dycache); returns the skip gradient buffer (pre-gate, full skip-crop grid)."""
+        dzbuf = self.gbuf[sp["zname"]]
         # data gradient of the skip branch (gated later, together with the max-pool gradient)
         dskip = self.gbuf["dskip%d" % sp["level"]]
         dd = self._dgrad_desc(layer, dy)
@@ -930,6 +947,23 @@ class UNetPlan:
             _clx.call("clx_colsum_ordered", _clx.ptr(dy), ld_dy, dy.shape[0], nbias, _clx.ptr(gb),
                       _clx.ptr(self._det_colsum), st)
 
+    def _unpack_step(self, layer, dwp, gw, wino_w):
+        """unpack(stream) for one layer: packed weight gradient `dwp` -> torch-layout gradient `gw`."""
+        def unpack(st):
+            if wino_w:
+                _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
+                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], 3, layer.kernel[0], st)
+            elif len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
+                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
+                          layer.taps, pad4(layer.cout), layer.cin_pad, st)
+            else:       # (torch ops: they run on torch's current stream, which is the caller's `st`)
+                tmp = torch.empty((layer.cout, layer.cin_pad, layer.taps), dtype=torch.float32,
+                                  device=self.device)
+                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(tmp), layer.cout, layer.cin_pad,
+                          layer.taps, pad4(layer.cout), layer.cin_pad, st)
+                gw.copy_(self._compress_cin(layer, tmp).reshape(gw.shape))
+        return unpack
+
     def _chain_forward(self, a, b, params, st):
         """y1 = relu(x w1^T + b1), y2 = act(y1 w2^T + b2) in one launch (clx_chain64_fwd)."""
         M = self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2]
@@ -947,7 +981,7 @@ class UNetPlan:
 
     def _chain_backward(self, a, b, prev, grads, st):
         """Both data gradients, both weight gradients and both bias gradients of the pair in one launch
-        (clx_chain64_bwd); the gradient w.r.t. the middle tensor is never written."""
+        (clx_chain64_bwd); the gradient w.r.t. the middle tensor is never written.  Returns unpack(stream)."""
         M = self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2]
         dp2 = self.gbuf[b.out]
         x, y1 = self.buf[a.sources[0].tensor], self.buf[a.out]
@@ -959,9 +993,12 @@ class UNetPlan:
                   x.shape[1], 1 if prev.relu else 0, M, _clx.ptr(self.wpack_dgrad[b.name]),
                   _clx.ptr(self.wpack_dgrad[a.name]), _clx.ptr(dp0), dp0.shape[1], _clx.ptr(dw2),
                   _clx.ptr(grads[2 * b.param_index + 1]), _clx.ptr(dw1), _clx.ptr(grads[2 * a.param_index + 1]), st)
-        for layer, dwp in ((b, dw2), (a, dw1)):
-            _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(grads[2 * layer.param_index]), layer.cout, layer.cin,
-                      1, pad4(layer.cout), layer.cin_pad, st)
+
+        def unpack(st):
+            for layer, dwp in ((b, dw2), (a, dw1)):
+                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(grads[2 * layer.param_index]), layer.cout,
+                          layer.cin, 1, pad4(layer.cout), layer.cin_pad, st)
+        return unpack
 
     def _pack_layer(self, layer, w, need_dgrad, st):
         wv = w.detach().reshape(layer.cout, layer.cin, layer.taps)
@@ -1064,8 +1101,9 @@ class UNetPlan:
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward
-    def forward(self, raw, params):
-        """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial)."""
+    def forward(self, raw, params, out=None):
+        """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial), written into `out`
+        (contiguous, that shape) when given."""
         t = self.topo
         st = _clx.stream_ptr(self.device)
         self._vcache_fresh = set()      # Winograd layers whose V this forward left in self.vcache
@@ -1105,7 +1143,9 @@ class UNetPlan:
                           self.B, D, H, W, pad4(op.channels), *op.factor, st)
         npix_out = t.out_shape[0] * t.out_shape[1] * t.out_shape[2]
         spatial = t.out_shape[3 - t.nd:]
-        out = torch.empty((self.B, t.out_channels) + tuple(spatial), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((self.B, t.out_channels) + tuple(spatial), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and tuple(out.shape) == (self.B, t.out_channels) + tuple(spatial)
         _clx.call("clx_pixel_to_planar", _clx.ptr(self.buf["h1"]), _clx.ptr(out), self.B,
                   t.out_channels, npix_out, pad4(t.out_channels), st)
         return out
@@ -1118,13 +1158,26 @@ class UNetPlan:
         on_layer_done(param_index): called once the kernels that write a layer's weight and bias
         gradient are enqueued (layers finish in reverse forward order: the data-parallel step
         starts reducing the tail of the flat gradient while the rest is still being computed)."""
-        t = self.topo
         st = _clx.stream_ptr(self.device)
-        assert self._bwd_ready, "pack_weights(need_dgrad=True) must run before backward"
-        npix_out = t.out_shape[0] * t.out_shape[1] * t.out_shape[2]
-        dout = dout.contiguous()
-        _clx.call("clx_planar_to_pixel", _clx.ptr(dout), _clx.ptr(self.gbuf["h1"]), self.B,
-                  t.out_channels, npix_out, pad4(t.out_channels), st)
+        self.zero_gradients(grads, flat_grad)
+        for done, unpack in self.backward_steps(dout, params, grads):
+            unpack(st)
+            if on_layer_done is not None:
+                for i in done:
+                    on_layer_done(i)
+
+    def train_pass(self, raw, params, grads, flat_grad, loss_fn, after_loss=None, on_layer_done=None):
+        """forward -> loss_fn(offsets, lo, hi) (enqueues the loss of crops lo..hi-1 on the current stream, returns the
+        gradient w.r.t. those offsets) -> after_loss() -> backward.  Returns the offsets."""
+        out = self.forward(raw, params)
+        dout = loss_fn(out, 0, self.B)
+        if after_loss is not None:
+            after_loss()
+        self.backward(dout, params, grads, on_layer_done=on_layer_done, flat_grad=flat_grad)
+        return out
+
+    def zero_gradients(self, grads, flat_grad=None):
+        """The accumulators the backward kernels add into: packed weight gradients and bias gradients."""
         self.dwpack.zero_()
         if flat_grad is not None:          # `grads` tile this buffer: one fill instead of one per bias
             flat_grad.zero_()
@@ -1132,6 +1185,20 @@ class UNetPlan:
             for g in grads[1::2]:
                 if g is not None:
                     g.zero_()
+
+    def backward_steps(self, dout, params, grads):
+        """The backward pass as a generator, one step per layer (or fused pair) in reverse order.  Each step
+        enqueues the layer's weight/bias-gradient kernels — they ADD into self.dwpack and the bias gradients, which
+        the caller has zeroed (zero_gradients) — and yields (param_indices, unpack): unpack(stream) enqueues the
+        launches that turn the packed weight gradient of those layers into `grads`; the layer's data gradient is
+        enqueued when the generator is resumed.  DualPlan drives two of these on two streams over one accumulator."""
+        t = self.topo
+        st = _clx.stream_ptr(self.device)
+        assert self._bwd_ready, "pack_weights(need_dgrad=True) must run before backward"
+        npix_out = t.out_shape[0] * t.out_shape[1] * t.out_shape[2]
+        dout = dout.contiguous()
+        _clx.call("clx_planar_to_pixel", _clx.ptr(dout), _clx.ptr(self.gbuf["h1"]), self.B,
+                  t.out_channels, npix_out, pad4(t.out_channels), st)
 
         by_out = {layer.out: layer for layer in t.convs}
         pool_by_out = {p.out: p for p in t.pools}
@@ -1148,18 +1215,14 @@ class UNetPlan:
                 continue                                    # done with its successor
             if layer.name in self.chain_second:
                 a, b = self.chain_second[layer.name]
-                self._chain_backward(a, b, by_out[a.sources[0].tensor], grads, st)
-                if on_layer_done is not None:
-                    on_layer_done(b.param_index)
-                    on_layer_done(a.param_index)
+                yield (b.param_index, a.param_index), self._chain_backward(a, b, by_out[a.sources[0].tensor], grads, st)
                 continue
             if layer.name in self.subpixel:
                 sp = self.subpixel[layer.name]
-                dskip = self._sp_backward(layer, sp, dy, grads[2 * layer.param_index],
-                                          grads[2 * layer.param_index + 1], st)
+                yield (layer.param_index,), self._sp_wgrad(layer, sp, dy, grads[2 * layer.param_index],
+                                                           grads[2 * layer.param_index + 1], st)
+                dskip = self._sp_dgrad(layer, sp, dy, st)
                 pending_skip[layer.sources[0].tensor] = (dskip, sp["C0p"], layer)
-                if on_layer_done is not None:
-                    on_layer_done(layer.param_index)
                 continue
             # ---- weight + bias gradient
             d = self._desc(layer)
@@ -1180,21 +1243,7 @@ class UNetPlan:
                 if dual:
                     d.dy_vcache = self.dycache.data_ptr()
             self._wgrad(d, dy, pad4(layer.cout), dwp, gb, layer.cout, st)
-            gw = grads[2 * layer.param_index]
-            if wino_w:
-                _clx.call("clx_unpack_wgrad_wino", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
-                          pad4(layer.cout), layer.cin_pad, WINO_TILE[wino_w], 3, layer.kernel[0], st)
-            elif len(layer.sources) == 1 or all(s.channels % 4 == 0 for s in layer.sources[:-1]):
-                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(gw), layer.cout, layer.cin,
-                          layer.taps, pad4(layer.cout), layer.cin_pad, st)
-            else:
-                tmp = torch.empty((layer.cout, layer.cin_pad, layer.taps), dtype=torch.float32,
-                                  device=self.device)
-                _clx.call("clx_unpack_wgrad", _clx.ptr(dwp), _clx.ptr(tmp), layer.cout, layer.cin_pad,
-                          layer.taps, pad4(layer.cout), layer.cin_pad, st)
-                gw.copy_(self._compress_cin(layer, tmp).reshape(gw.shape))
-            if on_layer_done is not None:
-                on_layer_done(layer.param_index)
+            yield (layer.param_index,), self._unpack_step(layer, dwp, grads[2 * layer.param_index], wino_w)
             # ---- data gradient
             if layer.param_index == 0:
                 continue
@@ -1250,3 +1299,180 @@ class UNetPlan:
                     dd.ld_out = pad4(prev.cout)
                     _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
         assert not pending_skip
+
+
+def forward_flops(topo, batch):
+    """2 M N K over the convolutions of one forward pass (direct form)."""
+    total = 0
+    for layer in topo.convs:
+        m = batch * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
+        total += 2 * m * layer.cout * layer.cin * layer.taps
+    return total
+
+
+class _Rows:
+    """Read-only view of a per-tensor buffer dict of the two halves as full-batch tensors (rows are pixels,
+    batch-major: the halves concatenate)."""
+
+    def __init__(self, parts, attr):
+        self._parts, self._attr = parts, attr
+
+    def __getitem__(self, name):
+        return torch.cat([getattr(p, self._attr)[name] for p in self._parts], dim=0)
+
+    def __contains__(self, name):
+        return name in getattr(self._parts[0], self._attr)
+
+    def __bool__(self):
+        return bool(getattr(self._parts[0], self._attr))
+
+    def get(self, name, default=None):
+        return self[name] if name in self else default
+
+    def keys(self):
+        return getattr(self._parts[0], self._attr).keys()
+
+
+def dual_stream_wanted(topo, batch, keep_activations):
+    """Two half batches on two streams (DualPlan)?  Training plans with an even batch whose halves are big enough
+    to fill the device (CLX_STREAMS_MIN_GFLOP per half-batch forward pass, default 100: below that the step is
+    launch-bound and twice the launches cost more than the overlap returns); never in reproducible mode.
+    CLX_STREAMS=1 switches it off."""
+    if not keep_activations or batch < 2 or batch % 2 or os.environ.get("CLX_STREAMS", "2") == "1":
+        return False
+    if os.environ.get("CLX_DETERMINISTIC", "0") == "1":
+        return False
+    return forward_flops(topo, batch // 2) >= float(os.environ.get("CLX_STREAMS_MIN_GFLOP", "100")) * 1e9
+
+
+class DualPlan:
+    """A training batch as two half batches on two HIP streams.
+
+    A step is a strict chain of launches, each either bound by the matrix cores (the GEMMs) or by HBM (Winograd
+    transforms, pooling, fills, the first layer): on one stream the two kinds never overlap.  Two independent half
+    batches do — the transforms of one half run under the GEMMs of the other, and the partial last round of one
+    half's tiles is filled by the other's.  Both halves use ONE set of packed weights and add their weight and bias
+    gradients into ONE set of accumulators (the kernels add with atomics anyway); a layer's packed gradient is
+    unpacked on the caller's stream once both halves have passed that layer, which is also when on_layer_done
+    fires — the data-parallel buckets leave exactly as they do with one stream.
+    Same interface as UNetPlan (pack_weights / forward / backward); CLX_STREAMS=1 keeps one stream."""
+
+    def __init__(self, topo, batch, device, keep_activations):
+        assert batch % 2 == 0 and keep_activations
+        self.topo, self.B, self.device, self.keep = topo, int(batch), device, True
+        self.parts = [UNetPlan(topo, batch // 2, device, True) for _ in range(2)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+        self._events = [[], [], []]
+        self._shared = False
+        self.buf = _Rows(self.parts, "buf")
+
+    def __getattr__(self, name):            # algo, chains, subpixel, gate, precision, ... : the halves agree
+        if name in ("parts", "streams"):
+            raise AttributeError(name)
+        if name == "gbuf":
+            return _Rows(self.parts, "gbuf")
+        return getattr(self.parts[0], name)
+
+    def pack_weights(self, params, version, need_dgrad):
+        a, b = self.parts
+        a.pack_weights(params, version, need_dgrad)
+        if need_dgrad and not self._shared:
+            b._alloc_backward()
+            b.share_from(a)
+            self._shared = True
+        b._packed_version = a._packed_version
+
+    def _fork(self):
+        main = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(main)
+        return main
+
+    def _join(self, main):
+        for s in self.streams:
+            main.wait_stream(s)
+
+    def forward(self, raw, params, out=None):
+        t = self.topo
+        assert self._shared, "pack_weights(need_dgrad=True) must run before forward"
+        raw = raw.contiguous()
+        if out is None:
+            out = torch.empty((self.B, t.out_channels) + tuple(t.out_shape[3 - t.nd:]), dtype=torch.float32,
+                              device=self.device)
+        h = self.B // 2
+        main = self._fork()
+        for i, (p, s) in enumerate(zip(self.parts, self.streams)):
+            with torch.cuda.stream(s):
+                p.forward(raw[i * h:(i + 1) * h], params, out=out[i * h:(i + 1) * h])
+        self._join(main)
+        return out
+
+    def _event(self, i, k):
+        ev = self._events[i]
+        while len(ev) <= k:
+            ev.append(torch.cuda.Event())
+        return ev[k]
+
+    def backward(self, dout, params, grads, on_layer_done=None, flat_grad=None):
+        dout = dout.contiguous()
+        h = self.B // 2
+        self.parts[0].zero_gradients(grads, flat_grad)           # the one set of accumulators, on the caller's stream
+        main = self._fork()
+        self._backward_halves([dout[:h], dout[h:]], params, grads, on_layer_done, main)
+        self._join(main)
+
+    def train_pass(self, raw, params, grads, flat_grad, loss_fn, after_loss=None, on_layer_done=None):
+        """UNetPlan.train_pass with each half's loss on its own stream (no join between the forward and the backward
+        pass); the accumulators are zeroed on the caller's stream while the halves run their forward passes."""
+        t = self.topo
+        assert self._shared, "pack_weights(need_dgrad=True) must run before train_pass"
+        raw = raw.contiguous()
+        out = torch.empty((self.B, t.out_channels) + tuple(t.out_shape[3 - t.nd:]), dtype=torch.float32,
+                          device=self.device)
+        h = self.B // 2
+        main = self._fork()
+        douts = []
+        for i, (p, s) in enumerate(zip(self.parts, self.streams)):
+            with torch.cuda.stream(s):
+                o = p.forward(raw[i * h:(i + 1) * h], params, out=out[i * h:(i + 1) * h])
+                douts.append(loss_fn(o, i * h, (i + 1) * h))
+                self._event(i, 0).record(s)
+        self.parts[0].zero_gradients(grads, flat_grad)
+        zeroed = self._event(2, 0)
+        zeroed.record(main)
+        for i, s in enumerate(self.streams):
+            main.wait_event(self._event(i, 0))
+            s.wait_event(zeroed)
+        if after_loss is not None:
+            after_loss()
+        self._backward_halves(douts, params, grads, on_layer_done, main)
+        self._join(main)
+        return out
+
+    def _backward_halves(self, douts, params, grads, on_layer_done, main):
+        st_main = _clx.stream_ptr(self.device)
+        gens = []
+        for p, s, d in zip(self.parts, self.streams, douts):
+            with torch.cuda.stream(s):
+                gens.append(p.backward_steps(d, params, grads))
+        k = 1
+        while True:
+            items = []
+            for i, (g, s) in enumerate(zip(gens, self.streams)):
+                with torch.cuda.stream(s):
+                    item = next(g, None)
+                    if item is not None:
+                        self._event(i, k).record(s)
+                items.append(item)
+            if items[0] is None:
+                assert items[1] is None
+                break
+            assert items[1] is not None and items[0][0] == items[1][0]
+            for i in range(2):
+                main.wait_event(self._event(i, k))
+            done, unpack = items[0]                  # (the halves share the accumulators: either closure does)
+            unpack(st_main)
+            if on_layer_done is not None:
+                for idx in done:
+                    on_layer_done(idx)
+            k += 1

@@ -17,7 +17,7 @@ import ctypes
 
 from .. import _clx
 from .._clx import ClxConvDesc, ClxSrc
-from .plan import UNetPlan, build_topology, pad4
+from .plan import DualPlan, UNetPlan, build_topology, dual_stream_wanted, pad4
 
 
 class _ConvPass(nn.Module):
@@ -305,7 +305,10 @@ class UNetModel(nn.Module):  # type: ignore
             # one plan (activation arena) per input shape; drop older ones to bound memory
             for k in [k for k in self._plans if k[2] == bool(keep)]:
                 del self._plans[k]
-            plan = UNetPlan(topo, raw.shape[0], raw.device, keep)
+            if dual_stream_wanted(topo, raw.shape[0], keep):
+                plan = DualPlan(topo, raw.shape[0], raw.device, keep)
+            else:
+                plan = UNetPlan(topo, raw.shape[0], raw.device, keep)
             self._plans[key] = plan
         return plan
 

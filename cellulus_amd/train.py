@@ -331,53 +331,70 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
     grads = model.attach_flat_grads()
     plan = model._plan_for(raw, keep=True)
     plan.pack_weights(params, model._param_version(), need_dgrad=True)
-    offsets = plan.forward(raw, params)
-
-    B, ND = offsets.shape[0], offsets.shape[1]
+    B = raw.shape[0]
+    ND = model.out_channels            # one offset channel per spatial dimension
     if anchor.ndim != 3 or anchor.shape != reference.shape or anchor.shape[0] != B or anchor.shape[2] != ND:
         raise ValueError(f"coordinates must be (B={B}, P, {ND}); got {tuple(anchor.shape)} and "
                          f"{tuple(reference.shape)}")
-    Z, Y, X = (1, offsets.shape[2], offsets.shape[3]) if ND == 2 else tuple(offsets.shape[2:])
     sums = torch.zeros(4, dtype=torch.float64, device=device)     # loss, oce, reg, bad-coordinate count
-    if plan.deterministic:
-        # CLX_DETERMINISTIC=1: fixed-point scatter of the anchor gradients, loss sums in block order
-        doffsets = torch.empty_like(offsets)
-        need = int(_clx.load().clx_oce_pairs_det_scratch_bytes(B, ND, Z * Y * X))
-        scratch = getattr(model, "_det_loss_scratch", None)
-        if scratch is None or scratch.numel() < need or scratch.device != device:
-            scratch = model._det_loss_scratch = torch.empty(need, dtype=torch.uint8, device=device)
-        _clx.call("clx_oce_pairs_fused_det", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
-                  _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
-                  float(criterion.temperature), float(criterion.regularization_weight), _clx.ptr(scratch),
-                  _clx.stream_ptr(device))
-    else:
-        doffsets = torch.zeros_like(offsets)
-        _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(anchor), _clx.ptr(reference),
-                  _clx.ptr(doffsets), _clx.ptr(sums), B, anchor.shape[1], ND, Z, Y, X,
-                  float(criterion.temperature), float(criterion.regularization_weight),
-                  _clx.stream_ptr(device))
-    early = None
-    if parallel.world_size() == 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
-        # One process: the sums are final HERE, before the backward pass.  They leave on a side stream into
-        # pinned memory now, and the host reads them after it has enqueued backward, update and packing —
-        # by then the copy is 25 ms old, so train_iteration returns while the device still works and the
-        # next call's Python runs under this step's kernels.  (Several ranks: the sums are all-reduced with
-        # the gradients and read at the end, below.)
-        early = _early_readback(model, sums, device)
+    geometry = []
+
+    def loss_fn(offsets, lo, hi):
+        """gather + OCE + scatter of crops lo..hi-1 on the current stream; adds into `sums` (the loss is a sum over
+        pairs: the halves of a two-stream step add up to the batch's)."""
+        Z, Y, X = (1, offsets.shape[2], offsets.shape[3]) if ND == 2 else tuple(offsets.shape[2:])
+        geometry[:] = [Z, Y, X]
+        a, r = anchor[lo:hi], reference[lo:hi]
+        if plan.deterministic:
+            # CLX_DETERMINISTIC=1: fixed-point scatter of the anchor gradients, loss sums in block order
+            doffsets = torch.empty_like(offsets)
+            need = int(_clx.load().clx_oce_pairs_det_scratch_bytes(hi - lo, ND, Z * Y * X))
+            scratch = getattr(model, "_det_loss_scratch", None)
+            if scratch is None or scratch.numel() < need or scratch.device != device:
+                scratch = model._det_loss_scratch = torch.empty(need, dtype=torch.uint8, device=device)
+            _clx.call("clx_oce_pairs_fused_det", _clx.ptr(offsets), _clx.ptr(a), _clx.ptr(r),
+                      _clx.ptr(doffsets), _clx.ptr(sums), hi - lo, a.shape[1], ND, Z, Y, X,
+                      float(criterion.temperature), float(criterion.regularization_weight), _clx.ptr(scratch),
+                      _clx.stream_ptr(device))
+        else:
+            doffsets = torch.zeros_like(offsets)
+            _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(a), _clx.ptr(r),
+                      _clx.ptr(doffsets), _clx.ptr(sums), hi - lo, a.shape[1], ND, Z, Y, X,
+                      float(criterion.temperature), float(criterion.regularization_weight),
+                      _clx.stream_ptr(device))
+        return doffsets
+
+    early = []
+    buckets = None
     if parallel.world_size() > 1 and parallel.bucket_bytes() > 0:
         # gradient buckets go out while the rest of the backward pass runs (parallel.GradientBuckets)
         buckets = parallel.GradientBuckets(model._flat_grad, grads)
-        buckets.add(sums)
-        plan.backward(doffsets, params, grads, on_layer_done=lambda i: buckets.params_done(2 * i, 2 * i + 1),
-                      flat_grad=model._flat_grad)
+
+    def after_loss():
+        """on the caller's stream, once the loss of every crop is enqueued (or waited for) there"""
+        if buckets is not None:
+            buckets.add(sums)
+        if parallel.world_size() == 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
+            # One process: the sums are final HERE, before the backward pass.  They leave on a side stream into
+            # pinned memory now, and the host reads them after it has enqueued backward, update and packing —
+            # by then the copy is 25 ms old, so train_iteration returns while the device still works and the
+            # next call's Python runs under this step's kernels.  (Several ranks: the sums are all-reduced with
+            # the gradients and read at the end, below.)
+            early.append(_early_readback(model, sums, device))
+
+    if buckets is not None:
+        offsets = plan.train_pass(raw, params, grads, model._flat_grad, loss_fn, after_loss,
+                                  on_layer_done=lambda i: buckets.params_done(2 * i, 2 * i + 1))
         buckets.finish()
         model._last_bucket_ranges = list(buckets.issued)      # (lo, hi) element ranges, in issue order
     else:
-        plan.backward(doffsets, params, grads, flat_grad=model._flat_grad)
+        offsets = plan.train_pass(raw, params, grads, model._flat_grad, loss_fn, after_loss)
         if parallel.world_size() > 1:
             parallel.all_reduce_sum_(model._flat_grad)
             parallel.all_reduce_sum_(sums)
             model._last_bucket_ranges = [(0, model._flat_grad.numel())]
+    Z, Y, X = geometry
+    early = early[0] if early else None
     if early is None and parallel.world_size() > 1 and os.environ.get("CLX_LOSS_EARLY", "1") != "0":
         # several ranks: the reduced sums exist once the last bucket is in; the copy then runs beside the update
         # and the packing, and the host returns while those still execute

@@ -43,6 +43,8 @@ for step in range(2):
     r = torch.from_numpy(data[f"r{step}"][rank * per:(rank + 1) * per])
     loss, _, _ = train_iteration((raw, a, r), model, crit, opt, dev)
     losses.append(loss)
+from cellulus_amd.models.plan import DualPlan
+assert isinstance(next(iter(model._plans.values())), DualPlan) == (os.environ["CLX_STREAMS_MIN_GFLOP"] == "0")
 # every rank issued the same gradient ranges in the same order (they depend on the plan only) ...
 ranges = [None] * world
 torch.distributed.all_gather_object(ranges, model._last_bucket_ranges)
@@ -79,9 +81,11 @@ def _launch(script, args, env_extra, nproc=2, port=None):
     return outs
 
 
-@pytest.mark.parametrize("world,bucket_mb", [(2, "4"), (2, "0.002"), (2, "0"), (8, "4"), (8, "0.002")])
-def test_ranks_equal_one_process_at_global_batch(tmp_path, device, world, bucket_mb):
-    """bucket_mb: default (one bucket at this model size), 2 KB buckets (every layer goes out on its own
+@pytest.mark.parametrize("world,bucket_mb,dual", [(2, "4", False), (2, "0.002", False), (2, "0", False), (8, "4", False),
+                                                  (8, "0.002", False), (2, "0.002", True), (2, "0", True)])
+def test_ranks_equal_one_process_at_global_batch(tmp_path, device, world, bucket_mb, dual):
+    """dual: every rank runs its crops as two halves on two streams (DualPlan, forced at this size); the buckets
+    must leave in the same order.  bucket_mb: default (one bucket at this model size), 2 KB buckets (every layer goes out on its own
     while the backward pass continues), 0 (single all-reduce after the backward pass).  world 8 = the
     node size of BASELINE configs[2] (one crop per rank here): same bucket sequence on every rank, same
     parameters on every rank, and those of one process at the global batch."""
@@ -102,7 +106,7 @@ def test_ranks_equal_one_process_at_global_batch(tmp_path, device, world, bucket
     script = tmp_path / "rank.py"
     script.write_text(_RANK_SCRIPT)
     _launch(str(script), [ROOT, str(tmp_path / "data.npz"), str(tmp_path / "out.npz")],
-            {"CLX_GRAD_BUCKET_MB": bucket_mb}, nproc=world)
+            {"CLX_GRAD_BUCKET_MB": bucket_mb, "CLX_STREAMS_MIN_GFLOP": "0" if dual else "1e9"}, nproc=world)
     got = np.load(tmp_path / "out.npz")
     assert got["nbuckets"] == 1 if bucket_mb != "0.002" else got["nbuckets"] > 4
 
