@@ -394,6 +394,15 @@ class UNetPlan:
             for key in ("w_skip", "weff", "wp_skip_fwd", "wp_z_fwd", "wp_skip_dgrad", "wp_z_dgrad", "dw_skip", "dw_z"):
                 sp[key] = other.subpixel[name][key]
 
+    def share_forward_from(self, other):
+        """Forward-only version of share_from: this plan reads `other`'s packed weights and never packs."""
+        assert other.B == self.B and other.algo == self.algo and other.keep == self.keep
+        self.wpack_fwd = other.wpack_fwd
+        for name, sp in self.subpixel.items():
+            for key in ("w_skip", "weff", "wp_skip_fwd", "wp_z_fwd"):
+                sp[key] = other.subpixel[name][key]
+        self._packed_version = other._packed_version
+
     def _find_chains(self):
         """Pairs of consecutive 64-channel 1x1 layers (conv_pass.2 -> conv_pass.4 of a level, head.0 ->
         head.2) that run as ONE launch each way (csrc/chain64.hip: the intermediate tensor is written once

@@ -10,6 +10,8 @@ forward/backward is a sequence of HIP kernel launches driven by ``UNetPlan``.
 
 from typing import List, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -17,7 +19,7 @@ import ctypes
 
 from .. import _clx
 from .._clx import ClxConvDesc, ClxSrc
-from .plan import DualPlan, UNetPlan, build_topology, dual_stream_wanted, pad4
+from .plan import DualPlan, UNetPlan, build_topology, dual_stream_wanted, forward_flops, pad4
 
 
 class _ConvPass(nn.Module):
@@ -315,6 +317,7 @@ class UNetModel(nn.Module):  # type: ignore
     def _apply(self, fn, *args, **kwargs):
         # .to()/.cuda() re-allocates parameters: forget flat views and plans
         self._plans = {}
+        self._infer_pair = None
         self._flat = None
         self._flat_grad = None
         return super()._apply(fn, *args, **kwargs)
@@ -338,6 +341,43 @@ class UNetModel(nn.Module):  # type: ignore
         plan = self._plan_for(raw, keep=False)
         plan.pack_weights(params, self._param_version(), need_dgrad=False)
         return plan.forward(raw, params)
+
+    def _forward_chunks(self, noisy, step):
+        """The network on `noisy` (T, C, *spatial) in chunks of `step` copies -> (T, out_channels, *out_spatial).
+        OPT-IN (CLX_INFER_STREAMS=2): with two or more whole chunks of a size that fills the device, the chunks
+        alternate between two plans on two streams that share one set of packed weights (the HBM-bound Winograd
+        transforms of one chunk run under the GEMMs of the other, as in plan.DualPlan).  Measured at the benchmark
+        tile (8 copies of 512 x 512 per chunk): embedding stage 215.0 -> 212.4 ms, infer() end to end unchanged —
+        a chunk this large already fills the device in every phase, so the default stays one stream."""
+        T = noisy.shape[0]
+        if T % step or T // step < 2 or os.environ.get("CLX_INFER_STREAMS", "1") != "2":
+            preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
+            return torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
+        first = noisy[:step].contiguous()
+        plan = self._plan_for(first, keep=False)
+        if forward_flops(plan.topo, step) < float(os.environ.get("CLX_STREAMS_MIN_GFLOP", "100")) * 1e9:
+            preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
+            return torch.cat(preds, dim=0)
+        params = self._ordered_params()
+        plan.pack_weights(params, self._param_version(), need_dgrad=False)
+        pair = getattr(self, "_infer_pair", None)
+        if pair is None or pair[0] is not plan:
+            other = UNetPlan(plan.topo, step, noisy.device, False)
+            pair = self._infer_pair = (plan, other, [torch.cuda.Stream(device=noisy.device) for _ in range(2)])
+        _plan, other, streams = pair
+        other.share_forward_from(plan)
+        t = plan.topo
+        preds = torch.empty((T, t.out_channels) + tuple(t.out_shape[3 - t.nd:]), dtype=torch.float32,
+                            device=noisy.device)
+        main = torch.cuda.current_stream(noisy.device)
+        for s in streams:
+            s.wait_stream(main)
+        for j, i in enumerate(range(0, T, step)):
+            with torch.cuda.stream(streams[j % 2]):
+                (plan, other)[j % 2].forward(noisy[i:i + step], params, out=preds[i:i + step])
+        for s in streams:
+            main.wait_stream(s)
+        return preds
 
     def forward(self, raw):
         if self.mode == "train":
@@ -380,11 +420,8 @@ class UNetModel(nn.Module):  # type: ignore
                 self._noise_vals_key = key
             vals = self._noise_vals.view((T,) + (1,) * (raw_sample.ndim - 1))
             noisy = torch.where(rnd <= self.p_salt_pepper, vals, raw_sample.expand_as(rnd))
-            preds = []
             step = max(1, min(T, int(self.max_infer_batch)))
-            for i in range(0, T, step):
-                preds.append(self._forward_nograd(noisy[i:i + step].contiguous()))
-            preds = torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
+            preds = self._forward_chunks(noisy, step)
             C = preds.shape[1]
             n = preds[0, 0].numel()
             out = torch.empty((C + 1,) + tuple(preds.shape[2:]), dtype=torch.float32, device=raw.device)
