@@ -168,17 +168,29 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int li = lane & 31, lh = lane >> 5;
-  const int a_base = lh * BMN + wm * TM * 32 + li;
-  const int b_base = lh * BNC + wn * TN * 32 + li;
+  // 2 x 2 accumulator sets per wave: fragments as ONE ds_read_b64 per operand and k-pair — lane i reads channels
+  // 2i, 2i + 1 of its pixel, the first feeds accumulator set 0, the second set 1 (MFMA row i of set a is channel
+  // 2i + a; the k order and the row order of an MFMA are free).  Half the LDS read instructions: 1-3 % per launch.
+  constexpr bool PAIR = TM == 2 && TN == 2;
+  const int a_base = lh * BMN + wm * TM * 32 + (PAIR ? 2 * li : li);
+  const int b_base = lh * BNC + wn * TN * 32 + (PAIR ? 2 * li : li);
 
   // fragments of k-pair k2+1 are read from LDS while the MFMAs of k-pair k2 issue; the global
   // loads of the next chunk and their LDS stores are slotted between MFMA groups.
   float af[2][TM], bf[2][TN];
   auto load_frags = [&](int buf, int k2, int slot) {
+    if constexpr (PAIR) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 va = *reinterpret_cast<const f32x2*>(&Ys[buf][a_base + 2 * k2 * BMN]);
+      const f32x2 vb = *reinterpret_cast<const f32x2*>(&Xs[buf][b_base + 2 * k2 * BNC]);
+      af[slot][0] = va[0]; af[slot][TM - 1] = va[1];
+      bf[slot][0] = vb[0]; bf[slot][TN - 1] = vb[1];
+    } else {
 #pragma unroll
-    for (int a = 0; a < TM; ++a) af[slot][a] = Ys[buf][a_base + 2 * k2 * BMN + a * 32];
+      for (int a = 0; a < TM; ++a) af[slot][a] = Ys[buf][a_base + 2 * k2 * BMN + a * 32];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) bf[slot][b] = Xs[buf][b_base + 2 * k2 * BNC + b * 32];
+      for (int b = 0; b < TN; ++b) bf[slot][b] = Xs[buf][b_base + 2 * k2 * BNC + b * 32];
+    }
   };
   if (nchunks > 0) {
     load_dy(0);
@@ -234,11 +246,12 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int c = tile_c * BNC + (wn * TN + b) * 32 + li;
+      const int c = PAIR ? tile_c * BNC + wn * TN * 32 + 2 * li + b : tile_c * BNC + (wn * TN + b) * 32 + li;
       if (c < p.Ctot) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int n = tile_n * BMN + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int n = PAIR ? tile_n * BMN + wm * TM * 32 + 2 * row + a : tile_n * BMN + (wm * TM + a) * 32 + row;
           if (n < p.N) atomicAdd(dst + (size_t)n * p.Ctot + c, acc[a][b][r]);
         }
       }

@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cellulus_amd import _clx
 from cellulus_amd._clx import ClxConvDesc, ClxSrc
 
+if os.environ.get("CLX_LIB"):
+    _clx.LIB_PATH = os.path.abspath(os.environ["CLX_LIB"])
 dev = torch.device("cuda:0")
 B, H, W, C, N, k = (int(v) for v in (sys.argv[1:7] if len(sys.argv) > 6 else (8, 124, 124, 768, 768, 1)))
 x = torch.randn(B * H * W, C, device=dev)
