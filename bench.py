@@ -622,11 +622,17 @@ def main():
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-train3d", action="store_true")
     ap.add_argument("--no-train-e2e", action="store_true")
+    ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
+                    help="0 (default): the product's default, two half batches on two streams per GPU (CLX_STREAMS "
+                         "unset).  1: one stream — every kernel alone on the device, the run the roofline numbers and "
+                         "the PMC profiles are taken from")
     ap.add_argument("--precision", default="f32", choices=["f32", "f32x3bf16"],
                     help="f32 (default, the headline): float32 MFMA.  f32x3bf16: ALSO time the 2-D workload with the "
                          "opt-in precision (plain GEMMs on the bf16 matrix cores, three-way exact split of the float32 "
                          "operands) and report it as the extra object `train2d_f32x3bf16`; never the headline value")
     args = ap.parse_args()
+    if args.streams:
+        os.environ["CLX_STREAMS"] = str(args.streams)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))

@@ -26,5 +26,8 @@ cp $R/pmc_lds_conflicts_f32.txt profiles/${P}_pmc_lds_conflicts_f32.txt
 cp $R/pmc_lds_conflicts_f32x3bf16.txt profiles/${P}_pmc_lds_conflicts_f32x3bf16.txt
 [ -f $R/streaming_kernels_4096.txt ] && cp $R/streaming_kernels_4096.txt profiles/${P}_streaming_kernels_4096.txt
 [ -f $R/prof_stream4k_kernel_stats.csv ] && cp $R/prof_stream4k_kernel_stats.csv profiles/${P}_streaming_4096_kernel_stats.csv
+[ -f $R/bench_one_stream.json ] && cp $R/bench_one_stream.json profiles/${P}_bench_one_stream.json
+[ -f $R/overlap_train2d.txt ] && cp $R/overlap_train2d.txt profiles/${P}_two_streams_overlap_train2d.txt
+[ -f $R/overlap_train3d.txt ] && cp $R/overlap_train3d.txt profiles/${P}_two_streams_overlap_train3d.txt
 [ -f $R/bench_deterministic.json ] && cp $R/bench_deterministic.json profiles/${P}_bench_deterministic.json
 true

@@ -30,6 +30,13 @@ for t, d, k in ev:
 span = (t1 - t0) / 1e3
 print('step span us', round(span), 'kernels', len(seg), 'queues', len(set(r.get('Queue_Id', '') for r in seg)))
 for k, v in acc.most_common(): print(f'  {k:10s} {v / 1e3:9.1f} us  {v / 1e3 / span:6.1%}')
-print(json.loads(open(O + '/bench.json').read().strip().splitlines()[-1])['ms_per_step'])
+c = collections.Counter(); tt = collections.Counter()
+for r in seg:
+    n = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0][:44]
+    c[n] += 1; tt[n] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+print('launches of that step (durations while sharing the device with the other stream):')
+for n, v in tt.most_common(12): print(f'  {n:46s} {c[n]:4d} launches {v / c[n]:9.1f} us average')
+b = json.loads(open(O + '/bench.json').read().strip().splitlines()[-1])
+print('bench.py under the trace: ms_per_step', b['ms_per_step'], 'one-stream pass', b['roofline'].get('one_stream_ms_per_step'))
 PY
 rm -rf $O/*/ 2>/dev/null; find $O -name "*.csv" -size +20M -delete
