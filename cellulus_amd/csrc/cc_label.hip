@@ -292,27 +292,39 @@ __global__ __launch_bounds__(256) void cc_count_roots(const int* __restrict__ se
 
 __global__ __launch_bounds__(1024) void cc_scan_counts(int* __restrict__ counts, int nblocks,
                                                        int* __restrict__ total_out) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
+  // exclusive scan in place: per-thread runs of `per` entries, wave scans by lane shuffles, the 16 wave
+  // totals by the first wave — two block barriers (the 1024-wide Hillis-Steele scan it replaces had twenty)
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int per = (nblocks + 1023) / 1024;
   const int lo = tid * per, hi = min(lo + per, nblocks);
   int s = 0;
   for (int i = lo; i < hi; ++i) s += counts[i];
-  part[tid] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int v = (tid >= o) ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
+  int incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
   }
-  int run = (tid == 0) ? 0 : part[tid - 1];
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  if (wid == 0) {
+    int w = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int v = __shfl_up(w, o, 64);
+      if (lane >= o) w += v;
+    }
+    if (lane < 16) wsum[lane] = w;
+  }
+  __syncthreads();
+  int run = incl - s + (wid ? wsum[wid - 1] : 0);
   for (int i = lo; i < hi; ++i) {
     const int c = counts[i];
     counts[i] = run;
     run += c;
   }
-  if (tid == 1023 && total_out) *total_out = part[1023];
+  if (tid == 1023 && total_out) *total_out = wsum[15];
 }
 
 // surviving root r gets id = 1 + (number of surviving roots before r); stored in size[r] as -id
@@ -428,10 +440,15 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
     const bool in_x = x < X;
     const int y0 = strip * STRIP_ROWS, y1 = min(y0 + STRIP_ROWS, Y);
     int pv = 0, pl = -1;
-    for (int yb = y0; yb < y1; yb += 4) {
-      int vv[4];                                            // four rows in flight
+    int nx[4];                                              // the next four rows: loaded while the current four are walked
 #pragma unroll
-      for (int k = 0; k < 4; ++k) vv[k] = (in_x && yb + k < y1) ? seg[(long long)(yb + k) * X + x] : 0;
+    for (int k = 0; k < 4; ++k) nx[k] = (in_x && y0 + k < y1) ? seg[(long long)(y0 + k) * X + x] : 0;
+    for (int yb = y0; yb < y1; yb += 4) {
+      int vv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) vv[k] = nx[k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) nx[k] = (in_x && yb + 4 + k < y1) ? seg[(long long)(yb + 4 + k) * X + x] : 0;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int y = yb + k;
@@ -493,7 +510,12 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
   }
 }
 
-__global__ void cc_link1(const int* __restrict__ seg, int* L, int Y, int X, int nseg, int nstrips) {
+__global__ void cc_link1(const int* __restrict__ seg, int* L, int Y, int X, int nseg, int nstrips,
+                         unsigned int* __restrict__ zero, long long nzero) {
+  // (also clears the survivor bitmap and the chunk counters of the later label passes: a fill beside this
+  //  latency-bound pass instead of a launch of its own)
+  for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nzero; k += (long long)gridDim.x * blockDim.x)
+    zero[k] = 0u;
   const long long n_rows = (long long)(nstrips - 1) * X;
   const long long n_cols = (long long)(nseg - 1) * Y;
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows + n_cols;
@@ -641,14 +663,11 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
     rank_chunk = ((rank_chunk < 2048 ? 2048 : rank_chunk) + 31) / 32 * 32;
     const int nchunks = (int)((npix + rank_chunk - 1) / rank_chunk);
     int* chunk = (int*)(bitmap + nwords);
-    if (hipMemsetAsync(bitmap, 0, (size_t)(nwords + nchunks) * sizeof(int), st) != hipSuccess) {
-      clx_set_error("clx_cc_label_filter: memset failed");
-      return CLX_ERR_LAUNCH;
-    }
     const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
     cc_strip1<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, out, sz, labelmask, Y, X, nseg, nstrips);
     const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
-    if (nb > 0) cc_link1<<<grid_for(nb, 256), 256, 0, st>>>(seg, out, Y, X, nseg, nstrips);
+    const long long nzero = nwords + nchunks;
+    cc_link1<<<grid_for(nb > nzero ? nb : nzero, 256), 256, 0, st>>>(seg, out, Y, X, nseg, nstrips, bitmap, nzero);
     const int lgrid = grid_for(nmask, 256);
     cc_fold<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X);
     cc_mark<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X, min_size, bitmap, chunk, (int)rank_chunk);
