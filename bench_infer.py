@@ -123,7 +123,8 @@ def streaming_rooflines(device, size=4096):
     order, cstart, corigin, (gx, gy, gz) = MS._center_grid(centers, 15.0)
     order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)
     corigin_c = (ctypes.c_double * 2)(*corigin.tolist())
-    t = _event_time(lambda: _clx.call("clx_ms_assign_grid", _clx.ptr(pts), _clx.ptr(idx), n_fg, _clx.ptr(cc),
+    cc_sorted = torch.from_numpy(np.ascontiguousarray(centers[order])).to(device)      # as mean_shift_on_device calls it
+    t = _event_time(lambda: _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(idx), n_fg, _clx.ptr(cc_sorted),
                                       len(centers), 2, _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, 15.0,
                                       gx, gy, gz, _clx.ptr(labels), st))
     row("ms_assign", t, n_fg * (16 + 4 + 4), "per foreground pixel 20 B read + 4 B label written",

@@ -170,7 +170,8 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
         order_d = torch.from_numpy(order).to(dev)
         cstart_d = torch.from_numpy(cstart).to(dev)
         corigin_c = (ctypes.c_double * nd)(*corigin.tolist())
-        _clx.call("clx_ms_assign_grid", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,
+        cc_sorted = torch.from_numpy(np.ascontiguousarray(cluster_centers[order])).to(dev)      # centres in cell order
+        _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc_sorted), ncc, nd,
                   _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, cell, gx, gy, gz, _clx.ptr(labels), st)
     else:
         _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,

@@ -449,6 +449,14 @@ int clx_ms_assign_grid(const double* X, const int* index, int nfg, const double*
                        int ncenters, int ND, const int* order, const int* cell_start,
                        const double* origin, double cell, int nx, int ny, int nz, int* labels,
                        clx_stream stream);
+/* The grid search with the centres handed over IN CELL ORDER (centers_sorted[j] = centre order[j]; 16-byte aligned
+ * in 2-D): a candidate is one load from a contiguous range instead of two dependent ones, the ranges of the
+ * neighbouring rows are fetched together — the same labels (same arithmetic, same tie rule) in about half the time
+ * (replaces the nearest-centre `predict` of sklearn MeanShift, cellulus/utils/mean_shift.py:93-104). */
+int clx_ms_assign_cells(const double* X, const int* index, int nfg, const double* centers_sorted,
+                        int ncenters, int ND, const int* order, const int* cell_start,
+                        const double* origin, double cell, int nx, int ny, int nz, int* labels,
+                        clx_stream stream);
 
 /* Seeds for use_seeds = true (cellulus/detect.py:128-132), float64, the libraries' operation order:
  *   clx_offset_magnitude    np.linalg.norm(emb[:ND], axis=0): emb (ND, npix) -> out (npix)

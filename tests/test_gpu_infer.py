@@ -413,7 +413,7 @@ def test_bucket_kernel_is_a_stable_sort_by_cell(nd, device):
 
 @pytest.mark.parametrize("nd", [2, 3])
 def test_grid_assignment_equals_the_plain_nearest_centre_loop(nd, device):
-    """clx_ms_assign_grid == clx_ms_assign (first minimum over all centres): pixels near their centre,
+    """clx_ms_assign_grid == clx_ms_assign_cells == clx_ms_assign (first minimum over all centres): pixels near their centre,
     pixels far from every centre (fall back to the full loop), exact ties between two centres
     (the smaller index wins), centres sharing a cell."""
     import ctypes
@@ -446,6 +446,13 @@ def test_grid_assignment_equals_the_plain_nearest_centre_loop(nd, device):
               _clx.ptr(order_d), _clx.ptr(cstart_d),
               (ctypes.c_double * nd)(*origin.tolist()), bw, gx, gy, gz, _clx.ptr(got), st)
     np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    # ... and the form the product calls: centres handed over in cell order (clx_ms_assign_cells)
+    got2 = torch.zeros(n, dtype=torch.int32, device=device)
+    cc_sorted = torch.from_numpy(np.ascontiguousarray(centers[order])).to(device)
+    _clx.call("clx_ms_assign_cells", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc_sorted), K, nd,
+              _clx.ptr(order_d), _clx.ptr(cstart_d),
+              (ctypes.c_double * nd)(*origin.tolist()), bw, gx, gy, gz, _clx.ptr(got2), st)
+    np.testing.assert_array_equal(got2.cpu().numpy(), ref.cpu().numpy())
     d2 = ((pts[:, None, :] - centers[None]) ** 2).sum(-1)
     np.testing.assert_array_equal(ref.cpu().numpy()[:-16], d2.argmin(1)[:-16] + 1)
     assert set(ref.cpu().numpy()[-16:].tolist()) <= {7, 8}

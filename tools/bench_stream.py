@@ -8,6 +8,10 @@ import torch
 
 sys.path.insert(0, ".")
 from bench_infer import streaming_rooflines  # noqa: E402
+import os
+if os.environ.get("CLX_LIB"):
+    from cellulus_amd import _clx
+    _clx.LIB_PATH = os.path.abspath(os.environ["CLX_LIB"])
 
 if __name__ == "__main__":
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
