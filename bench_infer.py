@@ -72,7 +72,7 @@ def synthetic_embeddings(shape, spacing=48, radius=12, noise=0.3, seed=1):
     return mean[np.newaxis].copy(), std
 
 
-def streaming_rooflines(device, size=4096):
+def streaming_rooflines(device, size=4096, only_mean_shift=False):
     """Every HBM-bound kernel of detect / segment on one size x size image (batch scale: size^2 /
     512^2 samples per launch).  bytes = the algorithm's compulsory traffic (stated per kernel)."""
     from cellulus_amd import _clx
@@ -98,7 +98,7 @@ def streaming_rooflines(device, size=4096):
     reps = size // 512
     emb0 = torch.from_numpy(np.tile(mean[0], (1, reps, reps))).to(device)
     sd = torch.from_numpy(np.tile(std, (reps, reps))).to(device)
-    ws = torch.empty(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)
+    ws = torch.zeros(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)   # zeroed once: the calls keep it so
     pts = torch.empty((npix, 2), dtype=torch.float64, device=device)
     idx = torch.empty(npix, dtype=torch.int32, device=device)
     nfg = torch.zeros(1, dtype=torch.int32, device=device)
@@ -129,6 +129,8 @@ def streaming_rooflines(device, size=4096):
                                       gx, gy, gz, _clx.ptr(labels), st))
     row("ms_assign", t, n_fg * (16 + 4 + 4), "per foreground pixel 20 B read + 4 B label written",
         centres=len(centers))
+    if only_mean_shift:
+        return dict(pixels_per_launch=npix, samples_of_512x512_per_launch=npix // (512 * 512), kernels=out)
     seg = labels.view(Y, X).clone()
     del emb, emb0, pts, idx
     # --- grow / shrink and connected components + size filter on that label map
@@ -331,6 +333,10 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     if with_streaming:
         try:
             out["streaming"] = streaming_rooflines(device)
+            torch.cuda.empty_cache()
+            # the two mean-shift kernels again at 256 samples per launch: what a launch of 64 samples loses is ramp and
+            # launch cost, not bandwidth
+            out["streaming"]["mean_shift_at_8192"] = streaming_rooflines(device, 8192, only_mean_shift=True)
         except Exception as e:
             out["streaming"] = {"error": f"{type(e).__name__}: {e}"}
     if with_e2e:

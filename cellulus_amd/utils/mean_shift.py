@@ -99,6 +99,19 @@ def dedup_centers(centers, counts, bandwidth):
     return centers[unique]
 
 
+_PREP_WS = {}
+
+
+def _prepare_workspace(nbytes, dev):
+    """clx_ms_prepare's workspace: zero-filled once, handed back zero-filled by every call (include/clx.h), so one
+    buffer per (device, stream) serves every image; grown when a larger image comes."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _PREP_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _PREP_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    return ws
+
+
 def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, seeds=None):
     """emb: (ND, *spatial) f64 device tensor (coordinates are ADDED IN PLACE, as the
     reference does to its argument); std: (*spatial) f64 device tensor.
@@ -114,7 +127,7 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     dev = emb.device
     st = _clx.stream_ptr(dev)
     lib = _clx.load()
-    ws = torch.empty(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=dev)
+    ws = _prepare_workspace(int(lib.clx_ms_prepare_workspace(npix)), dev)
     pts = torch.empty((npix, nd), dtype=torch.float64, device=dev)
     index = torch.empty(npix, dtype=torch.int32, device=dev)
     nfg_d = torch.zeros(1, dtype=torch.int32, device=dev)

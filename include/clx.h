@@ -405,7 +405,9 @@ int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
  *   emb:  (ND, [Z,] Y, X) f64, channel 0 += x, 1 += y, 2 += z
  *   X:    (nfg, ND) f64 out,  index: (nfg) int32 raster index of each fg pixel
  *   nfg_out: device int32, number of foreground pixels
- * workspace: clx_ms_prepare_workspace(npix) bytes. */
+ * workspace: clx_ms_prepare_workspace(npix) bytes, ZERO-FILLED by the caller before the first call that uses it;
+ * every call hands it back zero-filled, so the same buffer serves the next call on that stream as it is (one
+ * workspace per stream in flight). */
 size_t clx_ms_prepare_workspace(long long npix);
 int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
                    int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
