@@ -426,8 +426,8 @@ __device__ __forceinline__ int wave_shr1(int x, int fill) { return __builtin_amd
 __device__ __forceinline__ int wave_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
 
 __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, int* L, int* size,
-                                                 unsigned long long* __restrict__ labelmask, int Y, int X, int nseg,
-                                                 int nstrips) {
+                                                 unsigned long long* __restrict__ labelmask, int* __restrict__ colL,
+                                                 int* __restrict__ colR, int Y, int X, int nseg, int nstrips) {
   __shared__ int runlab[4][64];
   const int lane = threadIdx.x & 63;
   int* rl = runlab[threadIdx.x >> 6];
@@ -496,6 +496,12 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
         // (a single global list would serialise its appends on one counter: 162 us of a 4096^2 image)
         const unsigned long long created = __ballot(v != 0 && runmin == INF && sl == lane);
         if (lane == 0) labelmask[(long long)y * nseg + sg] = created;
+        // the segment's edge columns, transposed (contiguous in y): what the border pass compares instead of
+        // column-strided reads of the image (one 4-byte value per 64-byte sector: 0.21 GB at 8192^2)
+        if (colL != nullptr) {
+          if (lane == 0) colL[(long long)sg * Y + y] = v;
+          if (lane == 63) colR[(long long)sg * Y + y] = v;
+        }
         const bool j0 = c0 != INF && c0 != label, j1 = c1 != INF && c1 != label, j2 = c2 != INF && c2 != label;
         if (j0 || j1 || j2) {
           __threadfence();
@@ -510,7 +516,8 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
   }
 }
 
-__global__ void cc_link1(const int* __restrict__ seg, int* L, int Y, int X, int nseg, int nstrips,
+__global__ void cc_link1(const int* __restrict__ seg, int* L, const int* __restrict__ colL,
+                         const int* __restrict__ colR, int Y, int X, int nseg, int nstrips,
                          unsigned int* __restrict__ zero, long long nzero) {
   // (also clears the survivor bitmap and the chunk counters of the later label passes: a fill beside this
   //  latency-bound pass instead of a launch of its own)
@@ -533,15 +540,16 @@ __global__ void cc_link1(const int* __restrict__ seg, int* L, int Y, int X, int 
       }
     } else {
       const long long kk = k - n_rows;
-      const int x = (int)(kk / Y + 1) * 64, y = (int)(kk % Y);
+      const int b = (int)(kk / Y + 1), x = b * 64, y = (int)(kk % Y);
       const long long i = (long long)y * X + x;
-      const int v = seg[i];
+      const int v = colL != nullptr ? colL[(long long)b * Y + y] : seg[i];
       if (v == 0) continue;
       for (int dy = -1; dy <= 1; ++dy) {
         const int yy = y + dy;
         if (yy < 0 || yy >= Y) continue;
         const long long j = (long long)yy * X + x - 1;
-        if (seg[j] == v) uf1_union(L, (int)i, (int)j);
+        const int u = colR != nullptr ? colR[(long long)(b - 1) * Y + yy] : seg[j];
+        if (u == v) uf1_union(L, (int)i, (int)j);
       }
     }
   }
@@ -663,11 +671,17 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
     rank_chunk = ((rank_chunk < 2048 ? 2048 : rank_chunk) + 31) / 32 * 32;
     const int nchunks = (int)((npix + rank_chunk - 1) / rank_chunk);
     int* chunk = (int*)(bitmap + nwords);
+    int* colL = chunk + nchunks;                       // edge columns of the 64-pixel segments, [segment][y]
+    int* colR = colL + (long long)nseg * Y;
+    // (images a few pixels wide and very tall: the buffers do not fit the workspace — the border pass then reads the image)
+    if ((size_t)((unsigned char*)(colR + (long long)nseg * Y) - (unsigned char*)workspace) > clx_cc_workspace(npix))
+      colL = colR = nullptr;
     const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
-    cc_strip1<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, out, sz, labelmask, Y, X, nseg, nstrips);
+    cc_strip1<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, out, sz, labelmask, colL, colR, Y, X, nseg,
+                                                                             nstrips);
     const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
     const long long nzero = nwords + nchunks;
-    cc_link1<<<grid_for(nb > nzero ? nb : nzero, 256), 256, 0, st>>>(seg, out, Y, X, nseg, nstrips, bitmap, nzero);
+    cc_link1<<<grid_for(nb > nzero ? nb : nzero, 256), 256, 0, st>>>(seg, out, colL, colR, Y, X, nseg, nstrips, bitmap, nzero);
     const int lgrid = grid_for(nmask, 256);
     cc_fold<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X);
     cc_mark<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X, min_size, bitmap, chunk, (int)rank_chunk);
