@@ -14,6 +14,19 @@
 // Replaces nn.Conv{2,3}d(+ReLU) forward/backward-data of the reference U-Net
 // (cellulus/models/unet.py:24-63, funlib ConvPass) — exact f32 arithmetic.
 #include "clx_common.h"
+#include <stdlib.h>
+
+#ifdef IG_STAMP
+// diagnostic build (tools/build_variant.sh ... -DIG_STAMP): per block, wall-clock stamps (100 MHz counter) at start, first
+// MFMA, end of the K loop, end of the block, and the hardware id — read back with clx_debug_stamps
+__device__ unsigned long long g_stamps[8 * 32768];
+extern "C" int clx_debug_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : 1;
+}
+#define STAMP(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) g_stamps[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -76,6 +89,16 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   float (*As)[BM * LDS_LD] = reinterpret_cast<float (*)[BM * LDS_LD]>(smem);
   float (*Bs)[BN * LDS_LD] = reinterpret_cast<float (*)[BN * LDS_LD]>(smem + 2 * BM * LDS_LD);
 
+  STAMP(0);
+#ifdef IG_STAMP
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) {
+    unsigned int hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_stamps[blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
   const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
   const int tile_n = v % p.nbn;
   const int tile_m = v / p.nbn;
@@ -193,6 +216,13 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int li = lane & 31, lh = lane >> 5;
+  // bias of this lane's accumulator columns: fetched here, used in the epilogue
+  float bias_v[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int nb_ = n0 + (wn * TN + b) * 32 + li;
+    bias_v[b] = (p.bias && nb_ < p.N) ? p.bias[nb_] : 0.f;
+  }
   const int a_base = (wm * TM * 32 + li) * LDS_LD + (SWZ ? 0 : 4 * lh);
   const int b_base = (wn * TN * 32 + li) * LDS_LD + (SWZ ? 0 : 4 * lh);
   // k-group q reads 16-byte column 2q + lh of its row, swizzled: (2q + lh) ^ (row >> 1 & 7)
@@ -202,6 +232,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   load_chunk();
   store_chunk(0);
   __syncthreads();
+  STAMP(1);
 
   int buf = 0;
   bool more = advance();
@@ -235,6 +266,9 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   // vmcnt(<=3) — the B loads then waited for the A loads issued one MFMA group earlier, every
   // chunk.  The last chunk (nothing left to prefetch) runs after the loop.
   load_frags(buf, 0, 0);
+#ifdef IG_STAMP
+  unsigned long long stamp_prev_ = wall_clock64(), stamp_max_ = 0, stamp_min_ = ~0ull;
+#endif
   while (more) {
     load_a();
     load_frags(buf, 1, 1);
@@ -255,6 +289,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     mfma_group(1);
     __builtin_amdgcn_sched_barrier(0);     // keep the barrier BEHIND the last group: the MFMAs
     __syncthreads();                       // already issued absorb the skew between the waves
+#ifdef IG_STAMP
+    {
+      const unsigned long long now_ = wall_clock64();
+      const unsigned long long dt_ = now_ - stamp_prev_;
+      stamp_prev_ = now_;
+      if (dt_ > stamp_max_) stamp_max_ = dt_;
+      if (dt_ < stamp_min_) stamp_min_ = dt_;
+    }
+#endif
     buf ^= 1;
     load_frags(buf, 0, 0);
     more = advance();
@@ -273,79 +316,122 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   __builtin_amdgcn_sched_barrier(0);
   mfma_group(1);
 
-  // ---- epilogue: bias + ReLU in registers, transpose through LDS so that every lane
-  // stores (and reads the ReLU-gate mask as) 16-byte channel runs of one output pixel.
+  STAMP(2);
+#ifdef IG_STAMP
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) g_stamps[blockIdx.x * 8 + 7] = (stamp_max_ << 32) | (stamp_min_ & 0xffffffffull);
+#endif
+  // ---- epilogue: bias in registers, transpose through LDS so that every lane stores (and reads the ReLU-gate mask
+  // as) 16-byte channel runs of one output pixel.  Written in PHASES over eight rows-of-four at a time — all LDS
+  // reads, then each optional operand (previous output, gate bits, float mask) as one batch of loads, then the
+  // arithmetic, then the stores: with the options tested inside one loop body the compiler put an s_waitcnt vmcnt(0)
+  // behind every optional load (on gfx9 that also waits for the STORES before it) and never had two LDS reads in
+  // flight — 3.4-4.9 us of a 43-us tile at K = 256, plus 1.5-5 us for four bias loads waited for one by one
+  // (tools/exp/tile_stamps.py); the bias is now fetched before the K loop.
   __syncthreads();
+  STAMP(5);
   float* Cs = smem;
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int col = (wn * TN + b) * 32 + li;
-      const int n = n0 + col;
-      const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        Cs[row * LDC + col] = acc[a][b][r] + bv;
+        Cs[row * LDC + col] = acc[a][b][r] + bias_v[b];
       }
     }
   }
   __syncthreads();
+  STAMP(6);
   constexpr int F4_PER_ROW = BN / 4;
   constexpr int ITERS = BM * F4_PER_ROW / 256;
-#pragma unroll 4
-  for (int it = 0; it < ITERS; ++it) {
-    const int idx = tid + 256 * it;
-    const int row = idx / F4_PER_ROW, c4 = (idx % F4_PER_ROW) * 4;
-    const int m = m0 + row, n = n0 + c4;
-    const bool live = m < p.M && n < p.N;
-    f32x4 val = {0.f, 0.f, 0.f, 0.f};
-    float* dst = p.out + blockIdx.y * p.bs_out + (size_t)m * p.ld_out + n;
-    if (live) {
-      val = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
-      if (p.accumulate) {       // out = act(conv + bias + out): n + 3 < ld_out always (ld_out % 4 == 0)
-        const f32x4 prev = *reinterpret_cast<const f32x4*>(dst);
-        val += prev;
-      }
-      if (p.relu) {
+  constexpr int PH = 8;                       // rows-of-four per phase
+  static_assert(ITERS % PH == 0, "phases");
+  const int c4 = (tid % F4_PER_ROW) * 4;      // idx % F4_PER_ROW does not depend on the iteration (256 % F4_PER_ROW == 0)
+  const int n = n0 + c4;
+  const bool n_live = n < p.N;
+  const bool full4 = n + 3 < p.N;
+#pragma unroll 1
+  for (int h0 = 0; h0 < ITERS; h0 += PH) {
+    f32x4 val[PH];
+    int mrow[PH];
+    bool live[PH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = fmaxf(val[e], 0.f);
-      }
-      if (p.mask_bits) {          // gate of the producer's ReLU, one bit per channel
-        const unsigned int w = p.mask_bits[(size_t)m * p.ld_mask_bits + (n >> 5)] >> (n & 31);
+    for (int j = 0; j < PH; ++j) {
+      const int row = (tid + 256 * (h0 + j)) / F4_PER_ROW;
+      mrow[j] = m0 + row;
+      live[j] = mrow[j] < p.M && n_live;
+      val[j] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);          // (inside the tile: always readable)
+    }
+    float* const out_base = p.out + blockIdx.y * p.bs_out + n;
+    if (p.accumulate) {         // out = act(conv + bias + out): n + 3 < ld_out always (ld_out % 4 == 0)
+      f32x4 prev[PH];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = ((w >> e) & 1u) ? val[e] : 0.f;
-      }
+      for (int j = 0; j < PH; ++j)
+        prev[j] = *reinterpret_cast<const f32x4*>(live[j] ? out_base + (size_t)mrow[j] * p.ld_out : p.zeros);
+#pragma unroll
+      for (int j = 0; j < PH; ++j) val[j] += prev[j];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[j][e] = fmaxf(val[j][e], 0.f);
+    }
+    if (p.mask_bits) {          // gate of the producer's ReLU, one bit per channel
+      unsigned int w[PH];
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        w[j] = live[j] ? p.mask_bits[(size_t)mrow[j] * p.ld_mask_bits + (n >> 5)] : 0u;
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[j][e] = ((w[j] >> ((n & 31) + e)) & 1u) ? val[j][e] : 0.f;
     }
     if (p.gate_out) {
       // eight consecutive lanes hold the 32 channels of one word (F4_PER_ROW is 16 or 32, so a group of
       // eight never straddles a row): OR their nibbles together, the first lane of the group stores
-      unsigned int nib = 0u;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) nib |= (live && n + e < p.N && val[e] > 0.f) ? (1u << e) : 0u;
-      unsigned int word = nib << (4 * (lane & 7));
-      word |= __shfl_xor(word, 1, 64);
-      word |= __shfl_xor(word, 2, 64);
-      word |= __shfl_xor(word, 4, 64);
-      if ((lane & 7) == 0 && m < p.M && n < p.ld_out) p.gate_out[(size_t)m * p.ld_gate + (n >> 5)] = word;
-    }
-    if (!live) continue;
-    if (n + 3 < p.N) {
-      if (p.mask) {
-        const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + (size_t)m * p.ld_mask + n);
+      for (int j = 0; j < PH; ++j) {
+        unsigned int nib = 0u;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = (mk[e] > 0.f) ? val[e] : 0.f;
+        for (int e = 0; e < 4; ++e) nib |= (live[j] && n + e < p.N && val[j][e] > 0.f) ? (1u << e) : 0u;
+        unsigned int word = nib << (4 * (lane & 7));
+        word |= __shfl_xor(word, 1, 64);
+        word |= __shfl_xor(word, 2, 64);
+        word |= __shfl_xor(word, 4, 64);
+        if ((lane & 7) == 0 && mrow[j] < p.M && n < p.ld_out) p.gate_out[(size_t)mrow[j] * p.ld_gate + (n >> 5)] = word;
       }
-      *reinterpret_cast<f32x4*>(dst) = val;
-    } else {
-      for (int e = 0; e < 4 && n + e < p.N; ++e) {
-        float x = val[e];
-        if (p.mask) x = (p.mask[(size_t)m * p.ld_mask + n + e] > 0.f) ? x : 0.f;
-        dst[e] = x;
+    }
+    if (p.mask && full4) {
+      f32x4 mk[PH];
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        mk[j] = *reinterpret_cast<const f32x4*>(live[j] ? p.mask + (size_t)mrow[j] * p.ld_mask + n : p.zeros);
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[j][e] = (!live[j] || mk[j][e] > 0.f) ? val[j][e] : 0.f;
+    }
+    if (full4) {
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        if (live[j]) *reinterpret_cast<f32x4*>(out_base + (size_t)mrow[j] * p.ld_out) = val[j];
+    } else if (n_live) {        // the last, partial group of four channels of a row (N % 4 != 0)
+#pragma unroll 1
+      for (int j = 0; j < PH; ++j) {
+        if (!live[j]) continue;
+        float* dst = out_base + (size_t)mrow[j] * p.ld_out;
+        for (int e = 0; e < 4 && n + e < p.N; ++e) {
+          float x = val[j][e];
+          if (p.mask) x = (p.mask[(size_t)mrow[j] * p.ld_mask + n + e] > 0.f) ? x : 0.f;
+          dst[e] = x;
+        }
       }
     }
   }
+  STAMP(3);
 }
 
 }  // namespace
