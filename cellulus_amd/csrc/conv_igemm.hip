@@ -327,6 +327,25 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   // behind every optional load (on gfx9 that also waits for the STORES before it) and never had two LDS reads in
   // flight — 3.4-4.9 us of a 43-us tile at K = 256, plus 1.5-5 us for four bias loads waited for one by one
   // (tools/exp/tile_stamps.py); the bias is now fetched before the K loop.
+  // Plain products (no bias / ReLU / gates / accumulate: the per-xi products of the Winograd layers) on whole tiles
+  // leave the accumulators as they are — per register two full 128-byte lines, no LDS round trip, no barriers
+  // (+ 1 % on the step; with any of the options the transposed path below is the faster one)
+  if (!p.bias && !p.relu && !p.accumulate && !p.mask && !p.mask_bits && !p.gate_out && m0 + BM <= p.M && n0 + BN <= p.N) {
+    float* const ob = p.out + blockIdx.y * p.bs_out;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          ob[(size_t)row * p.ld_out + col] = acc[a][b][r];
+        }
+      }
+    STAMP(3);
+    return;
+  }
   __syncthreads();
   STAMP(5);
   float* Cs = smem;
