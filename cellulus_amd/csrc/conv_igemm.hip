@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   // (tools/exp/tile_stamps.py); the bias is now fetched before the K loop.
   // Plain products (no bias / ReLU / gates / accumulate: the per-xi products of the Winograd layers) on whole tiles
   // leave the accumulators as they are — per register two full 128-byte lines, no LDS round trip, no barriers
-  // (+ 1 % on the step; with any of the options the transposed path below is the faster one)
+  // (+ 1 % on the step.  With bias / ReLU / gate words by ballot / gate bits folded into this path as well the step was
+  //  1.5 % SLOWER than with the transposed path below for those launches: 225.0 against 228.3 crops/s)
   if (!p.bias && !p.relu && !p.accumulate && !p.mask && !p.mask_bits && !p.gate_out && m0 + BM <= p.M && n0 + BN <= p.N) {
     float* const ob = p.out + blockIdx.y * p.bs_out;
 #pragma unroll
