@@ -287,6 +287,8 @@ def run_workload(wl_key, args, rank, world, device):
     gc.collect()
     gc.disable()     # a cyclic-GC pause inside one step would be charged to the GPU path
     _clx.call("clx_profile_enable", 2)      # HIP events around every MFMA kernel launch, on its stream
+    _lib0 = _clx.load()
+    _lib0.clx_profile_clock(None, None, 1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -300,6 +302,12 @@ def run_workload(wl_key, args, rank, world, device):
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
              3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels"}
 
+    def read_clock(reset=True):
+        """MHz the MFMA kernels ran at since the last reset (clx_profile_clock), None if nothing was recorded"""
+        c, w = ctypes.c_double(), ctypes.c_double()
+        lib.clx_profile_clock(ctypes.byref(c), ctypes.byref(w), 1 if reset else 0)
+        return round(100.0 * c.value / w.value, 1) if w.value > 0 else None
+
     def read_profile():
         prof = {}
         for kind, kname in kinds.items():
@@ -310,6 +318,7 @@ def run_workload(wl_key, args, rank, world, device):
         return prof
 
     prof = read_profile()
+    clock_mhz = read_clock()
     # ---- what the data-parallel run saw
     dt, per_rank, ranks_seen, exposed = dt_local, [dt_local], 1, None
     if world > 1:
@@ -343,7 +352,7 @@ def run_workload(wl_key, args, rank, world, device):
     # timed a second time, alone, in K more steps of the same workload on ONE stream (every rank takes part);
     # `value` stays the two-stream figure, the roofline object says which pass its numbers are from.
     from cellulus_amd.models.plan import DualPlan
-    overlapped, one_stream_dt = None, None
+    overlapped, one_stream_dt, clock_one_stream = None, None, None
     if isinstance(next(iter(model._plans.values())), DualPlan):
         overlapped = prof
         keep_env = os.environ.get("CLX_STREAMS")
@@ -363,6 +372,7 @@ def run_workload(wl_key, args, rank, world, device):
             one_stream_dt = time.perf_counter() - t1
             gc.enable()
             prof = read_profile()
+            clock_one_stream = read_clock()
         finally:
             if keep_env is None:
                 del os.environ["CLX_STREAMS"]
@@ -414,6 +424,15 @@ def run_workload(wl_key, args, rank, world, device):
         winograd_layers=n_wino, winograd_tile=wino_tile,
         direct_equivalent_tflops=round(crops_per_s / world * train_flops / 1e12, 2),
     )
+    # the 157.3 TFLOP/s peak is the matrix cores at 2.4 GHz; under this load the part runs slower (power): the clock the
+    # GEMM kernels actually saw, and the fraction of the peak AT THAT CLOCK
+    mhz = clock_one_stream if overlapped is not None else clock_mhz
+    if mhz:
+        roofline["shader_clock_mhz"] = mhz
+        roofline["shader_clock_mhz_value_pass"] = clock_mhz
+        roofline["frac_at_measured_clock"] = round(achieved / (peak * mhz / 2400.0), 4)
+        roofline["shader_clock_note"] = ("s_memtime / s_memrealtime ticks of the middle block of every GEMM launch of the pass the "
+                                         "kernel numbers are from; `frac` stays against the 2.4-GHz peak")
     roofline["step_mfma_frac_note"] = ("FLOPs all MFMA kernels execute in one step / the step's wall time (the `value` "
                                        "pass) / peak: what the whole step makes of the matrix cores")
     if overlapped is not None:

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "clx_device_count": (_I, []),
     "clx_profile_enable": (_I, [_I]),
     "clx_profile_read": (_I, [_I, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
+    "clx_profile_clock": (_I, [POINTER(c_double), POINTER(c_double), _I]),
     "clx_conv_fwd": (_I, [POINTER(ClxConvDesc), _P]),
     "clx_conv_wgrad": (_I, [POINTER(ClxConvDesc), _P, _I, _P, _P, _P]),
     "clx_chain64_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _P, _I, _P]),

@@ -28,6 +28,28 @@ extern "C" int clx_debug_stamps(unsigned long long* host, int n) {
 #define STAMP(k) do {} while (0)
 #endif
 
+// Shader clock under load: the middle block of every launch adds the shader-clock ticks (s_memtime) and the 100-MHz wall-clock
+// ticks (s_memrealtime) of its own life to two counters — their ratio is the clock the matrix cores actually ran at
+// (bench.py: roofline.shader_clock_mhz; the 157.3 TFLOP/s peak is 2.4 GHz).  Two atomics per launch.
+__device__ unsigned long long g_clk_ticks[2];
+extern "C" int clx_profile_clock(double* shader_ticks, double* wall_ticks_100mhz, int reset) {
+  unsigned long long h[2] = {0ull, 0ull};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clk_ticks), sizeof(h)) != hipSuccess) {
+    clx_set_error("clx_profile_clock: copy failed");
+    return CLX_ERR_LAUNCH;
+  }
+  if (shader_ticks) *shader_ticks = (double)h[0];
+  if (wall_ticks_100mhz) *wall_ticks_100mhz = (double)h[1];
+  if (reset) {
+    const unsigned long long z[2] = {0ull, 0ull};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_clk_ticks), z, sizeof(z)) != hipSuccess) {
+      clx_set_error("clx_profile_clock: reset failed");
+      return CLX_ERR_LAUNCH;
+    }
+  }
+  return CLX_OK;
+}
+
 namespace {
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -89,6 +111,9 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   float (*As)[BM * LDS_LD] = reinterpret_cast<float (*)[BM * LDS_LD]>(smem);
   float (*Bs)[BN * LDS_LD] = reinterpret_cast<float (*)[BN * LDS_LD]>(smem + 2 * BM * LDS_LD);
 
+  const bool clk_block = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0;   // mid-launch
+  unsigned long long clk_c0 = 0, clk_w0 = 0;
+  if (clk_block) { clk_c0 = clock64(); clk_w0 = wall_clock64(); }
   STAMP(0);
 #ifdef IG_STAMP
   if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) {
@@ -345,6 +370,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
         }
       }
     STAMP(3);
+    if (clk_block) { atomicAdd(&g_clk_ticks[0], clock64() - clk_c0); atomicAdd(&g_clk_ticks[1], wall_clock64() - clk_w0); }
     return;
   }
   __syncthreads();
@@ -452,6 +478,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     }
   }
   STAMP(3);
+  if (clk_block) { atomicAdd(&g_clk_ticks[0], clock64() - clk_c0); atomicAdd(&g_clk_ticks[1], wall_clock64() - clk_w0); }
 }
 
 }  // namespace

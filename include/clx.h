@@ -57,6 +57,10 @@ enum clx_profile_kind {
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);
+/* Shader clock the MFMA kernels actually ran at: the middle block of every clx_conv_fwd GEMM launch adds the shader-clock
+ * ticks and the 100-MHz wall-clock ticks of its own life to two device counters; this reads (and optionally resets)
+ * them: MHz = 100 * shader_ticks / wall_ticks.  Synchronises the device.  (Measurement only: no reference counterpart.) */
+int clx_profile_clock(double* shader_ticks, double* wall_ticks_100mhz, int reset);
 
 /* ------------------------------------------------------------------------ */
 /* Convolution (valid, stride 1, kernel extent 1 or 3 per dim)              */
