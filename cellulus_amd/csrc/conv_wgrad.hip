@@ -54,14 +54,21 @@ struct WgradP {
   int* turns;
 };
 
-template <int BMN, int BNC, int WAVES_M, int WAVES_N>
+// KS: the k-pairs of a chunk are dealt out to KS groups of waves (WAVES_M * WAVES_N * KS = 4), every group holding its own
+// partial sums of the same output tile — they all end in the float-atomic combine anyway.  For the 64 x 64 tile
+// (KS = 2: two waves of 64 x 32 instead of four of 32 x 32) that is one ds_read_b64 + one ds_read_b32 per two MFMAs
+// where the 2 x 2 arrangement reads two b32 per MFMA.  MEASURED AND NOT DISPATCHED: the 3-D step's weight gradients 4.72
+// against 4.60 ms (twice the atomics per tile, and the kernel is not bound by its LDS reads); KS = 1 everywhere.
+template <int BMN, int BNC, int WAVES_M, int WAVES_N, int KS = 1>
 __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BKP = bkp<BMN, BNC>();
   constexpr int TM = BMN / WAVES_M / 32;
   constexpr int TN = BNC / WAVES_N / 32;
   constexpr int A_F4 = BMN / 4, A_RPP = 256 / A_F4, A_PASSES = BKP / A_RPP;
   constexpr int B_F4 = BNC / 4, B_RPP = 256 / B_F4, B_PASSES = BKP / B_RPP;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(WAVES_M * WAVES_N * KS == 4, "4 waves");
+  constexpr int NIT = BKP / 2 / KS;           // k-pairs per wave and chunk
+  static_assert(NIT * KS * 2 == BKP && NIT % 8 == 0 || KS == 1, "k-pairs divide");
 
   __shared__ float Ys[2][BKP * BMN];
   __shared__ float Xs[2][BKP * BNC];
@@ -86,7 +93,8 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   const int tx = tap % p.KW, ty = (tap / p.KW) % p.KH, tz = tap / (p.KW * p.KH);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+  const int ks = wid / (WAVES_M * WAVES_N);
+  const int wm = (wid % (WAVES_M * WAVES_N)) / WAVES_N, wn = wid % WAVES_N;
 
   // loader coordinates
   const int a_row = tid / A_F4, a_col = (tid % A_F4) * 4;
@@ -168,26 +176,29 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   const int li = lane & 31, lh = lane >> 5;
-  // 2 x 2 accumulator sets per wave: fragments as ONE ds_read_b64 per operand and k-pair — lane i reads channels
+  // two accumulator sets along an operand: its fragments as ONE ds_read_b64 per k-pair — lane i reads channels
   // 2i, 2i + 1 of its pixel, the first feeds accumulator set 0, the second set 1 (MFMA row i of set a is channel
   // 2i + a; the k order and the row order of an MFMA are free).  Half the LDS read instructions: 1-3 % per launch.
-  constexpr bool PAIR = TM == 2 && TN == 2;
-  const int a_base = lh * BMN + wm * TM * 32 + (PAIR ? 2 * li : li);
-  const int b_base = lh * BNC + wn * TN * 32 + (PAIR ? 2 * li : li);
+  constexpr bool PAIR_A = TM == 2, PAIR_B = TN == 2;
+  const int a_base = lh * BMN + wm * TM * 32 + (PAIR_A ? 2 * li : li);
+  const int b_base = lh * BNC + wn * TN * 32 + (PAIR_B ? 2 * li : li);
 
   // fragments of k-pair k2+1 are read from LDS while the MFMAs of k-pair k2 issue; the global
   // loads of the next chunk and their LDS stores are slotted between MFMA groups.
   float af[2][TM], bf[2][TN];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   auto load_frags = [&](int buf, int k2, int slot) {
-    if constexpr (PAIR) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
+    if constexpr (PAIR_A) {
       const f32x2 va = *reinterpret_cast<const f32x2*>(&Ys[buf][a_base + 2 * k2 * BMN]);
-      const f32x2 vb = *reinterpret_cast<const f32x2*>(&Xs[buf][b_base + 2 * k2 * BNC]);
       af[slot][0] = va[0]; af[slot][TM - 1] = va[1];
-      bf[slot][0] = vb[0]; bf[slot][TN - 1] = vb[1];
     } else {
 #pragma unroll
       for (int a = 0; a < TM; ++a) af[slot][a] = Ys[buf][a_base + 2 * k2 * BMN + a * 32];
+    }
+    if constexpr (PAIR_B) {
+      const f32x2 vb = *reinterpret_cast<const f32x2*>(&Xs[buf][b_base + 2 * k2 * BNC]);
+      bf[slot][0] = vb[0]; bf[slot][TN - 1] = vb[1];
+    } else {
 #pragma unroll
       for (int b = 0; b < TN; ++b) bf[slot][b] = Xs[buf][b_base + 2 * k2 * BNC + b * 32];
     }
@@ -198,7 +209,7 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
     store_chunk(0);
     __syncthreads();
     int buf = 0;
-    load_frags(0, 0, 0);
+    load_frags(0, ks, 0);
     // `MORE` is a compile-time flag, the last chunk runs after the loop: with a run-time
     // `if (more)` around the loads and the LDS stores the compiler's wait-count pass sees paths
     // on which a load is issued and never consumed, and guards later writes of those registers
@@ -207,25 +218,25 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
     auto chunk_body = [&](int ch, auto more_tag) {
       constexpr bool MORE = decltype(more_tag)::value;
 #pragma unroll
-      for (int k2 = 0; k2 < BKP / 2; ++k2) {
+      for (int it = 0; it < NIT; ++it) {          // this wave's k-pairs: it * KS + ks
         if constexpr (MORE) {
-          if (k2 == 0) load_dy(ch + 1);
-          if (k2 == BKP / 8) load_x(ch + 1);
-          if (k2 == 3 * BKP / 8) store_chunk(buf ^ 1);
+          if (it == 0) load_dy(ch + 1);
+          if (it == NIT / 4) load_x(ch + 1);
+          if (it == 3 * NIT / 4) store_chunk(buf ^ 1);
         }
-        if (k2 + 1 < BKP / 2) load_frags(buf, k2 + 1, (k2 + 1) & 1);
+        if (it + 1 < NIT) load_frags(buf, (it + 1) * KS + ks, (it + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
           for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[k2 & 1][a], bf[k2 & 1][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[it & 1][a], bf[it & 1][b], acc[a][b], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (MORE) {
         __syncthreads();
         buf ^= 1;
-        load_frags(buf, 0, 0);
+        load_frags(buf, ks, 0);
       }
     };
     for (int ch = 0; ch + 1 < nchunks; ++ch) chunk_body(ch, std::true_type{});
@@ -246,12 +257,12 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   for (int a = 0; a < TM; ++a) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const int c = PAIR ? tile_c * BNC + wn * TN * 32 + 2 * li + b : tile_c * BNC + (wn * TN + b) * 32 + li;
+      const int c = PAIR_B ? tile_c * BNC + wn * TN * 32 + 2 * li + b : tile_c * BNC + (wn * TN + b) * 32 + li;
       if (c < p.Ctot) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int n = PAIR ? tile_n * BMN + wm * TM * 32 + 2 * row + a : tile_n * BMN + (wm * TM + a) * 32 + row;
+          const int n = PAIR_A ? tile_n * BMN + wm * TM * 32 + 2 * row + a : tile_n * BMN + (wm * TM + a) * 32 + row;
           if (n < p.N) atomicAdd(dst + (size_t)n * p.Ctot + c, acc[a][b][r]);
         }
       }
