@@ -37,14 +37,17 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
   double lo = __longlong_as_double(0x7ff0000000000000ll), hi = -lo;
   const long long n2 = n >> 1;
   const f64x2* x2 = reinterpret_cast<const f64x2*>(x);
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n2; i += 4 * stride) {      // 4 independent 16-byte loads in flight
-    const f64x2 a = x2[i], b = x2[i + stride], c = x2[i + 2 * stride], d = x2[i + 3 * stride];
+  // a block reads ONE contiguous range (four 4-KB pieces of it in flight per round): with the grid-strided walk the four
+  // loads of a thread were 8 MB apart and a 4096^2 image ran at 2.3 TB/s
+  const long long per_block = (n2 + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < n2 ? b0 + per_block : n2;
+  long long i = b0 + threadIdx.x;
+  for (; i + 3 * 256 < b1; i += 4 * 256) {             // 4 independent 16-byte loads in flight
+    const f64x2 a = x2[i], b = x2[i + 256], c = x2[i + 512], d = x2[i + 768];
     lo = fmin(fmin(fmin(lo, a[0]), fmin(a[1], b[0])), fmin(fmin(b[1], c[0]), fmin(fmin(c[1], d[0]), d[1])));
     hi = fmax(fmax(fmax(hi, a[0]), fmax(a[1], b[0])), fmax(fmax(b[1], c[0]), fmax(fmax(c[1], d[0]), d[1])));
   }
-  for (; i < n2; i += stride) {
+  for (; i < b1; i += 256) {
     const f64x2 a = x2[i];
     lo = fmin(lo, fmin(a[0], a[1]));
     hi = fmax(hi, fmax(a[0], a[1]));
