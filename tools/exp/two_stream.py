@@ -37,10 +37,14 @@ def join(streams):
     for s in set(streams):
         s.wait_stream(main)
 
+DELAY_US = float(os.environ.get("DELAY_US", "0"))      # the second stream starts this much later (device-side spin)
+
 def run(plans, streams, raws, steps):
     outs = []
-    for p, s, r in zip(plans, streams, raws):
+    for k, (p, s, r) in enumerate(zip(plans, streams, raws)):
         with torch.cuda.stream(s):
+            if k == 1 and DELAY_US > 0 and len(set(streams)) > 1:
+                torch.cuda._sleep(int(DELAY_US * 2100))
             outs.append(p.forward(r, params))
     if JOIN >= 2:
         join(streams)
@@ -69,6 +73,8 @@ pa, pb = make(h), make(h)
 s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
 print("one stream, 2 x batch %d back to back: %.2f ms" % (h, timeit([pa, pb], [s0, s0], [raw[:h].contiguous(), raw[h:].contiguous()])))
 print("two streams, 2 x batch %d: %.2f ms" % (h, timeit([pa, pb], [s0, s1], [raw[:h].contiguous(), raw[h:].contiguous()])))
+if DELAY_US > 0:
+    sys.exit(0)
 del pa, pb
 torch.cuda.empty_cache()
 pa, pb = make(h), make(h)
