@@ -59,7 +59,10 @@ struct WgradP {
 // (KS = 2: two waves of 64 x 32 instead of four of 32 x 32) that is one ds_read_b64 + one ds_read_b32 per two MFMAs
 // where the 2 x 2 arrangement reads two b32 per MFMA.  MEASURED AND NOT DISPATCHED: the 3-D step's weight gradients 4.72
 // against 4.60 ms (twice the atomics per tile, and the kernel is not bound by its LDS reads); KS = 1 everywhere.
-template <int BMN, int BNC, int WAVES_M, int WAVES_N, int KS = 1>
+// LIN: output pixel m reads input pixel m of a single, uncropped, un-upsampled source (1 x 1(x1) layers, the per-xi products
+// of the 2-D Winograd layers): the row address is m * ld — no decode of the pixel index by three fast divisions, no
+// bounds, no upsampling divisions: ~45 VALU operations per staged row and chunk less.
+template <int BMN, int BNC, int WAVES_M, int WAVES_N, int KS = 1, bool LIN = false>
 __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BKP = bkp<BMN, BNC>();
   constexpr int TM = BMN / WAVES_M / 32;
@@ -138,6 +141,11 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const uint32_t m = wlin[j] + (uint32_t)chunk * BKP;
+      if constexpr (LIN) {
+        const bool ok = c_ok && m < (uint32_t)p.M;
+        rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + (size_t)m * S.ld + c_l : p.zeros);
+        continue;
+      }
       const uint32_t q1 = fdiv(m, p.dOW);
       const int ox = (int)(m - q1 * p.OW);
       const uint32_t q2 = fdiv(q1, p.dOH);
@@ -530,6 +538,12 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   p.zeros = wgrad_zero_buffer();
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_wgrad: cannot resolve the device zero buffer");
   p.taps = d->KD * d->KH * d->KW;
+  // output pixel m = input pixel m of one plain source?
+  static const bool lin_env = getenv("CLX_WGRAD_LINEAR") == nullptr || atoi(getenv("CLX_WGRAD_LINEAR")) != 0;
+  const bool linear = lin_env && p.taps == 1 && d->nsrc == 1 && d->PD == 0 && d->PH == 0 && d->PW == 0 &&
+                      d->src[0].fz == 1 && d->src[0].fy == 1 && d->src[0].fx == 1 &&
+                      d->src[0].oz == 0 && d->src[0].oy == 0 && d->src[0].ox == 0 &&
+                      d->src[0].D == p.OD && d->src[0].H == p.OH && d->src[0].W == p.OW;
 
   // 128-wide tiles unless padding the extent up to a multiple of 128 wastes > 15 % of the MFMAs
   auto wide = [](int n) { return n > 64 && (double)(cdiv(n, 128) * 128) / n <= 1.15; };
@@ -595,6 +609,8 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
     clx_prof_events(x3 ? CLX_PROF_WGRAD_X3 : CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, &e0, &e1);
   if (x3)
     CLX_LAUNCH_TIMED(wgrad_x3_kernel, grid, block, st, e0, e1, p);
+  else if (big_n && big_c && linear)
+    CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 128, 2, 2, 1, true>), grid, block, st, e0, e1, p);
   else if (big_n && big_c)
     CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 128, 2, 2>), grid, block, st, e0, e1, p);
   else if (big_n)
