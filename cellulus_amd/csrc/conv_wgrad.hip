@@ -62,7 +62,9 @@ struct WgradP {
 // LIN: output pixel m reads input pixel m of a single, uncropped, un-upsampled source (1 x 1(x1) layers, the per-xi products
 // of the 2-D Winograd layers): the row address is m * ld — no decode of the pixel index by three fast divisions, no
 // bounds, no upsampling divisions: ~45 VALU operations per staged row and chunk less.
-template <int BMN, int BNC, int WAVES_M, int WAVES_N, int KS = 1, bool LIN = false>
+// LIN = 2: the per-xi products of the 3-D Winograd layers — a (KD, 1, 1) "convolution" over [planes][tiles]: only the plane
+// index is decoded (two fast divisions instead of six).
+template <int BMN, int BNC, int WAVES_M, int WAVES_N, int KS = 1, int LIN = 0>
 __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_wgrad_kernel(const WgradP p) {
   constexpr int BKP = bkp<BMN, BNC>();
   constexpr int TM = BMN / WAVES_M / 32;
@@ -141,9 +143,19 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const uint32_t m = wlin[j] + (uint32_t)chunk * BKP;
-      if constexpr (LIN) {
+      if constexpr (LIN == 1) {
         const bool ok = c_ok && m < (uint32_t)p.M;
         rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + (size_t)m * S.ld + c_l : p.zeros);
+        continue;
+      }
+      if constexpr (LIN == 2) {       // OH = IH = 1, one plain source of ID planes x OW tiles
+        const uint32_t t = fdiv(m, p.dOW);
+        const int ox = (int)(m - t * p.OW);
+        const uint32_t ob = fdiv(t, p.dOD);
+        const int lz = (int)(t - ob * p.OD) + tz - p.PD;
+        const bool ok = c_ok && m < (uint32_t)p.M && (unsigned)lz < (unsigned)p.ID;
+        const int pix = ((int)ob * p.ID + lz) * p.OW + ox;
+        rb[j] = *reinterpret_cast<const f32x4*>(ok ? S.ptr + (size_t)pix * S.ld + c_l : p.zeros);
         continue;
       }
       const uint32_t q1 = fdiv(m, p.dOW);
@@ -544,6 +556,12 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
                       d->src[0].fz == 1 && d->src[0].fy == 1 && d->src[0].fx == 1 &&
                       d->src[0].oz == 0 && d->src[0].oy == 0 && d->src[0].ox == 0 &&
                       d->src[0].D == p.OD && d->src[0].H == p.OH && d->src[0].W == p.OW;
+  // ... or input plane (oz + tz - PD), same tile, of one plain source of single-row planes?
+  const bool zlinear = lin_env && !linear && d->KH == 1 && d->KW == 1 && d->nsrc == 1 && d->PH == 0 && d->PW == 0 &&
+                       d->IH == 1 && d->src[0].fz == 1 && d->src[0].fy == 1 && d->src[0].fx == 1 &&
+                       d->src[0].oz == 0 && d->src[0].oy == 0 && d->src[0].ox == 0 &&
+                       d->src[0].D == d->ID && d->src[0].H == 1 && d->src[0].W == p.OW && d->IW == p.OW;
+  const int lin_mode = linear ? 1 : zlinear ? 2 : 0;
 
   // 128-wide tiles unless padding the extent up to a multiple of 128 wastes > 15 % of the MFMAs
   auto wide = [](int n) { return n > 64 && (double)(cdiv(n, 128) * 128) / n <= 1.15; };
@@ -607,18 +625,21 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled())
     clx_prof_events(x3 ? CLX_PROF_WGRAD_X3 : CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, &e0, &e1);
-  if (x3)
+  if (x3) {
     CLX_LAUNCH_TIMED(wgrad_x3_kernel, grid, block, st, e0, e1, p);
-  else if (big_n && big_c && linear)
-    CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 128, 2, 2, 1, true>), grid, block, st, e0, e1, p);
-  else if (big_n && big_c)
-    CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 128, 2, 2>), grid, block, st, e0, e1, p);
-  else if (big_n)
-    CLX_LAUNCH_TIMED((conv_wgrad_kernel<128, 64, 4, 1>), grid, block, st, e0, e1, p);
-  else if (big_c)
-    CLX_LAUNCH_TIMED((conv_wgrad_kernel<64, 128, 1, 4>), grid, block, st, e0, e1, p);
-  else
-    CLX_LAUNCH_TIMED((conv_wgrad_kernel<64, 64, 2, 2>), grid, block, st, e0, e1, p);
+    return CLX_OK;
+  }
+#define CLX_WG(BMN_, BNC_, WM_, WN_)                                                                           \
+  do {                                                                                                         \
+    if (lin_mode == 1) CLX_LAUNCH_TIMED((conv_wgrad_kernel<BMN_, BNC_, WM_, WN_, 1, 1>), grid, block, st, e0, e1, p);      \
+    else if (lin_mode == 2) CLX_LAUNCH_TIMED((conv_wgrad_kernel<BMN_, BNC_, WM_, WN_, 1, 2>), grid, block, st, e0, e1, p); \
+    else CLX_LAUNCH_TIMED((conv_wgrad_kernel<BMN_, BNC_, WM_, WN_>), grid, block, st, e0, e1, p);                          \
+  } while (0)
+  if (big_n && big_c) CLX_WG(128, 128, 2, 2);
+  else if (big_n) CLX_WG(128, 64, 4, 1);
+  else if (big_c) CLX_WG(64, 128, 1, 4);
+  else CLX_WG(64, 64, 2, 2);
+#undef CLX_WG
   return CLX_OK;
 }
 
