@@ -89,7 +89,13 @@ struct ConvP {
   long long bs_in, bs_w, bs_out;   // per-batch strides in floats (gridDim.y batches; 0 = none)
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// FAST: no zero rows exist (no padding; channel counts are multiples of the 32-wide K chunk) and every offset fits 32 bits:
+// rows past M / N are CLAMPED into the tensor instead of zeroed (their results are never stored), so a staged load is
+// `uniform base + 32-bit lane offset` — the chunk's channel offset moves the scalar base — and costs no vector
+// instruction, where the general form spends ~6 per load on a 64-bit address and the zero-pointer select (the weight
+// gradient gained 9 % from losing its per-row index arithmetic; the K loop's other instructions share the issue port
+// with the MFMAs).
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST = false>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const ConvP p) {
   constexpr int LDS_LD = lds_ld<BN>();
   constexpr bool SWZ = LDS_LD == 32;
@@ -140,6 +146,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
 #pragma unroll
   for (int j = 0; j < A_PASSES; ++j) {
     uint32_t m = (uint32_t)(m0 + lrow + 32 * j);
+    if (FAST && m >= (uint32_t)p.M) m = (uint32_t)p.M - 1u;
     if (m >= (uint32_t)p.M) {
       rb[j] = -1; rz[j] = ry[j] = rx[j] = 0;
     } else {
@@ -154,15 +161,19 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   }
   // ---- B rows (output channels)
   const float* wrow[B_PASSES];
+  uint32_t woff[B_PASSES];          // FAST: byte offset of the row + this lane's column inside a chunk
+  const float* const wbase = p.wpack + blockIdx.y * p.bs_w;
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) {
     int n = n0 + lrow + 32 * j;
-    wrow[j] = (n < p.N) ? p.wpack + blockIdx.y * p.bs_w + (size_t)n * p.Ktot : nullptr;
+    wrow[j] = (n < p.N) ? wbase + (size_t)n * p.Ktot : nullptr;
+    woff[j] = ((uint32_t)(n < p.N ? n : p.N - 1) * (uint32_t)p.Ktot + (uint32_t)lcol) * 4u;      // bytes
   }
 
   // ---- K-loop state: (tap, source, channel chunk)
   int tz = 0, ty = 0, tx = 0, tap = 0, s = 0, c0 = 0;
   long long aoff[A_PASSES];   // float offset of the row in the current source, -1 = zero row
+  uint32_t aoff32[A_PASSES];  // FAST: the same + this lane's column inside a chunk, always valid
   const float* sptr = p.src[0].ptr + blockIdx.y * p.bs_in;
   int sC = p.src[0].C, cbase = 0;
 
@@ -182,11 +193,18 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
       if (S.fx > 1) sx /= S.fx;
       const long long pix = (((long long)rb[j] * S.D + sz) * S.H + sy) * S.W + sx;
       aoff[j] = ok ? pix * S.ld : -1;
+      if (FAST) aoff32[j] = ((uint32_t)pix * (uint32_t)S.ld + (uint32_t)lcol) * 4u;      // bytes
     }
   };
 
   f32x4 ra[A_PASSES], rw[B_PASSES];
   auto load_a = [&]() {
+    if constexpr (FAST) {
+      const char* const base = reinterpret_cast<const char*>(sptr + c0);             // uniform
+#pragma unroll
+      for (int j = 0; j < A_PASSES; ++j) ra[j] = *reinterpret_cast<const f32x4*>(base + aoff32[j]);
+      return;
+    }
     const int c = c0 + lcol;
     const bool cv = c < sC;
 #pragma unroll
@@ -198,6 +216,12 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     }
   };
   auto load_b = [&]() {
+    if constexpr (FAST) {
+      const char* const base = reinterpret_cast<const char*>(wbase + (tap * p.Ctot + cbase + c0));      // uniform
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j) rw[j] = *reinterpret_cast<const f32x4*>(base + woff[j]);
+      return;
+    }
     const int c = c0 + lcol;
     const bool cv = c < sC;
     const int kflat = tap * p.Ctot + cbase + c;
@@ -598,12 +622,21 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled())
     clx_prof_events(wide ? CLX_PROF_IGEMM_WIDE : CLX_PROF_IGEMM_NARROW, 2.0 * p.M * p.N * p.Ktot * batch, &e0, &e1);
+  // no zero rows and 32-bit offsets?  (valid convolutions over channel counts that are multiples of the K chunk)
+  static const bool fast_env = getenv("CLX_IGEMM_FAST") == nullptr || atoi(getenv("CLX_IGEMM_FAST")) != 0;
+  bool fast = fast_env && d->PD == 0 && d->PH == 0 && d->PW == 0 && (long long)p.N * p.Ktot < (1ll << 30);
+  for (int s = 0; s < d->nsrc && fast; ++s) {
+    const clx_src& S = d->src[s];
+    fast = S.C % BK == 0 && (long long)d->B * S.D * S.H * S.W * S.ld < (1ll << 30);      // byte offsets in 32 bits
+  }
   if (wide) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
-    CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    if (fast) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2, true>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    else CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   } else {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
-    CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    if (fast) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1, true>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    else CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   }
   return CLX_OK;
 }
