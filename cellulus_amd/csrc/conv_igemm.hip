@@ -95,7 +95,9 @@ struct ConvP {
 // instruction, where the general form spends ~6 per load on a 64-bit address and the zero-pointer select (the weight
 // gradient gained 9 % from losing its per-row index arithmetic; the K loop's other instructions share the issue port
 // with the MFMAs).
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool FAST = false>
+// FAST = 2: the same for PADDED convolutions (the data gradients): the rows are fetched with buffer loads whose range check
+// returns zeros for the offset 0x80000000 that a row outside the image gets (tensor < 2 GB).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int FAST = 0>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const ConvP p) {
   constexpr int LDS_LD = lds_ld<BN>();
   constexpr bool SWZ = LDS_LD == 32;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
 #pragma unroll
   for (int j = 0; j < A_PASSES; ++j) {
     uint32_t m = (uint32_t)(m0 + lrow + 32 * j);
-    if (FAST && m >= (uint32_t)p.M) m = (uint32_t)p.M - 1u;
+    if (FAST == 1 && m >= (uint32_t)p.M) m = (uint32_t)p.M - 1u;
     if (m >= (uint32_t)p.M) {
       rb[j] = -1; rz[j] = ry[j] = rx[j] = 0;
     } else {
@@ -193,13 +195,24 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
       if (S.fx > 1) sx /= S.fx;
       const long long pix = (((long long)rb[j] * S.D + sz) * S.H + sy) * S.W + sx;
       aoff[j] = ok ? pix * S.ld : -1;
-      if (FAST) aoff32[j] = ((uint32_t)pix * (uint32_t)S.ld + (uint32_t)lcol) * 4u;      // bytes
+      if (FAST == 1) aoff32[j] = ((uint32_t)pix * (uint32_t)S.ld + (uint32_t)lcol) * 4u;      // bytes
+      if (FAST == 2) aoff32[j] = ok ? ((uint32_t)pix * (uint32_t)S.ld + (uint32_t)lcol) * 4u : 0x80000000u;
     }
   };
 
   f32x4 ra[A_PASSES], rw[B_PASSES];
   auto load_a = [&]() {
-    if constexpr (FAST) {
+    if constexpr (FAST == 2) {
+      typedef int i32x4_ __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sptr), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < A_PASSES; ++j) {
+        const i32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)aoff32[j], c0 * 4, 0);
+        ra[j] = __builtin_bit_cast(f32x4, v);
+      }
+      return;
+    }
+    if constexpr (FAST == 1) {
       const char* const base = reinterpret_cast<const char*>(sptr + c0);             // uniform
 #pragma unroll
       for (int j = 0; j < A_PASSES; ++j) ra[j] = *reinterpret_cast<const f32x4*>(base + aoff32[j]);
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     }
   };
   auto load_b = [&]() {
-    if constexpr (FAST) {
+    if constexpr (FAST != 0) {
       const char* const base = reinterpret_cast<const char*>(wbase + (tap * p.Ctot + cbase + c0));      // uniform
 #pragma unroll
       for (int j = 0; j < B_PASSES; ++j) rw[j] = *reinterpret_cast<const f32x4*>(base + woff[j]);
@@ -624,18 +637,26 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
     clx_prof_events(wide ? CLX_PROF_IGEMM_WIDE : CLX_PROF_IGEMM_NARROW, 2.0 * p.M * p.N * p.Ktot * batch, &e0, &e1);
   // no zero rows and 32-bit offsets?  (valid convolutions over channel counts that are multiples of the K chunk)
   static const bool fast_env = getenv("CLX_IGEMM_FAST") == nullptr || atoi(getenv("CLX_IGEMM_FAST")) != 0;
-  bool fast = fast_env && d->PD == 0 && d->PH == 0 && d->PW == 0 && (long long)p.N * p.Ktot < (1ll << 30);
+  int fast = fast_env && (long long)p.N * p.Ktot < (1ll << 30) ? 1 : 0;
+  const bool padded = d->PD != 0 || d->PH != 0 || d->PW != 0;
   for (int s = 0; s < d->nsrc && fast; ++s) {
     const clx_src& S = d->src[s];
-    fast = S.C % BK == 0 && (long long)d->B * S.D * S.H * S.W * S.ld < (1ll << 30);      // byte offsets in 32 bits
+    const long long floats = (long long)d->B * S.D * S.H * S.W * S.ld + (long long)(batch - 1) * bs_in;
+    // byte offsets in 32 bits; with padding the rows come through buffer loads and 0x80000000 must lie outside the tensor
+    if (S.C % BK != 0 || floats >= (padded ? (1ll << 29) : (1ll << 30))) fast = 0;
   }
+  if (fast && padded) fast = 2;
+  static const bool dbg = getenv("CLX_IGEMM_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "igemm fast=%d wide=%d M=%d N=%d K=%d batch=%d pad=%d%d%d k=%d%d%d nsrc=%d C0=%d\n", (int)fast, (int)wide, p.M, p.N, p.Ktot, batch, d->PD, d->PH, d->PW, d->KD, d->KH, d->KW, d->nsrc, d->src[0].C);
   if (wide) {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 128);
-    if (fast) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2, true>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    if (fast == 1) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    else if (fast == 2) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
     else CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   } else {
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
-    if (fast) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1, true>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    if (fast == 1) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
+    else if (fast == 2) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
     else CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   }
   return CLX_OK;
