@@ -122,16 +122,30 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && tap == 0 && batch == 0;
 
-  // out-of-range rows read 16 zero bytes instead of branching around the load
-  auto load_dy = [&](int chunk) {
-    const int p0 = (chunk0 + chunk) * BKP;
+  // dY rows are linear in the pixel index: a chunk's rows come through a buffer descriptor that starts at the chunk's
+  // first row and ends with the tensor — a lane's byte offset inside the chunk is a constant, rows past M fall outside
+  // the descriptor and read as zeros, and a load costs no vector instruction (the 64-bit address + zero-pointer select
+  // of the plain form: ~6 per load, on the issue port the MFMAs use).  Columns past N read into the next row: their
+  // products land in rows of dW that are never stored.
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  int dyoff[A_PASSES];
 #pragma unroll
-    for (int j = 0; j < A_PASSES; ++j) {
-      const int pp = p0 + a_row + j * A_RPP;
-      const bool ok = n_ok && pp < p.M;
-      ra[j] = *reinterpret_cast<const f32x4*>(ok ? dyp + (size_t)pp * p.ld_dy + n_g : p.zeros);
-    }
+  for (int j = 0; j < A_PASSES; ++j) dyoff[j] = ((a_row + j * A_RPP) * p.ld_dy + n_g) * 4;
+  auto chunk_rsrc = [&](const float* base, int ld, int chunk) {
+    const long long row0 = (long long)(chunk0 + chunk) * BKP;
+    const long long left = ((long long)p.M - row0) * ld * 4;
+    const int records = left <= 0 ? 0 : left > 0x7fffffffll ? 0x7fffffff : (int)left;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + row0 * ld), 0, records, 0x00020000);
   };
+  auto load_dy = [&](int chunk) {
+    const __amdgpu_buffer_rsrc_t r = chunk_rsrc(dyp, p.ld_dy, chunk);
+#pragma unroll
+    for (int j = 0; j < A_PASSES; ++j)
+      ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, dyoff[j], 0, 0));
+  };
+  int xoff[B_PASSES];               // LIN == 1: the same for the input rows
+#pragma unroll
+  for (int j = 0; j < B_PASSES; ++j) xoff[j] = ((b_row + j * B_RPP) * S.ld + c_l) * 4;
   // Every chunk decodes its B_PASSES pixel rows from the linear pixel index with fast divisions:
   // straight-line code.  (An incremental walk with `while` wrap-arounds is fewer instructions, but
   // its divergent loops made the compiler put s_waitcnt vmcnt(<=3) in front of every row — the
@@ -140,6 +154,13 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
 #pragma unroll
   for (int j = 0; j < B_PASSES; ++j) wlin[j] = (uint32_t)chunk0 * BKP + (uint32_t)(b_row + j * B_RPP);
   auto load_x = [&](int chunk) {
+    if constexpr (LIN == 1) {
+      const __amdgpu_buffer_rsrc_t r = chunk_rsrc(S.ptr, S.ld, chunk);
+#pragma unroll
+      for (int j = 0; j < B_PASSES; ++j)
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, xoff[j], 0, 0));
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < B_PASSES; ++j) {
       const uint32_t m = wlin[j] + (uint32_t)chunk * BKP;
