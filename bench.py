@@ -736,6 +736,10 @@ def main():
         try:
             torch.cuda.empty_cache()
             out["train_e2e"] = train_e2e(args.workload, device)
+            # the reference's default of 8 loader processes bounds train() near 230 crops/s (27 ms of np.random pair
+            # sampling per crop); the same run with 16 says what the device side of train() does
+            more = train_e2e(args.workload, device, workers=16)
+            out["train_e2e"]["with_16_loader_procs"] = {k: more[k] for k in ("value", "unit", "ms_per_iteration", "loader_procs")}
         except Exception as e:
             out["train_e2e"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
