@@ -347,7 +347,7 @@ class UNetModel(nn.Module):  # type: ignore
         OPT-IN (CLX_INFER_STREAMS=2): with two or more whole chunks of a size that fills the device, the chunks
         alternate between two plans on two streams that share one set of packed weights (the HBM-bound Winograd
         transforms of one chunk run under the GEMMs of the other, as in plan.DualPlan).  Measured at the benchmark
-        tile (8 copies of 512 x 512 per chunk): embedding stage 215.0 -> 212.4 ms, infer() end to end unchanged —
+        tile (8 copies of 512 x 512 per chunk): embedding stage 204 -> 198 ms, infer() end to end unchanged —
         a chunk this large already fills the device in every phase, so the default stays one stream."""
         T = noisy.shape[0]
         if T % step or T // step < 2 or os.environ.get("CLX_INFER_STREAMS", "1") != "2":
