@@ -20,9 +20,12 @@ Extra objects on that line:
                  against the 157.3 TFLOP/s f32 MFMA peak.
   train3d      — BASELINE.json configs[3] (3-D 64^3, 64 fmaps) timed the same way,
                  with its own roofline object.
-  infer        — inference throughput (embed + mean-shift + CC) in Mpixels/s (1 GPU).
+  infer        — inference throughput (embed + mean-shift + CC) in Mpixels/s: kernel-level stages, rooflines and the
+                 real infer() on one GPU; with --gpus N the real infer() over a zarr whose samples are sharded over the
+                 ranks (no collective), whole-job Mpixels/s at 512^2 and at 256^2.
   train_e2e    — the real train() (zarr -> loader processes with the default augmentation and the
-                 np.random pair stream -> H2D -> step -> logging), steady-state crops/s (1 GPU).
+                 pair stream -> H2D -> step -> logging), steady-state crops/s; with --gpus N data-parallel, every
+                 rank with its own loader processes (train.loader_policy), whole-job crops/s.
   cpu_baseline — the oracle's CPU train step (plain PyTorch, host cores) on
                  a bounded sample of the same workload; baseline only (1 GPU).
   ranks_seen, per_rank_ms_per_step, allreduce_ms_exposed — what the data-parallel run saw.
@@ -79,6 +82,7 @@ def self_launch(n, argv):
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env["MASTER_PORT"] = str(_free_port())
     env["WORLD_SIZE"] = str(n)
+    env["LOCAL_WORLD_SIZE"] = str(n)          # one node: what torch.distributed.run would export
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = []
     for r in range(n):
@@ -173,6 +177,26 @@ def conv_flops(topo, batch):
     return fwd, train, per_layer
 
 
+def traffic_lookup(kernel, wl_key):
+    """HBM bytes per launch of `kernel` from the committed digest of the separate rocprofv3 --pmc passes
+    (tools/hbm_traffic.py -> profiles/hbm_traffic_<workload>.json); (None, None) if the digest has no such kernel.
+    The digest's names carry every template argument (`conv_igemm_kernel<128, 128, 2, 2, 1>`), the profile slots
+    of libclx the tile shape only (`conv_igemm_kernel<128,128,2,2>`): every instantiation of that tile counts,
+    weighted by its launches."""
+    tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{wl_key}.json")
+    if not os.path.exists(tpath):
+        return None, None
+    with open(tpath) as fh:
+        tdoc = json.load(fh)
+    stem = kernel.replace(" ", "").rstrip(">")
+    rows = [row for kname, row in tdoc["kernels"].items()
+            if kname.replace(" ", "").rstrip(">") == stem or kname.replace(" ", "").startswith(stem + ",")]
+    if not rows:
+        return None, None
+    n_l = sum(r["launches"] for r in rows)
+    return int(sum(r["bytes_per_launch"] * r["launches"] for r in rows) / max(n_l, 1)), "profiles/" + os.path.basename(tpath)
+
+
 class ConvTimer:
     """Brackets every clx_conv_fwd / clx_conv_wgrad CALL (all launches of the call: transforms +
     GEMMs) with HIP events on the launch stream; CLX_BENCH_DETAIL=1 prints the per-layer table."""
@@ -234,6 +258,35 @@ class ConvTimer:
         return sum(e0.elapsed_time(e1) for _n, _b, _f, e0, e1, _s in self.records)
 
 
+def build_step_inputs(wl_key, rank, device, broadcast=True):
+    """Model (seed 0, Kaiming-normal weights as train.py:65-68, rank 0's copy on every rank), loss, optimizer and
+    one HBM-resident batch of rank `rank` (crops and pair coordinates seeded by the rank)."""
+    import torch
+
+    from cellulus_amd import parallel
+    from cellulus_amd.criterions import get_loss
+    from cellulus_amd.models import get_model
+    from cellulus_amd.optim import Adam
+
+    wl = WORKLOADS[wl_key]
+    torch.manual_seed(0)
+    model = get_model(**wl["model"]).to(device)
+    for _n, layer in model.named_modules():
+        if isinstance(layer, torch.nn.modules.conv._ConvNd):
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+    flat, _ = model.flatten_parameters()
+    if broadcast:
+        parallel.broadcast_(flat, 0)
+    nd = wl["model"]["num_spatial_dims"]
+    criterion = get_loss(temperature=10.0, regularizer_weight=1e-5, density=wl["density"],
+                         num_spatial_dims=nd, device=device)
+    optimizer = Adam(model.parameters(), lr=4e-5, weight_decay=0.01)
+    B = wl["batch"]
+    raw = synthetic_raw(B, wl["crop"], seed=rank).to(device)
+    anchor, reference = sample_pairs(B, wl["crop"], wl["kappa"], wl["density"], seed=rank)
+    return model, criterion, optimizer, (raw, anchor.to(device), reference.to(device))
+
+
 # ------------------------------------------------------------------------------------------------
 # the timed workload
 # ------------------------------------------------------------------------------------------------
@@ -247,28 +300,13 @@ def run_workload(wl_key, args, rank, world, device):
 
     from cellulus_amd import _clx, parallel
     from cellulus_amd import train as train_mod
-    from cellulus_amd.criterions import get_loss
-    from cellulus_amd.models import get_model
-    from cellulus_amd.optim import Adam
     from cellulus_amd.train import train_iteration
 
     wl = WORKLOADS[wl_key]
-    torch.manual_seed(0)
-    model = get_model(**wl["model"]).to(device)
-    for _n, layer in model.named_modules():
-        if isinstance(layer, torch.nn.modules.conv._ConvNd):
-            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
-    flat, _ = model.flatten_parameters()
-    parallel.broadcast_(flat, 0)
-    nd = wl["model"]["num_spatial_dims"]
-    criterion = get_loss(temperature=10.0, regularizer_weight=1e-5, density=wl["density"],
-                         num_spatial_dims=nd, device=device)
-    optimizer = Adam(model.parameters(), lr=4e-5, weight_decay=0.01)
-
+    model, criterion, optimizer, batch = build_step_inputs(wl_key, rank, device)
     B = wl["batch"]
-    raw = synthetic_raw(B, wl["crop"], seed=rank).to(device)
-    anchor, reference = sample_pairs(B, wl["crop"], wl["kappa"], wl["density"], seed=rank)
-    batch = (raw, anchor.to(device), reference.to(device))
+    torch.cuda.reset_peak_memory_stats(device)
+    first_losses = []
 
     def barrier():
         if world > 1:
@@ -281,7 +319,7 @@ def run_workload(wl_key, args, rank, world, device):
         os.environ["CLX_STREAMS"] = "1"      # the per-layer table times calls one after the other: one stream
         timer.install()      # installed before the warm-up so lazy HIP-event setup is not timed
     for _ in range(args.warmup):
-        train_iteration(batch, model, criterion, optimizer, device)
+        first_losses.append(train_iteration(batch, model, criterion, optimizer, device)[0])
     torch.cuda.synchronize()
     timer.records.clear()
     gc.collect()
@@ -293,6 +331,7 @@ def run_workload(wl_key, args, rank, world, device):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, oce, _ = train_iteration(batch, model, criterion, optimizer, device)
+        first_losses.append(loss)
     barrier()
     dt_local = time.perf_counter() - t0
     gc.enable()
@@ -321,7 +360,22 @@ def run_workload(wl_key, args, rank, world, device):
     clock_mhz = read_clock()
     # ---- what the data-parallel run saw
     dt, per_rank, ranks_seen, exposed = dt_local, [dt_local], 1, None
+    dp = {}
     if world > 1:
+        # what every rank holds after the K steps: the same parameters, the same bucket ranges (they depend on the
+        # launch plan only), and its share of the device memory (ranks that share a device in a dress rehearsal)
+        mine = model._flat.clone()
+        parallel.broadcast_(mine, 0)
+        same = torch.tensor([1.0 if torch.equal(mine, model._flat) else 0.0], device=device)
+        torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MIN)
+        ranges = [None] * world
+        torch.distributed.all_gather_object(ranges, [list(r) for r in getattr(model, "_last_bucket_ranges", [])])
+        peaks = [None] * world
+        torch.distributed.all_gather_object(peaks, round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 3))
+        dp = dict(params_identical_on_all_ranks=bool(same.item() == 1.0),
+                  bucket_ranges_identical_on_all_ranks=all(r == ranges[0] for r in ranges),
+                  per_rank_peak_mem_gb=peaks)
+        del mine
         ones = torch.ones(1, dtype=torch.float32, device=device)
         torch.distributed.all_reduce(ones)            # RCCL (or the backend under test) counts the ranks
         ranks_seen = int(round(ones.item()))
@@ -398,14 +452,7 @@ def run_workload(wl_key, args, rank, world, device):
     wino_tile = max([{1: 2, 2: 4}.get(a.get("fwd"), 0) for a in plan_algo.values()] or [0])
     # HBM bytes per launch of that kernel: PMC counters cannot be read from inside the process, so the
     # figure comes from the committed digest of the separate rocprofv3 --pmc passes (tools/hbm_traffic.py)
-    traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", f"hbm_traffic_{wl_key}.json")
-    if os.path.exists(tpath):
-        with open(tpath) as fh:
-            tdoc = json.load(fh)
-        for kname, row in tdoc["kernels"].items():
-            if kname.replace(" ", "") == dom_name:
-                traffic, traffic_source = row["bytes_per_launch"], "profiles/" + os.path.basename(tpath)
+    traffic, traffic_source = traffic_lookup(dom_name, wl_key)
     roofline = dict(
         bound="mfma", kernel=dom_name,
         achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
@@ -469,6 +516,10 @@ def run_workload(wl_key, args, rank, world, device):
         out["allreduce_bytes"] = int(model._flat_grad.numel() * 4 + 4 * 8)
         out["allreduce_bucket_bytes"] = [int((hi - lo) * 4) for lo, hi in ranges]
         out["grad_bucket_mb"] = float(os.environ.get("CLX_GRAD_BUCKET_MB", "4"))
+        out.update(dp)
+    # the loss of every step from the first warm-up step on (several ranks: the all-reduced SUM over the ranks'
+    # crops — the loss is a sum over pairs); step 0 runs on the seeded initial weights
+    out["losses_from_first_step"] = [float(x) for x in first_losses]
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -480,16 +531,31 @@ def run_workload(wl_key, args, rank, world, device):
     return out
 
 
-def train_e2e(wl_key, device, iterations=140, settle=40, workers=8):
+def _shared_tmpdir(prefix, rank, world):
+    """A scratch directory every rank sees: rank 0 makes it, the others learn its path."""
+    import tempfile
+
+    import torch
+
+    box = [tempfile.mkdtemp(prefix=prefix) if rank == 0 else None]
+    if world > 1:
+        torch.distributed.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+def train_e2e(wl_key, device, iterations=140, settle=40, workers=8, rank=0, world=1):
     """The REAL ``cellulus_amd.train.train()`` at the benchmark configuration over a synthetic zarr: zarr
     reads, random crops, the reference's default elastic augmentation (train_config.py:124), the reference's
     np.random pair stream in the loader processes (train.py:38-44: DataLoader(num_workers=8)), H2D of every
     batch (train.py:161-166), loss logging — everything ``value`` leaves out.  Steady-state crops/s between
-    iteration ``settle`` and the end (the start-up — loader processes, plan build — is reported beside it)."""
+    iteration ``settle`` and the end (the start-up — loader processes, plan build — is reported beside it).
+
+    Several ranks (every rank calls this): ``train()`` runs data-parallel exactly as ``torch.distributed.run`` would
+    start it — each rank its own loader processes (``train.loader_policy``: the host's cores are shared) and crops,
+    gradients all-reduced — and ``value`` is the whole job's crops/s at the slowest rank's pace."""
     import contextlib
     import io
     import shutil
-    import tempfile
 
     import numpy as np
     import torch
@@ -501,7 +567,8 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8):
     wl = WORKLOADS[wl_key]
     crop = list(wl["crop"])
     nd = len(crop)
-    tmp = tempfile.mkdtemp(prefix="clx_e2e_")
+    settle = min(settle, iterations // 3)
+    tmp = _shared_tmpdir("clx_e2e_", rank, world)
     cwd = os.getcwd()
     stamps, mem = [], []
     real = T.train_iteration
@@ -514,11 +581,14 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8):
 
     try:
         os.chdir(tmp)
-        f = zarr_io.open("data.zarr")
-        # images larger than the crop, as the augmentation needs (zarr_dataset.py:123-132)
-        big = tuple(int(c * 1.5) for c in crop)
-        f["train/raw"] = np.concatenate([synthetic_raw(1, big, s).numpy() for s in range(16)])
-        f["train/raw"].attrs["axis_names"] = ["s", "c"] + ["z", "y", "x"][-nd:]
+        if rank == 0:
+            f = zarr_io.open("data.zarr")
+            # images larger than the crop, as the augmentation needs (zarr_dataset.py:123-132)
+            big = tuple(int(c * 1.5) for c in crop)
+            f["train/raw"] = np.concatenate([synthetic_raw(1, big, s).numpy() for s in range(16)])
+            f["train/raw"].attrs["axis_names"] = ["s", "c"] + ["z", "y", "x"][-nd:]
+        if world > 1:
+            torch.distributed.barrier()
         m = wl["model"]
         cfg = ExperimentConfig(
             normalization_factor=1.0, object_size=30,
@@ -529,7 +599,7 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8):
                               kappa=wl["kappa"], density=wl["density"], device=str(device),
                               save_model_every=10 ** 6, save_best_model_every=10 ** 6, save_snapshot_every=10 ** 6,
                               train_data_config=dict(container_path="data.zarr", dataset_name="train/raw")))
-        policy = T.loader_policy(1, cfg.train_config.num_workers)
+        policy = T.loader_policy(world, cfg.train_config.num_workers)
         T.train_iteration = spy
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
@@ -538,12 +608,23 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8):
     finally:
         T.train_iteration = real
         os.chdir(cwd)
-        shutil.rmtree(tmp, ignore_errors=True)
+        if world > 1:
+            torch.distributed.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
     steady = (stamps[-1] - stamps[settle]) / (len(stamps) - 1 - settle)
+    if world > 1:
+        t = torch.tensor([steady], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        steady = t.item()
+        if rank != 0:
+            return None
     return dict(
-        value=round(wl["batch"] / steady, 3), unit="crops/s", ms_per_iteration=round(steady * 1e3, 3),
-        iterations=iterations, steady_from_iteration=settle, seconds_total=round(total, 2),
-        loader_procs=policy["loader_procs"], pair_sampler="device" if policy["device_pairs"] else "np.random in the loader processes (reference stream)",
+        value=round(world * wl["batch"] / steady, 3), unit="crops/s", ms_per_iteration=round(steady * 1e3, 3),
+        iterations=iterations, steady_from_iteration=settle, seconds_total=round(total, 2), ranks=world,
+        loader_procs=policy["loader_procs"], loader_procs_note="per rank",
+        pair_sampler="device (clx_sample_pairs)" if policy["device_pairs"] else "np.random in the loader processes (reference stream)",
+        loader_policy=policy["why"],
         elastic_deform=bool(cfg.train_config.elastic_deform), host_cores=policy["host_cores_per_rank"],
         # (a reading may or may not include the prefetched next batch, 40 MB: compare window maxima)
         device_mem_growth_mb=round((max(mem[-20:]) - max(mem[settle:settle + 20])) / 2 ** 20, 3),
@@ -641,6 +722,9 @@ def main():
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-train3d", action="store_true")
     ap.add_argument("--no-train-e2e", action="store_true")
+    ap.add_argument("--e2e-iterations", type=int, default=140, help="iterations of the real train() behind `train_e2e`")
+    ap.add_argument("--infer-samples", type=int, default=16,
+                    help="samples PER RANK of the sharded infer() runs behind `infer` when --gpus > 1")
     ap.add_argument("--streams", type=int, default=0, choices=[0, 1, 2],
                     help="0 (default): the product's default, two half batches on two streams per GPU (CLX_STREAMS "
                          "unset).  1: one stream — every kernel alone on the device, the run the roofline numbers and "
@@ -687,7 +771,18 @@ def main():
     if args.workload == "train2d" and not args.no_train3d:
         torch.cuda.empty_cache()
         res3d = run_workload("train3d", args, rank, world, device)
+    # ---- the other half of the metric and the real train(), on every rank when there are several
+    infer_obj = e2e_obj = None
     if world > 1:
+        # (no try/except here: a rank that fails must EXIT, so that the launcher ends the ranks waiting in a barrier)
+        if not args.no_infer:
+            torch.cuda.empty_cache()
+            from bench_infer import infer_sharded
+
+            infer_obj = infer_sharded(device, rank, world, samples_per_rank=args.infer_samples)
+        if not args.no_train_e2e and args.workload in ("train2d", "train3d"):
+            torch.cuda.empty_cache()
+            e2e_obj = train_e2e(args.workload, device, iterations=args.e2e_iterations, rank=rank, world=world)
         torch.distributed.barrier()
     if rank != 0:
         if world > 1:
@@ -724,6 +819,10 @@ def main():
     if res3d is not None:
         out["train3d"] = dict(metric="train crops/sec, BASELINE configs[3]", steps=args.steps, warmup=args.warmup,
                               **res3d)
+    if infer_obj is not None:
+        out["infer"] = infer_obj
+    if e2e_obj is not None:
+        out["train_e2e"] = e2e_obj
     if world == 1 and not args.no_infer:
         try:
             torch.cuda.empty_cache()
@@ -735,10 +834,10 @@ def main():
     if world == 1 and not args.no_train_e2e and args.workload in ("train2d", "train3d"):
         try:
             torch.cuda.empty_cache()
-            out["train_e2e"] = train_e2e(args.workload, device)
+            out["train_e2e"] = train_e2e(args.workload, device, iterations=args.e2e_iterations)
             # the reference's default of 8 loader processes bounds train() near 230 crops/s (27 ms of np.random pair
             # sampling per crop); the same run with 16 says what the device side of train() does
-            more = train_e2e(args.workload, device, workers=16)
+            more = train_e2e(args.workload, device, iterations=args.e2e_iterations, workers=16)
             out["train_e2e"]["with_16_loader_procs"] = {k: more[k] for k in ("value", "unit", "ms_per_iteration", "loader_procs")}
         except Exception as e:
             out["train_e2e"] = {"error": f"{type(e).__name__}: {e}"}

@@ -159,24 +159,41 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
                 kernels=out)
 
 
-def e2e_infer(device, samples=16, size=512):
-    """The product's infer() on a synthetic zarr: S x 512^2 raw images in, embeddings / detection /
+def e2e_infer(device, samples=16, size=512, rank=0, world=1):
+    """The product's infer() on a synthetic zarr: S x size^2 raw images in, embeddings / detection /
     binary-segmentation / centered-embeddings / segmentation out, default inference settings
-    (16 noise iterations, reduction_probability 0.1, cell post-processing)."""
+    (16 noise iterations, reduction_probability 0.1, cell post-processing).
+
+    Several ranks (every rank calls this; `samples` is then PER RANK — weak scaling): one container, rank 0
+    creates the datasets, every rank fills its block of samples (parallel.shard_range), no collective on the
+    data path; the time is the slowest rank's, the rate the whole job's."""
     from cellulus_amd.configs import ExperimentConfig
     from cellulus_amd.infer import infer
     from cellulus_amd.models import get_model
     from cellulus_amd.utils import zarr_io
 
-    from bench import synthetic_raw
+    from bench import _shared_tmpdir, synthetic_raw
+
+    import contextlib
+    import io
+    import shutil
 
     mcfg = dict(num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64, downsampling_factors=[[2, 2]])
     cwd = os.getcwd()
-    with tempfile.TemporaryDirectory(prefix="clx_e2e_") as tmp:
-        os.chdir(tmp)
-        try:
-            container = os.path.join(tmp, "data.zarr")
-            raw = np.concatenate([synthetic_raw(1, (size, size), seed=s).numpy() for s in range(samples)], axis=0)
+    total = samples * world
+    tmp = _shared_tmpdir("clx_e2e_", rank, world)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    os.chdir(tmp)
+    try:
+        container = os.path.join(tmp, "data.zarr")
+        if rank == 0:
+            base = np.concatenate([synthetic_raw(1, (size, size), seed=s).numpy() for s in range(min(total, 16))], axis=0)
+            raw = np.concatenate([base] * ((total + len(base) - 1) // len(base)), axis=0)[:total]
             f = zarr_io.open(container)
             f["test/raw"] = raw
             f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
@@ -188,71 +205,87 @@ def e2e_infer(device, samples=16, size=512):
             os.makedirs("models", exist_ok=True)
             torch.save({"model_state_dict": m.state_dict()}, "models/best_loss.pth")
             del m
+        barrier()
 
-            def config(name):
-                return ExperimentConfig(
-                    model_config=dict(checkpoint="models/best_loss.pth", **mcfg), object_size=30,
-                    normalization_factor=1.0,
-                    inference_config=dict(
-                        dataset_config=dict(container_path=container, dataset_name="test/raw"),
-                        prediction_dataset_config=dict(container_path=container, dataset_name=f"{name}/embeddings"),
-                        detection_dataset_config=dict(container_path=container, dataset_name=f"{name}/detection",
-                                                      secondary_dataset_name=f"{name}/embeddings"),
-                        segmentation_dataset_config=dict(container_path=container,
-                                                         dataset_name=f"{name}/segmentation",
-                                                         secondary_dataset_name=f"{name}/detection"),
-                        crop_size=[size + 16, size + 16], device=str(device)))
+        def config(name):
+            return ExperimentConfig(
+                model_config=dict(checkpoint="models/best_loss.pth", **mcfg), object_size=30,
+                normalization_factor=1.0,
+                inference_config=dict(
+                    dataset_config=dict(container_path=container, dataset_name="test/raw"),
+                    prediction_dataset_config=dict(container_path=container, dataset_name=f"{name}/embeddings"),
+                    detection_dataset_config=dict(container_path=container, dataset_name=f"{name}/detection",
+                                                  secondary_dataset_name=f"{name}/embeddings"),
+                    segmentation_dataset_config=dict(container_path=container,
+                                                     dataset_name=f"{name}/segmentation",
+                                                     secondary_dataset_name=f"{name}/detection"),
+                    crop_size=[size + 16, size + 16], device=str(device)))
 
-            import contextlib
-            import io
-
-            times = []
-            for run in ("warm", "timed"):
-                torch.manual_seed(1)
-                np.random.seed(1)
+        times = []
+        for run in ("warm", "timed"):
+            torch.manual_seed(1 + rank)
+            np.random.seed(1 + rank)
+            if rank == 0:
                 f_out = zarr_io.open(container)
                 for extra in ("binary-segmentation", "centered-embeddings"):
                     if extra in f_out:
                         del f_out[extra]
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                with contextlib.redirect_stdout(io.StringIO()):
-                    infer(config(run))
-                torch.cuda.synchronize()
-                times.append(time.perf_counter() - t0)
-            seg = zarr_io.open(container, "r")["timed/segmentation"][...]
-        finally:
-            os.chdir(cwd)
+            barrier()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                infer(config(run))
+            barrier()
+            times.append(time.perf_counter() - t0)
+        seg = zarr_io.open(container, "r")["timed/segmentation"][...] if rank == 0 else None
+    finally:
+        os.chdir(cwd)
+        if world > 1:
+            torch.distributed.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
     dt = times[1]
-    return dict(mpixels_s=round(samples * size * size / dt / 1e6, 4), seconds=round(dt, 3), samples=samples,
-                ms_per_sample=round(dt / samples * 1e3, 2), first_run_seconds=round(times[0], 3),
+    if world > 1:
+        t = torch.tensor(times, dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        times = t.tolist()
+        dt = times[1]
+        if rank != 0:
+            return None
+    return dict(mpixels_s=round(total * size * size / dt / 1e6, 4), seconds=round(dt, 3), samples=total, ranks=world,
+                samples_per_rank=samples, tile=size,
+                ms_per_sample=round(dt / total * 1e3, 2), first_run_seconds=round(times[0], 3),
                 objects_per_sample=round(float(np.mean([len(np.unique(s)) - 1 for s in seg[:, 0]])), 1),
                 what="cellulus_amd.infer.infer(): zarr -> predict (32 noisy forwards per tile, CPU-generator noise "
                      "prefetched) -> detect (Otsu + mean-shift) -> segment (grow/shrink + size filter) -> 5 zarr "
-                     "datasets, random-weight network, model load and plan build included")
+                     "datasets, random-weight network, model load and plan build included"
+                     + ("; samples sharded over the ranks (parallel.shard_range), no collective on the data path, "
+                        "time = the slowest rank's between two barriers" if world > 1 else ""))
 
 
-def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=True):
+def infer_sharded(device, rank, world, samples_per_rank=16):
+    """The `infer` object of a multi-rank bench line (every rank calls this): the whole job's Mpixels/s through the
+    real infer() at the two tile sizes the metric names (512^2 = BASELINE configs[4], 256^2 = the metric string)."""
+    big = e2e_infer(device, samples=samples_per_rank, size=512, rank=rank, world=world)
+    small = e2e_infer(device, samples=samples_per_rank, size=256, rank=rank, world=world)
+    if rank != 0:
+        return None
+    return {"metric": f"infer Mpixels/s (embed + mean-shift detect + segment) through infer(), 2D 512x512, {world} GPU(s)",
+            "value": big["mpixels_s"], "unit": "Mpixels/s", "scaling": "weak", "n_gpus": world, "e2e": big,
+            "at_256": dict(small, metric="the same at 2D 256x256 (one 272^2 tile per sample)")}
+
+
+MFMA_KINDS = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
+              3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels"}
+
+
+def embed_stage(model, device, size, n_it, reps):
+    """2 * n_it noisy forwards + mean/std of one reflect-padded (size + 16)^2 tile, device-resident noise:
+    seconds per tile, the result, and what libclx's launch events saw of every MFMA kernel."""
     import ctypes
 
     from cellulus_amd import _clx
-    from cellulus_amd.models import get_model
-    from cellulus_amd.segment import grow_shrink_on_device
-    from cellulus_amd.utils.mean_shift import mean_shift_on_device
-    from cellulus_amd.utils.misc import label_on_device
-    from cellulus_amd.utils.otsu import threshold_otsu
 
-    size, crop, n_it = 512, 528, 16
-    cfg = dict(in_channels=1, out_channels=2, num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64,
-               downsampling_factors=[[2, 2]], num_spatial_dims=2)
-    torch.manual_seed(0)
-    model = get_model(**cfg).to(device)
-    for _n, layer in model.named_modules():
-        if isinstance(layer, torch.nn.modules.conv._ConvNd):
-            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
-    model.eval()
-    model.set_infer(p_salt_pepper=0.01, num_infer_iterations=n_it, device=device)
-    model.max_infer_batch = 8
+    crop = size + 16
     rng = np.random.default_rng(0)
     raw = torch.from_numpy(np.pad(rng.random((1, 1, size, size), dtype=np.float32),
                                   [(0, 0), (0, 0), (8, 8), (8, 8)], mode="reflect")).to(device)
@@ -262,13 +295,22 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     t_embed, emb = _sync_time(lambda: model.infer_on_device(raw, noise=noise), reps)
     lib = _clx.load()
     prof = {}
-    for kind, kname in {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>",
-                        3: "gemm_x3_kernel"}.items():
+    for kind, kname in MFMA_KINDS.items():
         n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         lib.clx_profile_read(kind, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
-        prof[kname] = (n_l.value, ms_l.value, fl_l.value)
+        prof[kname] = (n_l.value / reps, ms_l.value / reps, fl_l.value / reps)      # per tile
     _clx.call("clx_profile_enable", 0)
     assert tuple(emb.shape) == (1, 3, size, size)
+    return t_embed, emb, prof
+
+
+def post_stages(device, size, reps):
+    """detect (Otsu + mean-shift, reduction_probability 0.1) and segment (grow/shrink + size filter) on the synthetic
+    disc embeddings of SURVEY.md §8d at size^2: seconds each, the label maps, the inputs (for the CPU leg)."""
+    from cellulus_amd.segment import grow_shrink_on_device
+    from cellulus_amd.utils.mean_shift import mean_shift_on_device
+    from cellulus_amd.utils.misc import label_on_device
+    from cellulus_amd.utils.otsu import threshold_otsu
 
     mean, std = synthetic_embeddings((size, size), spacing=48, radius=12, noise=0.3, seed=1)
     mean_d = torch.from_numpy(mean[0]).to(device)
@@ -291,6 +333,30 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
 
     segment_once()
     t_segment, (seg, ncomp) = _sync_time(segment_once, max(reps, 3))
+    return t_detect, t_segment, (labels, centers, seg, ncomp), (mean, std, mean_d, std_d)
+
+
+def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=True):
+    from cellulus_amd.models import get_model
+    from cellulus_amd.utils.mean_shift import mean_shift_on_device
+
+    size, n_it = 512, 16
+    cfg = dict(in_channels=1, out_channels=2, num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64,
+               downsampling_factors=[[2, 2]], num_spatial_dims=2)
+    torch.manual_seed(0)
+    model = get_model(**cfg).to(device)
+    for _n, layer in model.named_modules():
+        if isinstance(layer, torch.nn.modules.conv._ConvNd):
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+    model.eval()
+    model.set_infer(p_salt_pepper=0.01, num_infer_iterations=n_it, device=device)
+    model.max_infer_batch = 8
+    # the metric string names 2-D 256^2 for inference too: the same pipeline on one 272^2 tile, first (its plan is
+    # dropped when the 528^2 one is built)
+    t_embed_s, _emb_s, prof_s = embed_stage(model, device, 256, n_it, reps)
+    t_detect_s, t_segment_s, (_l, centers_s, _s, ncomp_s), _inputs = post_stages(device, 256, reps)
+    t_embed, emb, prof = embed_stage(model, device, size, n_it, reps)
+    t_detect, t_segment, (labels, centers, seg, ncomp), (mean, std, mean_d, std_d) = post_stages(device, size, reps)
 
     # mean-shift at full density (reduction_probability 1.0: every foreground pixel is a seed —
     # the reference's 48.8 s case); reported as pair evaluations per second
@@ -303,13 +369,38 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     nfg = int((std < 0.5).sum())
 
     total = t_embed + t_detect + t_segment
-    from bench import conv_flops
+    total_s = t_embed_s + t_detect_s + t_segment_s
+    from bench import conv_flops, traffic_lookup
     plan = next(iter(model._plans.values()))
     fwd_flops, _, _ = conv_flops(plan.topo, 1)
-    dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
-    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    # (the opt-in precision prices its kernel against bf16 MFMA / 6)
-    peak = BF16_MFMA_PEAK_TFLOPS / 6 if dom == "gemm_x3_kernel" else F32_MFMA_PEAK_TFLOPS
+
+    def roofline_of(prof, t_embed_tile):
+        dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # (the opt-in precision prices its kernel against bf16 MFMA / 6)
+        peak = BF16_MFMA_PEAK_TFLOPS / 6 if dom == "gemm_x3_kernel" else F32_MFMA_PEAK_TFLOPS
+        mfma_ms = sum(v[1] for v in prof.values())
+        mfma_fl = sum(v[2] for v in prof.values())
+        traffic, traffic_source = traffic_lookup(dom, "infer")
+        return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1),
+                    unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
+                    launches_per_tile=int(round(launches)), avg_launch_ms=round(ms / max(launches, 1), 4),
+                    forwards_per_launch=model.max_infer_batch,
+                    share_of_embed_stage=round(ms * 1e-3 / t_embed_tile, 4),
+                    step_mfma_frac=round(mfma_fl / t_embed_tile / 1e12 / peak, 4),
+                    all_mfma_kernels=dict(tflops=round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else 0.0,
+                                          ms_per_tile=round(mfma_ms, 3),
+                                          share_of_embed_stage=round(mfma_ms * 1e-3 / t_embed_tile, 4)),
+                    per_kernel={k: dict(launches_per_tile=int(round(v[0])), ms_per_tile=round(v[1], 3),
+                                        tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0)
+                                for k, v in prof.items() if v[0]},
+                    note="achieved = FLOPs the dominant kernel executes / HIP-event time of its launches; "
+                         "share_of_embed_stage = its launches' time / the embedding stage's wall time per tile (the "
+                         "rest: the other MFMA kernels under all_mfma_kernels, Winograd transforms, first-layer and "
+                         "pooling / upsampling kernels, noise injection, mean/std: profiles/*_infer_tile_kernels.txt); "
+                         "step_mfma_frac = executed FLOPs of ALL MFMA kernels of a tile / the embedding stage's wall "
+                         "time / peak; the HBM-bound kernels of detect / segment are under `streaming`")
+
     out = {
         "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 512x512, 1 GPU",
         "value": round(size * size / total / 1e6, 4),
@@ -317,18 +408,19 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
-        "roofline": dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1),
-                         unit="TFLOP/s", frac=round(achieved / peak, 4),
-                         launches_per_tile=int(launches // reps), avg_launch_ms=round(ms / max(launches, 1), 4),
-                         forwards_per_launch=model.max_infer_batch,
-                         note="the embedding stage is 99 % of a tile's time and is this kernel (executed "
-                              "FLOPs / HIP-event time); the HBM-bound kernels of detect / segment are under "
-                              "`streaming`"),
+        "roofline": roofline_of(prof, t_embed),
+        "at_256": {
+            "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 256x256 (one 272^2 tile), 1 GPU",
+            "value": round(256 * 256 / total_s / 1e6, 4), "unit": "Mpixels/s",
+            "stage_ms": {"embed": round(t_embed_s * 1e3, 2), "detect": round(t_detect_s * 1e3, 3),
+                         "segment": round(t_segment_s * 1e3, 3)},
+            "roofline": roofline_of(prof_s, t_embed_s),
+            "objects": int(ncomp_s.item()), "clusters": int(len(centers_s))},
         "meanshift_rp1": {"ms": round(t_full * 1e3, 2), "seeds": nfg, "clusters": int(len(centers_full))},
         "objects": int(ncomp.item()),
         "clusters": int(len(centers)),
     }
-    del model, plan, noise, emb
+    del model, plan, emb
     torch.cuda.empty_cache()
     if with_streaming:
         try:
@@ -343,6 +435,8 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         try:
             out["e2e"] = e2e_infer(device)
             out["e2e"]["vs_kernel_only"] = round(out["e2e"]["mpixels_s"] / out["value"], 3)
+            out["at_256"]["e2e"] = e2e_infer(device, size=256)
+            out["at_256"]["e2e"]["vs_kernel_only"] = round(out["at_256"]["e2e"]["mpixels_s"] / out["at_256"]["value"], 3)
         except Exception as e:
             out["e2e"] = {"error": f"{type(e).__name__}: {e}"}
     if with_cpu:

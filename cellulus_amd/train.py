@@ -48,7 +48,9 @@ def loader_policy(world, num_workers):
 
     * One rank: the reference's behaviour — ``num_workers`` loader processes, pair coordinates from the
       ``np.random`` stream inside them.  ``CLX_DEVICE_PAIRS=1`` opts into the device sampler.
-    * Several ranks share one host: each gets ``cores // world`` cores.  The loader processes are capped to
+    * Several ranks share one host: each gets ``cores // local_world`` cores, where ``local_world`` is the number
+      of ranks ON THIS HOST (``LOCAL_WORLD_SIZE`` as torch.distributed.run exports it; the global world size when
+      it is unset, i.e. one node).  The loader processes are capped to
       that share minus one (the rank's own Python), and the pair coordinates are drawn on the device by
       default (``CLX_DEVICE_PAIRS=0`` keeps the np.random stream): at 8 ranks x 8 crops x 5 steps/s the
       np.random stream alone needs 8 cores PER RANK, the device sampler 2.5 for crops + augmentation."""
@@ -56,13 +58,16 @@ def loader_policy(world, num_workers):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    per_rank = max(1, cores // max(world, 1))
+    local_world = world
+    if world > 1 and os.environ.get("LOCAL_WORLD_SIZE", "").isdigit():
+        local_world = max(1, min(world, int(os.environ["LOCAL_WORLD_SIZE"])))
+    per_rank = max(1, cores // max(local_world, 1))
     env = os.environ.get("CLX_DEVICE_PAIRS")
     procs = int(num_workers)
     if world > 1:
         device_pairs = env != "0"
         cap = max(1, per_rank - 1)
-        why = f"{world} ranks share {cores} cores"
+        why = f"{local_world} of {world} ranks share this host's {cores} cores"
         if procs > cap:
             why += f": num_workers {procs} capped to {cap}"
             procs = cap

@@ -466,12 +466,18 @@ def test_multi_rank_train_defaults_to_device_pairs_and_caps_the_loaders(monkeypa
     from cellulus_amd.train import loader_policy
 
     monkeypatch.delenv("CLX_DEVICE_PAIRS", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(64)))
     one = loader_policy(1, 8)
     assert one["loader_procs"] == 8 and not one["device_pairs"] and one["host_cores_per_rank"] == 64
     eight = loader_policy(8, 8)
     assert eight["loader_procs"] == 7 and eight["device_pairs"] and eight["host_cores_per_rank"] == 8
     assert loader_policy(8, 4)["loader_procs"] == 4
+    # two nodes of eight ranks: a rank's share is the host's cores over the ranks ON THAT HOST
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    sixteen = loader_policy(16, 8)
+    assert sixteen["host_cores_per_rank"] == 8 and sixteen["loader_procs"] == 7 and sixteen["device_pairs"]
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
     monkeypatch.setenv("CLX_DEVICE_PAIRS", "0")
     assert not loader_policy(8, 8)["device_pairs"]
     monkeypatch.setenv("CLX_DEVICE_PAIRS", "1")

@@ -38,9 +38,11 @@ def main():
         write = sum(w) / max(len(w), 1)
         rows[short] = dict(launches=n, read_bytes_per_launch=round(read), write_bytes_per_launch=round(write),
                            bytes_per_launch=round(read + write))
+    import os
+
+    cmd = os.environ.get("CLX_TRAFFIC_CMD", "bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline")
     doc = dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of "
-                      "bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline; mean over all launches of "
-                      "both steps; FETCH_SIZE doubled (gfx950 correction)", kernels=rows)
+                      f"{cmd}; mean over all launches of the run; FETCH_SIZE doubled (gfx950 correction)", kernels=rows)
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in rows.items():
         print(f"{k[:60]:60s} launches {v['launches']:4d}  read {v['read_bytes_per_launch'] / 1e9:7.3f} GB  "

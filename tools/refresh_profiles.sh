@@ -34,7 +34,7 @@ rm -rf $O/pmc_rd $O/pmc_wr
 # ... the 3-D workload ...
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
-python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train3d.json conv_ wino_ chain64 > $O/hbm_traffic_train3d.txt
+CLX_TRAFFIC_CMD="bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e" python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train3d.json conv_ wino_ chain64 > $O/hbm_traffic_train3d.txt
 rm -rf $O/pmc_rd $O/pmc_wr
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --workload train3d --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
 python3 tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels_3d.txt
@@ -48,7 +48,7 @@ python tools/bench_stream.py 8192 > $O/streaming_kernels.txt 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
-python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_streaming.json ms_ cc_ gs_ grow_shrink bucket_ histogram_kernel minmax_kernel noise_stats > $O/hbm_traffic_streaming.txt
+CLX_TRAFFIC_CMD="tools/bench_stream.py 8192" python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_streaming.json ms_ cc_ gs_ grow_shrink bucket_ histogram_kernel minmax_kernel noise_stats > $O/hbm_traffic_streaming.txt
 rm -rf $O/pmc_rd $O/pmc_wr
 # ... and the opt-in precision f32x3bf16 (its own bench object; kernel statistics and matrix-pipe busy of that step)
 unset CLX_STREAMS

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Two-stream train step under the kernel trace: how much of a step has an MFMA kernel running, an HBM-bound
 # kernel running, both, or nothing.  gpurun -- bash tools/step_overlap.sh [train2d|train3d]
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/overlap_${1:-train2d}; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python3 bench.py --workload ${1:-train2d} --steps 3 --warmup 2 --no-infer --no-cpu-baseline --no-train3d --no-train-e2e > $O/bench.json 2>/dev/null
-python3 - $O <<'PY'
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?run through gpurun (GRAFT_REPO_ROOT unset)}"; export TMPDIR=/tmp
+O="gpurun_out/overlap_${1:-train2d}"; rm -rf "$O"; mkdir -p "$O"
+rocprofv3 --kernel-trace --output-format csv -d "$O" -o t -- python3 bench.py --workload "${1:-train2d}" --steps 3 --warmup 2 --no-infer --no-cpu-baseline --no-train3d --no-train-e2e > "$O/bench.json" 2>/dev/null
+python3 - "$O" <<'PY'
 import csv, glob, json, sys, collections
 O = sys.argv[1]
 f = glob.glob(O + '/**/*kernel_trace.csv', recursive=True)[0]
@@ -13,6 +14,8 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 MFMA = ('conv_igemm_kernel', 'conv_wgrad_kernel', 'chain64', 'gemm_x3', 'wgrad_x3', 'gemm_t')
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 # the two-stream pass is the first K steps after the warm-up: take the step between the 3rd and 4th Adam launch
+if len(idx) < 4:
+    sys.exit(f'the trace holds {len(idx)} Adam launches, 4 are needed (2 warm-up steps + 2 of the timed ones): did bench.py fail? see {O}/bench.json')
 a, b = idx[2], idx[3]
 seg = rows[a + 1:b + 1]
 t0, t1 = int(rows[a]['End_Timestamp']), int(seg[-1]['End_Timestamp'])
