@@ -356,7 +356,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ partial, int nbloc
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
     float sum = 0.f;
     for (int b = 0; b < nblocks; ++b) sum += partial[(size_t)b * Np + n];
-    out[n] = sum;
+    out[n] += sum;      // adds, like the atomic bias path of clx_conv_wgrad (the caller zeroes the gradient once per step)
   }
 }
 }  // namespace

@@ -225,7 +225,8 @@ __global__ void oce_pairs_det_finish(const unsigned long long* __restrict__ acc,
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     double o = 0., r = 0., bd = 0.;
     for (int k = 0; k < nblocks; ++k) { o += partial[4 * k]; r += partial[4 * k + 1]; bd += partial[4 * k + 2]; }
-    sums[0] = o + r; sums[1] = o; sums[2] = r; sums[3] = bd;
+    // ADDS, as clx_oce_pairs_fused does (the caller zeroes `sums` once per step: half batches add up)
+    sums[0] += o + r; sums[1] += o; sums[2] += r; sums[3] += bd;
   }
 }
 

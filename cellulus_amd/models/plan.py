@@ -254,6 +254,48 @@ def build_topology(in_channels, out_channels, num_fmaps, fmap_inc_factor, featur
     return topo
 
 
+def tensor_consumers(topo):
+    """How many operations READ each stored tensor: every source of every convolution (skip connections and
+    upsampled tensors are sources of a level's first convolution) and every pooling."""
+    n = {}
+    for layer in topo.convs:
+        for src in layer.sources:
+            n[src.tensor] = n.get(src.tensor, 0) + 1
+    for pool in topo.pools:
+        n[pool.src] = n.get(pool.src, 0) + 1
+    return n
+
+
+def find_chain_pairs(topo, algo_fwd, batch):
+    """The (a, b) pairs of consecutive 64-channel 1x1 layers that may run as one launch each way.
+
+    The fused backward pass OVERWRITES the gradient of the pair's input and never writes the gradient of the
+    middle tensor (and neither tensor gets ReLU gate bits), so a pair qualifies only if the middle tensor is read
+    by `b` alone and the pair's input by `a` alone: a tensor that is also a skip connection, pooled, or read by a
+    second convolution keeps the layer-by-layer path, where gradients add up."""
+    produced_by_conv = {layer.out: layer for layer in topo.convs}
+    readers = tensor_consumers(topo)
+    one = (1, 1, 1)
+    plain = lambda s: tuple(s.crop) == (0, 0, 0) and tuple(s.factor) == (1, 1, 1)       # noqa: E731
+    pairs = []
+    i = 0
+    while i + 1 < len(topo.convs):
+        a, b = topo.convs[i], topo.convs[i + 1]
+        ok = (tuple(a.kernel) == one and tuple(b.kernel) == one and len(a.sources) == 1 and len(b.sources) == 1
+              and plain(a.sources[0]) and plain(b.sources[0]) and b.sources[0].tensor == a.out
+              and a.sources[0].tensor in produced_by_conv and a.sources[0].channels == 64 and a.cout == 64
+              and a.relu and (b.cout == 64 or b.cout <= 8)
+              and readers.get(a.out, 0) == 1 and readers.get(a.sources[0].tensor, 0) == 1
+              and not algo_fwd[a.name] and not algo_fwd[b.name]
+              and batch * a.in_shape[0] * a.in_shape[1] * a.in_shape[2] < (1 << 31) - 256)
+        if ok:
+            pairs.append((a, b))
+            i += 2
+        else:
+            i += 1
+    return pairs
+
+
 class UNetPlan:
     """Executes a Topology for a fixed batch size on one HIP device."""
 
@@ -407,28 +449,12 @@ class UNetPlan:
         """Pairs of consecutive 64-channel 1x1 layers (conv_pass.2 -> conv_pass.4 of a level, head.0 ->
         head.2) that run as ONE launch each way (csrc/chain64.hip: the intermediate tensor is written once
         and never read back, its gradient never exists in HBM).  CLX_CHAIN64=0 keeps the layer-by-layer path."""
-        t = self.topo
         self.chains, self.chain_second = {}, {}
         if os.environ.get("CLX_CHAIN64", "1") == "0" or self.precision != 0 or self.deterministic:
             return
-        produced_by_conv = {layer.out: layer for layer in t.convs}
-        one = (1, 1, 1)
-        plain = lambda s: tuple(s.crop) == (0, 0, 0) and tuple(s.factor) == (1, 1, 1)       # noqa: E731
-        i = 0
-        while i + 1 < len(t.convs):
-            a, b = t.convs[i], t.convs[i + 1]
-            ok = (tuple(a.kernel) == one and tuple(b.kernel) == one and len(a.sources) == 1 and len(b.sources) == 1
-                  and plain(a.sources[0]) and plain(b.sources[0]) and b.sources[0].tensor == a.out
-                  and a.sources[0].tensor in produced_by_conv and a.sources[0].channels == 64 and a.cout == 64
-                  and a.relu and (b.cout == 64 or b.cout <= 8)
-                  and not self.algo[a.name]["fwd"] and not self.algo[b.name]["fwd"]
-                  and self.B * a.in_shape[0] * a.in_shape[1] * a.in_shape[2] < (1 << 31) - 256)
-            if ok:
-                self.chains[a.name] = (a, b)
-                self.chain_second[b.name] = (a, b)
-                i += 2
-            else:
-                i += 1
+        for a, b in find_chain_pairs(self.topo, {n: v["fwd"] for n, v in self.algo.items()}, self.B):
+            self.chains[a.name] = (a, b)
+            self.chain_second[b.name] = (a, b)
 
     def _alloc_backward(self):
         t = self.topo

@@ -131,8 +131,14 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     pts = torch.empty((npix, nd), dtype=torch.float64, device=dev)
     index = torch.empty(npix, dtype=torch.int32, device=dev)
     nfg_d = torch.zeros(1, dtype=torch.int32, device=dev)
-    _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
-              _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
+    try:
+        _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
+                  _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
+    except _clx.ClxError:
+        # a call that did not complete may leave tickets / descriptors behind: never reuse that buffer (the next
+        # image gets a freshly zeroed one)
+        _PREP_WS.clear()
+        raise
     labels = torch.zeros(spatial, dtype=torch.int32, device=dev)
     nfg = int(nfg_d.item())
     if nfg == 0:      # mean_shift.py:83-84,92-93 -> all -1, +1 -> 0

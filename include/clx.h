@@ -186,7 +186,7 @@ int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream);
 
 /* Bytes of device scratch clx_conv_desc.det_turns needs for this layer (0 if d is NULL). */
 size_t clx_conv_wgrad_turns_bytes(const clx_conv_desc* d);
-/* out[n] = sum_m x[m][n] in a FIXED order (block partials over contiguous row ranges, then one pass
+/* out[n] += sum_m x[m][n] (ADDS into out, like the bias path of clx_conv_wgrad: zero it once per step) in a FIXED order (block partials over contiguous row ranges, then one pass
  * over the partials in block order): the reproducible bias gradient, db = column sums of dY
  * (autograd of nn.ConvNd's bias, cellulus/train.py:178).  scratch: clx_colsum_scratch_bytes(N). */
 size_t clx_colsum_scratch_bytes(int N);
@@ -359,7 +359,8 @@ int clx_oce_pairs_fused(const float* offsets, const long long* anchor,
 /* The same with REPRODUCIBLE results: the scatter-add of the anchor gradients (every anchor pixel occurs
  * ~31 times) accumulates 2^-40 fixed-point integers — integer addition is associative, so the sum
  * does not depend on the order the atomics arrive in — and the loss sums are block partials reduced in
- * block order.  scratch: clx_oce_pairs_det_scratch_bytes(B, ND, Z * Y * X), need not be zeroed. */
+ * block order.  `sums` is ADDED to, as by clx_oce_pairs_fused; doffsets is overwritten.
+ * scratch: clx_oce_pairs_det_scratch_bytes(B, ND, Z * Y * X), need not be zeroed. */
 size_t clx_oce_pairs_det_scratch_bytes(int B, int ND, long long npix);
 int clx_oce_pairs_fused_det(const float* offsets, const long long* anchor, const long long* reference,
                             float* doffsets, double* sums, int B, int P, int ND, int Z, int Y, int X,

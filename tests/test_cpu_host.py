@@ -941,3 +941,38 @@ def test_ctypes_descriptor_layout_equals_the_c_struct(tmp_path):
     for name, off in zip(fields, vals[1:1 + len(fields)]):
         assert getattr(_clx.ClxConvDesc, name).offset == off, name
     assert vals[-1] == ctypes.sizeof(_clx.ClxSrc)
+
+
+def test_fused_1x1_pairs_need_exclusive_tensors():
+    """the fused backward of a 64-channel 1x1 pair overwrites the gradient of the pair's input and never writes
+    the middle tensor's, so a pair is formed only if the middle tensor is read by the second layer alone and the input by
+    the first layer alone.  The reference topology qualifies (two pairs: the top level's 1x1 layers and the head); a
+    tensor that is also pooled, a skip connection or read by a second convolution keeps the layer-by-layer path."""
+    import copy
+
+    from cellulus_amd.models import plan as P
+
+    topo = P.build_topology(1, 2, 64, 3, 64, [(2, 2)], 2, (64, 64))
+    direct = {layer.name: 0 for layer in topo.convs}
+    pairs = P.find_chain_pairs(topo, direct, 2)
+    assert [(a.name, b.name) for a, b in pairs] == [
+        ("backbone.l_conv.0.conv_pass.2", "backbone.l_conv.0.conv_pass.4"),
+        ("backbone.r_conv.0.0.conv_pass.2", "backbone.r_conv.0.0.conv_pass.4"), ("head.0", "head.2")]
+    readers = P.tensor_consumers(topo)
+    assert readers["l0.3"] == 2 and readers["l0.0"] == readers["l0.1"] == 1      # l0.3: pooled AND the skip connection
+    by_name = {layer.name: layer for layer in topo.convs}
+    # (1) the MIDDLE tensor of the first pair gets a second reader (a pooling): that pair is dropped, the others stay
+    t1 = copy.deepcopy(topo)
+    t1.pools.append(P.PoolOp(src="l0.1", out="extra", channels=64, in_shape=by_name["backbone.l_conv.0.conv_pass.2"].out_shape,
+                             factor=(1, 2, 2)))
+    assert [(a.name, b.name) for a, b in P.find_chain_pairs(t1, direct, 2)] == [
+        ("backbone.r_conv.0.0.conv_pass.2", "backbone.r_conv.0.0.conv_pass.4"), ("head.0", "head.2")]
+    # (2) the pair's INPUT is also a source of another convolution (a skip connection would be): dropped as well
+    t2 = copy.deepcopy(topo)
+    t2.convs[-1].sources.append(P.Source("r0.0", 64))
+    names = [(a.name, b.name) for a, b in P.find_chain_pairs(t2, direct, 2)]
+    assert ("backbone.r_conv.0.0.conv_pass.2", "backbone.r_conv.0.0.conv_pass.4") not in names
+    assert ("backbone.l_conv.0.conv_pass.2", "backbone.l_conv.0.conv_pass.4") in names
+    # a Winograd layer is never half of a pair
+    wino = dict(direct, **{"head.0": 2})
+    assert ("head.0", "head.2") not in [(a.name, b.name) for a, b in P.find_chain_pairs(topo, wino, 2)]

@@ -59,10 +59,15 @@ def _planar(plan, name, nd):
     return t[:, :, 0] if nd == 2 else t
 
 
-@pytest.mark.parametrize("name,cfg,crop,precision", [("cfg2", CFG2, (256, 256), "f32"), ("cfg4", CFG4, (64, 64, 64), "f32"),
-                                                    ("cfg2", CFG2, (256, 256), "f32x3bf16")])
-def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, precision, device, monkeypatch):
-    """Forward: < 1e-4 against the float32 AND the float64 oracle.  Gradients: every parameter
+@pytest.mark.parametrize("name,cfg,crop,precision,head_scale", [
+    ("cfg2", CFG2, (256, 256), "f32", 1.0), ("cfg4", CFG4, (64, 64, 64), "f32", 1.0),
+    ("cfg2", CFG2, (256, 256), "f32x3bf16", 1.0), ("cfg2-trained-scale", CFG2, (256, 256), "f32", 0.0)])
+def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, precision, head_scale, device, monkeypatch):
+    """Forward: < 1e-4 against the float32 AND the float64 oracle.  head_scale 0 = "trained scale": a Kaiming network
+    emits offsets of range ~0.3, a trained one offsets of O(object_size / 2) pixels — the head's last layer is scaled
+    so that the output range is 15 (the offsets of object_size 30), where the same RELATIVE error is 50x the absolute one.
+    There the bar is the reference's own arithmetic: |HIP - float64| <= 2 x |float32 CPU oracle - float64| (the absolute
+    errors are printed): this is where Winograd F(4x4) earns or loses its place.  Gradients: every parameter
     within 1e-4 (relative L2) of the float64 oracle run with the HIP forward pass's ReLU gates and
     pooling winners (oracle.unet_oracle.forced_decisions explains why: ~2e-6 of the 1.3e8 gate
     decisions differ between any float32 forward pass and the float64 one, which alone moves
@@ -82,6 +87,15 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, preci
     model.load_state_dict(oracle.state_dict(), strict=True)
     model = model.to(device)
     raw = _blobs(crop, seed=3)
+    if head_scale == 0.0:
+        with torch.no_grad():
+            last = oracle.head[2]
+            head_scale = 15.0 / oracle(raw).abs().max().item()
+            last.weight.mul_(head_scale)
+            last.bias.mul_(head_scale)
+        model = get_model(**cfg)
+        model.load_state_dict(oracle.state_dict(), strict=True)
+        model = model.to(device)
 
     # the default plan at this size is the one the benchmark runs
     got = model(raw.to(device))
@@ -113,7 +127,15 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, preci
     cpu_err = (ref32.double() - ref64).abs().max().item()
     print(f"{name}: output range {scale:.3f}, |hip - f32 oracle| {err32:.2e}, |hip - f64 oracle| {err64:.2e}, "
           f"|f32 oracle - f64 oracle| {cpu_err:.2e}")
-    assert err32 < 1e-4 and err64 < 1e-4
+    if head_scale == 1.0:
+        assert err32 < 1e-4 and err64 < 1e-4
+    else:
+        print(f"{name}: head scaled by {head_scale:.1f}: absolute error {err64:.2e} at output range {scale:.1f} "
+              f"(relative {err64 / scale:.2e}); the float32 CPU oracle's: {cpu_err:.2e} (relative {cpu_err / scale:.2e})")
+        assert 14.0 < scale < 16.5
+        assert err64 <= 2.0 * cpu_err, (err64, cpu_err)
+        assert err64 < 1e-3              # and in any case 1e-4 of the range of a trained network's offsets
+    out_bar = 1e-4 * max(1.0, scale / 0.3) if head_scale != 1.0 else 1e-4
 
     # ---- gradients: float64 arithmetic on the HIP forward pass's discrete decisions
     relu_layers = [layer for layer in plan.topo.convs if layer.relu]
@@ -126,7 +148,7 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, preci
     with O.gemm_convolutions(o64), O.forced_decisions(o64, masks, winners):
         forced = o64(raw.double())
         forced.backward(dout.double())
-    assert (out.double() - forced.detach()).abs().max().item() < 1e-4
+    assert (out.double() - forced.detach()).abs().max().item() < out_bar
     worst = worst_free = worst_cpu = 0.0
     for (n, po), g, g32, gf in zip(o64.named_parameters(), hip_grads, cpu32_grads, free64):
         l2 = ((g - po.grad).norm() / (po.grad.norm() + 1e-30)).item()

@@ -423,10 +423,13 @@ def test_ordered_column_sums_and_fixed_point_scatter_through_the_c_abi(device):
         scratch = torch.empty(int(lib.clx_colsum_scratch_bytes(N)), dtype=torch.uint8, device=device)
         outs = []
         for _ in range(2):
-            out = torch.full((N,), float("nan"), device=device)
+            out = torch.zeros(N, device=device)             # the call ADDS (as the atomic bias path does)
             _clx.call("clx_colsum_ordered", _clx.ptr(x), ld, M, N, _clx.ptr(out), _clx.ptr(scratch), st)
             outs.append(out)
         assert torch.equal(outs[0], outs[1])
+        twice = outs[1].clone()
+        _clx.call("clx_colsum_ordered", _clx.ptr(x), ld, M, N, _clx.ptr(twice), _clx.ptr(scratch), st)
+        assert torch.equal(twice, outs[0] + outs[0])
         ref = x[:, :N].double().sum(0)
         assert ((outs[0].double() - ref).abs() / (ref.abs() + M ** 0.5)).max().item() < 1e-5
     # the pair loss: against the atomic-float kernel and the oracle
@@ -444,6 +447,12 @@ def test_ordered_column_sums_and_fixed_point_scatter_through_the_c_abi(device):
                   _clx.ptr(sums), B, anchor.shape[1], ND, 1, Y, X, 10.0, 1e-5, _clx.ptr(scratch), st)
         res.append((d, sums.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    # ... and the loss sums ADD up over calls (half batches of a step), as clx_oce_pairs_fused's do
+    d = torch.empty_like(offsets)
+    sums = res[1][1].clone()
+    _clx.call("clx_oce_pairs_fused_det", _clx.ptr(offsets), _clx.ptr(a_d), _clx.ptr(r_d), _clx.ptr(d),
+              _clx.ptr(sums), B, anchor.shape[1], ND, 1, Y, X, 10.0, 1e-5, _clx.ptr(scratch), st)
+    assert torch.equal(sums, 2 * res[0][1]) and torch.equal(d, res[0][0])
     d0 = torch.zeros_like(offsets)
     s0 = torch.zeros(4, dtype=torch.float64, device=device)
     _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(a_d), _clx.ptr(r_d), _clx.ptr(d0), _clx.ptr(s0),

@@ -1,0 +1,124 @@
+"""GPU tier: end-to-end instance-mask parity on an OBJECT-CENTRED network.
+
+The reference's use case is a *trained* network (cellulus/infer.py:58-67 loads a checkpoint): its
+embeddings collapse onto object centres, so the mean-shift modes are well separated and the label map is
+stable under rounding-sized differences of the embeddings — unlike a random-weight network, whose fragile
+modes make the end-to-end comparison conditional (tests/test_gpu_fullsize_oracle.py, cfg-5).  Here the
+network of BASELINE configs[0] (16 feature maps, one level) is trained by ``train()`` on the GPU for a few
+hundred iterations on the synthetic blob zarr, the checkpoint it wrote is handed to ``infer()`` on a 512^2
+sample, and the all-oracle chain (CPU float32 network with the same weights and torch.rand sequence ->
+Otsu -> mean-shift -> grow/shrink -> size filter, seeded the same way) must produce the SAME label map.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import infer_oracle as IO
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+MODEL = dict(num_fmaps=16, fmap_inc_factor=3, features_in_last_layer=64, downsampling_factors=[[2, 2]])
+
+
+def _blobs(crop, seed):
+    """the benchmark's synthetic image (bench.py::synthetic_raw)"""
+    rs = np.random.RandomState(seed)
+    grids = np.meshgrid(*[np.arange(c, dtype=np.float32) for c in crop], indexing="ij")
+    img = np.zeros(crop, dtype=np.float32)
+    for c in np.stack(np.meshgrid(*[np.arange(24, c, 48) for c in crop], indexing="ij"), -1).reshape(-1, 2):
+        c = c + rs.randint(-6, 7, size=2)
+        img += np.exp(-sum((g - ci) ** 2 for g, ci in zip(grids, c)) / (2 * 6.0 ** 2))
+    img += rs.normal(0, 0.02, size=crop).astype(np.float32)
+    return np.clip(img, 0, 1)[None, None]
+
+
+def test_trained_network_label_maps_equal_the_all_oracle_chain(device, tmp_path, monkeypatch):
+    from cellulus_amd.configs import ExperimentConfig
+    from cellulus_amd.infer import infer
+    from cellulus_amd.train import train
+    from cellulus_amd.utils import zarr_io
+
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("CLX_DEVICE_PAIRS", "1")          # pair coordinates drawn on the device: seconds, not minutes
+    container = str(tmp_path / "data.zarr")
+    f = zarr_io.open(container)
+    f["train/raw"] = np.concatenate([_blobs((256, 256), seed=s) for s in range(8)], axis=0)
+    f["train/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    raw = _blobs((512, 512), seed=11)
+    f["test/raw"] = raw
+    f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
+    iterations = int(os.environ.get("CLX_TEST_TRAIN_ITERATIONS", "400"))
+    torch.manual_seed(0)
+    np.random.seed(0)
+    train(ExperimentConfig(
+        normalization_factor=1.0, object_size=30, model_config=dict(MODEL),
+        train_config=dict(crop_size=[256, 256], batch_size=8, max_iterations=iterations, num_workers=0,
+                          elastic_deform=False, initial_learning_rate=1e-3, device="cuda:0",
+                          save_model_every=10 ** 6, save_best_model_every=10 ** 6, save_snapshot_every=10 ** 6,
+                          train_data_config=dict(container_path=container, dataset_name="train/raw"))))
+    ckpt = os.path.join("models", f"{iterations - 1:06d}.pth")          # train.py:188-191: the last iteration is saved
+    assert os.path.exists(ckpt)
+    losses = np.atleast_1d(np.loadtxt("loss.csv", delimiter=",", skiprows=1, usecols=1)) if os.path.exists("loss.csv") else None
+
+    n_it, p, rp = 16, 0.01, 0.1                                            # the inference defaults (inference_config.py:140-159)
+    cfg = ExperimentConfig(
+        model_config=dict(checkpoint=ckpt, **MODEL), object_size=30, normalization_factor=1.0,
+        inference_config=dict(
+            dataset_config=dict(container_path=container, dataset_name="test/raw"),
+            prediction_dataset_config=dict(container_path=container, dataset_name="embeddings"),
+            detection_dataset_config=dict(container_path=container, dataset_name="detection",
+                                          secondary_dataset_name="embeddings"),
+            segmentation_dataset_config=dict(container_path=container, dataset_name="segmentation",
+                                             secondary_dataset_name="detection"),
+            crop_size=[528, 528], num_infer_iterations=n_it, p_salt_pepper=p, reduction_probability=rp,
+            device="cuda:0"))
+    torch.manual_seed(42)
+    np.random.seed(42)
+    infer(cfg)
+    bw, min_size = cfg.inference_config.bandwidth, cfg.inference_config.min_size
+    assert bw == 15.0 and min_size == 70
+    g = zarr_io.open(container, "r")
+    emb, det, seg = g["embeddings"][...], g["detection"][...], g["segmentation"][...]
+
+    # ---- the all-oracle chain, seeded the same way (infer() builds its model before it loads the checkpoint)
+    ocfg = dict(in_channels=1, out_channels=2, num_spatial_dims=2, **MODEL)
+    oracle = O.OracleUNetModel(**ocfg)
+    oracle.load_state_dict(torch.load(ckpt, map_location="cpu", weights_only=False)["model_state_dict"], strict=True)
+    torch.manual_seed(42)
+    np.random.seed(42)
+    O.OracleUNetModel(**ocfg)                                              # the draws of infer()'s model construction
+    ref_emb = O.predict_scan(oracle, raw, [528, 528], p, n_it, 1.0, literal_dry_run=False)
+    err = np.abs(emb - ref_emb).max()
+    rng_mean = np.abs(ref_emb[0, :2]).max()
+    _mask, _cen, ref_labels = IO.detect_sample(ref_emb[0], bw, 1, min_size, rp)
+    ref_seg = IO.segment_sample(ref_labels[0].astype(np.uint16).astype(np.int32), None, "cell", 3, 6, min_size)
+
+    n_obj, n_ref = int(len(np.unique(seg[0, 0])) - 1), int(len(np.unique(ref_seg)) - 1)
+    differ = int((seg[0, 0] != ref_seg).sum())
+    # F1 at IoU 0.5 through the joint histogram (oracle.infer_oracle.compute_pairwise_IoU loops over instance pairs)
+    ids_p, ids_g, joint = IO.joint_histogram(seg[0, 0].astype(np.int64), ref_seg.astype(np.int64))
+    jp, jg = joint[ids_p != 0][:, ids_g != 0], joint
+    area_p = joint.sum(axis=1)[ids_p != 0][:, None]
+    area_g = joint.sum(axis=0)[ids_g != 0][None, :]
+    iou = jp / np.maximum(area_p + area_g - jp, 1)
+    f1 = float(IO.compute_F1(iou)[0]) if n_obj and n_ref else float("nan")
+    print(f"trained cfg-1 network ({iterations} iterations"
+          + (f", loss {losses[0]:.1f} -> {losses[-1]:.1f}" if losses is not None and len(losses) else "")
+          + f"): offsets up to {rng_mean:.2f} px, |embeddings - oracle| {err:.2e}; {n_obj} instances (oracle chain {n_ref}); "
+          f"pixels that differ from the all-oracle chain: {differ} of {seg[0, 0].size}; F1 against it {f1}")
+    assert n_ref >= 20, "the trained network should separate the blobs (the test image holds ~100)"
+    # embeddings: the north-star tolerance, relative to the magnitude a trained network emits
+    assert err < 1e-4 * max(1.0, rng_mean), err
+    # label maps: bit-identical; a tie pixel (equidistant from two modes within rounding) may flip — then at most
+    # 1e-4 of the pixels and every instance still matched one to one
+    if differ:
+        assert differ <= 1e-4 * seg[0, 0].size and f1 == 1.0, (differ, f1)
+    # ... and on the embeddings the run wrote, bit for bit in any case
+    np.random.seed(42)
+    _mask, _cen, own_labels = IO.detect_sample(emb[0], bw, 1, min_size, rp)
+    np.testing.assert_array_equal(IO.label(det[0, 0]), IO.label(own_labels[0]))
+    np.testing.assert_array_equal(seg[0, 0], IO.segment_sample(det[0, 0].astype(np.int32), None, "cell", 3, 6, min_size))

@@ -18,8 +18,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--digest":
     print("largest gaps before a kernel (us):", sorted(gaps, reverse=True)[:5])
     per = collections.OrderedDict()
     for r in seg:
-        name = re.sub(r"^void ", "", r["Kernel_Name"])
-        name = re.sub(r"\(.*$", "", name)[:110]
+        name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+        name = re.sub(r"\(.*$", "", name)[:110] or r["Kernel_Name"][:110]
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         n, t = per.get(name, (0, 0.0))
         per[name] = (n + 1, t + d)
