@@ -49,6 +49,34 @@ def _event_time(fn, reps=5):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
+PROF_KIND = dict(ms_prepare=7, ms_assign=8, cc=9, grow_shrink=10, minmax=11, histogram=12, noise_stats=13)   # clx.h
+
+
+def _kernel_time(fn, kind, reps=5):
+    """(seconds per call between two HIP events on the stream around `reps` calls, seconds per call of the KERNELS of
+    profile kind `kind` alone: libclx stamps an event pair on every such launch, the kernel's own start and end — the
+    duration `rocprofv3 --kernel-trace --stats` reports).  The first includes what lies between the launches: the
+    host's launch rate (Python + ctypes: ~20 us per call) and the dependent-launch gaps of multi-kernel operations."""
+    import ctypes
+
+    from cellulus_amd import _clx
+
+    fn()
+    torch.cuda.synchronize()
+    lib = _clx.load()
+    _clx.call("clx_profile_enable", 2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    lib.clx_profile_read(kind, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+    _clx.call("clx_profile_enable", 0)
+    return e0.elapsed_time(e1) / reps * 1e-3, ms_l.value / reps * 1e-3, n_l.value / reps
+
+
 def synthetic_embeddings(shape, spacing=48, radius=12, noise=0.3, seed=1):
     """The benchmark's detection input: disc/ball objects on a jittered grid,
     embedding = (centre - pixel) + N(0, noise) in (x, y[, z]) channel order, std = 0.01 inside / 1.0
@@ -89,9 +117,11 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     rng = np.random.default_rng(0)
     out = {}
 
-    def row(name, seconds, nbytes, what, **extra):
-        out[name] = dict(ms=round(seconds * 1e3, 4), GBs=round(nbytes / seconds / 1e9, 1),
-                         frac=round(nbytes / seconds / HBM_PEAK, 4), bytes=what, **extra)
+    def row(name, times, nbytes, what, **extra):
+        call_s, kernel_s, launches = times
+        out[name] = dict(ms=round(kernel_s * 1e3, 4), GBs=round(nbytes / kernel_s / 1e9, 1),
+                         frac=round(nbytes / kernel_s / HBM_PEAK, 4), bytes=what, kernels_per_call=round(launches, 2),
+                         call_ms=round(call_s * 1e3, 4), **extra)
 
     # --- the benchmark's detection input, tiled up to size^2 (objects every 48 px, ~17 % foreground)
     mean, std = synthetic_embeddings((512, 512), spacing=48, radius=12, noise=0.3, seed=1)
@@ -103,11 +133,19 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     idx = torch.empty(npix, dtype=torch.int32, device=device)
     nfg = torch.zeros(1, dtype=torch.int32, device=device)
     emb = emb0.clone()
-    t = _event_time(lambda: _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts),
-                                      _clx.ptr(idx), _clx.ptr(nfg), _clx.ptr(ws), st))
+    t = _kernel_time(lambda: _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts),
+                                       _clx.ptr(idx), _clx.ptr(nfg), _clx.ptr(ws), st), PROF_KIND["ms_prepare"])
     n_fg = int(nfg.item())
     row("ms_prepare", t, npix * (3 * 8 + 2 * 8) + n_fg * (2 * 8 + 4),
         "per pixel 24 B read + 16 B written, per foreground pixel 20 B more", nfg=n_fg)
+    # the fused path's form: the network's float32 planes in, widened in registers, nothing written per background pixel
+    emb32, sd32 = emb0.float(), sd.float()
+    t = _kernel_time(lambda: _clx.call("clx_ms_prepare_f32", _clx.ptr(emb32), _clx.ptr(sd32), 0.5, 2, 1, Y, X, _clx.ptr(pts),
+                                       _clx.ptr(idx), _clx.ptr(nfg), _clx.ptr(ws), st), PROF_KIND["ms_prepare"])
+    assert int(nfg.item()) == n_fg
+    row("ms_prepare_f32", t, npix * 4 + n_fg * (2 * 4 + 2 * 8 + 4),
+        "per pixel 4 B read (std), per foreground pixel 8 B read + 20 B written (infer()'s fused hand-over)", nfg=n_fg)
+    del emb32
     # centres: one per object (their true centres), assignment of all foreground pixels
     emb = emb0.clone()
     _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts), _clx.ptr(idx),
@@ -119,14 +157,13 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
                                                  15.0, 0.1, 0.5, None)
     shifts = np.stack(np.meshgrid(np.arange(reps) * 512.0, np.arange(reps) * 512.0, indexing="ij"), -1).reshape(-1, 2)
     centers = (base_centers[None, :, :] + shifts[:, None, ::-1]).reshape(-1, 2)       # (x, y) columns
-    cc = torch.from_numpy(centers).to(device)
     order, cstart, corigin, (gx, gy, gz) = MS._center_grid(centers, 15.0)
     order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)
     corigin_c = (ctypes.c_double * 2)(*corigin.tolist())
     cc_sorted = torch.from_numpy(np.ascontiguousarray(centers[order])).to(device)      # as mean_shift_on_device calls it
-    t = _event_time(lambda: _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(idx), n_fg, _clx.ptr(cc_sorted),
-                                      len(centers), 2, _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, 15.0,
-                                      gx, gy, gz, _clx.ptr(labels), st))
+    t = _kernel_time(lambda: _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(idx), n_fg, _clx.ptr(cc_sorted),
+                                       len(centers), 2, _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, 15.0,
+                                       gx, gy, gz, _clx.ptr(labels), st), PROF_KIND["ms_assign"])
     row("ms_assign", t, n_fg * (16 + 4 + 4), "per foreground pixel 20 B read + 4 B label written",
         centres=len(centers))
     if only_mean_shift:
@@ -134,28 +171,37 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     seg = labels.view(Y, X).clone()
     del emb, emb0, pts, idx
     # --- grow / shrink and connected components + size filter on that label map
-    t = _event_time(lambda: grow_shrink_on_device(seg.clone(), 3, 6), reps=3)
-    t_clone = _event_time(lambda: seg.clone(), reps=3)
-    row("grow_shrink", max(t - t_clone, 1e-9), npix * 8, "per pixel 4 B read + 4 B written")
+    t = _kernel_time(lambda: grow_shrink_on_device(seg.clone(), 3, 6), PROF_KIND["grow_shrink"], reps=3)
+    row("grow_shrink", t, npix * 8, "per pixel 4 B read + 4 B written (call_ms includes the clone of the label map)")
     grown = grow_shrink_on_device(seg.clone(), 3, 6)
-    t = _event_time(lambda: label_on_device(grown, 70), reps=3)
+    t = _kernel_time(lambda: label_on_device(grown, 70), PROF_KIND["cc"], reps=3)
     row("cc_label_filter", t, npix * 8, "per pixel 4 B read + 4 B written")
     # --- Otsu: min/max + 256-bin histogram of the float64 std channel
     mm = torch.empty(2, dtype=torch.float64, device=device)
     x = sd.reshape(-1)
-    t = _event_time(lambda: _clx.call("clx_minmax_f64", _clx.ptr(x), npix, _clx.ptr(mm), st))
+    t = _kernel_time(lambda: _clx.call("clx_minmax_f64", _clx.ptr(x), npix, _clx.ptr(mm), st), PROF_KIND["minmax"])
     row("minmax_f64", t, npix * 8, "per pixel 8 B read")
     edges = torch.linspace(0, 1, 257, dtype=torch.float64, device=device)
     counts = torch.zeros(256, dtype=torch.int64, device=device)
-    t = _event_time(lambda: _clx.call("clx_histogram_f64", _clx.ptr(x), npix, _clx.ptr(edges), 256, _clx.ptr(counts), st))
+    t = _kernel_time(lambda: _clx.call("clx_histogram_f64", _clx.ptr(x), npix, _clx.ptr(edges), 256, _clx.ptr(counts), st),
+                     PROF_KIND["histogram"])
     row("histogram_f64", t, npix * 8, "per pixel 8 B read")
+    x32 = sd32.reshape(-1)
+    t = _kernel_time(lambda: _clx.call("clx_histogram_f32", _clx.ptr(x32), npix, _clx.ptr(edges), 256, _clx.ptr(counts), st),
+                     PROF_KIND["histogram"])
+    row("histogram_f32", t, npix * 4, "per pixel 4 B read (infer()'s fused hand-over: min / max come with the std plane)")
     # --- mean / std over the 32 noisy predictions
     T, C, n = 32, 2, 2048 * 2048
     preds = torch.randn(T, C, n, device=device)
     o = torch.empty(C + 1, n, device=device)
-    t = _event_time(lambda: _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(o), T, C, n, st))
+    t = _kernel_time(lambda: _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(o), T, C, n, st),
+                     PROF_KIND["noise_stats"])
     row("noise_stats", t, n * (T * C * 4 + (C + 1) * 4), "per pixel 256 B read + 12 B written")
     return dict(pixels_per_launch=npix, samples_of_512x512_per_launch=npix // (512 * 512), peak_GBs=HBM_PEAK / 1e9,
+                timed="ms / GBs / frac: the operation's kernels alone (event pairs libclx stamps on each launch: a kernel's own "
+                      "start and end on its stream, what rocprofv3 --kernel-trace --stats reports as its duration), summed "
+                      "per call; call_ms: HIP events on the stream around the calls, i.e. including the host's launch rate "
+                      "from Python and the gaps between dependent launches",
                 kernels=out)
 
 

@@ -132,8 +132,10 @@ PROTOTYPES = {
     "clx_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P]),
     "clx_adam_step_guarded": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P, _P]),
     "clx_noise_stats": (_I, [_P, _P, _I, _I, _LL, _P]),
+    "clx_noise_stats_minmax": (_I, [_P, _P, _I, _I, _LL, _P, _I, _P]),
     "clx_ms_prepare_workspace": (c_size_t, [_LL]),
     "clx_ms_prepare": (_I, [_P, _P, _D, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "clx_ms_prepare_f32": (_I, [_P, _P, _D, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "clx_ms_iterate": (_I, [_P, _I, _P, _I, _I, _D, _I, _P, _P, _P, _P]),
     "clx_ms_iterate_grid": (_I, [_P, _I, _P, POINTER(c_double), _D, _I, _I, _I, _P, _I, _I, _D, _I,
                                  _P, _P, _P, _P]),
@@ -154,6 +156,8 @@ PROTOTYPES = {
     "clx_grow_shrink": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "clx_minmax_f64": (_I, [_P, _LL, _P, _P]),
     "clx_histogram_f64": (_I, [_P, _LL, _P, _I, _P, _P]),
+    "clx_minmax_f32": (_I, [_P, _LL, _P, _P]),
+    "clx_histogram_f32": (_I, [_P, _LL, _P, _I, _P, _P]),
     "clx_inst_stats": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "clx_inst_histogram": (_I, [_P, _P, _I, _LL, _P, _I, _P, _I, _P, _P]),
     "clx_inst_refine": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),

@@ -677,34 +677,34 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
     if ((size_t)((unsigned char*)(colR + (long long)nseg * Y) - (unsigned char*)workspace) > clx_cc_workspace(npix))
       colL = colR = nullptr;
     const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
-    cc_strip1<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, out, sz, labelmask, colL, colR, Y, X, nseg,
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_strip1, dim3(grid_for((long long)nstrips * nseg * 64, 256)), dim3(256), 0, st, seg, out, sz, labelmask, colL, colR, Y, X, nseg,
                                                                              nstrips);
     const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
     const long long nzero = nwords + nchunks;
-    cc_link1<<<grid_for(nb > nzero ? nb : nzero, 256), 256, 0, st>>>(seg, out, colL, colR, Y, X, nseg, nstrips, bitmap, nzero);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_link1, dim3(grid_for(nb > nzero ? nb : nzero, 256)), dim3(256), 0, st, seg, out, colL, colR, Y, X, nseg, nstrips, bitmap, nzero);
     const int lgrid = grid_for(nmask, 256);
-    cc_fold<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X);
-    cc_mark<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X, min_size, bitmap, chunk, (int)rank_chunk);
-    cc_scan_counts<<<1, 1024, 0, st>>>(chunk, nchunks, ncomp_out);
-    cc_rank<<<lgrid, 256, 0, st>>>(out, sz, labelmask, nmask, nseg, X, bitmap, chunk, (int)rank_chunk);
-    cc_rewrite<<<grid_for(npix / 4 + 1, 256), 256, 0, st>>>(out, sz, npix);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_fold, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_mark, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X, min_size, bitmap, chunk, (int)rank_chunk);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_scan_counts, dim3(1), dim3(1024), 0, st, chunk, nchunks, ncomp_out);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rank, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X, bitmap, chunk, (int)rank_chunk);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rewrite, dim3(grid_for(npix / 4 + 1, 256)), dim3(256), 0, st, out, sz, npix);
     CLX_CHECK_LAUNCH("clx_cc_label_filter");
     return CLX_OK;
   }
   if (Z == 1 && strips) {
     const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
-    cc_strip_kernel<<<grid_for((long long)nstrips * nseg * 64, 256), 256, 0, st>>>(seg, L, size, Y, X, nseg, nstrips);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_strip_kernel, dim3(grid_for((long long)nstrips * nseg * 64, 256)), dim3(256), 0, st, seg, L, size, Y, X, nseg, nstrips);
     const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
-    if (nb > 0) cc_link_borders<<<grid_for(nb, 256), 256, 0, st>>>(seg, L, Y, X, nseg, nstrips);
+    if (nb > 0) CLX_LAUNCH_KIND(CLX_PROF_CC, cc_link_borders, dim3(grid_for(nb, 256)), dim3(256), 0, st, seg, L, Y, X, nseg, nstrips);
   } else {
-    cc_init_runs<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
-    cc_merge_runs<<<wgrid, 256, 0, st>>>(seg, L, Z, Y, X, nseg, nwaves);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_init_runs, dim3(wgrid), dim3(256), 0, st, seg, L, size, X, nseg, nwaves);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_merge_runs, dim3(wgrid), dim3(256), 0, st, seg, L, Z, Y, X, nseg, nwaves);
   }
-  cc_flatten_count<<<wgrid, 256, 0, st>>>(seg, L, size, X, nseg, nwaves);
-  cc_count_roots<<<nblocks, 256, 0, st>>>(seg, L, size, min_size, npix, counts);
-  cc_scan_counts<<<1, 1024, 0, st>>>(counts, nblocks, ncomp_out);
-  cc_number_roots<<<nblocks, 256, 0, st>>>(seg, L, size, min_size, npix, counts);
-  cc_write<<<grid, 256, 0, st>>>(seg, L, size, out, npix);
+  CLX_LAUNCH_KIND(CLX_PROF_CC, cc_flatten_count, dim3(wgrid), dim3(256), 0, st, seg, L, size, X, nseg, nwaves);
+  CLX_LAUNCH_KIND(CLX_PROF_CC, cc_count_roots, dim3(nblocks), dim3(256), 0, st, seg, L, size, min_size, npix, counts);
+  CLX_LAUNCH_KIND(CLX_PROF_CC, cc_scan_counts, dim3(1), dim3(1024), 0, st, counts, nblocks, ncomp_out);
+  CLX_LAUNCH_KIND(CLX_PROF_CC, cc_number_roots, dim3(nblocks), dim3(256), 0, st, seg, L, size, min_size, npix, counts);
+  CLX_LAUNCH_KIND(CLX_PROF_CC, cc_write, dim3(grid), dim3(256), 0, st, seg, L, size, out, npix);
   CLX_CHECK_LAUNCH("clx_cc_label_filter");
   return CLX_OK;
 }

@@ -90,3 +90,10 @@ void clx_prof_events(int kind, double flops, hipEvent_t* e0, hipEvent_t* e1);
 // kernel launch with the optional event pair of clx_prof_events (null events: a plain launch)
 #define CLX_LAUNCH_TIMED(kernel, grid, block, st, e0, e1, ...) \
   hipExtLaunchKernelGGL(kernel, grid, block, 0, st, e0, e1, 0, __VA_ARGS__)
+// a launch of profile kind `kind` (the HBM-bound kernels: no FLOPs) with `lds` bytes of dynamic LDS
+#define CLX_LAUNCH_KIND(kind, kernel, grid, block, lds, st, ...)                              \
+  do {                                                                                        \
+    hipEvent_t e0__ = nullptr, e1__ = nullptr;                                                \
+    if (clx_prof_enabled()) clx_prof_events(kind, 0.0, &e0__, &e1__);                         \
+    hipExtLaunchKernelGGL(kernel, grid, block, lds, st, e0__, e1__, 0, __VA_ARGS__);          \
+  } while (0)

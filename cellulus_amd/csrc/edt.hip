@@ -426,11 +426,11 @@ int grow_shrink_bitrows(int* seg, int Y, int X, int grow, int shrink, void* work
   unsigned long long* bits = (unsigned long long*)((unsigned char*)workspace + 16);
   if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return CLX_ERR_LAUNCH;
   const long long w1 = (long long)Y * W64, w2 = (long long)ntiles_y * W64;
-  gs_bits_kernel<<<grid_for(w1 * 64, 256), 256, 0, st>>>(seg, bits, Y, X, W64);
-  gs_rows_kernel<<<grid_for(w2 * 64, 256), 256, 0, st>>>(seg, bits, Y, X, W64, grow, shrink, rows_per_wave, ntiles_y,
+  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, gs_bits_kernel, dim3(grid_for(w1 * 64, 256)), dim3(256), 0, st, seg, bits, Y, X, W64);
+  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, gs_rows_kernel, dim3(grid_for(w2 * 64, 256)), dim3(256), 0, st, seg, bits, Y, X, W64, grow, shrink, rows_per_wave, ntiles_y,
                                                          flag);
   const long long npix = (long long)Y * X;
-  grow_shrink_phantom<<<grid_for(npix, 256) < 1024 ? grid_for(npix, 256) : 1024, 256, 0, st>>>(seg, 1, Y, X, shrink, flag);
+  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, grow_shrink_phantom, dim3(grid_for(npix, 256) < 1024 ? grid_for(npix, 256) : 1024), dim3(256), 0, st, seg, 1, Y, X, shrink, flag);
   return CLX_OK;
 }
 
@@ -452,7 +452,7 @@ int gs_launch(dim3 grid, size_t smem, int* seg, const unsigned char* mask, int Z
       hipFuncSetAttribute(reinterpret_cast<const void*>(&grow_shrink_tile_kernel<ND, GC, SC>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return CLX_ERR_LAUNCH;
-  grow_shrink_tile_kernel<ND, GC, SC><<<grid, 256, smem, st>>>(seg, mask, Z, Y, X, grow, shrink, flag);
+  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, (grow_shrink_tile_kernel<ND, GC, SC>), dim3(grid), dim3(256), smem, st, seg, mask, Z, Y, X, grow, shrink, flag);
   return CLX_OK;
 }
 
@@ -463,14 +463,14 @@ int grow_shrink_tiled(int* seg, int Z, int Y, int X, int grow, int shrink, void*
   int* flag = (int*)workspace;
   unsigned char* mask = (unsigned char*)workspace + 16;
   if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return CLX_ERR_LAUNCH;
-  fg_mask_kernel<<<grid_for((npix + 3) / 4, 256), 256, 0, st>>>(seg, mask, npix);
+  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, fg_mask_kernel, dim3(grid_for((npix + 3) / 4, 256)), dim3(256), 0, st, seg, mask, npix);
   const dim3 grid((X + T::TX - 1) / T::TX, (Y + T::TY - 1) / T::TY, (Z + T::TZ - 1) / T::TZ);
   const size_t smem = gs_smem_bytes<ND>(grow, shrink);
   const int rc = (grow == 3 && shrink == 6)      // segment.py's defaults (inference_config.py:158-159)
                      ? gs_launch<ND, 3, 6>(grid, smem, seg, mask, Z, Y, X, grow, shrink, flag, st)
                      : gs_launch<ND, -1, -1>(grid, smem, seg, mask, Z, Y, X, grow, shrink, flag, st);
   if (rc) return rc;
-  grow_shrink_phantom<<<grid_for(npix, 256) < 1024 ? grid_for(npix, 256) : 1024, 256, 0, st>>>(seg, Z, Y, X,
+  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, grow_shrink_phantom, dim3(grid_for(npix, 256) < 1024 ? grid_for(npix, 256) : 1024), dim3(256), 0, st, seg, Z, Y, X,
                                                                                                shrink, flag);
   return CLX_OK;
 }

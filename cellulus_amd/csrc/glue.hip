@@ -199,10 +199,18 @@ __global__ void noise_stats_kernel(const float* __restrict__ preds, float* __res
   }
 }
 
-// same arithmetic, the T samples of a pixel are read ONCE and kept in registers
+__global__ void noise_minmax_init(unsigned int* mm) {
+  mm[0] = 0x7f800000u;     // +inf: the running minimum
+  mm[1] = 0u;              // +0:   the running maximum (a sum of square roots is never negative)
+}
+
+// same arithmetic, the T samples of a pixel are read ONCE and kept in registers.  minmax (optional): running minimum /
+// maximum of the std plane as float bit patterns — for non-negative floats the unsigned order of the patterns is the
+// numeric order, so two integer atomics per wavefront do (a NaN, whose pattern lies above +inf, ends up as the maximum)
 template <int TCAP>
 __global__ void noise_stats_reg_kernel(const float* __restrict__ preds, float* __restrict__ out,
-                                       int T, int C, long long n) {
+                                       int T, int C, long long n, unsigned int* __restrict__ minmax) {
+  unsigned int lo = 0xffffffffu, hi = 0u;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
     float std_sum = 0.f;
@@ -224,6 +232,21 @@ __global__ void noise_stats_reg_kernel(const float* __restrict__ preds, float* _
       std_sum += sqrtf(var / (float)T);
     }
     out[(long long)C * n + i] = std_sum;
+    const unsigned int bits = __float_as_uint(std_sum + 0.f);      // (-0 + 0 = +0)
+    lo = bits < lo ? bits : lo;
+    hi = bits > hi ? bits : hi;
+  }
+  if (minmax != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+      lo = l2 < lo ? l2 : lo;
+      hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+      atomicMin(minmax, lo);
+      atomicMax(minmax + 1, hi);
+    }
   }
 }
 
@@ -280,16 +303,33 @@ extern "C" int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD,
   return CLX_OK;
 }
 
+static int noise_stats_launch(const float* preds, float* out, int T, int C, long long n, unsigned int* minmax,
+                              hipStream_t st) {
+  if (T <= 32)
+    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, (noise_stats_reg_kernel<32>), dim3(grid_for(n, 256)), dim3(256), 0, st, preds, out, T, C, n, minmax);
+  else if (T <= 64)
+    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, (noise_stats_reg_kernel<64>), dim3(grid_for(n, 256)), dim3(256), 0, st, preds, out, T, C, n, minmax);
+  else
+    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, noise_stats_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, preds, out, T, C, n);
+  return CLX_OK;
+}
+
 extern "C" int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
                                clx_stream stream) {
   CLX_REQUIRE(preds && out && T > 0 && C > 0 && n > 0, "clx_noise_stats: bad arguments");
-  if (T <= 32)
-    noise_stats_reg_kernel<32><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
-  else if (T <= 64)
-    noise_stats_reg_kernel<64><<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
-  else
-    noise_stats_kernel<<<grid_for(n, 256), 256, 0, (hipStream_t)stream>>>(preds, out, T, C, n);
+  noise_stats_launch(preds, out, T, C, n, nullptr, (hipStream_t)stream);
   CLX_CHECK_LAUNCH("clx_noise_stats");
+  return CLX_OK;
+}
+
+extern "C" int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long long n, float* std_minmax,
+                                      int init, clx_stream stream) {
+  CLX_REQUIRE(preds && out && std_minmax && T > 0 && C > 0 && n > 0, "clx_noise_stats_minmax: bad arguments");
+  CLX_REQUIRE(T <= 64, "clx_noise_stats_minmax: at most 64 predictions per pixel (32 noise iterations)");
+  hipStream_t st = (hipStream_t)stream;
+  if (init) CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, noise_minmax_init, dim3(1), dim3(1), 0, st, (unsigned int*)std_minmax);
+  noise_stats_launch(preds, out, T, C, n, (unsigned int*)std_minmax, st);
+  CLX_CHECK_LAUNCH("clx_noise_stats_minmax");
   return CLX_OK;
 }
 

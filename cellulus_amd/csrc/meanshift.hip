@@ -190,6 +190,161 @@ __global__ __launch_bounds__(256, MSP_WAVES) void ms_prepare_kernel(double* __re
   }
 }
 
+// The same compaction fed with the network's float32 output (the fused predict -> detect path of infer(): the float64
+// values the staged path reads back from the `embeddings` dataset are these floats widened, cellulus/predict.py:104-112,
+// so widening in registers gives the same bits): per pixel (ND + 1) * 4 B read and nothing written — the embedding is
+// NOT modified (the reference's in-place coordinate add lands in a copy that detect.py:155-160 throws away) —, per
+// foreground pixel ND * 8 + 4 B written.  A lane owns FOUR consecutive pixels (one 16-byte load per channel).
+template <int ND, int KQ>
+__global__ __launch_bounds__(256, 4) void ms_prepare_f32_kernel(const float* __restrict__ emb,
+                                                                const float* __restrict__ sd, double thr,
+                                                                FastDiv dX, FastDiv dY, int Y, int X,
+                                                                long long npix, int vec, int ntiles,
+                                                                unsigned int* __restrict__ ticket,
+                                                                unsigned long long* __restrict__ desc,
+                                                                double* __restrict__ Xout,
+                                                                int* __restrict__ index, int* __restrict__ nfg_out) {
+  constexpr int PREP_TILE = 1024 * KQ;
+  __shared__ int s_tile[2], s_excl;
+  __shared__ int wcount[KQ][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  if (tid == 0) s_tile[0] = (int)atomicAdd(ticket, 1u);
+  __syncthreads();
+  for (int round = 0;; ++round) {
+    const int tile = s_tile[round & 1];
+    if (tile >= ntiles) break;
+    if (tid == 0) s_tile[(round + 1) & 1] = (int)atomicAdd(ticket, 1u);
+    const long long base = (long long)tile * PREP_TILE;
+
+    // ---- (A) foreground flags (std < thr, compared in float64 as the reference does), counts, aggregate
+    unsigned int fgm[KQ];          // 4 flag bits per quad
+    int before[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      const long long i = base + (long long)(k * 256 + tid) * 4;
+      fgm[k] = 0u;
+      if (i < npix) {
+        if (vec) {
+          const f32x4 s4 = *reinterpret_cast<const f32x4*>(sd + i);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fgm[k] |= ((double)s4[e] < thr ? 1u : 0u) << e;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (i + e < npix) fgm[k] |= ((double)sd[i + e] < thr ? 1u : 0u) << e;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      int bef = 0, tot = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned long long b = __ballot((fgm[k] >> e) & 1u);
+        bef += __popcll(b & lower);
+        tot += __popcll(b);
+      }
+      before[k] = bef;            // raster order inside the wave: lane l owns pixels 4l .. 4l+3
+      if (lane == 0) wcount[k][wid] = tot;
+    }
+    __syncthreads();
+    int total = 0, mine[KQ];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        if (w == wid) mine[k] = total;
+        total += wcount[k][w];
+      }
+    if (tid == 0)
+      __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- (B) the embedding channels of the quads that hold a foreground pixel
+    float v[KQ][ND][4];
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      const long long i = base + (long long)(k * 256 + tid) * 4;
+      if (fgm[k]) {
+        if (vec) {
+#pragma unroll
+          for (int c = 0; c < ND; ++c) {
+            const f32x4 e4 = *reinterpret_cast<const f32x4*>(emb + (long long)c * npix + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][c][e] = e4[e];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][c][e] = (i + e < npix) ? emb[(long long)c * npix + i + e] : 0.f;
+        }
+      }
+    }
+
+    // ---- (C) decoupled look-back (as in ms_prepare_kernel)
+    if (wid == 0) {
+      int excl = 0;
+      for (int hi = tile - 1; hi >= 0; hi -= 64) {
+        const int j = hi - lane;
+        unsigned long long d = 2ull << 32;
+        if (j >= 0) {
+          do {
+            d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((unsigned int)(d >> 32) == 0);
+        }
+        const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
+        const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 64;
+        int a = (lane <= stop) ? (int)(unsigned int)d : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        excl += a;
+        if (has_prefix) break;
+      }
+      if (lane == 0) {
+        if (tile > 0)
+          __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        s_excl = excl;
+        if (tile == ntiles - 1) *nfg_out = excl + total;
+      }
+    }
+    __syncthreads();
+    const int excl = s_excl;
+#pragma unroll
+    for (int k = 0; k < KQ; ++k) {
+      if (!fgm[k]) continue;
+      int pos = excl + mine[k] + before[k];
+      const long long i = base + (long long)(k * 256 + tid) * 4;
+      // coordinates of the quad's first pixel; the others follow in raster order
+      const unsigned int t = fdiv((unsigned int)i, dX);
+      int cx = (int)((unsigned int)i - t * (unsigned int)X);
+      const unsigned int z0u = fdiv(t, dY);
+      int cy = (int)(t - z0u * (unsigned int)Y), cz = (int)z0u;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if ((fgm[k] >> e) & 1u) {
+          const int co[3] = {cx, cy, cz};
+#pragma unroll
+          for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = (double)v[k][c][e] + (double)co[c];
+          index[pos] = (int)(i + e);
+          ++pos;
+        }
+        if (++cx == X) { cx = 0; if (++cy == Y) { cy = 0; ++cz; } }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) s_excl = (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (s_excl) {
+    for (int j = tid; j < ntiles; j += 256)
+      __hip_atomic_store(&desc[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 2) __hip_atomic_store(ticket + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // One wavefront per seed: sklearn _mean_shift_single_seed.
 //   loop: members = fit points with |x - mean|^2 <= bw^2 ; if none: stop
 //         new = mean(members); if |new - mean| <= 1e-3 bw or it == max_iter: stop
@@ -654,13 +809,54 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
       return nb;                                                                                             \
     }();                                                                                                     \
     const int nblocks = ntiles < cus * per_cu ? ntiles : cus * per_cu;                                       \
-    ms_prepare_kernel<ND_, KP_><<<nblocks, 256, 0, st>>>(emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, \
+    CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_prepare_kernel<ND_, KP_>), dim3(nblocks), dim3(256), 0, st, emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, \
                                                          desc, Xout, index, nfg_out);                        \
   } while (0)
   if (ND == 2) { if (kp == 16) CLX_PREP(2, 16); else if (kp == 8) CLX_PREP(2, 8); else CLX_PREP(2, 4); }
   else         { if (kp >= 8) CLX_PREP(3, 8); else CLX_PREP(3, 4); }
 #undef CLX_PREP
   CLX_CHECK_LAUNCH("clx_ms_prepare");
+  return CLX_OK;
+}
+
+extern "C" int clx_ms_prepare_f32(const float* emb, const float* std, double threshold, int ND,
+                                  int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
+                                  void* workspace, clx_stream stream) {
+  CLX_REQUIRE(emb && std && Xout && index && nfg_out && workspace, "clx_ms_prepare_f32: null pointer");
+  CLX_REQUIRE((ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0, "clx_ms_prepare_f32: bad extents");
+  CLX_REQUIRE(ND == 3 || Z == 1, "clx_ms_prepare_f32: Z must be 1 for 2-D data");
+  CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare_f32: workspace must be 8-byte aligned");
+  const long long npix = (long long)Z * Y * X;
+  CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare_f32: too many pixels");
+  constexpr int KQ = 4;                     // 4096-pixel tiles: clx_ms_prepare_workspace(npix) covers them
+  const int ntiles = (int)((npix + 1024 * KQ - 1) / (1024 * KQ));
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int* ticket = (unsigned int*)workspace;
+  unsigned long long* desc = (unsigned long long*)workspace + 1;
+  // every channel plane starts at a multiple of npix floats: 16-byte loads need npix % 4 == 0 and aligned bases
+  const int vec = (npix % 4 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
+  const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
+  static const int cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+  }();
+#define CLX_PREP32(ND_)                                                                                      \
+  do {                                                                                                       \
+    static const int per_cu = [] {                                                                           \
+      int nb = 0;                                                                                            \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ms_prepare_f32_kernel<ND_, KQ>, 256, 0) != hipSuccess || nb < 1) \
+        nb = 2;                                                                                              \
+      return nb;                                                                                             \
+    }();                                                                                                     \
+    const int nblocks = ntiles < cus * per_cu ? ntiles : cus * per_cu;                                       \
+    CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_prepare_f32_kernel<ND_, KQ>), dim3(nblocks), dim3(256), 0, st, emb, std, \
+                    threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, desc, Xout, index, nfg_out);         \
+  } while (0)
+  if (ND == 2) CLX_PREP32(2); else CLX_PREP32(3);
+#undef CLX_PREP32
+  CLX_CHECK_LAUNCH("clx_ms_prepare_f32");
   return CLX_OK;
 }
 
@@ -717,9 +913,9 @@ extern "C" int clx_ms_assign(const double* X, const int* index, int nfg, const d
   const int grid = (nfg + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
   if (ND == 2)
-    ms_assign_kernel<2><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, labels);
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_kernel<2>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers, ncenters, labels);
   else
-    ms_assign_kernel<3><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, labels);
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_kernel<3>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers, ncenters, labels);
   CLX_CHECK_LAUNCH("clx_ms_assign");
   return CLX_OK;
 }
@@ -735,10 +931,10 @@ extern "C" int clx_ms_assign_grid(const double* X, const int* index, int nfg, co
   const int grid = (nfg + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
   if (ND == 2)
-    ms_assign_grid_kernel<2><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, order, cell_start, origin[0],
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_grid_kernel<2>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers, ncenters, order, cell_start, origin[0],
                                                     origin[1], 0.0, cell, nx, ny, nz, labels);
   else
-    ms_assign_grid_kernel<3><<<grid, 256, 0, st>>>(X, index, nfg, centers, ncenters, order, cell_start, origin[0],
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_grid_kernel<3>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers, ncenters, order, cell_start, origin[0],
                                                     origin[1], origin[2], cell, nx, ny, nz, labels);
   CLX_CHECK_LAUNCH("clx_ms_assign_grid");
   return CLX_OK;
@@ -756,10 +952,10 @@ extern "C" int clx_ms_assign_cells(const double* X, const int* index, int nfg, c
   const int grid = (nfg + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
   if (ND == 2)
-    ms_assign_cells_kernel<2><<<grid, 256, 0, st>>>(X, index, nfg, centers_sorted, order, cell_start, origin[0],
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_cells_kernel<2>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers_sorted, order, cell_start, origin[0],
                                                      origin[1], 0.0, cell, nx, ny, nz, labels);
   else
-    ms_assign_cells_kernel<3><<<grid, 256, 0, st>>>(X, index, nfg, centers_sorted, order, cell_start, origin[0],
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_cells_kernel<3>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers_sorted, order, cell_start, origin[0],
                                                      origin[1], origin[2], cell, nx, ny, nz, labels);
   CLX_CHECK_LAUNCH("clx_ms_assign_cells");
   return CLX_OK;

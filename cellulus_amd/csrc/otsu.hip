@@ -31,6 +31,46 @@ __global__ void minmax_init(double* mm) {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// float32 input (the network's std channel handed over in device memory, cellulus_amd/infer.py::fused_stages): the
+// float64 values the staged path reads back from zarr are these floats widened, so min / max / bin of the widened
+// value are the staged path's bits.  16 bytes = four floats per lane.
+__global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict__ x, long long n, double* mm) {
+  __shared__ double smin[4], smax[4];
+  float lo = __int_as_float(0x7f800000), hi = -lo;
+  const long long n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  const long long per_block = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < n4 ? b0 + per_block : n4;
+  long long i = b0 + threadIdx.x;
+  for (; i + 3 * 256 < b1; i += 4 * 256) {
+    const f32x4 a = x4[i], b = x4[i + 256], c = x4[i + 512], d = x4[i + 768];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      lo = fminf(fminf(lo, a[e]), fminf(b[e], fminf(c[e], d[e])));
+      hi = fmaxf(fmaxf(hi, a[e]), fmaxf(b[e], fmaxf(c[e], d[e])));
+    }
+  }
+  for (; i < b1; i += 256) {
+    const f32x4 a = x4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { lo = fminf(lo, a[e]); hi = fmaxf(hi, a[e]); }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+    lo = fminf(lo, x[(n4 << 2) + threadIdx.x]);
+    hi = fmaxf(hi, x[(n4 << 2) + threadIdx.x]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_down(lo, o, 64));
+    hi = fmaxf(hi, __shfl_down(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = (double)lo; smax[threadIdx.x >> 6] = (double)hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomic_min_f64(mm, fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3])));
+    atomic_max_f64(mm + 1, fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3])));
+  }
+}
+
 // 16-byte loads (two doubles per lane): 8-byte accesses run at 0.54-0.70x the 16-byte rate
 __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ x, long long n, double* mm) {
   __shared__ double smin[4], smax[4];
@@ -125,14 +165,69 @@ __global__ __launch_bounds__(256) void histogram_kernel(const double* __restrict
   }
 }
 
+// the same histogram of float32 values widened in registers (four per 16-byte load)
+__global__ __launch_bounds__(256) void histogram_f32_kernel(const float* __restrict__ x, long long n,
+                                                            const double* __restrict__ edges, int nbins,
+                                                            unsigned long long* __restrict__ counts) {
+  extern __shared__ unsigned char hist_smem[];
+  double* eds = reinterpret_cast<double*>(hist_smem);                       // [nbins + 1]
+  unsigned int* local = reinterpret_cast<unsigned int*>(eds + nbins + 1);   // [4][nbins]
+  for (int k = threadIdx.x; k <= nbins; k += blockDim.x) eds[k] = edges[k];
+  for (int k = threadIdx.x; k < 4 * nbins; k += blockDim.x) local[k] = 0u;
+  __syncthreads();
+  unsigned int* mine = local + (threadIdx.x >> 6) * nbins;
+  const double first = eds[0], last = eds[nbins];
+  const double denom = last - first;
+  const long long n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  int cur = 0;
+  unsigned int run = 0u;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = x4[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hist_one((double)v[e], first, last, denom, nbins, eds, mine, cur, run);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long long i = n4 << 2; i < n; ++i) hist_one((double)x[i], first, last, denom, nbins, eds, mine, cur, run);
+  if (run) atomicAdd(&mine[cur], run);
+  __syncthreads();
+  for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
+    const unsigned int c = local[k] + local[nbins + k] + local[2 * nbins + k] + local[3 * nbins + k];
+    if (c) atomicAdd(&counts[k], (unsigned long long)c);
+  }
+}
+
 }  // namespace
+
+extern "C" int clx_minmax_f32(const float* x, long long n, double* minmax, clx_stream stream) {
+  CLX_REQUIRE(x && minmax && n > 0, "clx_minmax_f32: bad arguments");
+  CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_minmax_f32: x must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_init, dim3(1), dim3(1), 0, st, minmax);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_f32_kernel, dim3(grid_for(n / 16 + 1, 256)), dim3(256), 0, st, x, n, minmax);
+  CLX_CHECK_LAUNCH("clx_minmax_f32");
+  return CLX_OK;
+}
+
+extern "C" int clx_histogram_f32(const float* x, long long n, const double* edges, int nbins,
+                                 long long* counts, clx_stream stream) {
+  CLX_REQUIRE(x && edges && counts && n > 0, "clx_histogram_f32: bad arguments");
+  CLX_REQUIRE(nbins > 0 && nbins <= 2048, "clx_histogram_f32: nbins must be in 1..2048");
+  CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_histogram_f32: x must be 16-byte aligned");
+  const size_t lds = (size_t)(nbins + 1) * sizeof(double) + (size_t)4 * nbins * sizeof(unsigned int);
+  CLX_LAUNCH_KIND(CLX_PROF_HISTOGRAM, histogram_f32_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), lds,
+                  (hipStream_t)stream, x, n, edges, nbins, (unsigned long long*)counts);
+  CLX_CHECK_LAUNCH("clx_histogram_f32");
+  return CLX_OK;
+}
 
 extern "C" int clx_minmax_f64(const double* x, long long n, double* minmax, clx_stream stream) {
   CLX_REQUIRE(x && minmax && n > 0, "clx_minmax_f64: bad arguments");
   CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_minmax_f64: x must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  minmax_init<<<1, 1, 0, st>>>(minmax);
-  minmax_kernel<<<grid_for(n / 8 + 1, 256), 256, 0, st>>>(x, n, minmax);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_init, dim3(1), dim3(1), 0, st, minmax);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, st, x, n, minmax);
   CLX_CHECK_LAUNCH("clx_minmax_f64");
   return CLX_OK;
 }
@@ -143,7 +238,7 @@ extern "C" int clx_histogram_f64(const double* x, long long n, const double* edg
   CLX_REQUIRE(nbins > 0 && nbins <= 2048, "clx_histogram_f64: nbins must be in 1..2048");
   CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_histogram_f64: x must be 16-byte aligned");
   const size_t lds = (size_t)(nbins + 1) * sizeof(double) + (size_t)4 * nbins * sizeof(unsigned int);
-  histogram_kernel<<<grid_for(n / 2 + 1, 256), 256, lds, (hipStream_t)stream>>>(
+  CLX_LAUNCH_KIND(CLX_PROF_HISTOGRAM, histogram_kernel, dim3(grid_for(n / 2 + 1, 256)), dim3(256), lds, (hipStream_t)stream, 
       x, n, edges, nbins, (unsigned long long*)counts);
   CLX_CHECK_LAUNCH("clx_histogram_f64");
   return CLX_OK;

@@ -143,10 +143,11 @@ def _labels_to_host(labels):
     return labels.numpy() if labels.device.type == "cpu" else labels.cpu().numpy()
 
 
-def detect_sample(embeddings, inference_config, nd, device, sample=0, emb_d=None, emit=None):
+def detect_sample(embeddings, inference_config, nd, device, sample=0, emb_d=None, emit=None, std_minmax=None):
     """detect.py:82-192 for ONE sample.  embeddings: (D+1, *spatial) float64 host array (what the
     ``embeddings`` dataset holds); emb_d: the same values already on the device, if the caller has
-    them (the fused driver does).  ``emit(kind, index, value)`` receives every output the moment
+    them (the fused driver does) — as float64, or as the float32 values they were widened from;
+    std_minmax: (min, max) of the std channel as a 2-element device tensor, if the caller has it.  ``emit(kind, index, value)`` receives every output the moment
     it exists — "binary" mask, "centered" embeddings, "detection" label tensor of bandwidth
     ``index`` — in the order the reference writes them.  Returns the list of label tensors."""
     if emit is None:
@@ -156,7 +157,7 @@ def detect_sample(embeddings, inference_config, nd, device, sample=0, emb_d=None
         emb_d = torch.from_numpy(np.ascontiguousarray(embeddings)).to(device)
     std_d = emb_d[-1].contiguous()
     if inference_config.threshold is None:
-        threshold = threshold_otsu(std_d)
+        threshold = threshold_otsu(std_d, minmax=std_minmax)
     else:
         threshold = inference_config.threshold
     print(f"For sample {sample}, binary threshold {threshold} was used.")
@@ -203,7 +204,10 @@ def detect_sample(embeddings, inference_config, nd, device, sample=0, emb_d=None
             mean_d, sd_d = src[:nd].contiguous().clone(), src[-1].contiguous()
         else:
             seeds = None
-            mean_d, sd_d = emb_d[:nd].contiguous().clone(), std_d
+            # (a float32 hand-over is not modified by the clustering: no copy; float64: the reference's in-place
+            # coordinate add lands in a copy that is dropped, detect.py:155-160)
+            mean_d = emb_d[:nd].contiguous()
+            mean_d, sd_d = (mean_d if mean_d.dtype == torch.float32 else mean_d.clone()), std_d
         labels, _ = mean_shift_on_device(
             mean_d, sd_d, bandwidth, inference_config.reduction_probability, threshold, seeds)
         if inference_config.use_seeds and centered_aliased:

@@ -29,7 +29,10 @@ def fused_stages(model, inference_config, normalization_factor, device):
     embeddings go from the U-Net to the mean-shift and on to the post-processing in HBM, the
     zarr datasets — the same ones, with the same contents — are written by a background thread
     while the next stage computes.  What the staged path reads back from disk is reproduced
-    exactly: float32 embeddings widened to float64, label maps through their uint16 storage type.
+    exactly: float32 embeddings widened to float64 (on the host for the datasets; in registers by the
+    kernels that consume them on the device: clx_histogram_f32, clx_ms_prepare_f32 — the widening is exact,
+    so thresholds, points and labels are the staged path's bits without a float64 copy in HBM), label maps
+    through their uint16 storage type.
     Every stage draws from its own generator in the staged order too (torch for the noise,
     numpy for the mean-shift sub-sampling), so interleaving them changes no random number."""
     from concurrent.futures import ThreadPoolExecutor
@@ -80,19 +83,22 @@ def fused_stages(model, inference_config, normalization_factor, device):
 
         def enqueue_predict(sample):
             raw = raw_ds[sample]
-            emb = scan.predict_sample(raw).double()              # == astype(float64) of the f32 result
+            # float32 (D+1, *spatial) + the std channel's (min, max) where the tiles partition the image
+            emb, std_minmax = scan.predict_sample(raw, want_std_minmax=True)
             done = torch.cuda.Event()
             done.record(main)
-            return raw, emb, done
+            return raw, (emb, std_minmax), done
 
         nxt = enqueue_predict(lo) if hi > lo else None
         for sample in range(lo, hi):
-            raw, emb_d, done = nxt
+            raw, (emb_d, std_minmax), done = nxt
             nxt = enqueue_predict(sample + 1) if sample + 1 < hi else None
             with torch.cuda.stream(post):
                 post.wait_event(done)
                 emb_d.record_stream(post)
-                embeddings = emb_d.cpu().numpy()
+                if std_minmax is not None:
+                    std_minmax.record_stream(post)
+                embeddings = emb_d.cpu().numpy().astype(np.float64)       # what predict() writes (predict.py:104-112)
                 write(ds_emb, sample, embeddings)
 
                 def emit(kind, index, value, sample=sample):
@@ -103,7 +109,8 @@ def fused_stages(model, inference_config, normalization_factor, device):
                     else:
                         write(ds_det, (sample, index, Ellipsis), _labels_to_host(value))
 
-                detections = detect_sample(embeddings, inference_config, nd, device, sample, emb_d=emb_d, emit=emit)
+                detections = detect_sample(embeddings, inference_config, nd, device, sample, emb_d=emb_d,
+                                           std_minmax=std_minmax, emit=emit)
                 for bandwidth_factor, labels in enumerate(detections):
                     # through the uint16 storage type, as segment() reads it back
                     seg_d = (labels.to(device=device, dtype=torch.int32) & 0xFFFF).contiguous()

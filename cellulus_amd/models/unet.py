@@ -391,7 +391,7 @@ class UNetModel(nn.Module):  # type: ignore
             return self.infer_on_device(raw).cpu()
 
     @torch.no_grad()
-    def infer_on_device(self, raw, noise=None):
+    def infer_on_device(self, raw, noise=None, std_minmax=None):
         """Infer-mode forward (unet.py:73-100) without the final D2H copy.
 
         For every sample: 2 * num_infer_iterations salt/pepper-noised copies
@@ -399,7 +399,10 @@ class UNetModel(nn.Module):  # type: ignore
         the copies; std summed over channels.  Returns (B, D+1, *out) on device.
         `noise`: optional (B, 2*N, C, *spatial) uniform randoms (CPU or device);
         default draws them with torch.rand on the CPU exactly like the reference
-        (one call per noisy copy, in the reference's order)."""
+        (one call per noisy copy, in the reference's order).
+        `std_minmax`: optional (float32[2] device tensor, reset) — the running minimum / maximum of the std channel
+        over the calls of one image's tiles (clx_noise_stats_minmax; reset = True on the first tile): the range the
+        Otsu histogram of cellulus/detect.py:88-91 needs, without another pass over the channel."""
         _clx.require_device(raw, "raw")
         n_it = int(self.num_infer_iterations)
         T = 2 * n_it
@@ -425,7 +428,12 @@ class UNetModel(nn.Module):  # type: ignore
             C = preds.shape[1]
             n = preds[0, 0].numel()
             out = torch.empty((C + 1,) + tuple(preds.shape[2:]), dtype=torch.float32, device=raw.device)
-            _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(out), T, C, n, st)
+            if std_minmax is None:
+                _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(out), T, C, n, st)
+            else:
+                mm, reset = std_minmax
+                _clx.call("clx_noise_stats_minmax", _clx.ptr(preds), _clx.ptr(out), T, C, n, _clx.ptr(mm),
+                          1 if (reset and sample == 0) else 0, st)
             embeddings.append(out)
         return torch.stack(embeddings, dim=0)
 

@@ -122,6 +122,9 @@ class PredictScan:
         self.offsets = [tile_offsets(s, t) for s, t in zip(self.spatial, self.out_tile)]
         self.pad = [(0, 0)] + [(c, c) for c in self.context]
         self.tiles_per_sample = int(np.prod([len(o) for o in self.offsets]))
+        # the tiles PARTITION the image (no last tile shifted back inside): a statistic folded over the tiles' outputs
+        # is then the statistic of the image
+        self.tiles_partition = all(s % t == 0 for s, t in zip(self.spatial, self.out_tile))
         self.noise = None
 
     def start_noise(self, num_samples):
@@ -135,7 +138,14 @@ class PredictScan:
         copies = 2 * int(self.model.num_infer_iterations)
         self.noise = NoisePrefetcher(num_samples * self.tiles_per_sample, copies, tile_shape, dry_run=copies)
 
-    def predict_sample(self, raw):
+    def predict_sample(self, raw, want_std_minmax=False):
+        """(D+1, *spatial) float32 device tensor; with want_std_minmax ALSO a float32[2] device tensor holding the
+        minimum and maximum of the std channel — or None where the tiles overlap (a later tile overwrites part of an
+        earlier one, whose values must not count)."""
+        mm = None
+        if want_std_minmax and self.tiles_partition:
+            mm = torch.empty(2, dtype=torch.float32, device=self.device)
+        first = True
         raw = raw.astype(np.float32) * np.float32(self.factor)             # gp.Normalize
         raw = np.pad(raw, self.pad, mode="reflect")                        # gp.Pad(mode="reflect")
         raw_d = torch.from_numpy(raw).to(self.device)
@@ -147,10 +157,11 @@ class PredictScan:
             if self.noise is not None:           # (T, 1, C, *crop) -> (1, T, C, *crop)
                 buf = self.noise.next()
                 rnd = buf.view((1, buf.shape[0]) + tuple(buf.shape[2:]))
-            emb = self.model.infer_on_device(tile, noise=rnd)[0]
+            emb = self.model.infer_on_device(tile, noise=rnd, std_minmax=None if mm is None else (mm, first))[0]
+            first = False
             out_sl = (slice(None),) + tuple(slice(o, o + t) for o, t in zip(off, self.out_tile))
             result[out_sl] = emb
-        return result
+        return (result, mm) if want_std_minmax else result
 
 
 def predict(model: torch.nn.Module, inference_config: InferenceConfig, normalization_factor: float) -> None:

@@ -115,13 +115,17 @@ def _prepare_workspace(nbytes, dev):
 def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, seeds=None):
     """emb: (ND, *spatial) f64 device tensor (coordinates are ADDED IN PLACE, as the
     reference does to its argument); std: (*spatial) f64 device tensor.
+    Both float32 instead (the network's output handed over in device memory by the fused predict -> detect path):
+    the values are read as float64 — what the staged path reads back from the float64 `embeddings` dataset — and
+    emb is left UNTOUCHED (that caller has no use for the coordinate-added copy, cellulus/detect.py:155-160).
     Returns (labels int32 device tensor of shape spatial — background 0 —, cluster centres)."""
     _clx.require_device(emb, "embedding")
     nd = emb.shape[0]
     spatial = tuple(emb.shape[1:])
     assert len(spatial) == nd and tuple(std.shape) == spatial
-    assert emb.dtype == torch.float64 and std.dtype == torch.float64
+    assert emb.dtype == std.dtype and emb.dtype in (torch.float64, torch.float32)
     assert emb.is_contiguous() and std.is_contiguous()
+    prepare = "clx_ms_prepare" if emb.dtype == torch.float64 else "clx_ms_prepare_f32"
     Z, Y, X = (1,) * (3 - nd) + spatial
     npix = Z * Y * X
     dev = emb.device
@@ -132,7 +136,7 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     index = torch.empty(npix, dtype=torch.int32, device=dev)
     nfg_d = torch.zeros(1, dtype=torch.int32, device=dev)
     try:
-        _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
+        _clx.call(prepare, _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
                   _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
     except _clx.ClxError:
         # a call that did not complete may leave tickets / descriptors behind: never reuse that buffer (the next

@@ -43,8 +43,8 @@ int clx_abi_version(void);
 int clx_device_count(void);
 
 /* Kernel timing for roofline reports: while enabled (on = 1; on = 2 also clears the
- * records, 0 disables and clears) every launch of an MFMA kernel is bracketed by HIP
- * events on its stream.  clx_profile_read sums launches / milliseconds / executed FLOPs
+ * records, 0 disables and clears) every launch of an MFMA kernel — and of the HBM-bound kernels of
+ * detect / segment listed below — carries a HIP event pair stamped with the kernel's own start and end on its stream.  clx_profile_read sums launches / milliseconds / executed FLOPs
  * (2*M*N*K per GEMM of the launch, real extents) of one kernel kind; it synchronises. */
 enum clx_profile_kind {
   CLX_PROF_IGEMM_WIDE = 0,   /* conv_igemm_kernel<128,128> */
@@ -53,7 +53,15 @@ enum clx_profile_kind {
   CLX_PROF_GEMM_X3 = 3,      /* gemm_x3_kernel (opt-in precision f32x3bf16; FLOPs = f32-equivalent 2*M*N*K) */
   CLX_PROF_WGRAD_X3 = 4,     /* wgrad_x3_kernel (weight gradient of the opt-in precision) */
   CLX_PROF_GEMM_T = 5,       /* gemm_t_kernel (plain products, weights as the MFMA's A operand) */
-  CLX_PROF_CHAIN64 = 6       /* chain64_fwd / _bwd kernels (fused pairs of 64-channel 1x1 layers) */
+  CLX_PROF_CHAIN64 = 6,      /* chain64_fwd / _bwd kernels (fused pairs of 64-channel 1x1 layers) */
+  /* the HBM-bound kernels of detect / segment (no FLOPs: total_flops of these kinds is 0; the caller prices them by bytes) */
+  CLX_PROF_MS_PREPARE = 7,   /* ms_prepare_kernel */
+  CLX_PROF_MS_ASSIGN = 8,    /* ms_assign_cells / _grid / ms_assign kernels */
+  CLX_PROF_CC = 9,           /* every kernel of clx_label_filter (connected components + size filter + relabel) */
+  CLX_PROF_GROW_SHRINK = 10, /* every kernel of clx_grow_shrink */
+  CLX_PROF_MINMAX = 11,      /* minmax_init + minmax_kernel */
+  CLX_PROF_HISTOGRAM = 12,   /* histogram_kernel */
+  CLX_PROF_NOISE_STATS = 13  /* noise_stats kernels */
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);
@@ -399,6 +407,13 @@ int clx_adam_step_guarded(float* param, const float* grad, float* exp_avg,
  * std, torch.std_mean(unbiased=False)). */
 int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
                     clx_stream stream);
+/* The same, ALSO keeping the running minimum and maximum of the std plane out[C] in std_minmax[0..1] (float32):
+ * the range numpy.histogram needs for the Otsu threshold of that plane (cellulus/detect.py:88-91 ->
+ * skimage.filters.threshold_otsu), so the fused predict -> detect path reads the plane once (histogram) instead
+ * of twice.  init != 0 resets the pair first; with init == 0 the call folds into what earlier calls (the other tiles
+ * of the sample) left.  T <= 64. */
+int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long long n, float* std_minmax,
+                           int init, clx_stream stream);
 
 /* ------------------------------------------------------------------------ */
 /* Mean-shift clustering (cellulus/utils/mean_shift.py:6-121 ->             */
@@ -417,6 +432,14 @@ size_t clx_ms_prepare_workspace(long long npix);
 int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
                    int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
                    void* workspace, clx_stream stream);
+/* The same compaction for the fused predict -> detect hand-off of infer() (cellulus/infer.py:69-73 without the
+ * round trip through the float64 `embeddings` dataset, cellulus/predict.py:104-112 -> cellulus/detect.py:83): emb
+ * and std are the network's float32 output, widened to float64 in registers — the values the staged path reads
+ * back — so X and index are bit-identical to clx_ms_prepare's on the widened tensors.  emb is NOT modified (the
+ * caller of this form discards the coordinate-added copy, as cellulus/detect.py:155-160 does).  Same workspace. */
+int clx_ms_prepare_f32(const float* emb, const float* std, double threshold, int ND,
+                       int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
+                       void* workspace, clx_stream stream);
 /* Flat-kernel mean-shift of every seed over the fit points until
  * |shift| <= 1e-3*bandwidth or max_iter (sklearn _mean_shift_single_seed).
  * fit: (nfit, ND) f64; seeds: (nseeds, ND) f64; outputs centers (nseeds, ND)
@@ -542,6 +565,12 @@ int clx_minmax_f64(const double* x, long long n, double* minmax, clx_stream stre
  * caller-supplied edges (np.linspace) — counts (nbins) int64, zeroed by caller. */
 int clx_histogram_f64(const double* x, long long n, const double* edges,
                       int nbins, long long* counts, clx_stream stream);
+/* The same two primitives for a float32 image whose values are to be read as float64 (the network's std plane handed
+ * over in device memory; the staged path reads exactly these values widened from the `embeddings` dataset):
+ * minmax and counts are bit-identical to the float64 entry points on the widened image. */
+int clx_minmax_f32(const float* x, long long n, double* minmax, clx_stream stream);
+int clx_histogram_f32(const float* x, long long n, const double* edges, int nbins,
+                      long long* counts, clx_stream stream);
 
 /* ------------------------------------------------------------------------ */
 /* "nucleus" post-processing (cellulus/segment.py:52-101): per-instance Otsu */

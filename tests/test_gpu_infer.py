@@ -790,3 +790,88 @@ def test_evaluate_over_zarr_writes_the_reference_report(device, tmp_path, monkey
             tps, fps, fns, seg_sum, n_ids = tps + tp, fps + fp, fns + fn, seg_sum + seg_img, n_ids + n
         assert lines[-2] == f"F1 for complete dataset is {2 * tps / (2 * tps + fps + fns):.05f} "
         assert lines[-1] == f"SEG for complete dataset is {seg_sum / n_ids:.05f} "
+
+
+# --------------------------------------------- float32 hand-over of the fused predict -> detect path
+@pytest.mark.parametrize("shape", [(64, 80), (61, 67), (129, 1031), (12, 20, 24), (7, 9, 11)])
+def test_float32_handover_kernels_equal_the_float64_ones_on_the_widened_values(shape, device):
+    """clx_ms_prepare_f32 / clx_minmax_f32 / clx_histogram_f32 read the network's float32 output and widen in
+    registers: points, raster indices, foreground count, min / max and bin counts are BIT-identical to the float64
+    entry points on the widened tensors (what the staged path reads back from the `embeddings` dataset), for aligned
+    and unaligned extents, and the float32 embedding is left untouched."""
+    from cellulus_amd import _clx
+
+    nd = len(shape)
+    rng = np.random.default_rng(5)
+    emb32 = torch.from_numpy((rng.normal(0, 6, size=(nd,) + shape)).astype(np.float32)).to(device)
+    std32 = torch.from_numpy(rng.random(shape, dtype=np.float32)).to(device)
+    Z, Y, X = (1,) * (3 - nd) + shape
+    npix = Z * Y * X
+    st = _clx.stream_ptr(device)
+    lib = _clx.load()
+    thr = 0.3
+
+    def prepare(name, emb, std):
+        ws = torch.zeros(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)
+        pts = torch.full((npix, nd), float("nan"), dtype=torch.float64, device=device)
+        idx = torch.full((npix,), -1, dtype=torch.int32, device=device)
+        nfg = torch.zeros(1, dtype=torch.int32, device=device)
+        for _ in range(2):                                   # the workspace comes back zeroed: a second call works
+            e = emb.clone()
+            _clx.call(name, _clx.ptr(e), _clx.ptr(std), thr, nd, Z, Y, X, _clx.ptr(pts), _clx.ptr(idx), _clx.ptr(nfg),
+                      _clx.ptr(ws), st)
+        assert int(ws.max().item()) == 0
+        n = int(nfg.item())
+        return pts[:n].cpu().numpy(), idx[:n].cpu().numpy(), e
+
+    p64, i64, e64 = prepare("clx_ms_prepare", emb32.double(), std32.double())
+    p32, i32, e32 = prepare("clx_ms_prepare_f32", emb32, std32)
+    assert len(i64) == int((std32.double() < thr).sum().item()) > 0
+    np.testing.assert_array_equal(i32, i64)
+    np.testing.assert_array_equal(p32, p64)
+    assert torch.equal(e32, emb32) and not torch.equal(e64, emb32.double())     # only the float64 form adds in place
+    # Otsu primitives
+    for x in (std32.reshape(-1), std32.reshape(-1)[: npix - 3]):
+        x = x.clone()
+        mm32 = torch.empty(2, dtype=torch.float64, device=device)
+        mm64 = torch.empty(2, dtype=torch.float64, device=device)
+        _clx.call("clx_minmax_f32", _clx.ptr(x), x.numel(), _clx.ptr(mm32), st)
+        _clx.call("clx_minmax_f64", _clx.ptr(x.double()), x.numel(), _clx.ptr(mm64), st)
+        assert torch.equal(mm32, mm64) and mm32[0].item() == float(x.min().item())
+        c32, e32_ = histogram_on_device(x)
+        c64, e64_ = histogram_on_device(x.double())
+        np.testing.assert_array_equal(c32, c64)
+        np.testing.assert_array_equal(e32_, e64_)
+        ref_counts, _ = np.histogram(x.cpu().numpy().astype(np.float64), bins=256)
+        np.testing.assert_array_equal(c32, ref_counts)
+    assert threshold_otsu(std32) == threshold_otsu(std32.double())
+    mm = (float(std32.min().item()), float(std32.max().item()))
+    assert threshold_otsu(std32, minmax=mm) == threshold_otsu(std32.double())
+    assert threshold_otsu(torch.full((5, 7), 1.25, dtype=torch.float32, device=device)) == 1.25
+
+
+def test_noise_stats_emits_the_std_range(device):
+    """clx_noise_stats_minmax: the same (mean, std) planes as clx_noise_stats, plus the running minimum / maximum of the
+    std plane, folded over several calls (the tiles of one image) when init is 0."""
+    from cellulus_amd import _clx
+
+    st = _clx.stream_ptr(device)
+    torch.manual_seed(3)
+    T, C = 32, 2
+    mm = torch.empty(2, dtype=torch.float32, device=device)
+    lo, hi = float("inf"), 0.0
+    for k, n in enumerate((4096, 1000, 333 * 7)):
+        preds = torch.randn(T, C, n, device=device) * (k + 1)
+        if k == 1:
+            preds[:, :, 17] = 0.25                      # a pixel whose std is exactly 0
+        ref = torch.empty(C + 1, n, device=device)
+        out = torch.empty(C + 1, n, device=device)
+        _clx.call("clx_noise_stats", _clx.ptr(preds), _clx.ptr(ref), T, C, n, st)
+        _clx.call("clx_noise_stats_minmax", _clx.ptr(preds), _clx.ptr(out), T, C, n, _clx.ptr(mm), 1 if k == 0 else 0, st)
+        assert torch.equal(out, ref)
+        lo, hi = min(lo, float(ref[C].min().item())), max(hi, float(ref[C].max().item()))
+        assert mm.cpu().tolist() == [lo, hi]
+    assert lo == 0.0
+    # reset
+    _clx.call("clx_noise_stats_minmax", _clx.ptr(preds), _clx.ptr(out), T, C, n, _clx.ptr(mm), 1, st)
+    assert mm.cpu().tolist() == [float(ref[C].min().item()), float(ref[C].max().item())]
