@@ -177,7 +177,7 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     t = _kernel_time(lambda: label_on_device(grown, 70), PROF_KIND["cc"], reps=3)
     row("cc_label_filter", t, npix * 8, "per pixel 4 B read + 4 B written")
     # --- Otsu: min/max + 256-bin histogram of the float64 std channel
-    mm = torch.empty(2, dtype=torch.float64, device=device)
+    mm = torch.empty(_clx.MINMAX_DOUBLES, dtype=torch.float64, device=device)
     x = sd.reshape(-1)
     t = _kernel_time(lambda: _clx.call("clx_minmax_f64", _clx.ptr(x), npix, _clx.ptr(mm), st), PROF_KIND["minmax"])
     row("minmax_f64", t, npix * 8, "per pixel 8 B read")

@@ -170,6 +170,9 @@ PROTOTYPES = {
     "clx_joint_histogram": (_I, [_P, _P, _LL, _P, _P, _I, _P, _P]),
 }
 
+MINMAX_DOUBLES = 2 + 2 * 512            # CLX_MINMAX_DOUBLES (include/clx.h): results + per-block partials
+NOISE_MINMAX_FLOATS = 2 + 2 * 1024      # CLX_NOISE_MINMAX_FLOATS
+
 _lib = None
 
 

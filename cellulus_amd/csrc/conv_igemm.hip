@@ -641,7 +641,10 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   const bool padded = d->PD != 0 || d->PH != 0 || d->PW != 0;
   for (int s = 0; s < d->nsrc && fast; ++s) {
     const clx_src& S = d->src[s];
-    const long long floats = (long long)d->B * S.D * S.H * S.W * S.ld + (long long)(batch - 1) * bs_in;
+    // ONE batch's tensor: the batch stride goes into the 64-bit base pointer (sptr = S.ptr + blockIdx.y * bs_in), only the
+    // offsets inside a batch are 32-bit.  (The whole batched tensor counted here until round 4: the 36 x tiles x C operand
+    // of a Winograd layer over eight 526^2 inference copies is 1.3 G floats, and those launches took the general path.)
+    const long long floats = (long long)d->B * S.D * S.H * S.W * S.ld;
     // byte offsets in 32 bits; with padding the rows come through buffer loads and 0x80000000 must lie outside the tensor
     if (S.C % BK != 0 || floats >= (padded ? (1ll << 29) : (1ll << 30))) fast = 0;
   }
@@ -654,6 +657,9 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
     else if (fast == 2) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
     else CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 128, 2, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
   } else {
+    // (256-row tiles for narrow N — a wave owning 64 x 64 like the wide kernel's, two 80-KB blocks per CU — measured in round
+    //  4: 106 against 111 TFLOP/s over the 3-D step's fifteen launches, 91 against 96 on the 2-D step's three: three blocks
+    //  per CU matter more to these short-K launches than the fragment reads saved)
     p.nbm = cdiv(p.M, 128); p.nbn = cdiv(p.N, 64);
     if (fast == 1) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1, 1>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);
     else if (fast == 2) CLX_LAUNCH_TIMED((conv_igemm_kernel<128, 64, 4, 1, 2>), dim3(p.nbm * p.nbn, batch), dim3(256), st, e0, e1, p);

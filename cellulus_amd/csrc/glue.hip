@@ -199,14 +199,38 @@ __global__ void noise_stats_kernel(const float* __restrict__ preds, float* __res
   }
 }
 
-__global__ void noise_minmax_init(unsigned int* mm) {
-  mm[0] = 0x7f800000u;     // +inf: the running minimum
-  mm[1] = 0u;              // +0:   the running maximum (a sum of square roots is never negative)
+constexpr int NOISE_MM_BLOCKS = 1024;     // == (CLX_NOISE_MINMAX_FLOATS - 2) / 2
+
+// std_minmax: [0] min, [1] max of the std plane so far, [2 + 2 b], [3 + 2 b] the partials of block b of the last launch.
+// Bit patterns of non-negative floats order like the numbers, so the reductions are unsigned-integer min / max; one
+// small block folds the partials into [0..1] (no two blocks ever meet on an address: same-address atomics are served
+// one after the other, ~12 ns each — csrc/otsu.hip).
+__global__ __launch_bounds__(256) void noise_minmax_final(unsigned int* mm, int nblocks, int init) {
+  __shared__ unsigned int slo[4], shi[4];
+  unsigned int lo = 0xffffffffu, hi = 0u;
+  for (int b = threadIdx.x; b < nblocks; b += 256) {
+    const unsigned int l = mm[2 + 2 * b], h = mm[3 + 2 * b];
+    lo = l < lo ? l : lo;
+    hi = h > hi ? h : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < 4; ++w) { lo = slo[w] < lo ? slo[w] : lo; hi = shi[w] > hi ? shi[w] : hi; }
+    if (!init) { lo = mm[0] < lo ? mm[0] : lo; hi = mm[1] > hi ? mm[1] : hi; }
+    mm[0] = lo;
+    mm[1] = hi;
+  }
 }
 
-// same arithmetic, the T samples of a pixel are read ONCE and kept in registers.  minmax (optional): running minimum /
-// maximum of the std plane as float bit patterns — for non-negative floats the unsigned order of the patterns is the
-// numeric order, so two integer atomics per wavefront do (a NaN, whose pattern lies above +inf, ends up as the maximum)
+// same arithmetic, the T samples of a pixel are read ONCE and kept in registers.  minmax (optional): the block's
+// minimum / maximum of the std plane as float bit patterns (a NaN, whose pattern lies above +inf, ends up as the maximum)
 template <int TCAP>
 __global__ void noise_stats_reg_kernel(const float* __restrict__ preds, float* __restrict__ out,
                                        int T, int C, long long n, unsigned int* __restrict__ minmax) {
@@ -237,15 +261,19 @@ __global__ void noise_stats_reg_kernel(const float* __restrict__ preds, float* _
     hi = bits > hi ? bits : hi;
   }
   if (minmax != nullptr) {
+    __shared__ unsigned int slo[4], shi[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned int l2 = __shfl_xor(lo, o, 64), h2 = __shfl_xor(hi, o, 64);
       lo = l2 < lo ? l2 : lo;
       hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-      atomicMin(minmax, lo);
-      atomicMax(minmax + 1, hi);
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 0; w < 4; ++w) { lo = slo[w] < lo ? slo[w] : lo; hi = shi[w] > hi ? shi[w] : hi; }
+      minmax[2 + 2 * blockIdx.x] = lo;          // (a block without pixels: lo = all ones, hi = 0 — neutral)
+      minmax[3 + 2 * blockIdx.x] = hi;
     }
   }
 }
@@ -304,11 +332,14 @@ extern "C" int clx_upsample_bwd(const float* dcat, int ld_cat, int coff, int LD,
 }
 
 static int noise_stats_launch(const float* preds, float* out, int T, int C, long long n, unsigned int* minmax,
-                              hipStream_t st) {
+                              hipStream_t st, int* grid_out = nullptr) {
+  int g = grid_for(n, 256);
+  if (minmax != nullptr && g > NOISE_MM_BLOCKS) g = NOISE_MM_BLOCKS;
+  if (grid_out) *grid_out = g;
   if (T <= 32)
-    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, (noise_stats_reg_kernel<32>), dim3(grid_for(n, 256)), dim3(256), 0, st, preds, out, T, C, n, minmax);
+    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, (noise_stats_reg_kernel<32>), dim3(g), dim3(256), 0, st, preds, out, T, C, n, minmax);
   else if (T <= 64)
-    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, (noise_stats_reg_kernel<64>), dim3(grid_for(n, 256)), dim3(256), 0, st, preds, out, T, C, n, minmax);
+    CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, (noise_stats_reg_kernel<64>), dim3(g), dim3(256), 0, st, preds, out, T, C, n, minmax);
   else
     CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, noise_stats_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, preds, out, T, C, n);
   return CLX_OK;
@@ -327,8 +358,9 @@ extern "C" int clx_noise_stats_minmax(const float* preds, float* out, int T, int
   CLX_REQUIRE(preds && out && std_minmax && T > 0 && C > 0 && n > 0, "clx_noise_stats_minmax: bad arguments");
   CLX_REQUIRE(T <= 64, "clx_noise_stats_minmax: at most 64 predictions per pixel (32 noise iterations)");
   hipStream_t st = (hipStream_t)stream;
-  if (init) CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, noise_minmax_init, dim3(1), dim3(1), 0, st, (unsigned int*)std_minmax);
-  noise_stats_launch(preds, out, T, C, n, (unsigned int*)std_minmax, st);
+  int g = 0;
+  noise_stats_launch(preds, out, T, C, n, (unsigned int*)std_minmax, st, &g);
+  CLX_LAUNCH_KIND(CLX_PROF_NOISE_STATS, noise_minmax_final, dim3(1), dim3(256), 0, st, (unsigned int*)std_minmax, g, init);
   CLX_CHECK_LAUNCH("clx_noise_stats_minmax");
   return CLX_OK;
 }

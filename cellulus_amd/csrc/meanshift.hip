@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256, MSP_WAVES) void ms_prepare_kernel(double* __re
   __shared__ int wcount[KP][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const unsigned long long lower = (1ull << lane) - 1ull;
+  // (taking several tiles per ticket — the word serves ~88 returning atomics per microsecond — delays the later tiles'
+  //  aggregates, and every look-back behind them waits: 13 ms instead of 0.17.  Fewer tickets need larger units whose
+  //  aggregate is published at once: ms_compact_kernel below.)
   if (tid == 0) s_tile[0] = (int)atomicAdd(ticket, 1u);
   __syncthreads();
   for (int round = 0;; ++round) {
@@ -190,156 +193,253 @@ __global__ __launch_bounds__(256, MSP_WAVES) void ms_prepare_kernel(double* __re
   }
 }
 
-// The same compaction fed with the network's float32 output (the fused predict -> detect path of infer(): the float64
-// values the staged path reads back from the `embeddings` dataset are these floats widened, cellulus/predict.py:104-112,
-// so widening in registers gives the same bits): per pixel (ND + 1) * 4 B read and nothing written — the embedding is
-// NOT modified (the reference's in-place coordinate add lands in a copy that detect.py:155-160 throws away) —, per
-// foreground pixel ND * 8 + 4 B written.  A lane owns FOUR consecutive pixels (one 16-byte load per channel).
-template <int ND, int KQ>
-__global__ __launch_bounds__(256, 4) void ms_prepare_f32_kernel(const float* __restrict__ emb,
-                                                                const float* __restrict__ sd, double thr,
-                                                                FastDiv dX, FastDiv dY, int Y, int X,
-                                                                long long npix, int vec, int ntiles,
-                                                                unsigned int* __restrict__ ticket,
-                                                                unsigned long long* __restrict__ desc,
-                                                                double* __restrict__ Xout,
-                                                                int* __restrict__ index, int* __restrict__ nfg_out) {
-  constexpr int PREP_TILE = 1024 * KQ;
-  __shared__ int s_tile[2], s_excl;
-  __shared__ int wcount[KQ][4];
+// ---------------------------------------------------------------------------------------------
+// Round 4: the same single-pass compaction in SUPER-TILES, for the float32 hand-over of infer()'s fused predict -> detect
+// path (clx_ms_prepare_f32): the float64 values the staged path reads back from the `embeddings` dataset are the network's
+// floats widened (cellulus/predict.py:104-112), so widening in registers gives the same bits; the embedding is NOT
+// modified (the reference's in-place coordinate add lands in a copy that detect.py:155-160 throws away) and is read
+// only where a 16-byte group holds a foreground pixel: per pixel 4 B read, per foreground pixel ND * 4 B read and
+// ND * 8 + 4 B written.  With so few bytes per pixel the per-TILE costs of the float64 kernel's structure dominated (a
+// first float32 version with 4096-pixel tiles: 119 us at 4096^2): one returning atomic per tile on ONE ticket word —
+// the word serves ~88 of them per microsecond, 46 us — and a prefix that travels 64 tiles per look-back hop.  Here a
+// block takes a super-tile of R sub-tiles (16 K pixels) per ticket: all of its std values first (flags in one 64-bit
+// register, counts scanned in LDS, ONE aggregate published), a look-back by all 256 threads (256 predecessors per hop),
+// then sub-tile by sub-tile the embedding values, whose loads run one sub-tile ahead of the point writes: 91 us.
+// (TIn = double, WB = true is the float64 form with the in-place add; measured slower than ms_prepare_kernel — 219
+// against 175 us at 4096^2: half the bytes in flight per block — and not dispatched.)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<double> { typedef f64x2 type; static constexpr int N = 2; };
+template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
+
+template <int ND, typename TIn, int G, int R, bool WB, int BLOCKS>
+__global__ __launch_bounds__(256, BLOCKS) void ms_compact_kernel(TIn* __restrict__ emb, const TIn* __restrict__ sd,
+                                                                     double thr, FastDiv dX, FastDiv dY, int Y, int X,
+                                                                     long long npix, int vec, int nsuper,
+                                                                     unsigned int* __restrict__ ticket,
+                                                                     unsigned long long* __restrict__ desc,
+                                                                     double* __restrict__ Xout, int* __restrict__ index,
+                                                                     int* __restrict__ nfg_out) {
+  using V = typename Vec16<TIn>::type;
+  constexpr int PXL = Vec16<TIn>::N;            // pixels per 16-byte group
+  constexpr int SUB = 256 * G * PXL;            // pixels per sub-tile
+  constexpr int SUPER = SUB * R;
+  constexpr int NK = R * G * 4;                 // (sub-tile, group, wave) counts, in raster order
+  constexpr unsigned int GMASK = (1u << PXL) - 1u;
+  constexpr unsigned int SMASK = (G * PXL == 32) ? 0xffffffffu : ((1u << (G * PXL)) - 1u);
+  static_assert(R * G * PXL <= 64 && NK <= 256 && R % 2 == 0, "flags of a super-tile fit one 64-bit register; one scan pass");
+  __shared__ int s_tile[2];
+  __shared__ int woff[NK + 1];
+  __shared__ int lb_sum[4], lb_stop[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const unsigned long long lower = (1ull << lane) - 1ull;
   if (tid == 0) s_tile[0] = (int)atomicAdd(ticket, 1u);
   __syncthreads();
   for (int round = 0;; ++round) {
     const int tile = s_tile[round & 1];
-    if (tile >= ntiles) break;
+    if (tile >= nsuper) break;
     if (tid == 0) s_tile[(round + 1) & 1] = (int)atomicAdd(ticket, 1u);
-    const long long base = (long long)tile * PREP_TILE;
+    const long long base = (long long)tile * SUPER;
 
-    // ---- (A) foreground flags (std < thr, compared in float64 as the reference does), counts, aggregate
-    unsigned int fgm[KQ];          // 4 flag bits per quad
-    int before[KQ];
+    // ---- (A) every std value of the super-tile: foreground flags (one bit per pixel of this thread, sub-tile r in
+    // bits r * G * PXL ..), counts per (sub-tile, group, wave); two sub-tiles' loads in flight at a time
+    unsigned long long allbits = 0ull;
+#pragma unroll 2
+    for (int r = 0; r < R; ++r) {
+      unsigned int b = 0u;
+      if (vec) {
+        V sv[G];
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-      const long long i = base + (long long)(k * 256 + tid) * 4;
-      fgm[k] = 0u;
-      if (i < npix) {
-        if (vec) {
-          const f32x4 s4 = *reinterpret_cast<const f32x4*>(sd + i);
+        for (int g = 0; g < G; ++g) {
+          const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
+          if (i < npix) sv[g] = *reinterpret_cast<const V*>(sd + i);
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) fgm[k] |= ((double)s4[e] < thr ? 1u : 0u) << e;
-        } else {
+        for (int g = 0; g < G; ++g) {
+          const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
+          if (i < npix) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (i + e < npix) fgm[k] |= ((double)sd[i + e] < thr ? 1u : 0u) << e;
+            for (int e = 0; e < PXL; ++e) b |= ((double)sv[g][e] < thr ? 1u : 0u) << (g * PXL + e);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
+#pragma unroll
+          for (int e = 0; e < PXL; ++e)
+            if (i + e < npix) b |= ((double)sd[i + e] < thr ? 1u : 0u) << (g * PXL + e);
         }
       }
+      allbits |= (unsigned long long)b << (r * G * PXL);
     }
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+      const unsigned int b = (unsigned int)(allbits >> (r * G * PXL)) & SMASK;
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-      int bef = 0, tot = 0;
+      for (int g = 0; g < G; ++g) {
+        int tot = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned long long b = __ballot((fgm[k] >> e) & 1u);
-        bef += __popcll(b & lower);
-        tot += __popcll(b);
+        for (int e = 0; e < PXL; ++e) tot += __popcll(__ballot((b >> (g * PXL + e)) & 1u));
+        if (lane == 0) woff[(r * G + g) * 4 + wid] = tot;
       }
-      before[k] = bef;            // raster order inside the wave: lane l owns pixels 4l .. 4l+3
-      if (lane == 0) wcount[k][wid] = tot;
     }
     __syncthreads();
-    int total = 0, mine[KQ];
+    // exclusive scan of the NK counts by the first wavefront; the super-tile's aggregate goes out at once
+    int total;
+    if (wid == 0) {
+      constexpr int PER = (NK + 63) / 64;
+      int c[PER], sum = 0;
 #pragma unroll
-    for (int k = 0; k < KQ; ++k)
+      for (int u = 0; u < PER; ++u) {
+        const int idx = lane * PER + u;
+        c[u] = idx < NK ? woff[idx] : 0;
+        sum += c[u];
+      }
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      int ex = incl - sum;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int idx = lane * PER + u;
+        if (idx < NK) woff[idx] = ex;
+        ex += c[u];
+      }
+      if (lane == 63) {
+        woff[NK] = incl;
+        __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)incl, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- the first sub-tile's embedding values, in flight during the look-back
+    V ev[2][G][ND];
+    auto load_emb = [&](int r, V (&dst)[G][ND]) {
+      const unsigned int sb = (unsigned int)(allbits >> (r * G * PXL)) & SMASK;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
+        const bool need = i < npix && (WB || ((sb >> (g * PXL)) & GMASK) != 0u);
+        if (need) {
+          if (vec) {
+#pragma unroll
+            for (int c = 0; c < ND; ++c) dst[g][c] = *reinterpret_cast<const V*>(emb + (long long)c * npix + i);
+          } else {
+#pragma unroll
+            for (int c = 0; c < ND; ++c)
+#pragma unroll
+              for (int e = 0; e < PXL; ++e) dst[g][c][e] = (i + e < npix) ? emb[(long long)c * npix + i + e] : (TIn)0;
+          }
+        }
+      }
+    };
+    load_emb(0, ev[0]);
+    __syncthreads();
+    total = woff[NK];
+
+    // ---- (C) look-back by the whole block: thread t inspects predecessor tile - 1 - t of the current window of 256
+    int excl = 0;
+    for (int hi = tile - 1; hi >= 0; hi -= 256) {
+      const int j = hi - tid;
+      unsigned long long d = 2ull << 32;              // tiles before the first: prefix 0
+      if (j >= 0) {
+        do {
+          d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned int)(d >> 32) == 0);       // predecessor has not published yet
+      }
+      const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
+      const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 64;      // nearest tile of this wave's 64 with a prefix
+      int a = (lane <= stop) ? (int)(unsigned int)d : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+      if (lane == 0) { lb_sum[wid] = a; lb_stop[wid] = has_prefix ? 1 : 0; }
+      __syncthreads();
+      bool found = false;
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        if (w == wid) mine[k] = total;
-        total += wcount[k][w];
+        if (!found) {
+          excl += lb_sum[w];
+          found = lb_stop[w] != 0;
+        }
       }
-    if (tid == 0)
-      __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)total, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (found) break;
+    }
+    if (tid == 0) {
+      if (tile > 0)
+        __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      if (tile == nsuper - 1) *nfg_out = excl + total;
+    }
 
-    // ---- (B) the embedding channels of the quads that hold a foreground pixel
-    float v[KQ][ND][4];
+    // ---- (D) sub-tile by sub-tile: coordinates added (in place for WB), points and raster indices written; the next
+    // sub-tile's loads are issued before the current one is written (two register sets, used alternately)
+    auto emit = [&](int r, V (&cur)[G][ND]) {
+      const unsigned int sb = (unsigned int)(allbits >> (r * G * PXL)) & SMASK;
 #pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-      const long long i = base + (long long)(k * 256 + tid) * 4;
-      if (fgm[k]) {
-        if (vec) {
+      for (int g = 0; g < G; ++g) {
+        const unsigned int gb = (sb >> (g * PXL)) & GMASK;
+        int bef = 0;
 #pragma unroll
-          for (int c = 0; c < ND; ++c) {
-            const f32x4 e4 = *reinterpret_cast<const f32x4*>(emb + (long long)c * npix + i);
+        for (int e = 0; e < PXL; ++e) bef += __popcll(__ballot((gb >> e) & 1u) & lower);
+        const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
+        if (i < npix && (WB || gb != 0u)) {
+          int pos = excl + woff[(r * G + g) * 4 + wid] + bef;
+          const unsigned int t = fdiv((unsigned int)i, dX);
+          int cx = (int)((unsigned int)i - t * (unsigned int)X);
+          const unsigned int z0u = fdiv(t, dY);
+          int cy = (int)(t - z0u * (unsigned int)Y), cz = (int)z0u;
+          V (&e4)[ND] = cur[g];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[k][c][e] = e4[e];
+          for (int e = 0; e < PXL; ++e) {
+            const int co[3] = {cx, cy, cz};
+            double val[ND];
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+              val[c] = (double)e4[c][e] + (double)co[c];
+              if (WB) e4[c][e] = (TIn)val[c];
+            }
+            if ((gb >> e) & 1u) {
+#pragma unroll
+              for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = val[c];
+              index[pos] = (int)(i + e);
+              ++pos;
+            }
+            if (++cx == X) { cx = 0; if (++cy == Y) { cy = 0; ++cz; } }
           }
-        } else {
+          if (WB) {
+            if (vec) {
 #pragma unroll
-          for (int c = 0; c < ND; ++c)
+              for (int c = 0; c < ND; ++c) *reinterpret_cast<V*>(emb + (long long)c * npix + i) = e4[c];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[k][c][e] = (i + e < npix) ? emb[(long long)c * npix + i + e] : 0.f;
+              for (int c = 0; c < ND; ++c)
+#pragma unroll
+                for (int e = 0; e < PXL; ++e)
+                  if (i + e < npix) emb[(long long)c * npix + i + e] = e4[c][e];
+            }
+          }
         }
       }
+    };
+#pragma unroll 1
+    for (int r = 0; r < R; r += 2) {
+      load_emb(r + 1, ev[1]);
+      emit(r, ev[0]);
+      if (r + 2 < R) load_emb(r + 2, ev[0]);
+      emit(r + 1, ev[1]);
     }
-
-    // ---- (C) decoupled look-back (as in ms_prepare_kernel)
-    if (wid == 0) {
-      int excl = 0;
-      for (int hi = tile - 1; hi >= 0; hi -= 64) {
-        const int j = hi - lane;
-        unsigned long long d = 2ull << 32;
-        if (j >= 0) {
-          do {
-            d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((unsigned int)(d >> 32) == 0);
-        }
-        const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
-        const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 64;
-        int a = (lane <= stop) ? (int)(unsigned int)d : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-        excl += a;
-        if (has_prefix) break;
-      }
-      if (lane == 0) {
-        if (tile > 0)
-          __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        s_excl = excl;
-        if (tile == ntiles - 1) *nfg_out = excl + total;
-      }
-    }
-    __syncthreads();
-    const int excl = s_excl;
-#pragma unroll
-    for (int k = 0; k < KQ; ++k) {
-      if (!fgm[k]) continue;
-      int pos = excl + mine[k] + before[k];
-      const long long i = base + (long long)(k * 256 + tid) * 4;
-      // coordinates of the quad's first pixel; the others follow in raster order
-      const unsigned int t = fdiv((unsigned int)i, dX);
-      int cx = (int)((unsigned int)i - t * (unsigned int)X);
-      const unsigned int z0u = fdiv(t, dY);
-      int cy = (int)(t - z0u * (unsigned int)Y), cz = (int)z0u;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if ((fgm[k] >> e) & 1u) {
-          const int co[3] = {cx, cy, cz};
-#pragma unroll
-          for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = (double)v[k][c][e] + (double)co[c];
-          index[pos] = (int)(i + e);
-          ++pos;
-        }
-        if (++cx == X) { cx = 0; if (++cy == Y) { cy = 0; ++cz; } }
-      }
-    }
-    __syncthreads();
+    __syncthreads();      // woff, lb_* and the ticket slots are reused by the next round
   }
-  if (tid == 0) s_excl = (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) ? 1 : 0;
+  // the workspace is handed back ZEROED by the block that finishes last (every other block has left its last look-back)
+  __shared__ int s_last;
+  if (tid == 0) s_last = (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) ? 1 : 0;
   __syncthreads();
-  if (s_excl) {
-    for (int j = tid; j < ntiles; j += 256)
+  if (s_last) {
+    for (int j = tid; j < nsuper; j += 256)
       __hip_atomic_store(&desc[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 2) __hip_atomic_store(ticket + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -772,6 +872,39 @@ static int prep_pairs() {      // pairs of pixels per thread: 8 (4096-pixel tile
   return env == 4 ? 4 : env == 16 ? 16 : 8;
 }
 
+
+template <int ND, typename TIn, int G, int R, bool WB, int BLOCKS>
+static int launch_compact(TIn* emb, const TIn* std, double threshold, int Z, int Y, int X, double* Xout, int* index,
+                          int* nfg_out, void* workspace, hipStream_t st) {
+  constexpr int PXL = 16 / (int)sizeof(TIn);
+  constexpr long long SUPER = 256ll * G * PXL * R;
+  const long long npix = (long long)Z * Y * X;
+  const int nsuper = (int)((npix + SUPER - 1) / SUPER);
+  unsigned int* ticket = (unsigned int*)workspace;
+  unsigned long long* desc = (unsigned long long*)workspace + 1;
+  // every channel plane starts at a multiple of npix elements: 16-byte accesses need npix % PXL == 0 and aligned bases
+  const int vec = (npix % PXL == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
+  const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
+  static const int cus = [] {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+  }();
+  static const int per_cu = [] {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ms_compact_kernel<ND, TIn, G, R, WB, BLOCKS>, 256, 0) != hipSuccess || nb < 1)
+      nb = 2;
+    return nb;
+  }();
+  // persistent blocks: as many as are resident at once, not more than there are super-tiles
+  const int nblocks = nsuper < cus * per_cu ? nsuper : cus * per_cu;
+  CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_compact_kernel<ND, TIn, G, R, WB, BLOCKS>), dim3(nblocks), dim3(256), 0, st, emb, std,
+                  threshold, dX, dY, Y, X, npix, vec, nsuper, ticket, desc, Xout, index, nfg_out);
+  return CLX_OK;
+}
+
+
 extern "C" size_t clx_ms_prepare_workspace(long long npix) {
   const long long ntiles = (npix + 2048 - 1) / 2048;          // the smaller tile: enough for either
   return (size_t)(ntiles + 2) * sizeof(unsigned long long);
@@ -786,9 +919,9 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare: workspace must be 8-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare: too many pixels");
+  hipStream_t st = (hipStream_t)stream;
   const int kp = (ND == 3 && prep_pairs() == 16) ? 8 : prep_pairs();
   const int ntiles = (int)((npix + 512 * kp - 1) / (512 * kp));
-  hipStream_t st = (hipStream_t)stream;
   unsigned int* ticket = (unsigned int*)workspace;
   unsigned long long* desc = (unsigned long long*)workspace + 1;
   const int vec = (npix % 2 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
@@ -828,34 +961,11 @@ extern "C" int clx_ms_prepare_f32(const float* emb, const float* std, double thr
   CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare_f32: workspace must be 8-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare_f32: too many pixels");
-  constexpr int KQ = 4;                     // 4096-pixel tiles: clx_ms_prepare_workspace(npix) covers them
-  const int ntiles = (int)((npix + 1024 * KQ - 1) / (1024 * KQ));
-  hipStream_t st = (hipStream_t)stream;
-  unsigned int* ticket = (unsigned int*)workspace;
-  unsigned long long* desc = (unsigned long long*)workspace + 1;
-  // every channel plane starts at a multiple of npix floats: 16-byte loads need npix % 4 == 0 and aligned bases
-  const int vec = (npix % 4 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
-  const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
-  static const int cus = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount;
-  }();
-#define CLX_PREP32(ND_)                                                                                      \
-  do {                                                                                                       \
-    static const int per_cu = [] {                                                                           \
-      int nb = 0;                                                                                            \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ms_prepare_f32_kernel<ND_, KQ>, 256, 0) != hipSuccess || nb < 1) \
-        nb = 2;                                                                                              \
-      return nb;                                                                                             \
-    }();                                                                                                     \
-    const int nblocks = ntiles < cus * per_cu ? ntiles : cus * per_cu;                                       \
-    CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_prepare_f32_kernel<ND_, KQ>), dim3(nblocks), dim3(256), 0, st, emb, std, \
-                    threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, desc, Xout, index, nfg_out);         \
-  } while (0)
-  if (ND == 2) CLX_PREP32(2); else CLX_PREP32(3);
-#undef CLX_PREP32
+  // super-tiles of 4 sub-tiles x 4096 pixels (4 groups of four float32 pixels per thread); clx_ms_prepare_workspace(npix)
+  // (one descriptor per 2048 pixels) covers them
+  float* e = const_cast<float*>(emb);
+  if (ND == 2) launch_compact<2, float, 4, 4, false, 3>(e, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, (hipStream_t)stream);
+  else launch_compact<3, float, 4, 4, false, 2>(e, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, (hipStream_t)stream);
   CLX_CHECK_LAUNCH("clx_ms_prepare_f32");
   return CLX_OK;
 }

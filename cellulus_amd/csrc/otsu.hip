@@ -5,50 +5,79 @@
 // counts are bit-exact.  Compiled with the default contraction but the index
 // expression has no multiply-add pair to fuse.
 #include "clx_common.h"
+#include <stdlib.h>
 
 namespace {
 
 inline int grid_for(long long total, int block) {
   long long g = (total + block - 1) / block;
-  if (g > 2048) g = 2048;
+  static const int cap = getenv("CLX_OTSU_GRID") ? atoi(getenv("CLX_OTSU_GRID")) : 1024;     // (sweeps)
+  if (g > cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
 }
 
-// gfx950 has float64 min / max atomics in hardware (global_atomic_min_f64 / max_f64): fire-and-forget, where a
-// compare-and-swap loop made the 2048 blocks of a launch queue up on two addresses (15 of 57 us at 4096^2)
-__device__ __forceinline__ void atomic_min_f64(double* addr, double v) {
-  __builtin_amdgcn_global_atomic_fmin_f64(addr, v);
-}
-__device__ __forceinline__ void atomic_max_f64(double* addr, double v) {
-  __builtin_amdgcn_global_atomic_fmax_f64(addr, v);
-}
-
-__global__ void minmax_init(double* mm) {
-  mm[0] = __longlong_as_double(0x7ff0000000000000ll);   // +inf
-  mm[1] = __longlong_as_double(0xfff0000000000000ll);   // -inf
-}
-
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int MM_BLOCKS = 512;      // == (CLX_MINMAX_DOUBLES - 2) / 2
+
+// Block partials, then one small block over them: no two blocks meet on an address.  (Until round 4 every block ended
+// with two float64 atomics on the SAME two words: they are served one after the other at the memory side, ~12 ns each —
+// the kernel's time was proportional to its grid, 32 / 61 / 104 / 196 us for 512 / 2048 / 4096 / 8192 blocks over a
+// 134-MB image that streams in 25 us.)  mm: [0] min, [1] max, [2 + 2 b], [3 + 2 b] the partials of block b.
+template <typename T>
+__device__ __forceinline__ void minmax_block_out(T lo, T hi, double* mm) {
+  __shared__ double smin[4], smax[4];
+  for (int o = 32; o > 0; o >>= 1) {
+    // (the shuffles are issued with all lanes active, BEFORE the comparison: inside a conditional expression they would run
+    //  under a partial EXEC mask and read zeros from the inactive lanes)
+    const T l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = (double)lo; smax[threadIdx.x >> 6] = (double)hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[2 + 2 * blockIdx.x] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    mm[3 + 2 * blockIdx.x] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void minmax_final(double* mm, int nblocks) {
+  __shared__ double smin[4], smax[4];
+  double lo = __longlong_as_double(0x7ff0000000000000ll), hi = -lo;
+  for (int b = threadIdx.x; b < nblocks; b += 256) { lo = fmin(lo, mm[2 + 2 * b]); hi = fmax(hi, mm[3 + 2 * b]); }
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fmin(lo, __shfl_down(lo, o, 64));
+    hi = fmax(hi, __shfl_down(hi, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[0] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+    mm[1] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+  }
+}
 
 // float32 input (the network's std channel handed over in device memory, cellulus_amd/infer.py::fused_stages): the
 // float64 values the staged path reads back from zarr are these floats widened, so min / max / bin of the widened
 // value are the staged path's bits.  16 bytes = four floats per lane.
+// A block reads ONE contiguous range, eight 4-KB pieces of it in flight per round.
 __global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict__ x, long long n, double* mm) {
-  __shared__ double smin[4], smax[4];
   float lo = __int_as_float(0x7f800000), hi = -lo;
   const long long n4 = n >> 2;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   const long long per_block = (n4 + gridDim.x - 1) / gridDim.x;
   const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < n4 ? b0 + per_block : n4;
   long long i = b0 + threadIdx.x;
-  for (; i + 3 * 256 < b1; i += 4 * 256) {
-    const f32x4 a = x4[i], b = x4[i + 256], c = x4[i + 512], d = x4[i + 768];
+  for (; i + 7 * 256 < b1; i += 8 * 256) {
+    f32x4 v[8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      lo = fminf(fminf(lo, a[e]), fminf(b[e], fminf(c[e], d[e])));
-      hi = fmaxf(fmaxf(hi, a[e]), fmaxf(b[e], fmaxf(c[e], d[e])));
-    }
+    for (int u = 0; u < 8; ++u) v[u] = x4[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo = fminf(lo, v[u][e]); hi = fmaxf(hi, v[u][e]); }
   }
   for (; i < b1; i += 256) {
     const f32x4 a = x4[i];
@@ -59,33 +88,28 @@ __global__ __launch_bounds__(256) void minmax_f32_kernel(const float* __restrict
     lo = fminf(lo, x[(n4 << 2) + threadIdx.x]);
     hi = fmaxf(hi, x[(n4 << 2) + threadIdx.x]);
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    lo = fminf(lo, __shfl_down(lo, o, 64));
-    hi = fmaxf(hi, __shfl_down(hi, o, 64));
-  }
-  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = (double)lo; smax[threadIdx.x >> 6] = (double)hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    atomic_min_f64(mm, fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3])));
-    atomic_max_f64(mm + 1, fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3])));
-  }
+  minmax_block_out(lo, hi, mm);
 }
 
 // 16-byte loads (two doubles per lane): 8-byte accesses run at 0.54-0.70x the 16-byte rate
 __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ x, long long n, double* mm) {
-  __shared__ double smin[4], smax[4];
   double lo = __longlong_as_double(0x7ff0000000000000ll), hi = -lo;
   const long long n2 = n >> 1;
   const f64x2* x2 = reinterpret_cast<const f64x2*>(x);
-  // a block reads ONE contiguous range (four 4-KB pieces of it in flight per round): with the grid-strided walk the four
+  // a block reads ONE contiguous range (eight 4-KB pieces of it in flight per round): with the grid-strided walk the
   // loads of a thread were 8 MB apart and a 4096^2 image ran at 2.3 TB/s
   const long long per_block = (n2 + gridDim.x - 1) / gridDim.x;
   const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < n2 ? b0 + per_block : n2;
   long long i = b0 + threadIdx.x;
-  for (; i + 3 * 256 < b1; i += 4 * 256) {             // 4 independent 16-byte loads in flight
-    const f64x2 a = x2[i], b = x2[i + 256], c = x2[i + 512], d = x2[i + 768];
-    lo = fmin(fmin(fmin(lo, a[0]), fmin(a[1], b[0])), fmin(fmin(b[1], c[0]), fmin(fmin(c[1], d[0]), d[1])));
-    hi = fmax(fmax(fmax(hi, a[0]), fmax(a[1], b[0])), fmax(fmax(b[1], c[0]), fmax(fmax(c[1], d[0]), d[1])));
+  for (; i + 7 * 256 < b1; i += 8 * 256) {
+    f64x2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x2[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      lo = fmin(lo, fmin(v[u][0], v[u][1]));
+      hi = fmax(hi, fmax(v[u][0], v[u][1]));
+    }
   }
   for (; i < b1; i += 256) {
     const f64x2 a = x2[i];
@@ -96,18 +120,7 @@ __global__ __launch_bounds__(256) void minmax_kernel(const double* __restrict__ 
     lo = fmin(lo, x[n - 1]);
     hi = fmax(hi, x[n - 1]);
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    lo = fmin(lo, __shfl_down(lo, o, 64));
-    hi = fmax(hi, __shfl_down(hi, o, 64));
-  }
-  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    lo = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
-    hi = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
-    atomic_min_f64(mm, lo);
-    atomic_max_f64(mm + 1, hi);
-  }
+  minmax_block_out(lo, hi, mm);
 }
 
 // A thread keeps the bin of its previous value and a count: images are smooth (the std channel of a
@@ -150,8 +163,22 @@ __global__ __launch_bounds__(256) void histogram_kernel(const double* __restrict
   const f64x2* x2 = reinterpret_cast<const f64x2*>(x);
   int cur = 0;
   unsigned int run = 0u;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-       i += (long long)gridDim.x * blockDim.x) {
+  // a block takes ONE contiguous range, four 4-KB pieces of it in flight per round (consecutive values of a thread are
+  // then 4 KB apart instead of the whole grid's stride: same plateau, same bin, one LDS atomic per run)
+  const long long per_block = (n2 + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < n2 ? b0 + per_block : n2;
+  long long i = b0 + threadIdx.x;
+  for (; i + 3 * 256 < b1; i += 4 * 256) {
+    f64x2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x2[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      hist_one(v[u][0], first, last, denom, nbins, eds, mine, cur, run);
+      hist_one(v[u][1], first, last, denom, nbins, eds, mine, cur, run);
+    }
+  }
+  for (; i < b1; i += 256) {
     const f64x2 v = x2[i];
     hist_one(v[0], first, last, denom, nbins, eds, mine, cur, run);
     hist_one(v[1], first, last, denom, nbins, eds, mine, cur, run);
@@ -182,8 +209,19 @@ __global__ __launch_bounds__(256) void histogram_f32_kernel(const float* __restr
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   int cur = 0;
   unsigned int run = 0u;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (long long)gridDim.x * blockDim.x) {
+  const long long per_block = (n4 + gridDim.x - 1) / gridDim.x;
+  const long long b0 = (long long)blockIdx.x * per_block, b1 = b0 + per_block < n4 ? b0 + per_block : n4;
+  long long i = b0 + threadIdx.x;
+  for (; i + 3 * 256 < b1; i += 4 * 256) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = x4[i + 256 * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hist_one((double)v[u][e], first, last, denom, nbins, eds, mine, cur, run);
+  }
+  for (; i < b1; i += 256) {
     const f32x4 v = x4[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) hist_one((double)v[e], first, last, denom, nbins, eds, mine, cur, run);
@@ -198,14 +236,22 @@ __global__ __launch_bounds__(256) void histogram_f32_kernel(const float* __restr
   }
 }
 
+inline int mm_grid(long long work) {
+  static const int cap = getenv("CLX_MINMAX_GRID") ? atoi(getenv("CLX_MINMAX_GRID")) : MM_BLOCKS;
+  long long g = (work + 255) / 256;
+  const int c = cap < MM_BLOCKS ? (cap < 1 ? 1 : cap) : MM_BLOCKS;
+  return (int)(g > c ? c : (g < 1 ? 1 : g));
+}
+
 }  // namespace
 
 extern "C" int clx_minmax_f32(const float* x, long long n, double* minmax, clx_stream stream) {
   CLX_REQUIRE(x && minmax && n > 0, "clx_minmax_f32: bad arguments");
   CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_minmax_f32: x must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_init, dim3(1), dim3(1), 0, st, minmax);
-  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_f32_kernel, dim3(grid_for(n / 16 + 1, 256)), dim3(256), 0, st, x, n, minmax);
+  const int g = mm_grid(n / 32 + 1);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_f32_kernel, dim3(g), dim3(256), 0, st, x, n, minmax);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_final, dim3(1), dim3(256), 0, st, minmax, g);
   CLX_CHECK_LAUNCH("clx_minmax_f32");
   return CLX_OK;
 }
@@ -226,8 +272,9 @@ extern "C" int clx_minmax_f64(const double* x, long long n, double* minmax, clx_
   CLX_REQUIRE(x && minmax && n > 0, "clx_minmax_f64: bad arguments");
   CLX_REQUIRE(((uintptr_t)x & 15) == 0, "clx_minmax_f64: x must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_init, dim3(1), dim3(1), 0, st, minmax);
-  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, st, x, n, minmax);
+  const int g = mm_grid(n / 16 + 1);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_kernel, dim3(g), dim3(256), 0, st, x, n, minmax);
+  CLX_LAUNCH_KIND(CLX_PROF_MINMAX, minmax_final, dim3(1), dim3(256), 0, st, minmax, g);
   CLX_CHECK_LAUNCH("clx_minmax_f64");
   return CLX_OK;
 }

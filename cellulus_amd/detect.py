@@ -82,7 +82,7 @@ def seeds_on_device(emb_d, nd):
     _clx.call("clx_negate_f64", _clx.ptr(smooth), _clx.ptr(mag), npix, st)        # mag := -smooth
     if min(spatial) < 3:
         return np.zeros((0, nd), dtype=np.int64)             # every pixel is on the excluded border
-    mm = torch.empty(2, dtype=torch.float64, device=dev)
+    mm = torch.empty(_clx.MINMAX_DOUBLES, dtype=torch.float64, device=dev)       # [0..1] min, max (+ block partials)
     _clx.call("clx_minmax_f64", _clx.ptr(mag), npix, _clx.ptr(mm), st)
     capacity = max(1024, npix // 9 + 16)                     # a 3^ND maximum per 3^ND block at most ...
     peaks = torch.empty(capacity, dtype=torch.int32, device=dev)

@@ -22,7 +22,7 @@ import itertools
 import numpy as np
 import torch
 
-from . import parallel
+from . import _clx, parallel
 from .configs.inference_config import InferenceConfig
 from .datasets.meta_data import DatasetMetaData
 from .datasets.zarr_dataset import default_normalization_factor
@@ -144,7 +144,7 @@ class PredictScan:
         earlier one, whose values must not count)."""
         mm = None
         if want_std_minmax and self.tiles_partition:
-            mm = torch.empty(2, dtype=torch.float32, device=self.device)
+            mm = torch.empty(_clx.NOISE_MINMAX_FLOATS, dtype=torch.float32, device=self.device)     # [0..1] + partials
         first = True
         raw = raw.astype(np.float32) * np.float32(self.factor)             # gp.Normalize
         raw = np.pad(raw, self.pad, mode="reflect")                        # gp.Pad(mode="reflect")

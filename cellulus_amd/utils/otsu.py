@@ -23,10 +23,10 @@ def minmax_on_device(x):
     _clx.require_device(x, "image")
     assert x.dtype in (torch.float64, torch.float32)
     x = _aligned(x)
-    mm = torch.empty(2, dtype=torch.float64, device=x.device)
+    mm = torch.empty(_clx.MINMAX_DOUBLES, dtype=torch.float64, device=x.device)      # results + block partials
     _clx.call("clx_minmax_f64" if x.dtype == torch.float64 else "clx_minmax_f32", _clx.ptr(x), x.numel(), _clx.ptr(mm),
               _clx.stream_ptr(x.device))
-    lo, hi = mm.cpu().tolist()
+    lo, hi = mm[:2].cpu().tolist()
     return lo, hi
 
 
@@ -80,7 +80,7 @@ def threshold_otsu(image, nbins=256, minmax=None):
     if minmax is None:
         lo, hi = minmax_on_device(image)
     elif torch.is_tensor(minmax):
-        lo, hi = (float(v) for v in minmax.cpu().tolist())       # float32 -> Python float: exact
+        lo, hi = (float(v) for v in minmax[:2].cpu().tolist())   # float32 -> Python float: exact
     else:
         lo, hi = float(minmax[0]), float(minmax[1])
     if lo == hi:                 # min == max: every pixel equals the first one

@@ -410,8 +410,10 @@ int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
 /* The same, ALSO keeping the running minimum and maximum of the std plane out[C] in std_minmax[0..1] (float32):
  * the range numpy.histogram needs for the Otsu threshold of that plane (cellulus/detect.py:88-91 ->
  * skimage.filters.threshold_otsu), so the fused predict -> detect path reads the plane once (histogram) instead
- * of twice.  init != 0 resets the pair first; with init == 0 the call folds into what earlier calls (the other tiles
- * of the sample) left.  T <= 64. */
+ * of twice.  init != 0 starts a new image; with init == 0 the call folds into what earlier calls (the other tiles
+ * of the sample) left.  std_minmax: CLX_NOISE_MINMAX_FLOATS floats — the two results followed by scratch for the
+ * per-block partials.  T <= 64. */
+#define CLX_NOISE_MINMAX_FLOATS (2 + 2 * 1024)
 int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long long n, float* std_minmax,
                            int init, clx_stream stream);
 
@@ -559,7 +561,10 @@ int clx_grow_shrink(int* seg, int Z, int Y, int X, int grow, int shrink,
 /* ------------------------------------------------------------------------ */
 /* Otsu histogram (skimage.filters.threshold_otsu, cellulus/detect.py:88-91) */
 /* ------------------------------------------------------------------------ */
-/* minmax[0..1] = min, max of x (f64, n elements). */
+/* minmax[0..1] = min, max of x (f64, n elements).  minmax: CLX_MINMAX_DOUBLES doubles — the two results followed by
+ * scratch for the per-block partials (no two blocks meet on an address: same-address float64 atomics are served one after
+ * the other at the memory side, which made the kernel's time proportional to its grid). */
+#define CLX_MINMAX_DOUBLES (2 + 2 * 512)
 int clx_minmax_f64(const double* x, long long n, double* minmax, clx_stream stream);
 /* numpy.histogram(x, bins=nbins, range=(edges[0], edges[nbins])) with the
  * caller-supplied edges (np.linspace) — counts (nbins) int64, zeroed by caller. */

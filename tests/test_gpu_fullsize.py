@@ -47,6 +47,21 @@ def test_forward_is_deterministic_and_samples_are_independent(model, device):
     assert torch.isfinite(full).all()
 
 
+def test_inference_chunk_of_eight_528_tiles_equals_its_halves_bit_for_bit(model, device):
+    """The benchmark's inference chunk: eight 528^2 copies per forward.  The Winograd operand of its first wide layer
+    (36 x tiles x 256 channels) is 1.3 G floats, above what a 32-bit byte offset reaches — the batched GEMM launches
+    address it as a 64-bit per-product base + 32-bit offsets INSIDE one product (csrc/conv_igemm.hip::clx_igemm_launch),
+    on the same staging path as the four-copy forward, whose operands are small: the same bits, sample by sample."""
+    torch.manual_seed(4)
+    raw = torch.rand(8, 1, 528, 528, device=device)
+    with torch.no_grad():
+        full = model(raw).clone()
+        assert full.shape == (8, 2, 512, 512) and torch.isfinite(full).all()
+        for lo in (0, 4):
+            half = model(raw[lo:lo + 4].contiguous())
+            assert torch.equal(half, full[lo:lo + 4]), f"copies {lo}..{lo + 3}"
+
+
 def test_translation_equivariance_at_multiples_of_the_downsampling(model, device):
     """crop_to_factor makes the valid U-Net equivariant to shifts that are multiples of the
     cumulative downsampling factor: shifting the input window by 4 px shifts the output by 4 px."""

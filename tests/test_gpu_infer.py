@@ -833,11 +833,11 @@ def test_float32_handover_kernels_equal_the_float64_ones_on_the_widened_values(s
     # Otsu primitives
     for x in (std32.reshape(-1), std32.reshape(-1)[: npix - 3]):
         x = x.clone()
-        mm32 = torch.empty(2, dtype=torch.float64, device=device)
-        mm64 = torch.empty(2, dtype=torch.float64, device=device)
+        mm32 = torch.empty(_clx.MINMAX_DOUBLES, dtype=torch.float64, device=device)
+        mm64 = torch.empty(_clx.MINMAX_DOUBLES, dtype=torch.float64, device=device)
         _clx.call("clx_minmax_f32", _clx.ptr(x), x.numel(), _clx.ptr(mm32), st)
         _clx.call("clx_minmax_f64", _clx.ptr(x.double()), x.numel(), _clx.ptr(mm64), st)
-        assert torch.equal(mm32, mm64) and mm32[0].item() == float(x.min().item())
+        assert torch.equal(mm32[:2], mm64[:2]) and mm32[0].item() == float(x.min().item()) and mm32[1].item() == float(x.max().item())
         c32, e32_ = histogram_on_device(x)
         c64, e64_ = histogram_on_device(x.double())
         np.testing.assert_array_equal(c32, c64)
@@ -858,7 +858,7 @@ def test_noise_stats_emits_the_std_range(device):
     st = _clx.stream_ptr(device)
     torch.manual_seed(3)
     T, C = 32, 2
-    mm = torch.empty(2, dtype=torch.float32, device=device)
+    mm = torch.full((_clx.NOISE_MINMAX_FLOATS,), float("nan"), dtype=torch.float32, device=device)
     lo, hi = float("inf"), 0.0
     for k, n in enumerate((4096, 1000, 333 * 7)):
         preds = torch.randn(T, C, n, device=device) * (k + 1)
@@ -870,8 +870,8 @@ def test_noise_stats_emits_the_std_range(device):
         _clx.call("clx_noise_stats_minmax", _clx.ptr(preds), _clx.ptr(out), T, C, n, _clx.ptr(mm), 1 if k == 0 else 0, st)
         assert torch.equal(out, ref)
         lo, hi = min(lo, float(ref[C].min().item())), max(hi, float(ref[C].max().item()))
-        assert mm.cpu().tolist() == [lo, hi]
+        assert mm[:2].cpu().tolist() == [lo, hi]
     assert lo == 0.0
     # reset
     _clx.call("clx_noise_stats_minmax", _clx.ptr(preds), _clx.ptr(out), T, C, n, _clx.ptr(mm), 1, st)
-    assert mm.cpu().tolist() == [float(ref[C].min().item()), float(ref[C].max().item())]
+    assert mm[:2].cpu().tolist() == [float(ref[C].min().item()), float(ref[C].max().item())]
