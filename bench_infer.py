@@ -399,9 +399,26 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     model.max_infer_batch = 8
     # the metric string names 2-D 256^2 for inference too: the same pipeline on one 272^2 tile, first (its plan is
     # dropped when the 528^2 one is built)
-    t_embed_s, _emb_s, prof_s = embed_stage(model, device, 256, n_it, reps)
+    # `value` is timed with the product's default (the chunks of noisy copies alternate between two plans on two streams
+    # where a chunk fills the device); the kernels' own durations — the rooflines — come from a second pass with
+    # CLX_INFER_STREAMS=1, every kernel alone on the device (as bench.py does for the training step)
+    def both_passes(sz):
+        keep = os.environ.get("CLX_INFER_STREAMS")
+        t_default, emb_, _prof = embed_stage(model, device, sz, n_it, reps)
+        two = getattr(model, "_infer_pair", None) is not None and model._infer_pair[0] is next(iter(model._plans.values()))
+        os.environ["CLX_INFER_STREAMS"] = "1"
+        try:
+            t_one, _e, prof_one = embed_stage(model, device, sz, n_it, reps)
+        finally:
+            if keep is None:
+                del os.environ["CLX_INFER_STREAMS"]
+            else:
+                os.environ["CLX_INFER_STREAMS"] = keep
+        return t_default, emb_, prof_one, t_one, (2 if two else 1)
+
+    t_embed_s, _emb_s, prof_s, t_one_s, streams_s = both_passes(256)
     t_detect_s, t_segment_s, (_l, centers_s, _s, ncomp_s), _inputs = post_stages(device, 256, reps)
-    t_embed, emb, prof = embed_stage(model, device, size, n_it, reps)
+    t_embed, emb, prof, t_one, streams = both_passes(size)
     t_detect, t_segment, (labels, centers, seg, ncomp), (mean, std, mean_d, std_d) = post_stages(device, size, reps)
 
     # mean-shift at full density (reduction_probability 1.0: every foreground pixel is a seed —
@@ -420,7 +437,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     plan = next(iter(model._plans.values()))
     fwd_flops, _, _ = conv_flops(plan.topo, 1)
 
-    def roofline_of(prof, t_embed_tile):
+    def roofline_of(prof, t_embed_tile, t_value_pass, nstreams):
         dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # (the opt-in precision prices its kernel against bf16 MFMA / 6)
@@ -440,12 +457,17 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
                     per_kernel={k: dict(launches_per_tile=int(round(v[0])), ms_per_tile=round(v[1], 3),
                                         tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0)
                                 for k, v in prof.items() if v[0]},
+                    timed_in=f"a second pass on ONE stream (every kernel alone on the device: {t_embed_tile * 1e3:.2f} ms per tile); "
+                             f"the `value` pass runs the chunks on {nstreams} stream(s): {t_value_pass * 1e3:.2f} ms per tile",
+                    one_stream_embed_ms=round(t_embed_tile * 1e3, 2), streams_value_pass=nstreams,
+                    step_mfma_frac_value_pass=round(mfma_fl / t_value_pass / 1e12 / peak, 4),
                     note="achieved = FLOPs the dominant kernel executes / HIP-event time of its launches; "
                          "share_of_embed_stage = its launches' time / the embedding stage's wall time per tile (the "
                          "rest: the other MFMA kernels under all_mfma_kernels, Winograd transforms, first-layer and "
                          "pooling / upsampling kernels, noise injection, mean/std: profiles/*_infer_tile_kernels.txt); "
                          "step_mfma_frac = executed FLOPs of ALL MFMA kernels of a tile / the embedding stage's wall "
-                         "time / peak; the HBM-bound kernels of detect / segment are under `streaming`")
+                         "time (one-stream pass; step_mfma_frac_value_pass: the `value` pass) / peak; the HBM-bound "
+                         "kernels of detect / segment are under `streaming`")
 
     out = {
         "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 512x512, 1 GPU",
@@ -454,13 +476,13 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
-        "roofline": roofline_of(prof, t_embed),
+        "roofline": roofline_of(prof, t_one, t_embed, streams),
         "at_256": {
             "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 256x256 (one 272^2 tile), 1 GPU",
             "value": round(256 * 256 / total_s / 1e6, 4), "unit": "Mpixels/s",
             "stage_ms": {"embed": round(t_embed_s * 1e3, 2), "detect": round(t_detect_s * 1e3, 3),
                          "segment": round(t_segment_s * 1e3, 3)},
-            "roofline": roofline_of(prof_s, t_embed_s),
+            "roofline": roofline_of(prof_s, t_one_s, t_embed_s, streams_s),
             "objects": int(ncomp_s.item()), "clusters": int(len(centers_s))},
         "meanshift_rp1": {"ms": round(t_full * 1e3, 2), "seeds": nfg, "clusters": int(len(centers_full))},
         "objects": int(ncomp.item()),

@@ -344,13 +344,16 @@ class UNetModel(nn.Module):  # type: ignore
 
     def _forward_chunks(self, noisy, step):
         """The network on `noisy` (T, C, *spatial) in chunks of `step` copies -> (T, out_channels, *out_spatial).
-        OPT-IN (CLX_INFER_STREAMS=2): with two or more whole chunks of a size that fills the device, the chunks
-        alternate between two plans on two streams that share one set of packed weights (the HBM-bound Winograd
-        transforms of one chunk run under the GEMMs of the other, as in plan.DualPlan).  Measured at the benchmark
-        tile (8 copies of 512 x 512 per chunk): embedding stage 204 -> 198 ms, infer() end to end unchanged —
-        a chunk this large already fills the device in every phase, so the default stays one stream."""
+        With two or more whole chunks of a size that fills the device (>= CLX_STREAMS_MIN_GFLOP of forward pass each, default
+        100) and room for a second set of activations, the chunks alternate between two plans on two streams that share one
+        set of packed weights: the HBM-bound Winograd transforms of one chunk run under the GEMMs of the other, as in
+        plan.DualPlan.  Same kernels on the same rows: bit-identical to the plain loop (tests/test_gpu_unet.py).  Measured at
+        the benchmark tile (8 copies of 528 x 528 per chunk): embedding stage 201.4 -> 193.8 ms (round 4, after the batched
+        Winograd products of such a chunk got the clamped-row staging path; 204 -> 198 before).  CLX_INFER_STREAMS=1: the
+        plain loop."""
         T = noisy.shape[0]
-        if T % step or T // step < 2 or os.environ.get("CLX_INFER_STREAMS", "1") != "2":
+        nstreams = min(int(os.environ.get("CLX_INFER_STREAMS", "2") or 2), 4, T // max(step, 1))
+        if T % step or nstreams < 2:
             preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
             return torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
         first = noisy[:step].contiguous()
@@ -361,11 +364,24 @@ class UNetModel(nn.Module):  # type: ignore
         params = self._ordered_params()
         plan.pack_weights(params, self._param_version(), need_dgrad=False)
         pair = getattr(self, "_infer_pair", None)
-        if pair is None or pair[0] is not plan:
-            other = UNetPlan(plan.topo, step, noisy.device, False)
-            pair = self._infer_pair = (plan, other, [torch.cuda.Stream(device=noisy.device) for _ in range(2)])
-        _plan, other, streams = pair
-        other.share_forward_from(plan)
+        if pair is None or pair[0] is not plan or len(pair[2]) != nstreams:
+            # a second set of activations must fit beside the first (several ranks may share a device in a rehearsal)
+            need = sum(t.numel() * t.element_size() for t in plan.buf.values())
+            if plan.workspace is not None:
+                need += plan.workspace.numel() * plan.workspace.element_size()
+            free = torch.cuda.mem_get_info(noisy.device)[0] + torch.cuda.memory_reserved(noisy.device) \
+                - torch.cuda.memory_allocated(noisy.device)
+            if free < 1.25 * need * (nstreams - 1):
+                preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
+                return torch.cat(preds, dim=0)
+            self._infer_pair = None
+            others = [UNetPlan(plan.topo, step, noisy.device, False) for _ in range(nstreams - 1)]
+            pair = self._infer_pair = (plan, others[0], [torch.cuda.Stream(device=noisy.device) for _ in range(nstreams)],
+                                       others)
+        _plan, _other, streams, others = pair
+        plans = [plan] + list(others)
+        for o in others:
+            o.share_forward_from(plan)
         t = plan.topo
         preds = torch.empty((T, t.out_channels) + tuple(t.out_shape[3 - t.nd:]), dtype=torch.float32,
                             device=noisy.device)
@@ -373,8 +389,8 @@ class UNetModel(nn.Module):  # type: ignore
         for s in streams:
             s.wait_stream(main)
         for j, i in enumerate(range(0, T, step)):
-            with torch.cuda.stream(streams[j % 2]):
-                (plan, other)[j % 2].forward(noisy[i:i + step], params, out=preds[i:i + step])
+            with torch.cuda.stream(streams[j % nstreams]):
+                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step])
         for s in streams:
             main.wait_stream(s)
         return preds

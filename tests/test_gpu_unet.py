@@ -228,7 +228,7 @@ def test_infer_mode_matches_oracle(device):
 @pytest.mark.parametrize("name", ["2d_wide", "3d_small"])
 def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, monkeypatch):
     """infer_on_device runs the noisy copies in chunks of max_infer_batch; with two or more whole chunks they alternate
-    between two plans on two streams sharing the packed weights (opt-in CLX_INFER_STREAMS=2, forced at this size).  The same kernels see the same
+    between two plans on two streams sharing the packed weights (the default; CLX_INFER_STREAMS=1 = the plain loop; forced at this size).  The same kernels see the same
     rows: embeddings identical to the one-stream loop, also after a weight change and with a ragged last chunk."""
     oracle, model, raw = _make(name, device, seed=2)
     n_it = 4
@@ -236,10 +236,10 @@ def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, 
     model.set_infer(p_salt_pepper=0.05, num_infer_iterations=n_it, device=device)
     model.max_infer_batch = 2
     x = raw.to(device)
-    monkeypatch.delenv("CLX_INFER_STREAMS", raising=False)
+    monkeypatch.setenv("CLX_INFER_STREAMS", "1")
     one = model.infer_on_device(x, noise=noise).clone()
     assert getattr(model, "_infer_pair", None) is None
-    monkeypatch.setenv("CLX_INFER_STREAMS", "2")
+    monkeypatch.delenv("CLX_INFER_STREAMS", raising=False)
     monkeypatch.setenv("CLX_STREAMS_MIN_GFLOP", "0")
     two = model.infer_on_device(x, noise=noise).clone()
     assert model._infer_pair is not None and model._infer_pair[1].wpack_fwd is model._infer_pair[0].wpack_fwd
@@ -256,7 +256,7 @@ def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, 
     monkeypatch.setenv("CLX_INFER_STREAMS", "1")
     one_b = model.infer_on_device(x, noise=noise)
     assert torch.equal(one_b, two_b) and not torch.equal(two_b, two)
-    monkeypatch.setenv("CLX_INFER_STREAMS", "2")
+    monkeypatch.delenv("CLX_INFER_STREAMS", raising=False)
     model.max_infer_batch = 3                       # 8 copies = 3 + 3 + 2: ragged, the plain loop
     assert torch.equal(model.infer_on_device(x, noise=noise), one_b)
 

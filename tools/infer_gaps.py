@@ -29,6 +29,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--digest":
     print(f"{'(idle)':112s} {'':8s} {span - busy:10.1f} {'':9s} {(span - busy) / span:7.3f}")
     sys.exit(0)
 sys.path.insert(0, ".")
+import os
+os.environ.setdefault("CLX_INFER_STREAMS", "1")      # every kernel alone on the device: the pass bench_infer.py takes its rooflines from
 import numpy as np
 import torch
 from cellulus_amd.models import get_model
