@@ -128,7 +128,7 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     reps = size // 512
     emb0 = torch.from_numpy(np.tile(mean[0], (1, reps, reps))).to(device)
     sd = torch.from_numpy(np.tile(std, (reps, reps))).to(device)
-    ws = torch.zeros(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)   # zeroed once: the calls keep it so
+    ws = torch.empty(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)   # plain scratch
     pts = torch.empty((npix, 2), dtype=torch.float64, device=device)
     idx = torch.empty(npix, dtype=torch.int32, device=device)
     nfg = torch.zeros(1, dtype=torch.int32, device=device)

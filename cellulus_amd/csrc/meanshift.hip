@@ -10,438 +10,220 @@
 
 namespace {
 
-constexpr int PREP_TILE_MAX = 4096;   // pixels per block of the compaction: 256 threads x KP pairs, KP = 4 or 8
-
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// Coordinate add + stable (raster-order) compaction of the foreground pixels in ONE pass over
-// the image [mean_shift.py:15-32,83-90]: every block takes the next tile (atomic ticket), adds the
-// pixel coordinates to the embedding in place, counts its foreground pixels, publishes the count
-// and obtains the number of foreground pixels before its tile by decoupled look-back over the
-// predecessors' published counts / prefixes (one 64-bit word each: status in the high half,
-// value in the low half, so a reader never sees one without the other — and because that word is
-// ALL the blocks tell each other, the atomics are relaxed: an agent-scope release / acquire on this
-// 8-XCD part writes back / invalidates a whole L2 per descriptor), then writes its points.
-// Per pixel: (ND + 1) * 8 B read, ND * 8 B written; per foreground pixel ND * 8 + 4 B more.
-#ifndef MSP_WAVES
-#define MSP_WAVES 3
-#endif
-template <int ND, int KP>
-__global__ __launch_bounds__(256, MSP_WAVES) void ms_prepare_kernel(double* __restrict__ emb,
-                                                         const double* __restrict__ sd, double thr,
-                                                         FastDiv dX, FastDiv dY, int Y, int X,
-                                                         long long npix, int vec, int ntiles,
-                                                         unsigned int* __restrict__ ticket,   // [0] next tile, [1] blocks done
-                                                         unsigned long long* __restrict__ desc,
-                                                         double* __restrict__ Xout,
-                                                         int* __restrict__ index, int* __restrict__ nfg_out) {
-  // Persistent blocks: a block takes the next tile by ticket until the tiles run out (no partial last round of
-  // blocks; the NEXT ticket is requested while the current tile is processed, so its latency is never waited for).
-  // Per tile: (A) the std channel alone decides foreground — load it first, count, and PUBLISH the tile's
-  // aggregate before anything else, (B) the embedding channels: add the coordinates in place, (C) look back — by now
-  // the predecessors' aggregates are old — and write the tile's points.  (With the aggregate published after all of a
-  // tile's loads, as in round 2, the look-back cost 35-55 us of a 4096^2 image's 170.  Looking back BEFORE (B) and
-  // writing the points as the values arrive needs half the registers but serialises the loads: 238 against 179 us.)
-  constexpr int PREP_TILE = 512 * KP;
-  __shared__ int s_tile[2], s_excl;
-  __shared__ int wcount[KP][4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const unsigned long long lower = (1ull << lane) - 1ull;
-  // (taking several tiles per ticket — the word serves ~88 returning atomics per microsecond — delays the later tiles'
-  //  aggregates, and every look-back behind them waits: 13 ms instead of 0.17.  Fewer tickets need larger units whose
-  //  aggregate is published at once: ms_compact_kernel below.)
-  if (tid == 0) s_tile[0] = (int)atomicAdd(ticket, 1u);
-  __syncthreads();
-  for (int round = 0;; ++round) {
-    const int tile = s_tile[round & 1];
-    if (tile >= ntiles) break;
-    if (tid == 0) s_tile[(round + 1) & 1] = (int)atomicAdd(ticket, 1u);
-    const long long base = (long long)tile * PREP_TILE;
-
-    // ---- (A) foreground flags, counts, aggregate
-    bool fg[KP][2];
-    int before[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      const long long i = base + (long long)(k * 256 + tid) * 2;
-      fg[k][0] = fg[k][1] = false;
-      if (i < npix) {
-        if (vec) {              // npix even and 16-byte aligned: i + 1 < npix, 16-byte accesses
-          const f64x2 s2 = *reinterpret_cast<const f64x2*>(sd + i);
-          fg[k][0] = s2[0] < thr; fg[k][1] = s2[1] < thr;
-        } else {
-          fg[k][0] = sd[i] < thr;
-          fg[k][1] = i + 1 < npix && sd[i + 1] < thr;
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      const unsigned long long b0 = __ballot(fg[k][0]), b1 = __ballot(fg[k][1]);
-      // raster order inside the wave: lane l owns pixels 2l, 2l+1
-      before[k] = __popcll(b0 & lower) + __popcll(b1 & lower);
-      if (lane == 0) wcount[k][wid] = __popcll(b0) + __popcll(b1);
-    }
-    __syncthreads();
-    int total = 0, mine[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (w == wid) mine[k] = total;
-        total += wcount[k][w];
-      }
-    if (tid == 0)
-      __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)total, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-
-    // ---- (B) coordinates added to the embedding in place (all of the tile's loads in flight at once; issuing them
-    // before (A)'s barrier as well costs a third block per CU: 201 against 179 us)
-    double v[KP][2][ND];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      const long long i = base + (long long)(k * 256 + tid) * 2;
-      if (i < npix) {
-        const bool two = i + 1 < npix;
-        const unsigned int t = fdiv((unsigned int)i, dX);
-        const int x0 = (int)((unsigned int)i - t * (unsigned int)X);
-        const unsigned int z0u = fdiv(t, dY);
-        const int y0 = (int)(t - z0u * (unsigned int)Y), z0 = (int)z0u;
-        int x1 = x0 + 1, y1 = y0, z1 = z0;
-        if (x1 == X) { x1 = 0; if (++y1 == Y) { y1 = 0; ++z1; } }
-        const int c0[3] = {x0, y0, z0}, c1[3] = {x1, y1, z1};
-        if (vec) {
-#pragma unroll
-          for (int c = 0; c < ND; ++c) {
-            f64x2 e = *reinterpret_cast<const f64x2*>(emb + (long long)c * npix + i);
-            e[0] += (double)c0[c]; e[1] += (double)c1[c];
-            *reinterpret_cast<f64x2*>(emb + (long long)c * npix + i) = e;
-            v[k][0][c] = e[0]; v[k][1][c] = e[1];
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < ND; ++c) {
-            double e0 = emb[(long long)c * npix + i] + (double)c0[c];
-            emb[(long long)c * npix + i] = e0;
-            v[k][0][c] = e0;
-            if (two) {
-              double e1 = emb[(long long)c * npix + i + 1] + (double)c1[c];
-              emb[(long long)c * npix + i + 1] = e1;
-              v[k][1][c] = e1;
-            }
-          }
-        }
-      }
-    }
-
-    // ---- (C) decoupled look-back by the first wavefront: lane l inspects predecessor tile - 1 - l of the
-    // current window of 64; the nearest predecessor that already knows its inclusive prefix ends
-    // the walk, the aggregates in front of it are summed (a single thread doing this one
-    // descriptor at a time serialises the whole grid)
-    if (wid == 0) {
-      int excl = 0;
-      for (int hi = tile - 1; hi >= 0; hi -= 64) {
-        const int j = hi - lane;
-        unsigned long long d = 2ull << 32;              // tiles before the first: prefix 0
-        if (j >= 0) {
-          do {
-            d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((unsigned int)(d >> 32) == 0);       // predecessor has not published yet
-        }
-        const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
-        const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 64;      // nearest tile with a prefix
-        int a = (lane <= stop) ? (int)(unsigned int)d : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-        excl += a;
-        if (has_prefix) break;
-      }
-      if (lane == 0) {
-        if (tile > 0)
-          __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
-        s_excl = excl;
-        if (tile == ntiles - 1) *nfg_out = excl + total;
-      }
-    }
-    __syncthreads();
-    const int excl = s_excl;
-#pragma unroll
-    for (int k = 0; k < KP; ++k) {
-      int pos = excl + mine[k] + before[k];
-      const long long i = base + (long long)(k * 256 + tid) * 2;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        if (fg[k][e]) {
-#pragma unroll
-          for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = v[k][e][c];
-          index[pos] = (int)(i + e);
-          ++pos;
-        }
-      }
-    }
-    __syncthreads();      // s_excl, wcount and the ticket slots are reused by the next round
-  }
-  // The workspace is handed back ZEROED: the block that finishes last (every other block has left its last look-back)
-  // clears the descriptors and the two counters — a fill launch in front of every call was 4 % of a 4096^2 image.
-  if (tid == 0) s_excl = (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (s_excl) {
-    for (int j = tid; j < ntiles; j += 256)
-      __hip_atomic_store(&desc[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 2) __hip_atomic_store(ticket + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Round 4: the same single-pass compaction in SUPER-TILES, for the float32 hand-over of infer()'s fused predict -> detect
-// path (clx_ms_prepare_f32): the float64 values the staged path reads back from the `embeddings` dataset are the network's
-// floats widened (cellulus/predict.py:104-112), so widening in registers gives the same bits; the embedding is NOT
-// modified (the reference's in-place coordinate add lands in a copy that detect.py:155-160 throws away) and is read
-// only where a 16-byte group holds a foreground pixel: per pixel 4 B read, per foreground pixel ND * 4 B read and
-// ND * 8 + 4 B written.  With so few bytes per pixel the per-TILE costs of the float64 kernel's structure dominated (a
-// first float32 version with 4096-pixel tiles: 119 us at 4096^2): one returning atomic per tile on ONE ticket word —
-// the word serves ~88 of them per microsecond, 46 us — and a prefix that travels 64 tiles per look-back hop.  Here a
-// block takes a super-tile of R sub-tiles (16 K pixels) per ticket: all of its std values first (flags in one 64-bit
-// register, counts scanned in LDS, ONE aggregate published), a look-back by all 256 threads (256 predecessors per hop),
-// then sub-tile by sub-tile the embedding values, whose loads run one sub-tile ahead of the point writes: 91 us.
-// (TIn = double, WB = true is the float64 form with the in-place add; measured slower than ms_prepare_kernel — 219
-// against 175 us at 4096^2: half the bytes in flight per block — and not dispatched.)
+// Coordinate add + stable (raster-order) compaction of the foreground pixels [mean_shift.py:15-32,83-90] as THREE
+// plain streaming launches — no ticket, no look-back, no persistent blocks, no barrier, no state in the workspace.
+// The unit is a WAVE-TILE: 1024 consecutive pixels, lane l of the wavefront owning the 16-byte groups g * 64 + l.
+//   ms_flags_kernel    reads the std plane once: per wave-tile the foreground flags as the wavefront's ballot words (1 bit
+//                      per pixel, in the (group, pixel-of-group) order the scatter pass reads them back in) and the count;
+//   ms_tile_scan       exclusive prefix of the wave-tile counts (one block; a 4096^2 image is 16 K counts), total -> nfg;
+//   ms_scatter_kernel  per wave-tile: positions from the ballot words (popcounts), the embedding values — all of the
+//                      tile's loads in flight at once —, coordinates added (in place for float64), points and raster
+//                      indices written.
+// History: rounds 2-3 did this in ONE launch — persistent blocks taking tiles by an atomic ticket, counts
+// published and prefixes obtained by decoupled look-back.  At 4096^2 that form lost 15 us to the ticket word (one word
+// serves ~88 returning atomics per microsecond) and 40 us to the look-back (a hop is a round trip to the memory side)
+// of its 175 us; batching tickets serialised the look-back (13 ms), super-tiles with a 256-wide look-back halved the
+// bytes in flight (219 us).  Three launches cost two boundaries (~2 us each): 147 us, 0.63 of the HBM peak.
+// TIn = double: the reference's float64 arrays, coordinates added IN PLACE (WB).  TIn = float: the network's float32
+// output handed over in device memory by infer()'s fused predict -> detect path — the float64 values the staged path
+// reads back from the `embeddings` dataset are these floats widened (cellulus/predict.py:104-112), so widening in
+// registers gives the same bits; the embedding is not modified (the reference's in-place add lands in a copy that
+// detect.py:155-160 throws away) and is read only where a 16-byte group holds a foreground pixel.
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct Vec16;
 template <> struct Vec16<double> { typedef f64x2 type; static constexpr int N = 2; };
 template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4; };
 
-template <int ND, typename TIn, int G, int R, bool WB, int BLOCKS>
-__global__ __launch_bounds__(256, BLOCKS) void ms_compact_kernel(TIn* __restrict__ emb, const TIn* __restrict__ sd,
-                                                                     double thr, FastDiv dX, FastDiv dY, int Y, int X,
-                                                                     long long npix, int vec, int nsuper,
-                                                                     unsigned int* __restrict__ ticket,
-                                                                     unsigned long long* __restrict__ desc,
-                                                                     double* __restrict__ Xout, int* __restrict__ index,
-                                                                     int* __restrict__ nfg_out) {
+template <typename TIn, int G>
+__global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ sd, double thr, long long npix, int vec,
+                                                       int nwt, unsigned long long* __restrict__ flags,
+                                                       int* __restrict__ counts) {
   using V = typename Vec16<TIn>::type;
-  constexpr int PXL = Vec16<TIn>::N;            // pixels per 16-byte group
-  constexpr int SUB = 256 * G * PXL;            // pixels per sub-tile
-  constexpr int SUPER = SUB * R;
-  constexpr int NK = R * G * 4;                 // (sub-tile, group, wave) counts, in raster order
-  constexpr unsigned int GMASK = (1u << PXL) - 1u;
-  constexpr unsigned int SMASK = (G * PXL == 32) ? 0xffffffffu : ((1u << (G * PXL)) - 1u);
-  static_assert(R * G * PXL <= 64 && NK <= 256 && R % 2 == 0, "flags of a super-tile fit one 64-bit register; one scan pass");
-  __shared__ int s_tile[2];
-  __shared__ int woff[NK + 1];
-  __shared__ int lb_sum[4], lb_stop[4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const unsigned long long lower = (1ull << lane) - 1ull;
-  if (tid == 0) s_tile[0] = (int)atomicAdd(ticket, 1u);
-  __syncthreads();
-  for (int round = 0;; ++round) {
-    const int tile = s_tile[round & 1];
-    if (tile >= nsuper) break;
-    if (tid == 0) s_tile[(round + 1) & 1] = (int)atomicAdd(ticket, 1u);
-    const long long base = (long long)tile * SUPER;
+  constexpr int PXL = Vec16<TIn>::N;
+  constexpr int WT = 64 * G * PXL;
+  const int lane = threadIdx.x & 63;
+  for (int wt = blockIdx.x * 4 + (threadIdx.x >> 6); wt < nwt; wt += gridDim.x * 4) {
+    const long long base = (long long)wt * WT;
+    unsigned int b = 0u;
+    if (vec && base + WT <= npix) {
+      // whole tile inside the image (wave-uniform): unconditional loads — behind per-lane conditions the compiler's
+      // wait-count pass puts a wait behind every load and the kernel ran at half the rate of minmax_kernel
+      V sv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) sv[g] = *reinterpret_cast<const V*>(sd + base + (long long)(g * 64 + lane) * PXL);
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int e = 0; e < PXL; ++e) b |= ((double)sv[g][e] < thr ? 1u : 0u) << (g * PXL + e);
+    } else if (vec) {
+      V sv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const long long i = base + (long long)(g * 64 + lane) * PXL;
+        if (i < npix) sv[g] = *reinterpret_cast<const V*>(sd + i);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const long long i = base + (long long)(g * 64 + lane) * PXL;
+        if (i < npix) {
+#pragma unroll
+          for (int e = 0; e < PXL; ++e) b |= ((double)sv[g][e] < thr ? 1u : 0u) << (g * PXL + e);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const long long i = base + (long long)(g * 64 + lane) * PXL;
+#pragma unroll
+        for (int e = 0; e < PXL; ++e)
+          if (i + e < npix) b |= ((double)sd[i + e] < thr ? 1u : 0u) << (g * PXL + e);
+      }
+    }
+    // the G * PXL = 16 ballot words of the tile leave as ONE 128-byte store (lane k keeps word k), not as sixteen
+    // single-lane stores
+    int total = 0;
+    unsigned long long mine = 0ull;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < PXL; ++e) {
+        const unsigned long long w = __ballot((b >> (g * PXL + e)) & 1u);
+        if (lane == g * PXL + e) mine = w;
+        total += __popcll(w);
+      }
+    if (lane < G * PXL) flags[(long long)wt * (G * PXL) + lane] = mine;
+    if (lane == 0) counts[wt] = total;
+  }
+}
 
-    // ---- (A) every std value of the super-tile: foreground flags (one bit per pixel of this thread, sub-tile r in
-    // bits r * G * PXL ..), counts per (sub-tile, group, wave); two sub-tiles' loads in flight at a time
-    unsigned long long allbits = 0ull;
-#pragma unroll 2
-    for (int r = 0; r < R; ++r) {
-      unsigned int b = 0u;
-      if (vec) {
-        V sv[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
-          if (i < npix) sv[g] = *reinterpret_cast<const V*>(sd + i);
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
-          if (i < npix) {
-#pragma unroll
-            for (int e = 0; e < PXL; ++e) b |= ((double)sv[g][e] < thr ? 1u : 0u) << (g * PXL + e);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
-#pragma unroll
-          for (int e = 0; e < PXL; ++e)
-            if (i + e < npix) b |= ((double)sd[i + e] < thr ? 1u : 0u) << (g * PXL + e);
-        }
-      }
-      allbits |= (unsigned long long)b << (r * G * PXL);
-    }
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-      const unsigned int b = (unsigned int)(allbits >> (r * G * PXL)) & SMASK;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        int tot = 0;
-#pragma unroll
-        for (int e = 0; e < PXL; ++e) tot += __popcll(__ballot((b >> (g * PXL + e)) & 1u));
-        if (lane == 0) woff[(r * G + g) * 4 + wid] = tot;
-      }
-    }
+// exclusive scan of counts[0..n) into prefix[0..n) (n a multiple of 4: whole groups of four wave-tiles, 16-byte accesses),
+// total -> *nfg_out.  One block; a thread takes consecutive groups of four (a 4096^2 image: 16 K counts, four groups each).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(1024) void ms_tile_scan(const int* __restrict__ counts, int n4, int* __restrict__ prefix,
+                                                     int* __restrict__ nfg_out) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const i32x4* c4 = reinterpret_cast<const i32x4*>(counts);
+  i32x4* p4 = reinterpret_cast<i32x4*>(prefix);
+  const int per = (n4 + 1023) / 1024;
+  const int lo = min(tid * per, n4), hi = min(lo + per, n4);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) {
+    const i32x4 c = c4[i];
+    s += c[0] + c[1] + c[2] + c[3];
+  }
+  part[tid] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (tid >= o) ? part[tid - o] : 0;
     __syncthreads();
-    // exclusive scan of the NK counts by the first wavefront; the super-tile's aggregate goes out at once
-    int total;
-    if (wid == 0) {
-      constexpr int PER = (NK + 63) / 64;
-      int c[PER], sum = 0;
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = (tid == 0) ? 0 : part[tid - 1];
+  for (int i = lo; i < hi; ++i) {
+    const i32x4 c = c4[i];
+    i32x4 p;
+    p[0] = run; p[1] = run + c[0]; p[2] = p[1] + c[1]; p[3] = p[2] + c[2];
+    p4[i] = p;
+    run = p[3] + c[3];
+  }
+  if (tid == 1023) *nfg_out = part[1023];
+}
+
+template <int ND, typename TIn, int G, bool WB, int BLOCKS>
+__global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict__ emb, FastDiv dX, FastDiv dY, int Y, int X,
+                                                                 long long npix, int vec, int nwt,
+                                                                 const unsigned long long* __restrict__ flags,
+                                                                 const int* __restrict__ prefix,
+                                                                 double* __restrict__ Xout, int* __restrict__ index) {
+  using V = typename Vec16<TIn>::type;
+  constexpr int PXL = Vec16<TIn>::N;
+  constexpr int WT = 64 * G * PXL;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  for (int wt = blockIdx.x * 4 + (threadIdx.x >> 6); wt < nwt; wt += gridDim.x * 4) {
+    const long long base = (long long)wt * WT;
+    const unsigned long long* tf = flags + (long long)wt * G * PXL;
+    unsigned long long B[G][PXL];            // wave-uniform: this tile's ballot words
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int idx = lane * PER + u;
-        c[u] = idx < NK ? woff[idx] : 0;
-        sum += c[u];
-      }
-      int incl = sum;
+    for (int g = 0; g < G; ++g)
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      int ex = incl - sum;
+      for (int e = 0; e < PXL; ++e) B[g][e] = tf[g * PXL + e];
+    // the tile's embedding values: every load in flight before the first is used
+    V ev[G][ND];
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int idx = lane * PER + u;
-        if (idx < NK) woff[idx] = ex;
-        ex += c[u];
-      }
-      if (lane == 63) {
-        woff[NK] = incl;
-        __hip_atomic_store(&desc[tile], ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned int)incl, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    for (int g = 0; g < G; ++g) {
+      const long long i = base + (long long)(g * 64 + lane) * PXL;
+      bool any = WB;
+#pragma unroll
+      for (int e = 0; e < PXL; ++e) any = any || ((B[g][e] >> lane) & 1ull);
+      if (i < npix && any) {
+        if (vec) {
+#pragma unroll
+          for (int c = 0; c < ND; ++c) ev[g][c] = *reinterpret_cast<const V*>(emb + (long long)c * npix + i);
+        } else {
+#pragma unroll
+          for (int c = 0; c < ND; ++c)
+#pragma unroll
+            for (int e = 0; e < PXL; ++e) ev[g][c][e] = (i + e < npix) ? emb[(long long)c * npix + i + e] : (TIn)0;
+        }
       }
     }
-    // ---- the first sub-tile's embedding values, in flight during the look-back
-    V ev[2][G][ND];
-    auto load_emb = [&](int r, V (&dst)[G][ND]) {
-      const unsigned int sb = (unsigned int)(allbits >> (r * G * PXL)) & SMASK;
+    int run = prefix[wt];                     // points before group g of this tile
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
-        const bool need = i < npix && (WB || ((sb >> (g * PXL)) & GMASK) != 0u);
-        if (need) {
+    for (int g = 0; g < G; ++g) {
+      const long long i = base + (long long)(g * 64 + lane) * PXL;
+      unsigned int gb = 0u;
+      int bef = 0, cnt = 0;
+#pragma unroll
+      for (int e = 0; e < PXL; ++e) {
+        gb |= (unsigned int)((B[g][e] >> lane) & 1ull) << e;
+        bef += __popcll(B[g][e] & lower);
+        cnt += __popcll(B[g][e]);
+      }
+      if (i < npix && (WB || gb != 0u)) {
+        int pos = run + bef;
+        const unsigned int t = fdiv((unsigned int)i, dX);
+        int cx = (int)((unsigned int)i - t * (unsigned int)X);
+        const unsigned int z0u = fdiv(t, dY);
+        int cy = (int)(t - z0u * (unsigned int)Y), cz = (int)z0u;
+        V (&e4)[ND] = ev[g];
+#pragma unroll
+        for (int e = 0; e < PXL; ++e) {
+          const int co[3] = {cx, cy, cz};
+          double val[ND];
+#pragma unroll
+          for (int c = 0; c < ND; ++c) {
+            val[c] = (double)e4[c][e] + (double)co[c];
+            if (WB) e4[c][e] = (TIn)val[c];
+          }
+          if ((gb >> e) & 1u) {
+#pragma unroll
+            for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = val[c];
+            index[pos] = (int)(i + e);
+            ++pos;
+          }
+          if (++cx == X) { cx = 0; if (++cy == Y) { cy = 0; ++cz; } }
+        }
+        if (WB) {
           if (vec) {
 #pragma unroll
-            for (int c = 0; c < ND; ++c) dst[g][c] = *reinterpret_cast<const V*>(emb + (long long)c * npix + i);
+            for (int c = 0; c < ND; ++c) *reinterpret_cast<V*>(emb + (long long)c * npix + i) = e4[c];
           } else {
 #pragma unroll
             for (int c = 0; c < ND; ++c)
 #pragma unroll
-              for (int e = 0; e < PXL; ++e) dst[g][c][e] = (i + e < npix) ? emb[(long long)c * npix + i + e] : (TIn)0;
+              for (int e = 0; e < PXL; ++e)
+                if (i + e < npix) emb[(long long)c * npix + i + e] = e4[c][e];
           }
         }
       }
-    };
-    load_emb(0, ev[0]);
-    __syncthreads();
-    total = woff[NK];
-
-    // ---- (C) look-back by the whole block: thread t inspects predecessor tile - 1 - t of the current window of 256
-    int excl = 0;
-    for (int hi = tile - 1; hi >= 0; hi -= 256) {
-      const int j = hi - tid;
-      unsigned long long d = 2ull << 32;              // tiles before the first: prefix 0
-      if (j >= 0) {
-        do {
-          d = __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((unsigned int)(d >> 32) == 0);       // predecessor has not published yet
-      }
-      const unsigned long long has_prefix = __ballot((unsigned int)(d >> 32) == 2u);
-      const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 64;      // nearest tile of this wave's 64 with a prefix
-      int a = (lane <= stop) ? (int)(unsigned int)d : 0;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-      if (lane == 0) { lb_sum[wid] = a; lb_stop[wid] = has_prefix ? 1 : 0; }
-      __syncthreads();
-      bool found = false;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        if (!found) {
-          excl += lb_sum[w];
-          found = lb_stop[w] != 0;
-        }
-      }
-      __syncthreads();
-      if (found) break;
+      run += cnt;
     }
-    if (tid == 0) {
-      if (tile > 0)
-        __hip_atomic_store(&desc[tile], (2ull << 32) | (unsigned int)(excl + total), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      if (tile == nsuper - 1) *nfg_out = excl + total;
-    }
-
-    // ---- (D) sub-tile by sub-tile: coordinates added (in place for WB), points and raster indices written; the next
-    // sub-tile's loads are issued before the current one is written (two register sets, used alternately)
-    auto emit = [&](int r, V (&cur)[G][ND]) {
-      const unsigned int sb = (unsigned int)(allbits >> (r * G * PXL)) & SMASK;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const unsigned int gb = (sb >> (g * PXL)) & GMASK;
-        int bef = 0;
-#pragma unroll
-        for (int e = 0; e < PXL; ++e) bef += __popcll(__ballot((gb >> e) & 1u) & lower);
-        const long long i = base + (long long)r * SUB + (long long)(g * 256 + tid) * PXL;
-        if (i < npix && (WB || gb != 0u)) {
-          int pos = excl + woff[(r * G + g) * 4 + wid] + bef;
-          const unsigned int t = fdiv((unsigned int)i, dX);
-          int cx = (int)((unsigned int)i - t * (unsigned int)X);
-          const unsigned int z0u = fdiv(t, dY);
-          int cy = (int)(t - z0u * (unsigned int)Y), cz = (int)z0u;
-          V (&e4)[ND] = cur[g];
-#pragma unroll
-          for (int e = 0; e < PXL; ++e) {
-            const int co[3] = {cx, cy, cz};
-            double val[ND];
-#pragma unroll
-            for (int c = 0; c < ND; ++c) {
-              val[c] = (double)e4[c][e] + (double)co[c];
-              if (WB) e4[c][e] = (TIn)val[c];
-            }
-            if ((gb >> e) & 1u) {
-#pragma unroll
-              for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = val[c];
-              index[pos] = (int)(i + e);
-              ++pos;
-            }
-            if (++cx == X) { cx = 0; if (++cy == Y) { cy = 0; ++cz; } }
-          }
-          if (WB) {
-            if (vec) {
-#pragma unroll
-              for (int c = 0; c < ND; ++c) *reinterpret_cast<V*>(emb + (long long)c * npix + i) = e4[c];
-            } else {
-#pragma unroll
-              for (int c = 0; c < ND; ++c)
-#pragma unroll
-                for (int e = 0; e < PXL; ++e)
-                  if (i + e < npix) emb[(long long)c * npix + i + e] = e4[c][e];
-            }
-          }
-        }
-      }
-    };
-#pragma unroll 1
-    for (int r = 0; r < R; r += 2) {
-      load_emb(r + 1, ev[1]);
-      emit(r, ev[0]);
-      if (r + 2 < R) load_emb(r + 2, ev[0]);
-      emit(r + 1, ev[1]);
-    }
-    __syncthreads();      // woff, lb_* and the ticket slots are reused by the next round
-  }
-  // the workspace is handed back ZEROED by the block that finishes last (every other block has left its last look-back)
-  __shared__ int s_last;
-  if (tid == 0) s_last = (atomicAdd(ticket + 1, 1u) == gridDim.x - 1) ? 1 : 0;
-  __syncthreads();
-  if (s_last) {
-    for (int j = tid; j < nsuper; j += 256)
-      __hip_atomic_store(&desc[j], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 2) __hip_atomic_store(ticket + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -867,47 +649,36 @@ __global__ __launch_bounds__(256) void ms_assign_cells_kernel(
 
 }  // namespace
 
-static int prep_pairs() {      // pairs of pixels per thread: 8 (4096-pixel tiles, measured 0.74 vs 0.82 ms at
-  static const int env = getenv("CLX_MS_PREP_K") ? atoi(getenv("CLX_MS_PREP_K")) : 8;             // 8192^2), 4 or 16
-  return env == 4 ? 4 : env == 16 ? 16 : 8;
+// workspace of the compaction: [flags: one bit per pixel, whole wave-tiles][counts: nwt ints][prefix: nwt + 1 ints]
+static long long wave_tiles(long long npix) { return (npix + 4095) / 4096 * 4; }      // whole groups of four
+
+extern "C" size_t clx_ms_prepare_workspace(long long npix) {
+  const long long nwt = wave_tiles(npix);
+  return (size_t)nwt * 128 + (size_t)(2 * nwt + 2) * sizeof(int) + 64;
 }
 
-
-template <int ND, typename TIn, int G, int R, bool WB, int BLOCKS>
-static int launch_compact(TIn* emb, const TIn* std, double threshold, int Z, int Y, int X, double* Xout, int* index,
-                          int* nfg_out, void* workspace, hipStream_t st) {
+template <int ND, typename TIn, int G, bool WB, int BLOCKS>
+static void launch_prepare(TIn* emb, const TIn* std, double threshold, int Z, int Y, int X, double* Xout, int* index,
+                           int* nfg_out, void* workspace, hipStream_t st) {
   constexpr int PXL = 16 / (int)sizeof(TIn);
-  constexpr long long SUPER = 256ll * G * PXL * R;
+  static_assert(64 * G * PXL == 1024, "wave-tiles of 1024 pixels");
   const long long npix = (long long)Z * Y * X;
-  const int nsuper = (int)((npix + SUPER - 1) / SUPER);
-  unsigned int* ticket = (unsigned int*)workspace;
-  unsigned long long* desc = (unsigned long long*)workspace + 1;
+  const int nwt = (int)wave_tiles(npix);
+  unsigned long long* flags = (unsigned long long*)workspace;
+  int* counts = (int*)(flags + (size_t)nwt * 16);          // 16-byte aligned: nwt is a multiple of 4
+  int* prefix = counts + nwt;
   // every channel plane starts at a multiple of npix elements: 16-byte accesses need npix % PXL == 0 and aligned bases
   const int vec = (npix % PXL == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
   const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
-  static const int cus = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount;
-  }();
-  static const int per_cu = [] {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ms_compact_kernel<ND, TIn, G, R, WB, BLOCKS>, 256, 0) != hipSuccess || nb < 1)
-      nb = 2;
-    return nb;
-  }();
-  // persistent blocks: as many as are resident at once, not more than there are super-tiles
-  const int nblocks = nsuper < cus * per_cu ? nsuper : cus * per_cu;
-  CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_compact_kernel<ND, TIn, G, R, WB, BLOCKS>), dim3(nblocks), dim3(256), 0, st, emb, std,
-                  threshold, dX, dY, Y, X, npix, vec, nsuper, ticket, desc, Xout, index, nfg_out);
-  return CLX_OK;
-}
-
-
-extern "C" size_t clx_ms_prepare_workspace(long long npix) {
-  const long long ntiles = (npix + 2048 - 1) / 2048;          // the smaller tile: enough for either
-  return (size_t)(ntiles + 2) * sizeof(unsigned long long);
+  static const int g1cap = getenv("CLX_MS_FLAGS_GRID") ? atoi(getenv("CLX_MS_FLAGS_GRID")) : 2048;        // (sweeps)
+  static const int g3cap = getenv("CLX_MS_SCATTER_GRID") ? atoi(getenv("CLX_MS_SCATTER_GRID")) : 1 << 20;
+  const int nb = (nwt + 3) / 4;
+  const int g1 = nb < g1cap ? nb : g1cap, g3 = nb < g3cap ? nb : g3cap;
+  CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_flags_kernel<TIn, G>), dim3(g1), dim3(256), 0, st, std, threshold, npix, vec,
+                  nwt, flags, counts);
+  CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, ms_tile_scan, dim3(1), dim3(1024), 0, st, counts, nwt / 4, prefix, nfg_out);
+  CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_scatter_kernel<ND, TIn, G, WB, BLOCKS>), dim3(g3), dim3(256), 0, st, emb, dX, dY,
+                  Y, X, npix, vec, nwt, flags, prefix, Xout, index);
 }
 
 extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
@@ -916,38 +687,12 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
   CLX_REQUIRE(emb && std && Xout && index && nfg_out && workspace, "clx_ms_prepare: null pointer");
   CLX_REQUIRE((ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0, "clx_ms_prepare: bad extents");
   CLX_REQUIRE(ND == 3 || Z == 1, "clx_ms_prepare: Z must be 1 for 2-D data");
-  CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare: workspace must be 8-byte aligned");
+  CLX_REQUIRE(((uintptr_t)workspace & 15) == 0, "clx_ms_prepare: workspace must be 16-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare: too many pixels");
   hipStream_t st = (hipStream_t)stream;
-  const int kp = (ND == 3 && prep_pairs() == 16) ? 8 : prep_pairs();
-  const int ntiles = (int)((npix + 512 * kp - 1) / (512 * kp));
-  unsigned int* ticket = (unsigned int*)workspace;
-  unsigned long long* desc = (unsigned long long*)workspace + 1;
-  const int vec = (npix % 2 == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
-  const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
-  // persistent blocks: as many as are resident at once, not more than there are tiles
-  static const int cus = [] {
-    hipDeviceProp_t prop;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-    return prop.multiProcessorCount;
-  }();
-#define CLX_PREP(ND_, KP_)                                                                                   \
-  do {                                                                                                       \
-    static const int per_cu = [] {                                                                           \
-      int nb = 0;                                                                                            \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ms_prepare_kernel<ND_, KP_>, 256, 0) != hipSuccess || nb < 1) \
-        nb = 2;                                                                                              \
-      return nb;                                                                                             \
-    }();                                                                                                     \
-    const int nblocks = ntiles < cus * per_cu ? ntiles : cus * per_cu;                                       \
-    CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_prepare_kernel<ND_, KP_>), dim3(nblocks), dim3(256), 0, st, emb, std, threshold, dX, dY, Y, X, npix, vec, ntiles, ticket, \
-                                                         desc, Xout, index, nfg_out);                        \
-  } while (0)
-  if (ND == 2) { if (kp == 16) CLX_PREP(2, 16); else if (kp == 8) CLX_PREP(2, 8); else CLX_PREP(2, 4); }
-  else         { if (kp >= 8) CLX_PREP(3, 8); else CLX_PREP(3, 4); }
-#undef CLX_PREP
+  if (ND == 2) launch_prepare<2, double, 8, true, 3>(emb, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, st);
+  else launch_prepare<3, double, 8, true, 2>(emb, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, st);
   CLX_CHECK_LAUNCH("clx_ms_prepare");
   return CLX_OK;
 }
@@ -958,14 +703,13 @@ extern "C" int clx_ms_prepare_f32(const float* emb, const float* std, double thr
   CLX_REQUIRE(emb && std && Xout && index && nfg_out && workspace, "clx_ms_prepare_f32: null pointer");
   CLX_REQUIRE((ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0, "clx_ms_prepare_f32: bad extents");
   CLX_REQUIRE(ND == 3 || Z == 1, "clx_ms_prepare_f32: Z must be 1 for 2-D data");
-  CLX_REQUIRE(((uintptr_t)workspace & 7) == 0, "clx_ms_prepare_f32: workspace must be 8-byte aligned");
+  CLX_REQUIRE(((uintptr_t)workspace & 15) == 0, "clx_ms_prepare_f32: workspace must be 16-byte aligned");
   const long long npix = (long long)Z * Y * X;
   CLX_REQUIRE(npix < (1ll << 31), "clx_ms_prepare_f32: too many pixels");
-  // super-tiles of 4 sub-tiles x 4096 pixels (4 groups of four float32 pixels per thread); clx_ms_prepare_workspace(npix)
-  // (one descriptor per 2048 pixels) covers them
-  float* e = const_cast<float*>(emb);
-  if (ND == 2) launch_compact<2, float, 4, 4, false, 3>(e, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, (hipStream_t)stream);
-  else launch_compact<3, float, 4, 4, false, 2>(e, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  float* e = const_cast<float*>(emb);          // (WB = false: never written)
+  if (ND == 2) launch_prepare<2, float, 4, false, 4>(e, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, st);
+  else launch_prepare<3, float, 4, false, 3>(e, std, threshold, Z, Y, X, Xout, index, nfg_out, workspace, st);
   CLX_CHECK_LAUNCH("clx_ms_prepare_f32");
   return CLX_OK;
 }

@@ -103,12 +103,12 @@ _PREP_WS = {}
 
 
 def _prepare_workspace(nbytes, dev):
-    """clx_ms_prepare's workspace: zero-filled once, handed back zero-filled by every call (include/clx.h), so one
-    buffer per (device, stream) serves every image; grown when a larger image comes."""
+    """clx_ms_prepare's scratch (flags, tile counts and prefix; no state between calls): one buffer per (device, stream),
+    grown when a larger image comes."""
     key = (dev, torch.cuda.current_stream(dev).cuda_stream)
     ws = _PREP_WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _PREP_WS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        ws = _PREP_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return ws
 
 
@@ -135,14 +135,8 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     pts = torch.empty((npix, nd), dtype=torch.float64, device=dev)
     index = torch.empty(npix, dtype=torch.int32, device=dev)
     nfg_d = torch.zeros(1, dtype=torch.int32, device=dev)
-    try:
-        _clx.call(prepare, _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
-                  _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
-    except _clx.ClxError:
-        # a call that did not complete may leave tickets / descriptors behind: never reuse that buffer (the next
-        # image gets a freshly zeroed one)
-        _PREP_WS.clear()
-        raise
+    _clx.call(prepare, _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
+              _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
     labels = torch.zeros(spatial, dtype=torch.int32, device=dev)
     nfg = int(nfg_d.item())
     if nfg == 0:      # mean_shift.py:83-84,92-93 -> all -1, +1 -> 0

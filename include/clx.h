@@ -427,9 +427,9 @@ int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long lo
  *   emb:  (ND, [Z,] Y, X) f64, channel 0 += x, 1 += y, 2 += z
  *   X:    (nfg, ND) f64 out,  index: (nfg) int32 raster index of each fg pixel
  *   nfg_out: device int32, number of foreground pixels
- * workspace: clx_ms_prepare_workspace(npix) bytes, ZERO-FILLED by the caller before the first call that uses it;
- * every call hands it back zero-filled, so the same buffer serves the next call on that stream as it is (one
- * workspace per stream in flight). */
+ * workspace: clx_ms_prepare_workspace(npix) bytes of plain scratch (16-byte aligned; no contents are expected and none
+ * are kept: the foreground flags as one bit per pixel + the per-tile counts and their prefix).  Three launches: flags +
+ * counts from the std plane, a scan of the counts, the scatter pass. */
 size_t clx_ms_prepare_workspace(long long npix);
 int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
                    int Z, int Y, int X, double* Xout, int* index, int* nfg_out,

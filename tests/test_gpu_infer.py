@@ -812,15 +812,14 @@ def test_float32_handover_kernels_equal_the_float64_ones_on_the_widened_values(s
     thr = 0.3
 
     def prepare(name, emb, std):
-        ws = torch.zeros(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)
+        ws = torch.full((int(lib.clx_ms_prepare_workspace(npix)),), 0xA5, dtype=torch.uint8, device=device)   # plain scratch
         pts = torch.full((npix, nd), float("nan"), dtype=torch.float64, device=device)
         idx = torch.full((npix,), -1, dtype=torch.int32, device=device)
         nfg = torch.zeros(1, dtype=torch.int32, device=device)
-        for _ in range(2):                                   # the workspace comes back zeroed: a second call works
+        for _ in range(2):                                   # (the workspace carries no state from call to call)
             e = emb.clone()
             _clx.call(name, _clx.ptr(e), _clx.ptr(std), thr, nd, Z, Y, X, _clx.ptr(pts), _clx.ptr(idx), _clx.ptr(nfg),
                       _clx.ptr(ws), st)
-        assert int(ws.max().item()) == 0
         n = int(nfg.item())
         return pts[:n].cpu().numpy(), idx[:n].cpu().numpy(), e
 
