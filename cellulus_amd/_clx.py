@@ -84,6 +84,8 @@ class ClxConvDesc(Structure):
         ("ld_mask_bits", c_int),
         ("det_turns", c_void_p),
         ("adjoint", c_int),
+        ("pool_out", c_void_p),
+        ("ld_pool", c_int),
     ]
 
 

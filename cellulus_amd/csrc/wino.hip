@@ -151,9 +151,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           float* __restrict__ out, int ld_out, int Nreal,
                                                           int accumulate, unsigned int* __restrict__ gate_out,
                                                           int ld_gate, const unsigned int* __restrict__ mask_bits,
-                                                          int ld_mask_bits, long long total) {
+                                                          int ld_mask_bits, float* __restrict__ pool_out, int ld_pool,
+                                                          long long total) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
+  constexpr int MP = MT / 2;          // 2 x 2 pooling windows per tile side (MT = 2 or 4: windows never straddle tiles)
   const int N = N4 * 4;
   const long long plane = g.T * N;
   // gate bits (N4 % 8 == 0, checked by the launcher): the 8 lanes i .. i + 7, i % 8 == 0, are the 32
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) bv[e] = (n + e < Nreal) ? bias[n + e] : 0.f;
     }
+    f32x4 pm[MP][MP];                  // running maxima of the tile's pooling windows (pool_out only)
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
       const int oy = MT * ty + a;
@@ -237,6 +240,17 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             float xv = v[e];
             if (mask) xv = (mask[m * ld_mask + n + e] > 0.f) ? xv : 0.f;
             out[m * ld_out + n + e] = xv;
+          }
+        }
+        if (pool_out) {                // (the launcher admits pool_out only with whole channel groups and no mask)
+          if ((a & 1) == 0 && (cc & 1) == 0) pm[a >> 1][cc >> 1] = v;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pm[a >> 1][cc >> 1][e] = fmaxf(pm[a >> 1][cc >> 1][e], v[e]);
+          }
+          if ((a & 1) && (cc & 1)) {   // the window's last pixel (OH, OW even: windows are whole)
+            const long long pm_ = ((long long)b * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
+            st4(pool_out + pm_ * ld_pool + n, pm[a >> 1][cc >> 1]);
           }
         }
       }
@@ -761,10 +775,17 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   CLX_REQUIRE((d->gate_out == nullptr && d->mask_bits == nullptr) || Np % 32 == 0,
               "clx_conv_fwd(winograd): gate_out / mask_bits need a channel count that is a multiple of 32");
   CLX_REQUIRE(d->gate_out == nullptr || d->relu, "clx_conv_fwd(winograd): gate_out needs relu");
+  if (d->pool_out != nullptr) {
+    CLX_REQUIRE(d->KD == 1 && d->ID == 1 && gout.OH % 2 == 0 && gout.OW % 2 == 0,
+                "clx_conv_fwd(winograd): pool_out needs a 2-D layer with even output height and width");
+    CLX_REQUIRE(d->N % 4 == 0 && d->ld_pool % 4 == 0 && d->ld_pool >= d->N && ((uintptr_t)d->pool_out & 15) == 0 &&
+                    d->mask == nullptr && d->mask_bits == nullptr && !d->accumulate,
+                "clx_conv_fwd(winograd): pool_out needs N %% 4 == 0, an aligned ld_pool >= N, and no mask / accumulate");
+  }
   wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, gout, d->bias, d->relu, d->mask,
                                                                       d->ld_mask, d->out, d->ld_out, d->N, d->accumulate,
                                                                       d->gate_out, d->ld_gate, d->mask_bits,
-                                                                      d->ld_mask_bits, tot_out);
+                                                                      d->ld_mask_bits, d->pool_out, d->ld_pool, tot_out);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }

@@ -425,6 +425,17 @@ class UNetPlan:
         self.vcache = {}
         self._vcache_fresh = set()
         self._find_chains()
+        # 2 x 2 max-pooling written by the Winograd output transform of the layer that produces the pooled tensor (2-D:
+        # a pooling window lies inside one output tile; clx_conv_desc.pool_out).  CLX_FUSED_POOL=0: the separate pass
+        self.fused_pool = {}
+        if os.environ.get("CLX_FUSED_POOL", "1") != "0":
+            by_out = {layer.out: layer for layer in t.convs}
+            for pool in t.pools:
+                layer = by_out.get(pool.src)
+                if (layer is not None and self.algo[layer.name]["fwd"] and layer.kernel[0] == 1 and layer.in_shape[0] == 1
+                        and tuple(pool.factor) == (1, 2, 2) and layer.cout % 4 == 0 and layer.name not in self.subpixel
+                        and layer.out_shape[1] % 2 == 0 and layer.out_shape[2] % 2 == 0):
+                    self.fused_pool[layer.name] = pool
 
     def share_from(self, other):
         """Use `other`'s packed weights and gradient accumulators (same topology, batch size and switches): this
@@ -1171,7 +1182,13 @@ class UNetPlan:
                     if self.keep and self._bwd_ready and op.name in self.vcache:
                         d.vcache = self.vcache[op.name].data_ptr()
                         self._vcache_fresh.add(op.name)
+                    pool = self.fused_pool.get(op.name)
+                    if pool is not None:
+                        d.pool_out = self.buf[pool.out].data_ptr()
+                        d.ld_pool = pad4(pool.channels)
                 _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+            elif any(p is op for p in self.fused_pool.values()):
+                continue                                    # written by the producing layer's output transform
             else:
                 D, H, W = op.in_shape
                 _clx.call("clx_maxpool_fwd", _clx.ptr(self.buf[op.src]), _clx.ptr(self.buf[op.out]),

@@ -364,14 +364,18 @@ class UNetModel(nn.Module):  # type: ignore
         params = self._ordered_params()
         plan.pack_weights(params, self._param_version(), need_dgrad=False)
         pair = getattr(self, "_infer_pair", None)
-        if pair is None or pair[0] is not plan or len(pair[2]) != nstreams:
-            # a second set of activations must fit beside the first (several ranks may share a device in a rehearsal)
+        if pair is not None and pair[0] is plan and len(pair[2]) <= nstreams:
+            nstreams = len(pair[2])                      # (built when less memory was free: keep it)
+        if pair is None or pair[0] is not plan:
+            # every further set of activations must fit beside the first (several ranks may share a device in a rehearsal):
+            # as many streams as there is room for
             need = sum(t.numel() * t.element_size() for t in plan.buf.values())
             if plan.workspace is not None:
                 need += plan.workspace.numel() * plan.workspace.element_size()
             free = torch.cuda.mem_get_info(noisy.device)[0] + torch.cuda.memory_reserved(noisy.device) \
                 - torch.cuda.memory_allocated(noisy.device)
-            if free < 1.25 * need * (nstreams - 1):
+            nstreams = min(nstreams, 1 + int(free // (1.25 * need)))
+            if nstreams < 2:
                 preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
                 return torch.cat(preds, dim=0)
             self._infer_pair = None

@@ -159,6 +159,13 @@ typedef struct clx_conv_desc {
    * B [U^T (A dY A^T)] B^T — so dY is not transformed a second time (src[0].ptr is not read).  wpack must come
    * from clx_pack_weights(CLX_PACK_WINO4_ADJOINT).  Epilogues: mask / mask_bits (no bias, ReLU, accumulate). */
   int adjoint;
+  /* clx_conv_fwd, Winograd algorithms on 2-D layers (KD = 1) only, optional: ALSO write the 2 x 2 max-pooled output
+   * (funlib's Downsample after a level's last convolution, cellulus/models/unet.py:24-51: nn.MaxPool2d(2) of this very
+   * tensor) — pool_out[(b, y / 2, x / 2)][n] = max over the 2 x 2 window of out, after bias / ReLU / mask —, whose four
+   * pixels lie inside one output tile of the transform: the separate pooling pass (a full read of `out`) disappears.
+   * Output height and width must be even; ld_pool % 4 == 0; the same values clx_maxpool_fwd(out, 1, 2, 2) writes. */
+  float* pool_out;
+  int ld_pool;
 } clx_conv_desc;
 
 enum clx_conv_algo {

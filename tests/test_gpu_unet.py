@@ -225,6 +225,33 @@ def test_infer_mode_matches_oracle(device):
     assert (got2 - ref2).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("name", ["2d_chain64", "3d_chain64"])
+def test_pooling_written_by_the_winograd_output_transform_equals_the_pooling_pass(name, device, monkeypatch):
+    """2-D levels whose last convolution runs as Winograd write the 2 x 2 max-pooled tensor from that layer's output
+    transform (clx_conv_desc.pool_out: a pooling window lies inside one output tile) instead of a separate pass over
+    the tensor: same values bit for bit — the pooled buffer, the network output, and the gradients' agreement with the
+    oracle (test_backward_matches_oracle runs on this default).  3-D pools across z planes: never fused."""
+    _oracle, model, raw = _make(name, device, seed=4)
+    x = raw.to(device)
+    with torch.no_grad():
+        fused = model(x).clone()
+    plan = next(iter(model._plans.values()))
+    if name.startswith("3d"):
+        assert not plan.fused_pool
+        return
+    assert len(plan.fused_pool) == 1
+    pooled = {p.out: plan.buf[p.out].clone() for p in plan.fused_pool.values()}
+    monkeypatch.setenv("CLX_FUSED_POOL", "0")
+    model._plans = {}
+    with torch.no_grad():
+        plain = model(x).clone()
+    plan2 = next(iter(model._plans.values()))
+    assert not plan2.fused_pool
+    assert torch.equal(fused, plain)
+    for k, v in pooled.items():
+        assert torch.equal(v, plan2.buf[k]), k
+
+
 @pytest.mark.parametrize("name", ["2d_wide", "3d_small"])
 def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, monkeypatch):
     """infer_on_device runs the noisy copies in chunks of max_infer_batch; with two or more whole chunks they alternate
