@@ -30,4 +30,11 @@ cp $R/pmc_lds_conflicts_f32x3bf16.txt profiles/${P}_pmc_lds_conflicts_f32x3bf16.
 [ -f $R/overlap_train2d.txt ] && cp $R/overlap_train2d.txt profiles/${P}_two_streams_overlap_train2d.txt
 [ -f $R/overlap_train3d.txt ] && cp $R/overlap_train3d.txt profiles/${P}_two_streams_overlap_train3d.txt
 [ -f $R/bench_deterministic.json ] && cp $R/bench_deterministic.json profiles/${P}_bench_deterministic.json
+
+[ -f $R/infer_kernel_stats.csv ] && cp $R/infer_kernel_stats.csv profiles/${P}_infer_kernel_stats.csv
+[ -f $R/infer_tile_kernels.txt ] && cp $R/infer_tile_kernels.txt profiles/${P}_infer_tile_kernels.txt
+[ -f $R/hbm_traffic_infer.json ] && cp $R/hbm_traffic_infer.json profiles/hbm_traffic_infer.json
+[ -f $R/hbm_traffic_infer.txt ] && cp $R/hbm_traffic_infer.txt profiles/${P}_hbm_traffic_infer.txt
+[ -f $R/pmc_infer_kernels.txt ] && cp $R/pmc_infer_kernels.txt profiles/${P}_pmc_infer_kernels.txt
+
 true

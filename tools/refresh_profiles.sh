@@ -72,3 +72,7 @@ unset CLX_STREAMS
 CLX_DETERMINISTIC=1 python bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-train-e2e > $O/bench_deterministic.json 2>/dev/null
 ls -la $O
 echo refresh done
+# the inference tile (one stream: every kernel alone): kernel statistics, per-kernel table of one tile, HBM traffic, matrix-pipe busy
+bash tools/infer_profile.sh > $O/infer_profile.log 2>&1
+cp gpurun_out/infer_prof/* $O/ 2>/dev/null
+echo refresh complete
