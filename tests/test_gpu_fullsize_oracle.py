@@ -431,3 +431,44 @@ def test_cfg5_infer_512_at_256_feature_maps_end_to_end_against_the_oracle_pipeli
     # (one draw each of a high-variance quantity — a moved mode changes a whole instance: measured 0.124
     # for the HIP run against 0.070 for the perturbed oracle)
     assert (1 - agree) < 3 * (1 - agree_self) + 0.01, (agree, agree_self)
+
+
+def test_benchmark_step_batch_8_on_two_streams_matches_the_oracle_step(device):
+    """The step `bench.py` times — cfg-2, batch 8, run as two half batches on two HIP streams (plan.DualPlan, the default
+    at this size) — against the oracle's train step (cellulus/train.py:160-180 restated on the CPU) on the same batch
+    and weights: the loss (a sum over the 1.2 M pairs of the batch) to 1e-6 relative, every parameter's gradient close to
+    the float32 CPU path's (free-running: a handful of the 1e9 ReLU decisions of a batch differ between any two float32
+    implementations, which moves gradients by ~1e-3 relative — the bar is 1e-2, far below what a lost half batch, a
+    missing bucket or a double count would show), and the updated parameters within one Adam step's reach."""
+    import bench
+    from cellulus_amd.models.plan import DualPlan
+    from cellulus_amd.train import train_iteration
+
+    model, crit, opt, batch = bench.build_step_inputs("train2d", 0, device, broadcast=False)
+    oracle = O.OracleUNetModel(**CFG2)
+    oracle.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=True)
+    before = [p.detach().cpu().clone() for p in model.parameters()]
+    ref_opt = torch.optim.Adam(oracle.parameters(), lr=4e-5, weight_decay=0.01)
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    raw, anchor, reference = (t.cpu() for t in batch)
+    l_ref, o_ref, _off = O.train_step(oracle, ref_opt, raw, anchor, reference, 10.0, 1e-5)
+    torch.set_num_threads(threads_before)
+    loss, oce, _offsets = train_iteration(batch, model, crit, opt, device)
+    assert isinstance(next(iter(model._plans.values())), DualPlan), "the benchmark step runs on two streams"
+    assert abs(loss - l_ref) <= 1e-6 * abs(l_ref) and abs(oce - o_ref) <= 1e-6 * abs(o_ref), (loss, l_ref)
+    worst, worst_name = 0.0, ""
+    flat = model._flat_grad.detach().cpu()
+    off = 0
+    for (n, po), p0, pm in zip(oracle.named_parameters(), before, model.parameters()):
+        g = flat[off:off + po.numel()].view(po.shape)
+        off += po.numel()
+        rel = ((g - po.grad).norm() / (po.grad.norm() + 1e-30)).item()
+        if rel > worst:
+            worst, worst_name = rel, n
+        # one Adam step moves an element by at most lr (+ weight decay): both ends started from the same weights
+        assert (pm.detach().cpu() - po.detach()).abs().max().item() <= 2.1 * 4e-5, n
+        assert not torch.equal(pm.detach().cpu(), p0), n
+    print(f"cfg-2 batch 8, two streams: loss {loss:.3f} (oracle {l_ref:.3f}); worst relative L2 distance of a parameter "
+          f"gradient from the float32 CPU oracle's: {worst:.2e} ({worst_name})")
+    assert worst < 1e-2, (worst_name, worst)
