@@ -325,6 +325,32 @@ __global__ __launch_bounds__(256) void gs_bits_kernel(const int* __restrict__ se
   }
 }
 
+// The same with 16-byte loads (row length a multiple of 4, aligned image): a wavefront takes 256 pixels of a row = four
+// words; a lane's four pixels are one nibble, sixteen lanes' nibbles one word (OR over xor-shuffles).  One 4-byte load
+// per lane ran at 2.3 TB/s (round 4: 119 us at 8192^2 for 268 MB).
+typedef int gs_i32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gs_bits4_kernel(const int* __restrict__ seg, unsigned long long* __restrict__ bits,
+                                                       int Y, int X, int W64) {
+  const int lane = threadIdx.x & 63;
+  const int G4 = (W64 + 3) >> 2;
+  const long long nwaves = (long long)Y * G4;
+  for (long long w = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < nwaves;
+       w += ((long long)gridDim.x * blockDim.x) >> 6) {
+    const int y = (int)(w / G4), wg = (int)(w - (long long)y * G4);
+    const int x = wg * 256 + 4 * lane;
+    gs_i32x4 v = {0, 0, 0, 0};
+    if (x < X) v = *reinterpret_cast<const gs_i32x4*>(seg + (long long)y * X + x);       // X % 4 == 0: x + 3 < X
+    const unsigned int nib = (v[0] != 0 ? 1u : 0u) | (v[1] != 0 ? 2u : 0u) | (v[2] != 0 ? 4u : 0u) | (v[3] != 0 ? 8u : 0u);
+    unsigned long long word = (unsigned long long)nib << (4 * (lane & 15));
+    word |= __shfl_xor(word, 1, 64);
+    word |= __shfl_xor(word, 2, 64);
+    word |= __shfl_xor(word, 4, 64);
+    word |= __shfl_xor(word, 8, 64);
+    const int wi = wg * 4 + (lane >> 4);
+    if ((lane & 15) == 0 && wi < W64) bits[(long long)y * W64 + wi] = word;
+  }
+}
+
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
   const int lo = __shfl((int)(unsigned int)v, src, 64), hi = __shfl((int)(unsigned int)(v >> 32), src, 64);
   return ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
@@ -426,7 +452,10 @@ int grow_shrink_bitrows(int* seg, int Y, int X, int grow, int shrink, void* work
   unsigned long long* bits = (unsigned long long*)((unsigned char*)workspace + 16);
   if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return CLX_ERR_LAUNCH;
   const long long w1 = (long long)Y * W64, w2 = (long long)ntiles_y * W64;
-  CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, gs_bits_kernel, dim3(grid_for(w1 * 64, 256)), dim3(256), 0, st, seg, bits, Y, X, W64);
+  if (X % 4 == 0 && ((uintptr_t)seg & 15) == 0)
+    CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, gs_bits4_kernel, dim3(grid_for((long long)Y * ((W64 + 3) / 4) * 64, 256)), dim3(256), 0, st, seg, bits, Y, X, W64);
+  else
+    CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, gs_bits_kernel, dim3(grid_for(w1 * 64, 256)), dim3(256), 0, st, seg, bits, Y, X, W64);
   CLX_LAUNCH_KIND(CLX_PROF_GROW_SHRINK, gs_rows_kernel, dim3(grid_for(w2 * 64, 256)), dim3(256), 0, st, seg, bits, Y, X, W64, grow, shrink, rows_per_wave, ntiles_y,
                                                          flag);
   const long long npix = (long long)Y * X;
