@@ -1147,9 +1147,10 @@ class UNetPlan:
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward
-    def forward(self, raw, params, out=None):
+    def forward(self, raw, params, out=None, on_op=None):
         """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial), written into `out`
-        (contiguous, that shape) when given."""
+        (contiguous, that shape) when given.  on_op(i): called after the launches of the i-th operation of the forward
+        order are enqueued (a second stream can be started behind a chosen point of this one)."""
         t = self.topo
         st = _clx.stream_ptr(self.device)
         self._vcache_fresh = set()      # Winograd layers whose V this forward left in self.vcache
@@ -1157,7 +1158,9 @@ class UNetPlan:
         raw = raw.contiguous()
         _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
                   t.in_channels, npix_in, pad4(t.in_channels), st)
-        for op in t.fwd_order:
+        for op_index, op in enumerate(t.fwd_order):
+            if on_op is not None and op_index > 0:
+                on_op(op_index - 1)
             if isinstance(op, ConvLayer) and op.name in self.chain_second:
                 continue                                    # computed with its predecessor
             if isinstance(op, ConvLayer) and op.name in self.chains:
@@ -1484,6 +1487,8 @@ class DualPlan:
         h = self.B // 2
         main = self._fork()
         douts = []
+        # (starting the second half behind operation 0 .. 8 of the first — which gains 1.5-3 % on the inference chunks,
+        #  models/unet.py — LOSES 0.3-3 % here, round 4: the step ends at a join and the delay is not recovered)
         for i, (p, s) in enumerate(zip(self.parts, self.streams)):
             with torch.cuda.stream(s):
                 o = p.forward(raw[i * h:(i + 1) * h], params, out=out[i * h:(i + 1) * h])

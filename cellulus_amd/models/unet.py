@@ -348,8 +348,8 @@ class UNetModel(nn.Module):  # type: ignore
         100) and room for a second set of activations, the chunks alternate between two plans on two streams that share one
         set of packed weights: the HBM-bound Winograd transforms of one chunk run under the GEMMs of the other, as in
         plan.DualPlan.  Same kernels on the same rows: bit-identical to the plain loop (tests/test_gpu_unet.py).  Measured at
-        the benchmark tile (8 copies of 528 x 528 per chunk): embedding stage 201.4 -> 193.8 ms (round 4, after the batched
-        Winograd products of such a chunk got the clamped-row staging path; 204 -> 198 before).  CLX_INFER_STREAMS=1: the
+        the benchmark tile (8 copies of 528 x 528 per chunk): embedding stage 199.7 -> 189.5 ms (round 4, with the second
+        stream started behind the first chunk's second layer; 204 -> 198 in round 3's form).  CLX_INFER_STREAMS=1: the
         plain loop."""
         T = noisy.shape[0]
         nstreams = min(int(os.environ.get("CLX_INFER_STREAMS", "2") or 2), 4, T // max(step, 1))
@@ -392,9 +392,24 @@ class UNetModel(nn.Module):  # type: ignore
         main = torch.cuda.current_stream(noisy.device)
         for s in streams:
             s.wait_stream(main)
+        # the second stream starts BEHIND the first chunk's second layer (operation 1 of the forward order): two streams
+        # that run the same launch sequence from the same instant stay in phase — transforms beside transforms, GEMMs beside
+        # GEMMs — and overlap little; out of phase, one stream's HBM-bound transforms fall under the other's GEMMs.
+        # Measured at the benchmark tile (ms per tile, two runs): no offset 192.7 / 196.2; behind operation 0: 200.0 /
+        # 192.9; 1: 189.1 / 189.9; 2: 192.2 / 193.0; 3: 191.1 / 192.0; 4-8: 191.5-199.6.  CLX_INFER_OFFSET_OP=-1: none
+        offset_op = int(os.environ.get("CLX_INFER_OFFSET_OP", "1"))
+        started = torch.cuda.Event() if offset_op >= 0 and nstreams == 2 else None
+
+        def mark(k):
+            if k == offset_op:
+                started.record(streams[0])
+
         for j, i in enumerate(range(0, T, step)):
             with torch.cuda.stream(streams[j % nstreams]):
-                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step])
+                if started is not None and j == 1:
+                    streams[1].wait_event(started)
+                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step],
+                                            on_op=mark if (started is not None and j == 0) else None)
         for s in streams:
             main.wait_stream(s)
         return preds

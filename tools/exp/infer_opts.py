@@ -15,9 +15,10 @@ for _n, layer in model.named_modules():
 model.eval()
 model.set_infer(p_salt_pepper=0.01, num_infer_iterations=16, device=dev)
 ref = None
-for rep in range(3):
-  for streams in ("1", "2", "4"):
+for rep in range(2):
+  for streams, off in (("1", "-1"), ("2", "-1"), ("2", "0"), ("2", "1"), ("2", "2"), ("2", "3"), ("2", "4"), ("2", "5"), ("2", "6"), ("2", "8")):
     for mb in (8,):
+        os.environ["CLX_INFER_OFFSET_OP"] = off
         os.environ["CLX_INFER_STREAMS"] = streams
         model.max_infer_batch = mb
         model._plans = {}
@@ -26,5 +27,5 @@ for rep in range(3):
         t, emb, prof = embed_stage(model, dev, 512, 16, 3)
         if ref is None:
             ref = emb.clone()
-        print(f"streams {streams} chunk {mb:2d}: {t * 1e3:8.2f} ms/tile  identical to the first: {torch.equal(ref, emb)}  "
+        print(f"streams {streams} offset-op {off:>2s} chunk {mb:2d}: {t * 1e3:8.2f} ms/tile  identical to the first: {torch.equal(ref, emb)}  "
               f"mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GB", flush=True)
