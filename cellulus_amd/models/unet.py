@@ -398,18 +398,18 @@ class UNetModel(nn.Module):  # type: ignore
         # Measured at the benchmark tile (ms per tile, two runs): no offset 192.7 / 196.2; behind operation 0: 200.0 /
         # 192.9; 1: 189.1 / 189.9; 2: 192.2 / 193.0; 3: 191.1 / 192.0; 4-8: 191.5-199.6.  CLX_INFER_OFFSET_OP=-1: none
         offset_op = int(os.environ.get("CLX_INFER_OFFSET_OP", "1"))
-        started = torch.cuda.Event() if offset_op >= 0 and nstreams == 2 else None
-
-        def mark(k):
-            if k == offset_op:
-                started.record(streams[0])
+        # (with more than two streams: each behind its predecessor)
+        started = [torch.cuda.Event() for _ in range(nstreams - 1)] if offset_op >= 0 else None
 
         for j, i in enumerate(range(0, T, step)):
             with torch.cuda.stream(streams[j % nstreams]):
-                if started is not None and j == 1:
-                    streams[1].wait_event(started)
-                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step],
-                                            on_op=mark if (started is not None and j == 0) else None)
+                on_op = None
+                if started is not None and j < nstreams:
+                    if j > 0:
+                        streams[j].wait_event(started[j - 1])
+                    if j < nstreams - 1:
+                        on_op = (lambda k, j=j: started[j].record(streams[j]) if k == offset_op else None)
+                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step], on_op=on_op)
         for s in streams:
             main.wait_stream(s)
         return preds
