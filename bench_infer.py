@@ -396,7 +396,6 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
             torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
     model.eval()
     model.set_infer(p_salt_pepper=0.01, num_infer_iterations=n_it, device=device)
-    model.max_infer_batch = 8
     # the metric string names 2-D 256^2 for inference too: the same pipeline on one 272^2 tile, first (its plan is
     # dropped when the 528^2 one is built)
     # `value` is timed with the product's default (the chunks of noisy copies alternate between two plans on two streams
@@ -437,7 +436,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     plan = next(iter(model._plans.values()))
     fwd_flops, _, _ = conv_flops(plan.topo, 1)
 
-    def roofline_of(prof, t_embed_tile, t_value_pass, nstreams):
+    def roofline_of(prof, t_embed_tile, t_value_pass, nstreams, plan_batch):
         dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         # (the opt-in precision prices its kernel against bf16 MFMA / 6)
@@ -448,7 +447,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1),
                     unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                     launches_per_tile=int(round(launches)), avg_launch_ms=round(ms / max(launches, 1), 4),
-                    forwards_per_launch=model.max_infer_batch,
+                    forwards_per_launch=int(plan_batch),
                     share_of_embed_stage=round(ms * 1e-3 / t_embed_tile, 4),
                     step_mfma_frac=round(mfma_fl / t_embed_tile / 1e12 / peak, 4),
                     all_mfma_kernels=dict(tflops=round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else 0.0,
@@ -476,13 +475,13 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
-        "roofline": roofline_of(prof, t_one, t_embed, streams),
+        "roofline": roofline_of(prof, t_one, t_embed, streams, model.infer_chunk(2 * n_it, (size + 16, size + 16))),
         "at_256": {
             "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 256x256 (one 272^2 tile), 1 GPU",
             "value": round(256 * 256 / total_s / 1e6, 4), "unit": "Mpixels/s",
             "stage_ms": {"embed": round(t_embed_s * 1e3, 2), "detect": round(t_detect_s * 1e3, 3),
                          "segment": round(t_segment_s * 1e3, 3)},
-            "roofline": roofline_of(prof_s, t_one_s, t_embed_s, streams_s),
+            "roofline": roofline_of(prof_s, t_one_s, t_embed_s, streams_s, model.infer_chunk(2 * n_it, (272, 272))),
             "objects": int(ncomp_s.item()), "clusters": int(len(centers_s))},
         "meanshift_rp1": {"ms": round(t_full * 1e3, 2), "seeds": nfg, "clusters": int(len(centers_full))},
         "objects": int(ncomp.item()),

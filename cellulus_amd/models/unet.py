@@ -222,7 +222,7 @@ class UNetModel(nn.Module):  # type: ignore
         self._flat = None
         self._flat_grad = None
         self._weights_epoch = 0
-        self.max_infer_batch = 8
+        self.max_infer_batch = None        # copies per forward of the infer-mode noise loop; None: by tile size (infer_chunk)
 
     # ------------------------------------------------------------ plumbing
     def _ordered_params(self):
@@ -458,7 +458,7 @@ class UNetModel(nn.Module):  # type: ignore
                 self._noise_vals_key = key
             vals = self._noise_vals.view((T,) + (1,) * (raw_sample.ndim - 1))
             noisy = torch.where(rnd <= self.p_salt_pepper, vals, raw_sample.expand_as(rnd))
-            step = max(1, min(T, int(self.max_infer_batch)))
+            step = self.infer_chunk(T, raw_sample.shape[2:])
             preds = self._forward_chunks(noisy, step)
             C = preds.shape[1]
             n = preds[0, 0].numel()
@@ -471,6 +471,25 @@ class UNetModel(nn.Module):  # type: ignore
                           1 if (reset and sample == 0) else 0, st)
             embeddings.append(out)
         return torch.stack(embeddings, dim=0)
+
+    def infer_chunk(self, T, spatial):
+        """Noisy copies per forward of the infer-mode loop (unet.py:75-88 runs them one by one).  ``max_infer_batch`` if
+        set; else as many as give the chunk the pixel count of eight 528^2 tiles (2.2 M input pixels: every launch fills
+        the device and the batched Winograd operands stay inside 32-bit offsets), a divisor of T: 8 copies of a 528^2 tile, 16
+        of a 272^2 one (two chunks for the two streams), all of them for small tiles."""
+        if self.max_infer_batch is not None:
+            return max(1, min(T, int(self.max_infer_batch)))
+        npix = 1
+        for s in spatial:
+            npix *= int(s)
+        want = max(1, (8 * 528 * 528) // max(npix, 1))
+        if want >= T:
+            return T                   # small tiles: all copies in one forward
+        best = 1
+        for step in range(1, T + 1):
+            if T % step == 0 and step <= want:
+                best = step
+        return best
 
     def set_infer(self, p_salt_pepper, num_infer_iterations, device):
         self.mode = "infer"

@@ -44,7 +44,6 @@ for _n, layer in model.named_modules():
         torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
 model.eval()
 model.set_infer(p_salt_pepper=0.01, num_infer_iterations=16, device=dev)
-model.max_infer_batch = 8
 raw = torch.rand(1, 1, 528, 528, device=dev)
 noise = torch.rand(1, 32, 1, 528, 528, device=dev)
 for _ in range(4):
