@@ -296,10 +296,22 @@ __global__ __launch_bounds__(1024) void cc_scan_counts(int* __restrict__ counts,
   // totals by the first wave — two block barriers (the 1024-wide Hillis-Steele scan it replaces had twenty)
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int per = (nblocks + 1023) / 1024;
-  const int lo = tid * per, hi = min(lo + per, nblocks);
+  // (runs of a multiple of four entries: a thread's run is read and written in 16-byte groups, all loads in flight
+  //  at once — eight dependent 4-byte round trips each way were 8 us for 8192 entries)
+  const int per = ((nblocks + 1023) / 1024 + 3) & ~3;
+  const int lo = min(tid * per, nblocks), hi = min(lo + per, nblocks);
+  const bool wide = (((uintptr_t)counts) & 15) == 0 && hi - lo == per && per <= 16;
+  int4 q[4] = {};
   int s = 0;
-  for (int i = lo; i < hi; ++i) s += counts[i];
+  if (wide) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (g * 4 < per) q[g] = *reinterpret_cast<const int4*>(counts + lo + g * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s += q[g].x + q[g].y + q[g].z + q[g].w;
+  } else {
+    for (int i = lo; i < hi; ++i) s += counts[i];
+  }
   int incl = s;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -319,10 +331,23 @@ __global__ __launch_bounds__(1024) void cc_scan_counts(int* __restrict__ counts,
   }
   __syncthreads();
   int run = incl - s + (wid ? wsum[wid - 1] : 0);
-  for (int i = lo; i < hi; ++i) {
-    const int c = counts[i];
-    counts[i] = run;
-    run += c;
+  if (wide) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if (g * 4 < per) {
+        int4 o;
+        o.x = run; run += q[g].x;
+        o.y = run; run += q[g].y;
+        o.z = run; run += q[g].z;
+        o.w = run; run += q[g].w;
+        *reinterpret_cast<int4*>(counts + lo + g * 4) = o;
+      }
+  } else {
+    for (int i = lo; i < hi; ++i) {
+      const int c = counts[i];
+      counts[i] = run;
+      run += c;
+    }
   }
   if (tid == 1023 && total_out) *total_out = wsum[15];
 }
@@ -374,17 +399,28 @@ __global__ void cc_write(const int* __restrict__ seg, const int* __restrict__ L,
 // and never touched again), and everything between the strip pass and the final rewrite works on
 // the (few thousand) strip-local LABELS instead of on pixels:
 //   1. cc_strip1   seg -> out (label + 1 | 0); every run adds its length to its provisional label's
-//                  size; the labels a row creates are recorded as one 64-bit mask per (row, segment)
-//   2. cc_link1    unions across strip / segment borders
+//                  size; per (row, segment) one 64-bit mask of the labels the row creates and one of its
+//                  foreground pixels; rows without foreground take a wave-uniform branch around the lane work
+//   2. cc_link1    unions across strip / segment borders, one per pair of touching runs
 //   3. cc_fold     per label: root = find(label); size[root] += size[label]; out[label] = root + 1
-//   4. cc_mark     per label: surviving roots set their bit in a pixel bitmap + count per chunk (>= 2048 pixels)
-//   5. cc_scan_counts over the (<= 8192) chunks
-//   6. cc_rank     per label: id of its root = roots before it in raster order (chunk prefix + popcounts of
-//                  the chunk's bitmap words) + 1, 0 if removed; stored in size[label]
-//   7. cc_rewrite  out[i] = out[i] ? size[out[i] - 1] : 0, in place, 16 bytes per lane, untouched quads not written
-// Bytes per pixel: 4 read + 4 written (1), 4 read + 4 written at foreground pixels only (7); passes 2-6
-// touch borders and labels (3-6: a few microseconds each).  Round 2 read or wrote every pixel nine times
+//   4. cc_mark     per label: surviving roots set their bit in a pixel bitmap
+//   5. cc_word_prefix  survivors in front of each 32-pixel bitmap word inside its chunk (>= 2048 pixels) + per chunk
+//   6. cc_scan_counts over the (<= 8192) chunks
+//   7. cc_rank     per label: id of its root = chunk prefix + word prefix + popcount inside the word + 1, 0 if
+//                  removed; stored in size[label]
+//   8. cc_rewrite_masked  out[i] = out[i] ? size[out[i] - 1] : 0, in place, 16 bytes per lane; groups without
+//                  foreground (by the masks of pass 1) are neither read nor written
+// Bytes per pixel: 4 read + 4 written (1), 4 read + 4 written at foreground groups only (8); passes 2-7
+// touch borders and labels (a few microseconds each).  Round 2 read or wrote every pixel nine times
 // (36 B per pixel).
+// Round 4, measured at 4096^2 (PMC: profiles/r04_cc_pmc.txt): pass 1 is bound by instruction ISSUE, not by bytes — its
+// access pattern alone (load a row, store it) runs in 23 us, the pass in 48: 71 vector + 45 scalar instructions per
+// row of 64 pixels, one instruction per wavefront per four cycles, 256 rows per SIMD.  A tile form of the pass (all
+// rows of a 16- or 32-row tile loaded at once, runs linked through a union-find in LDS, one size store per root
+// instead of an atomic per run) was written and measured: the same instruction count per row, lower occupancy
+// (LDS + 130 registers), 63 / 89 us — dropped.  What did pay: run-based border links (cc_link1 43 -> 10 us: a
+// 26-pixel-wide object crossing a border cost 78 unions for one useful link), word prefixes for the ranks
+// (cc_rank 17 -> 5 + 4.6 us), 16-byte accesses in the scan (8 -> 4.4 us).
 // ---------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ int uf1_find(const int* L, int a) {
@@ -426,7 +462,8 @@ __device__ __forceinline__ int wave_shr1(int x, int fill) { return __builtin_amd
 __device__ __forceinline__ int wave_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }
 
 __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, int* L, int* size,
-                                                 unsigned long long* __restrict__ labelmask, int* __restrict__ colL,
+                                                 unsigned long long* __restrict__ labelmask,
+                                                 unsigned long long* __restrict__ fgmask, int* __restrict__ colL,
                                                  int* __restrict__ colR, int Y, int X, int nseg, int nstrips) {
   __shared__ int runlab[4][64];
   const int lane = threadIdx.x & 63;
@@ -455,6 +492,22 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
         if (y >= y1) break;
         const long long i = (long long)y * X + x;
         const int v = vv[k];
+        // The pass is bound by instruction issue (a SIMD issues one wavefront instruction per four cycles, 256 rows
+        // of 64 pixels per SIMD at 4096^2: a hundred instructions per row are 43 us), and half the rows of a cell
+        // image hold no foreground in a 64-pixel segment: those take this wave-uniform branch.
+        const unsigned long long fgrow = __ballot(v != 0);
+        if (lane == 0) fgmask[(long long)y * nseg + sg] = fgrow;
+        if (fgrow == 0ull) {
+          if (in_x) L[i] = 0;
+          if (lane == 0) labelmask[(long long)y * nseg + sg] = 0ull;
+          if (colL != nullptr) {
+            if (lane == 0) colL[(long long)sg * Y + y] = 0;
+            if (lane == 63) colR[(long long)sg * Y + y] = 0;
+          }
+          pv = 0;
+          pl = -1;
+          continue;
+        }
         // runs of equal non-zero values inside the segment (background lanes: runs of their own)
         // (every DPP move is issued with all lanes active, before any lane-dependent condition: a move under a
         //  partial EXEC mask treats the inactive source lanes as out of range)
@@ -517,45 +570,53 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
 }
 
 __global__ void cc_link1(const int* __restrict__ seg, int* L, const int* __restrict__ colL,
-                         const int* __restrict__ colR, int Y, int X, int nseg, int nstrips,
+                         const int* __restrict__ colR, int Y, int X, int nseg, int nstrips, int strip_rows,
                          unsigned int* __restrict__ zero, long long nzero) {
   // (also clears the survivor bitmap and the chunk counters of the later label passes: a fill beside this
   //  latency-bound pass instead of a launch of its own)
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nzero; k += (long long)gridDim.x * blockDim.x)
     zero[k] = 0u;
+  // One link per pair of touching runs, as inside the tiles (a 26-pixel-wide object crossing a border used to cost
+  // 78 unions — three per pixel, each a chain of dependent global accesses — for one useful link): the pixel straight
+  // across links unless the previous pixel of the border run already did; a diagonal pixel links only where neither
+  // the pixel straight across nor the neighbour along the border covers it.
   const long long n_rows = (long long)(nstrips - 1) * X;
   const long long n_cols = (long long)(nseg - 1) * Y;
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n_rows + n_cols;
        k += (long long)gridDim.x * blockDim.x) {
     if (k < n_rows) {
-      const int y = (int)(k / X + 1) * STRIP_ROWS, x = (int)(k % X);
+      const int y = (int)(k / X + 1) * strip_rows, x = (int)(k % X);
       const long long i = (long long)y * X + x;
       const int v = seg[i];
       if (v == 0) continue;
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = x + dx;
-        if (xx < 0 || xx >= X) continue;
-        const long long j = i - X + dx;
-        if (seg[j] == v) uf1_union(L, (int)i, (int)j);
-      }
+      const long long j = i - X;
+      // (left / right: the neighbour along the border IN THE SAME TILE — a link is left to a neighbour only if the
+      //  tile pass has joined this pixel to it)
+      const bool left = (x & 63) != 0 && seg[i - 1] == v, right = ((x + 1) & 63) != 0 && x + 1 < X && seg[i + 1] == v;
+      const bool a = x > 0 && seg[j - 1] == v, b = seg[j] == v, c = x + 1 < X && seg[j + 1] == v;
+      if (b && !(left && a)) uf1_union(L, (int)i, (int)j);
+      if (a && !b && !left) uf1_union(L, (int)i, (int)(j - 1));
+      if (c && !b && !right) uf1_union(L, (int)i, (int)(j + 1));
     } else {
       const long long kk = k - n_rows;
-      const int b = (int)(kk / Y + 1), x = b * 64, y = (int)(kk % Y);
+      const int sb = (int)(kk / Y + 1), x = sb * 64, y = (int)(kk % Y);
       const long long i = (long long)y * X + x;
-      const int v = colL != nullptr ? colL[(long long)b * Y + y] : seg[i];
+      const int* mine = colL != nullptr ? colL + (long long)sb * Y : nullptr;          // this column, contiguous in y
+      const int* other = colR != nullptr ? colR + (long long)(sb - 1) * Y : nullptr;   // the column left of it
+      const int v = mine ? mine[y] : seg[i];
       if (v == 0) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = y + dy;
-        if (yy < 0 || yy >= Y) continue;
-        const long long j = (long long)yy * X + x - 1;
-        const int u = colR != nullptr ? colR[(long long)(b - 1) * Y + yy] : seg[j];
-        if (u == v) uf1_union(L, (int)i, (int)j);
-      }
+      const bool up = y % strip_rows != 0 && (mine ? mine[y - 1] : seg[i - X]) == v;
+      const bool down = (y + 1) % strip_rows != 0 && y + 1 < Y && (mine ? mine[y + 1] : seg[i + X]) == v;
+      const bool a = y > 0 && (other ? other[y - 1] : seg[i - X - 1]) == v;
+      const bool b = (other ? other[y] : seg[i - 1]) == v;
+      const bool c = y + 1 < Y && (other ? other[y + 1] : seg[i + X - 1]) == v;
+      if (b && !(up && a)) uf1_union(L, (int)i, (int)(i - 1));
+      if (a && !b && !up) uf1_union(L, (int)i, (int)(i - X - 1));
+      if (c && !b && !down) uf1_union(L, (int)i, (int)(i + X - 1));
     }
   }
 }
 
-// the label passes: one thread per (row, segment) word of labelmask, one iteration per label in it
 #define CC_FOR_EACH_LABEL(l)                                                                        \
   for (long long wd = (long long)blockIdx.x * blockDim.x + threadIdx.x; wd < nwords;                \
        wd += (long long)gridDim.x * blockDim.x)                                                     \
@@ -581,46 +642,110 @@ __global__ void cc_fold(int* L, int* size, const unsigned long long* __restrict_
 
 __global__ void cc_mark(const int* __restrict__ L, const int* __restrict__ size,
                         const unsigned long long* __restrict__ labelmask, long long nwords, int nseg, int X,
-                        int min_size, unsigned int* bitmap, int* chunk_count, int rank_chunk) {
+                        int min_size, unsigned int* bitmap) {
   CC_FOR_EACH_LABEL(l) {
-    if (L[l] == l + 1 && size[l] >= min_size) {
-      atomicOr(&bitmap[l >> 5], 1u << (l & 31));
-      atomicAdd(&chunk_count[l / rank_chunk], 1);
+    if (L[l] == l + 1 && size[l] >= min_size) atomicOr(&bitmap[l >> 5], 1u << (l & 31));
+  }
+}
+
+// survivors before each 32-pixel word of the bitmap inside its rank chunk + the chunk's total: one wavefront per
+// chunk (cc_rank used to count the words in front of a root one by one: up to 63 loads per label, 17 us)
+__global__ __launch_bounds__(256) void cc_word_prefix(const unsigned int* __restrict__ bitmap, long long nbitwords,
+                                                      int words_per_chunk, int nchunks, int* __restrict__ wprefix,
+                                                      int* __restrict__ chunk_count) {
+  const int lane = threadIdx.x & 63;
+  for (long long c = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; c < nchunks;
+       c += ((long long)gridDim.x * blockDim.x) >> 6) {
+    int running = 0;
+    for (int w0 = 0; w0 < words_per_chunk; w0 += 64) {
+      const long long wd = c * words_per_chunk + w0 + lane;
+      const bool in = w0 + lane < words_per_chunk && wd < nbitwords;
+      const int n = in ? __popc(bitmap[wd]) : 0;
+      int incl = n;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      if (in) wprefix[wd] = running + incl - n;
+      running += __shfl(incl, 63, 64);
     }
+    if (lane == 0) chunk_count[c] = running;
   }
 }
 
 __global__ void cc_rank(const int* __restrict__ L, int* size, const unsigned long long* __restrict__ labelmask,
                         long long nwords, int nseg, int X, const unsigned int* __restrict__ bitmap,
-                        const int* __restrict__ chunk_prefix, int rank_chunk) {
+                        const int* __restrict__ chunk_prefix, const int* __restrict__ wprefix, int rank_chunk) {
   CC_FOR_EACH_LABEL(l) {
     const int r = L[l] - 1;             // cc_fold left the root here
     int id = 0;
     const unsigned int word = bitmap[r >> 5];
-    if ((word >> (r & 31)) & 1u) {
-      const int c = r / rank_chunk;
-      id = chunk_prefix[c] + 1 + __popc(word & ((1u << (r & 31)) - 1u));
-      for (int wd2 = (int)(((long long)c * rank_chunk) >> 5); wd2 < (r >> 5); ++wd2) id += __popc(bitmap[wd2]);
-    }
+    if ((word >> (r & 31)) & 1u)
+      id = chunk_prefix[r / rank_chunk] + wprefix[r >> 5] + __popc(word & ((1u << (r & 31)) - 1u)) + 1;
     size[l] = id;
   }
 }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// the four labels of a 16-byte group through as few look-ups as they need: a group inside an object holds one label
+// (the pass was bound by the texture path — 4 gathers per group, 15 us whether a group was read or skipped)
+__device__ __forceinline__ i32x4 relabel4(i32x4 v, const int* __restrict__ size) {
+  const int first = v[0] ? v[0] : (v[1] ? v[1] : (v[2] ? v[2] : v[3]));
+  const int id = first ? size[first - 1] : 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (v[e] == first) v[e] = v[e] ? id : 0;
+    else if (v[e]) v[e] = size[v[e] - 1];
+  }
+  return v;
+}
+
 __global__ void cc_rewrite(int* out, const int* __restrict__ size, long long npix) {
   const long long nquads = npix >> 2;
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (long long)gridDim.x * blockDim.x) {
     i32x4 v = *reinterpret_cast<const i32x4*>(out + 4 * q);
     if ((v[0] | v[1] | v[2] | v[3]) == 0) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = v[e] ? size[v[e] - 1] : 0;
-    *reinterpret_cast<i32x4*>(out + 4 * q) = v;
+    *reinterpret_cast<i32x4*>(out + 4 * q) = relabel4(v, size);
   }
   if (blockIdx.x == 0 && threadIdx.x < (npix & 3)) {        // the last 1-3 pixels
     const long long i = (nquads << 2) + threadIdx.x;
     const int p = out[i];
     if (p) out[i] = size[p - 1];
+  }
+}
+
+// the same with the foreground masks of the first pass ([row][segment], X % 4 == 0): a 16-byte group of the label
+// image is read only if one of its four pixels is foreground — the background of `out` was final after the first
+// pass.  Block (bx, by): 1024 pixels of RY rows (+ multiples of the grid's rows); a thread's mask words, then its
+// groups, then its look-ups are each in flight together.  (Ablation at 4096^2, 24 % foreground: masks + groups alone
+// 7.8 us — two dependent round trips and the launch —, + stores 12.4, + look-ups 16.1; the unmasked pass 16.9 us but
+// 64 MB instead of 20 MB read.)
+__global__ __launch_bounds__(256) void cc_rewrite_masked(int* out, const int* __restrict__ size,
+                                                         const unsigned long long* __restrict__ fgmask, int Y, int X,
+                                                         int nseg) {
+  constexpr int RY = 8;
+  const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x >= X) return;
+  for (int y0 = blockIdx.y * RY; y0 < Y; y0 += gridDim.y * RY) {
+    bool act[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      const int y = min(y0 + r, Y - 1);
+      act[r] = y0 + r < Y && ((fgmask[(long long)y * nseg + (x >> 6)] >> (x & 63)) & 15ull) != 0ull;
+    }
+    i32x4 v[RY];
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+      v[r] = i32x4{0, 0, 0, 0};
+      if (act[r]) v[r] = *reinterpret_cast<const i32x4*>(out + (long long)(y0 + r) * X + x);
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) v[r] = relabel4(v[r], size);
+#pragma unroll
+    for (int r = 0; r < RY; ++r)
+      if (act[r]) *reinterpret_cast<i32x4*>(out + (long long)(y0 + r) * X + x) = v[r];
   }
 }
 
@@ -637,7 +762,7 @@ extern "C" size_t clx_cc_workspace(long long npix) {
   // the larger of the two layouts: [L | size | block counts] (3-D) and
   // [size | label masks (one 64-bit word per row and 64-pixel segment, <= npix / 32 + 2 Y ints) | bitmap | chunk counts] (2-D)
   const long long nblocks = (npix + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  return (size_t)(3 * npix + npix / 32 + MAX_RANK_CHUNKS + nblocks + 64) * sizeof(int);
+  return (size_t)(3 * npix + npix / 16 + MAX_RANK_CHUNKS + nblocks + 128) * sizeof(int);
 }
 
 extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X, int min_size,
@@ -659,35 +784,44 @@ extern "C" int clx_cc_label_filter(const int* seg, int* out, int Z, int Y, int X
   const int wgrid = grid_for(nwaves * 64, 256);
   static const bool strips = getenv("CLX_CC_STRIPS") == nullptr || atoi(getenv("CLX_CC_STRIPS")) != 0;
   static const bool labels = getenv("CLX_CC_LABELS") == nullptr || atoi(getenv("CLX_CC_LABELS")) != 0;
-  if (Z == 1 && strips && labels && ((uintptr_t)out & 15) == 0) {
-    // label-list path: `out` is the parent array
-    int* sz = (int*)workspace;
-    unsigned long long* labelmask = (unsigned long long*)(sz + npix + (npix & 1));
-    const long long nmask = (long long)Y * nseg;
-    unsigned int* bitmap = (unsigned int*)(labelmask + nmask);
-    const long long nwords = (npix + 31) / 32;
-    // rank chunks: >= 2048 pixels, a multiple of 32, at most MAX_RANK_CHUNKS of them
-    long long rank_chunk = (npix + MAX_RANK_CHUNKS - 1) / MAX_RANK_CHUNKS;
-    rank_chunk = ((rank_chunk < 2048 ? 2048 : rank_chunk) + 31) / 32 * 32;
-    const int nchunks = (int)((npix + rank_chunk - 1) / rank_chunk);
-    int* chunk = (int*)(bitmap + nwords);
-    int* colL = chunk + nchunks;                       // edge columns of the 64-pixel segments, [segment][y]
-    int* colR = colL + (long long)nseg * Y;
-    // (images a few pixels wide and very tall: the buffers do not fit the workspace — the border pass then reads the image)
-    if ((size_t)((unsigned char*)(colR + (long long)nseg * Y) - (unsigned char*)workspace) > clx_cc_workspace(npix))
-      colL = colR = nullptr;
+  // label-list path (2-D): `out` is the parent array.  Workspace: [size | label masks | foreground masks |
+  // survivor bitmap | survivors before each bitmap word | chunk counts | edge columns left, right]
+  static const bool masked = getenv("CLX_CC_MASKED_REWRITE") == nullptr || atoi(getenv("CLX_CC_MASKED_REWRITE")) != 0;
+  const long long nwords = (npix + 31) / 32;
+  // rank chunks: >= 2048 pixels, a multiple of 32, at most MAX_RANK_CHUNKS of them
+  long long rank_chunk = (npix + MAX_RANK_CHUNKS - 1) / MAX_RANK_CHUNKS;
+  rank_chunk = ((rank_chunk < 2048 ? 2048 : rank_chunk) + 31) / 32 * 32;
+  const int nchunks = (int)((npix + rank_chunk - 1) / rank_chunk);
+  const long long nmask = (long long)Y * nseg;
+  int* sz = (int*)workspace;
+  unsigned long long* labelmask = (unsigned long long*)(sz + npix + (npix & 1));
+  unsigned long long* fgmask = labelmask + nmask;
+  unsigned int* bitmap = (unsigned int*)(fgmask + nmask);
+  int* wprefix = (int*)(bitmap + nwords);
+  int* chunk = wprefix + nwords;
+  chunk += (4 - (((uintptr_t)chunk >> 2) & 3)) & 3;                           // 16-byte groups in cc_scan_counts
+  int* colL = chunk + nchunks;                       // edge columns of the 64-pixel segments, [segment][y]
+  int* colR = colL + (long long)nseg * Y;
+  // (images a few pixels wide and very tall: the edge columns do not fit the workspace — the border pass then reads
+  //  the image; if the masks do not fit either — one 64-bit word per row for a handful of pixels — the pixel-list path below)
+  if ((size_t)((unsigned char*)(colR + (long long)nseg * Y) - (unsigned char*)workspace) > clx_cc_workspace(npix))
+    colL = colR = nullptr;
+  const bool fits = (size_t)((unsigned char*)(chunk + nchunks) - (unsigned char*)workspace) <= clx_cc_workspace(npix);
+  if (Z == 1 && strips && labels && fits && ((uintptr_t)out & 15) == 0) {
     const int nstrips = (Y + STRIP_ROWS - 1) / STRIP_ROWS;
-    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_strip1, dim3(grid_for((long long)nstrips * nseg * 64, 256)), dim3(256), 0, st, seg, out, sz, labelmask, colL, colR, Y, X, nseg,
-                                                                             nstrips);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_strip1, dim3(grid_for((long long)nstrips * nseg * 64, 256)), dim3(256), 0, st, seg, out, sz, labelmask, fgmask, colL, colR, Y, X, nseg, nstrips);
     const long long nb = (long long)(nstrips - 1) * X + (long long)(nseg - 1) * Y;
-    const long long nzero = nwords + nchunks;
-    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_link1, dim3(grid_for(nb > nzero ? nb : nzero, 256)), dim3(256), 0, st, seg, out, colL, colR, Y, X, nseg, nstrips, bitmap, nzero);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_link1, dim3(grid_for(nb > nwords ? nb : nwords, 256)), dim3(256), 0, st, seg, out, colL, colR, Y, X, nseg, nstrips, STRIP_ROWS, bitmap, nwords);
     const int lgrid = grid_for(nmask, 256);
     CLX_LAUNCH_KIND(CLX_PROF_CC, cc_fold, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X);
-    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_mark, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X, min_size, bitmap, chunk, (int)rank_chunk);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_mark, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X, min_size, bitmap);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_word_prefix, dim3(grid_for((long long)nchunks * 64, 256)), dim3(256), 0, st, bitmap, nwords, (int)(rank_chunk / 32), nchunks, wprefix, chunk);
     CLX_LAUNCH_KIND(CLX_PROF_CC, cc_scan_counts, dim3(1), dim3(1024), 0, st, chunk, nchunks, ncomp_out);
-    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rank, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X, bitmap, chunk, (int)rank_chunk);
-    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rewrite, dim3(grid_for(npix / 4 + 1, 256)), dim3(256), 0, st, out, sz, npix);
+    CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rank, dim3(lgrid), dim3(256), 0, st, out, sz, labelmask, nmask, nseg, X, bitmap, chunk, wprefix, (int)rank_chunk);
+    if (masked && X % 4 == 0)
+      CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rewrite_masked, dim3((X / 4 + 255) / 256, (Y + 7) / 8 < 32768 ? (Y + 7) / 8 : 32768), dim3(256), 0, st, out, sz, fgmask, Y, X, nseg);
+    else
+      CLX_LAUNCH_KIND(CLX_PROF_CC, cc_rewrite, dim3(grid_for(npix / 4 + 1, 256)), dim3(256), 0, st, out, sz, npix);
     CLX_CHECK_LAUNCH("clx_cc_label_filter");
     return CLX_OK;
   }

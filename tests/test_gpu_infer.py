@@ -111,7 +111,7 @@ def test_label_and_size_filter_bit_exact_vs_skimage_golden(case, device):
     assert size_filter(seg, 0, device=device) is seg                          # misc.py:12-13
 
 
-@pytest.mark.parametrize("shape", [(512, 512), (37, 61), (48, 64, 56), (1, 1), (1, 300)])
+@pytest.mark.parametrize("shape", [(512, 512), (37, 61), (48, 64, 56), (1, 1), (1, 300), (3000, 2), (200, 260)])
 def test_size_filter_matches_oracle_random(shape, device):
     rng = np.random.default_rng(sum(shape))
     seg = (rng.random(shape) < 0.55).astype(np.int32) * rng.integers(1, 4, size=shape).astype(np.int32)
