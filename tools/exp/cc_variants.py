@@ -1,7 +1,7 @@
 """A/B of the connected-component passes at 4096^2 (run one process per variant: the switches are read once).
-    CLX_CC_TILES=0|1  CLX_CC_TILE_ROWS=16|32  CLX_CC_MASKED_REWRITE=0|1  python tools/exp/cc_variants.py
+    CLX_CC_MASKED_REWRITE=0|1  CLX_CC_LABELS=0|1  python tools/exp/cc_variants.py
 Prints the kernels' time per call (libclx's event pairs, kind CLX_PROF_CC; per kernel: run it under rocprofv3 --kernel-trace --stats) and checks the labels against the
-row-walking pass's (computed in a child process with CLX_CC_TILES=0)."""
+pixel-list path's (computed in a child process with CLX_CC_LABELS=0)."""
 import os
 import subprocess
 import sys
@@ -39,15 +39,15 @@ def main():
     from bench_infer import PROF_KIND, _kernel_time
     t_call, t_k, n_k = min((_kernel_time(lambda: label_on_device(seg, 70), PROF_KIND["cc"], reps=5) for _ in range(3)),
                            key=lambda r: r[1])
-    print({k: os.environ.get(k) for k in ("CLX_CC_TILES", "CLX_CC_TILE_ROWS", "CLX_CC_MASKED_REWRITE")},
+    print({k: os.environ.get(k) for k in ("CLX_CC_LABELS", "CLX_CC_MASKED_REWRITE")},
           f"kernels {t_k * 1e6:.1f} us in {n_k:.0f} launches, call {t_call * 1e6:.1f} us,",
           "frac of 8 TB/s", round(n * n * 8 / t_k / 8e12, 3), "ncomp", int(ncomp.item()))
     ref_path = "/tmp/cc_ref_%d.npy" % n
     if not os.path.exists(ref_path):
-        env = dict(os.environ, CLX_CC_TILES="0")
+        env = dict(os.environ, CLX_CC_LABELS="0")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", ref_path], env=env, check=True)
     ref = np.load(ref_path)
-    print("   identical to the row-walking pass:", bool((ref == out.cpu().numpy()).all()))
+    print("   identical to the pixel-list path:", bool((ref == out.cpu().numpy()).all()))
 
 
 if __name__ == "__main__":
