@@ -475,34 +475,38 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
     const int strip = (int)(w / nseg), sg = (int)(w - (long long)strip * nseg);
     const int x = sg * 64 + lane;
     const bool in_x = x < X;
+    const int xc = min(x, X - 1);                           // loads are unconditional (clamped), values masked after
     const int y0 = strip * STRIP_ROWS, y1 = min(y0 + STRIP_ROWS, Y);
     int pv = 0, pl = -1;
     int nx[4];                                              // the next four rows: loaded while the current four are walked
 #pragma unroll
-    for (int k = 0; k < 4; ++k) nx[k] = (in_x && y0 + k < y1) ? seg[(long long)(y0 + k) * X + x] : 0;
+    for (int k = 0; k < 4; ++k) nx[k] = seg[min(y0 + k, Y - 1) * X + xc];      // (npix < 2^31: 32-bit indices)
     for (int yb = y0; yb < y1; yb += 4) {
       int vv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) vv[k] = nx[k];
+      for (int k = 0; k < 4; ++k) vv[k] = (in_x && yb + k < y1) ? nx[k] : 0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) nx[k] = (in_x && yb + 4 + k < y1) ? seg[(long long)(yb + 4 + k) * X + x] : 0;
+      for (int k = 0; k < 4; ++k) nx[k] = seg[min(yb + 4 + k, Y - 1) * X + xc];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int y = yb + k;
         if (y >= y1) break;
-        const long long i = (long long)y * X + x;
+        const int i = y * X + x;
+        const int mrow = y * nseg + sg, crow = sg * Y + y;
         const int v = vv[k];
         // The pass is bound by instruction issue (a SIMD issues one wavefront instruction per four cycles, 256 rows
-        // of 64 pixels per SIMD at 4096^2: a hundred instructions per row are 43 us), and half the rows of a cell
-        // image hold no foreground in a 64-pixel segment: those take this wave-uniform branch.
-        const unsigned long long fgrow = __ballot(v != 0);
-        if (lane == 0) fgmask[(long long)y * nseg + sg] = fgrow;
+        // of 64 pixels per SIMD at 4096^2: a hundred instructions per row are 43 us), and a third to a half of the
+        // rows of a cell image hold no foreground in a 64-pixel segment: those take this wave-uniform branch.
+        const unsigned long long fgrow = __builtin_amdgcn_ballot_w64(v != 0);
         if (fgrow == 0ull) {
           if (in_x) L[i] = 0;
-          if (lane == 0) labelmask[(long long)y * nseg + sg] = 0ull;
+          if (lane == 0) {
+            fgmask[mrow] = 0ull;
+            labelmask[mrow] = 0ull;
+          }
           if (colL != nullptr) {
-            if (lane == 0) colL[(long long)sg * Y + y] = 0;
-            if (lane == 63) colR[(long long)sg * Y + y] = 0;
+            if (lane == 0) colL[crow] = 0;
+            if (lane == 63) colR[crow] = 0;
           }
           pv = 0;
           pl = -1;
@@ -511,11 +515,11 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
         // runs of equal non-zero values inside the segment (background lanes: runs of their own)
         // (every DPP move is issued with all lanes active, before any lane-dependent condition: a move under a
         //  partial EXEC mask treats the inactive source lanes as out of range)
-        const int v_left = wave_shr1(v, 0);
+        const int v_left = wave_shr1(v, 0), v_right = wave_shl1(v, 0);
         const int pv_left = wave_shr1(pv, 0), pl_left = wave_shr1(pl, INF);
         const int pv_right = wave_shl1(pv, 0), pl_right = wave_shl1(pl, INF);
         const bool same_left = v != 0 && v_left == v;
-        const unsigned long long starts = __ballot(!same_left);
+        const unsigned long long starts = __builtin_amdgcn_ballot_w64(!same_left);
         const int sl = 63 - __builtin_clzll(starts & ((2ull << lane) - 1ull));
         // labels of the (up to three) touching pixels of the row above.  If the pixel straight above
         // matches, its two neighbours belong to the same run; otherwise up-left and up-right are two
@@ -530,30 +534,26 @@ __global__ __launch_bounds__(256) void cc_strip1(const int* __restrict__ seg, in
         if (sl == lane) rl[lane] = INF;
         if (cand != INF) atomicMin(&rl[sl], cand);
         const int runmin = rl[sl];
-        const unsigned long long above = (lane == 63) ? 0ull : (starts >> (lane + 1));
-        const int el = above ? lane + __builtin_ctzll(above) : 63;
-        int label = -1;
-        if (v != 0) {
-          const bool fresh = runmin == INF;
-          label = fresh ? (int)(i - lane + sl) : runmin;
-          L[i] = label + 1;
-          if (sl == lane) {                                 // once per run: its length goes to its label
-            const int len = el - lane + 1;
-            if (fresh) atomicExch(&size[label], len);       // creates the label (no zero-filled array needed)
-            else atomicAdd(&size[label], len);
-          }
-        } else if (in_x) {
-          L[i] = 0;
+        const bool fresh = runmin == INF;
+        const int label = v != 0 ? (fresh ? i - lane + sl : runmin) : -1;
+        if (in_x) L[i] = label + 1;
+        if (v != 0 && v_right != v) {                       // once per run, at its last pixel: its length goes to its label
+          const int len = lane - sl + 1;
+          if (fresh) atomicExch(&size[label], len);         // creates the label (no zero-filled array needed)
+          else atomicAdd(&size[label], len);
         }
         // the labels this row created, one 64-bit word per (row, segment): what the label passes iterate over
         // (a single global list would serialise its appends on one counter: 162 us of a 4096^2 image)
-        const unsigned long long created = __ballot(v != 0 && runmin == INF && sl == lane);
-        if (lane == 0) labelmask[(long long)y * nseg + sg] = created;
+        const unsigned long long created = __builtin_amdgcn_ballot_w64(v != 0 && fresh && sl == lane);
+        if (lane == 0) {
+          fgmask[mrow] = fgrow;
+          labelmask[mrow] = created;
+        }
         // the segment's edge columns, transposed (contiguous in y): what the border pass compares instead of
         // column-strided reads of the image (one 4-byte value per 64-byte sector: 0.21 GB at 8192^2)
         if (colL != nullptr) {
-          if (lane == 0) colL[(long long)sg * Y + y] = v;
-          if (lane == 63) colR[(long long)sg * Y + y] = v;
+          if (lane == 0) colL[crow] = v;
+          if (lane == 63) colR[crow] = v;
         }
         const bool j0 = c0 != INF && c0 != label, j1 = c1 != INF && c1 != label, j2 = c2 != INF && c2 != label;
         if (j0 || j1 || j2) {
@@ -576,7 +576,7 @@ __global__ void cc_link1(const int* __restrict__ seg, int* L, const int* __restr
   //  latency-bound pass instead of a launch of its own)
   for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nzero; k += (long long)gridDim.x * blockDim.x)
     zero[k] = 0u;
-  // One link per pair of touching runs, as inside the tiles (a 26-pixel-wide object crossing a border used to cost
+  // One link per pair of touching runs, as inside the strips (a 26-pixel-wide object crossing a border used to cost
   // 78 unions — three per pixel, each a chain of dependent global accesses — for one useful link): the pixel straight
   // across links unless the previous pixel of the border run already did; a diagonal pixel links only where neither
   // the pixel straight across nor the neighbour along the border covers it.
@@ -590,8 +590,8 @@ __global__ void cc_link1(const int* __restrict__ seg, int* L, const int* __restr
       const int v = seg[i];
       if (v == 0) continue;
       const long long j = i - X;
-      // (left / right: the neighbour along the border IN THE SAME TILE — a link is left to a neighbour only if the
-      //  tile pass has joined this pixel to it)
+      // (left / right: the neighbour along the border IN THE SAME 64 x 32 BLOCK of the strip pass — a link is left to a neighbour only if
+      //  that pass has joined this pixel to it)
       const bool left = (x & 63) != 0 && seg[i - 1] == v, right = ((x + 1) & 63) != 0 && x + 1 < X && seg[i + 1] == v;
       const bool a = x > 0 && seg[j - 1] == v, b = seg[j] == v, c = x + 1 < X && seg[j + 1] == v;
       if (b && !(left && a)) uf1_union(L, (int)i, (int)j);
