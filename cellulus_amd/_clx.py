@@ -118,6 +118,11 @@ PROTOTYPES = {
     "clx_subpixel_split_weights": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
     "clx_subpixel_fold_grads": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
     "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "clx_changed_rows_workspace": (c_size_t, [_I, _I, _I, _I]),
+    "clx_changed_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _LL, _P, _P]),
+    "clx_gather_rows": (_I, [_P, _I, _P, _LL, _I, _P, _I, _P]),
+    "clx_scatter_rows": (_I, [_P, _I, _P, _LL, _I, _P, _I, _P]),
+    "clx_broadcast_rows": (_I, [_P, _LL, _P, _I, _P]),
     "clx_maxpool_bwd": (_I, [_P, _P, _P, _P] + [_I] * 7 + [_P] + [_I] * 8 + [_P]),
     "clx_upsample_bwd": (_I, [_P] + [_I] * 8 + [_P, _P] + [_I] * 8 + [_P]),
     "clx_gather_add_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),

@@ -1147,12 +1147,130 @@ class UNetPlan:
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward
-    def forward(self, raw, params, out=None, on_op=None):
-        """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial), written into `out`
-        (contiguous, that shape) when given.  on_op(i): called after the launches of the i-th operation of the forward
-        order are enqueued (a second stream can be started behind a chosen point of this one)."""
+    # ------------------------------------------------- changed rows of noisy copies (csrc/sparse_rows.hip)
+    def pointwise_prefix(self):
+        """(first convolution, [the 1x1 layers straight behind it]) if the forward order starts that way with plain
+        launches — conv_pass.0 (k x k on the image), conv_pass.2, conv_pass.4 (1 x 1) of the first level — else None.
+        These are the layers a noisy copy of an image shares with the clean image outside the window-dilated set of
+        its noise pixels (UNetModel._forward_chunks)."""
+        ops = self.topo.fwd_order
+        if not ops or not isinstance(ops[0], ConvLayer):
+            return None
+        special = lambda op: op.name in self.chains or op.name in self.chain_second or op.name in self.subpixel
+        first = ops[0]
+        if special(first) or len(first.sources) != 1 or first.sources[0].tensor != "raw":
+            return None
+        tail, src = [], first.out
+        for op in ops[1:]:
+            if not isinstance(op, ConvLayer) or op.taps != 1 or special(op) or self.algo[op.name]["fwd"]:
+                break
+            s = op.sources[0]
+            if len(op.sources) != 1 or s.tensor != src or tuple(s.crop) != (0, 0, 0) or tuple(s.factor) != (1, 1, 1):
+                break
+            tail.append(op)
+            src = op.out
+        return (first, tail) if tail else None
+
+    def _compact(self, slot, rows, width):
+        """grow-only scratch for `rows` compact rows of `width` floats"""
+        bufs = self.__dict__.setdefault("_compact_bufs", {})
+        b = bufs.get(slot)
+        if b is None or b.shape[0] < rows or b.shape[1] != width:
+            b = bufs[slot] = torch.empty((max(rows, 1), width), dtype=torch.float32, device=self.device)
+        return b
+
+    def forward_prefix(self, raw, params, nlayers):
+        """the first convolution and the `nlayers` 1x1 layers behind it on `raw` -> the last one's output rows
+        (B * pixels, padded channels), in this plan's buffer"""
         t = self.topo
         st = _clx.stream_ptr(self.device)
+        npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
+        raw = raw.contiguous()
+        _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
+                  t.in_channels, npix_in, pad4(t.in_channels), st)
+        for op in t.fwd_order[:1 + nlayers]:
+            self._conv_forward(op, params, st)
+        return self.buf[t.fwd_order[nlayers].out]
+
+    def _conv_forward(self, op, params, st):
+        """one plain convolution layer of the forward pass"""
+        d = self._desc(op)
+        d.N = op.cout
+        d.wpack = self.wpack_fwd[op.name].data_ptr()
+        b = params[2 * op.param_index + 1]
+        d.bias = b.data_ptr() if b is not None else None
+        d.relu = 1 if op.relu else 0
+        d.mask = None
+        d.ld_mask = 0
+        d.out = self.buf[op.out].data_ptr()
+        d.ld_out = pad4(op.cout)
+        if op.relu and self.keep:
+            self._set_gate_out(d, op.out)
+        if self.algo[op.name]["fwd"]:
+            self._use_workspace(d, self.algo[op.name]["fwd"])
+            if self.keep and self._bwd_ready and op.name in self.vcache:
+                d.vcache = self.vcache[op.name].data_ptr()
+                self._vcache_fresh.add(op.name)
+            pool = self.fused_pool.get(op.name)
+            if pool is not None:
+                d.pool_out = self.buf[pool.out].data_ptr()
+                d.ld_pool = pad4(pool.channels)
+        _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+
+    def _pointwise_on_rows(self, tail, params, sparse, st):
+        """The 1x1 layers `tail` for a chunk of noisy copies: once on the clean image (done by the caller: sparse
+        ["clean_rows"]) and here on the copies' CHANGED rows — gathered from the first convolution's dense output, run
+        through the layers as a (1, 1, n) image, scattered over the broadcast clean rows.  A row of a 1x1 layer depends on
+        its own input row alone, so the tensor is the dense computation's, bit for bit."""
+        n, rows = int(sparse["n"]), sparse["rows"]
+        src = self.buf[tail[0].sources[0].tensor]
+        width = src.shape[1]
+        cur = None
+        if n > 0:
+            cur = self._compact(0, n, width)
+            _clx.call("clx_gather_rows", _clx.ptr(src), width, _clx.ptr(rows), n, width, _clx.ptr(cur), width, st)
+            for k, op in enumerate(tail):
+                y = self._compact(1 + k % 2, n, pad4(op.cout))
+                d = ClxConvDesc()
+                d.nsrc = 1
+                src_d = ClxSrc()
+                src_d.ptr = cur.data_ptr()
+                src_d.C = src_d.ld = cur.shape[1]
+                src_d.D, src_d.H, src_d.W = 1, 1, n
+                src_d.oz = src_d.oy = src_d.ox = 0
+                src_d.fz = src_d.fy = src_d.fx = 1
+                d.src[0] = src_d
+                d.B = 1
+                d.ID, d.IH, d.IW = 1, 1, n
+                d.KD = d.KH = d.KW = 1
+                d.PD = d.PH = d.PW = 0
+                d.N = op.cout
+                d.wpack = self.wpack_fwd[op.name].data_ptr()
+                b = params[2 * op.param_index + 1]
+                d.bias = b.data_ptr() if b is not None else None
+                d.relu = 1 if op.relu else 0
+                d.out = y.data_ptr()
+                d.ld_out = y.shape[1]
+                d.precision = self.precision
+                _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+                cur = y
+        dense = self.buf[tail[-1].out]
+        clean = sparse["clean_rows"]
+        assert clean.shape[1] == dense.shape[1] and clean.shape[0] * self.B == dense.shape[0]
+        _clx.call("clx_broadcast_rows", _clx.ptr(clean), clean.numel(), _clx.ptr(dense), self.B, st)
+        if n > 0:
+            _clx.call("clx_scatter_rows", _clx.ptr(cur), cur.shape[1], _clx.ptr(rows), n, dense.shape[1],
+                      _clx.ptr(dense), dense.shape[1], st)
+
+    def forward(self, raw, params, out=None, on_op=None, sparse=None):
+        """raw: (B, C, *spatial) f32 on device -> offsets (B, out_channels, *out_spatial), written into `out`
+        (contiguous, that shape) when given.  on_op(i): called after the launches of the i-th operation of the forward
+        order are enqueued (a second stream can be started behind a chosen point of this one).
+        sparse: {"clean_rows", "rows", "n"} — the batch is noisy copies of ONE image whose pointwise prefix
+        (pointwise_prefix) was computed on the clean image: the 1x1 layers run on the changed rows only."""
+        t = self.topo
+        st = _clx.stream_ptr(self.device)
+        sparse_tail = self.pointwise_prefix()[1] if sparse is not None else None
         self._vcache_fresh = set()      # Winograd layers whose V this forward left in self.vcache
         npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
         raw = raw.contiguous()
@@ -1167,29 +1285,12 @@ class UNetPlan:
                 self._chain_forward(*self.chains[op.name], params, st)
             elif isinstance(op, ConvLayer) and op.name in self.subpixel:
                 self._sp_forward(op, self.subpixel[op.name], params[2 * op.param_index + 1], st)
+            elif isinstance(op, ConvLayer) and sparse_tail and op is sparse_tail[0]:
+                self._pointwise_on_rows(sparse_tail, params, sparse, st)
+            elif isinstance(op, ConvLayer) and sparse_tail and any(op is q for q in sparse_tail):
+                continue                                    # computed with the first 1x1 layer of the prefix
             elif isinstance(op, ConvLayer):
-                d = self._desc(op)
-                d.N = op.cout
-                d.wpack = self.wpack_fwd[op.name].data_ptr()
-                b = params[2 * op.param_index + 1]
-                d.bias = b.data_ptr() if b is not None else None
-                d.relu = 1 if op.relu else 0
-                d.mask = None
-                d.ld_mask = 0
-                d.out = self.buf[op.out].data_ptr()
-                d.ld_out = pad4(op.cout)
-                if op.relu and self.keep:
-                    self._set_gate_out(d, op.out)
-                if self.algo[op.name]["fwd"]:
-                    self._use_workspace(d, self.algo[op.name]["fwd"])
-                    if self.keep and self._bwd_ready and op.name in self.vcache:
-                        d.vcache = self.vcache[op.name].data_ptr()
-                        self._vcache_fresh.add(op.name)
-                    pool = self.fused_pool.get(op.name)
-                    if pool is not None:
-                        d.pool_out = self.buf[pool.out].data_ptr()
-                        d.ld_pool = pad4(pool.channels)
-                _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+                self._conv_forward(op, params, st)
             elif any(p is op for p in self.fused_pool.values()):
                 continue                                    # written by the producing layer's output transform
             else:

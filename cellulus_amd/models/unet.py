@@ -318,6 +318,7 @@ class UNetModel(nn.Module):  # type: ignore
         # .to()/.cuda() re-allocates parameters: forget flat views and plans
         self._plans = {}
         self._infer_pair = None
+        self._clean_plan = None
         self._flat = None
         self._flat_grad = None
         return super()._apply(fn, *args, **kwargs)
@@ -342,8 +343,61 @@ class UNetModel(nn.Module):  # type: ignore
         plan.pack_weights(params, self._param_version(), need_dgrad=False)
         return plan.forward(raw, params)
 
-    def _forward_chunks(self, noisy, step):
+    def _sparse_prepare(self, plan, noisy, clean, step, params):
+        """Noisy copies of ONE image (`clean`, (1, C, *spatial)): per chunk of `step` copies the rows of the first
+        convolution's output that differ from the clean image's, and the clean image's rows behind the 1x1 layers that
+        follow (plan.pointwise_prefix) -> a list of per-chunk dicts for UNetPlan.forward(sparse=...), or None where the
+        dense path is the better one: no such prefix, CLX_SPARSE_NOISE=0, or more than CLX_SPARSE_NOISE_MAX (default
+        0.3) of the rows changed.  One host synchronisation (the row counts size the launches)."""
+        if clean is None or os.environ.get("CLX_SPARSE_NOISE", "1") == "0":
+            return None
+        prefix = plan.pointwise_prefix()
+        if prefix is None:
+            return None
+        first, tail = prefix
+        T = noisy.shape[0]
+        if T % step or T < 2 or tuple(clean.shape[1:]) != tuple(noisy.shape[1:]) or clean.shape[0] != 1:
+            return None
+        npix_out = first.out_shape[0] * first.out_shape[1] * first.out_shape[2]
+        nchunks = T // step
+        cap = max(1, int(float(os.environ.get("CLX_SPARSE_NOISE_MAX", "0.3")) * step * npix_out))
+        dev = noisy.device
+        rows = torch.empty(nchunks * cap, dtype=torch.int32, device=dev)
+        counts = torch.empty(nchunks, dtype=torch.int32, device=dev)
+        noisy = noisy.contiguous()
+        clean = clean.contiguous()
+        st = _clx.stream_ptr(dev)
+        ws = torch.empty(int(_clx.load().clx_changed_rows_workspace(T, *first.in_shape)), dtype=torch.uint8, device=dev)
+        _clx.call("clx_changed_rows", _clx.ptr(clean), _clx.ptr(noisy), T, noisy.shape[1], *first.in_shape,
+                  *first.kernel, step, _clx.ptr(rows), _clx.ptr(counts), cap, _clx.ptr(ws), st)
+        # the counts size the launches: they leave for pinned memory now and the host waits for THAT copy only, after
+        # it has enqueued the clean image's pass (the device works on it meanwhile)
+        host = getattr(self, "_counts_host", None)
+        if host is None or host.numel() < nchunks:
+            host = self._counts_host = torch.empty(max(nchunks, 64), dtype=torch.int32).pin_memory()
+        host[:nchunks].copy_(counts, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
+        # the clean image through the prefix, on a one-image plan that reads the chunk plan's packed weights
+        cp = getattr(self, "_clean_plan", None)
+        if cp is None or cp[0] is not plan:
+            one = UNetPlan(plan.topo, 1, dev, False)
+            assert all(one.algo[op.name] == plan.algo[op.name] for op in [first] + tail)
+            cp = self._clean_plan = (plan, one)
+        one = cp[1]
+        one.wpack_fwd = plan.wpack_fwd
+        clean_rows = one.forward_prefix(clean, params, len(tail))
+        copied.synchronize()
+        n = host[:nchunks].tolist()
+        if max(n) > cap:
+            return None
+        return [dict(clean_rows=clean_rows, rows=rows[j * cap:j * cap + n[j]], n=n[j]) for j in range(nchunks)]
+
+    def _forward_chunks(self, noisy, step, clean=None):
         """The network on `noisy` (T, C, *spatial) in chunks of `step` copies -> (T, out_channels, *out_spatial).
+        clean: the image the copies are noisy versions of, if they are (infer_on_device): the 1x1 layers behind the first
+        convolution then run once on the clean image and on the changed rows of the copies (_sparse_prepare; the same
+        bits, tests/test_gpu_unet.py).
         With two or more whole chunks of a size that fills the device (>= CLX_STREAMS_MIN_GFLOP of forward pass each, default
         100) and room for a second set of activations, the chunks alternate between two plans on two streams that share one
         set of packed weights: the HBM-bound Winograd transforms of one chunk run under the GEMMs of the other, as in
@@ -353,16 +407,23 @@ class UNetModel(nn.Module):  # type: ignore
         plain loop."""
         T = noisy.shape[0]
         nstreams = min(int(os.environ.get("CLX_INFER_STREAMS", "2") or 2), 4, T // max(step, 1))
-        if T % step or nstreams < 2:
+        if T % step:
             preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
             return torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
         first = noisy[:step].contiguous()
         plan = self._plan_for(first, keep=False)
-        if forward_flops(plan.topo, step) < float(os.environ.get("CLX_STREAMS_MIN_GFLOP", "100")) * 1e9:
-            preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
-            return torch.cat(preds, dim=0)
         params = self._ordered_params()
         plan.pack_weights(params, self._param_version(), need_dgrad=False)
+        big = forward_flops(plan.topo, step) >= float(os.environ.get("CLX_STREAMS_MIN_GFLOP", "100")) * 1e9
+        sparse = self._sparse_prepare(plan, noisy, clean, step, params) if big else None
+
+        def plain_loop():
+            preds = [plan.forward(noisy[i:i + step].contiguous(), params, sparse=sparse[j] if sparse else None)
+                     for j, i in enumerate(range(0, T, step))]
+            return torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
+
+        if nstreams < 2 or not big:
+            return plain_loop()
         pair = getattr(self, "_infer_pair", None)
         if pair is not None and pair[0] is plan and len(pair[2]) <= nstreams:
             nstreams = len(pair[2])                      # (built when less memory was free: keep it)
@@ -376,8 +437,7 @@ class UNetModel(nn.Module):  # type: ignore
                 - torch.cuda.memory_allocated(noisy.device)
             nstreams = min(nstreams, 1 + int(free // (1.25 * need)))
             if nstreams < 2:
-                preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
-                return torch.cat(preds, dim=0)
+                return plain_loop()
             self._infer_pair = None
             others = [UNetPlan(plan.topo, step, noisy.device, False) for _ in range(nstreams - 1)]
             pair = self._infer_pair = (plan, others[0], [torch.cuda.Stream(device=noisy.device) for _ in range(nstreams)],
@@ -409,7 +469,8 @@ class UNetModel(nn.Module):  # type: ignore
                         streams[j].wait_event(started[j - 1])
                     if j < nstreams - 1:
                         on_op = (lambda k, j=j: started[j].record(streams[j]) if k == offset_op else None)
-                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step], on_op=on_op)
+                plans[j % nstreams].forward(noisy[i:i + step], params, out=preds[i:i + step], on_op=on_op,
+                                            sparse=sparse[j] if sparse else None)
         for s in streams:
             main.wait_stream(s)
         return preds
@@ -459,7 +520,7 @@ class UNetModel(nn.Module):  # type: ignore
             vals = self._noise_vals.view((T,) + (1,) * (raw_sample.ndim - 1))
             noisy = torch.where(rnd <= self.p_salt_pepper, vals, raw_sample.expand_as(rnd))
             step = self.infer_chunk(T, raw_sample.shape[2:])
-            preds = self._forward_chunks(noisy, step)
+            preds = self._forward_chunks(noisy, step, clean=raw_sample)
             C = preds.shape[1]
             n = preds[0, 0].numel()
             out = torch.empty((C + 1,) + tuple(preds.shape[2:]), dtype=torch.float32, device=raw.device)

@@ -424,6 +424,33 @@ int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
 int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long long n, float* std_minmax,
                            int init, clx_stream stream);
 
+/* The noisy copies of one tile (cellulus/models/unet.py:75-88: 2 * num_infer_iterations forwards of the same image
+ * with salt / pepper noise in p_salt_pepper of its pixels) differ from the clean image only around those pixels.  Behind
+ * the first k x k convolution the changed output pixels are the window-dilated set, and 1 x 1 layers keep it; a row of a
+ * 1 x 1 layer depends on the same row of its input alone, so those layers are computed once on the clean image and
+ * again on the CHANGED rows of each copy — the same bits as the dense computation.  The four calls below move the rows.
+ *
+ * clx_changed_rows: clean (C, ID, IH, IW) and noisy (T, C, ID, IH, IW), planar float32.  An output pixel of a
+ * (KD, KH, KW) valid convolution of copy t is CHANGED if any input value in its window differs from the clean image's.
+ * The copies are taken in chunks of `chunk`; chunk c's changed rows are written to rows[c * cap ...] as
+ * (t - c * chunk) * npix_out + output pixel (any order), their number to counts[c] (which may exceed cap: rows beyond
+ * cap are not written — the caller then takes the dense path).  counts: ceil(T / chunk) ints.
+ * workspace: clx_changed_rows_workspace(T, ID, IH, IW) bytes of scratch (one bit per input pixel and copy), 8-byte
+ * aligned.  KW < 64. */
+size_t clx_changed_rows_workspace(int T, int ID, int IH, int IW);
+int clx_changed_rows(const float* clean, const float* noisy, int T, int C, int ID, int IH, int IW, int KD, int KH,
+                     int KW, int chunk, int* rows, int* counts, long long cap, void* workspace, clx_stream stream);
+/* dst[r][0..width) = src[rows[r]][0..width) for r < n (row strides ld_src / ld_dst floats; width, strides % 4 == 0,
+ * 16-byte aligned bases). */
+int clx_gather_rows(const float* src, int ld_src, const int* rows, long long n, int width, float* dst, int ld_dst,
+                    clx_stream stream);
+/* dst[rows[r]][0..width) = src[r][0..width) for r < n. */
+int clx_scatter_rows(const float* src, int ld_src, const int* rows, long long n, int width, float* dst, int ld_dst,
+                     clx_stream stream);
+/* dst[k][0..nfloats) = src[0..nfloats) for k < copies (nfloats % 4 == 0, 16-byte aligned): the clean image's rows
+ * under every copy, before clx_scatter_rows overwrites the changed ones. */
+int clx_broadcast_rows(const float* src, long long nfloats, float* dst, int copies, clx_stream stream);
+
 /* ------------------------------------------------------------------------ */
 /* Mean-shift clustering (cellulus/utils/mean_shift.py:6-121 ->             */
 /* sklearn.cluster.MeanShift.fit/predict), float64                          */

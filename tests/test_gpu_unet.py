@@ -288,6 +288,108 @@ def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, 
     assert torch.equal(model.infer_on_device(x, noise=noise), one_b)
 
 
+@pytest.mark.parametrize("name", ["2d_wide", "2d_odd_channels", "3d_small", "2d_chain64"])
+def test_noisy_copies_through_changed_rows_equal_the_dense_forward_bit_for_bit(name, device, monkeypatch):
+    """The noisy copies of infer mode (unet.py:73-100) differ from the image in p_salt_pepper of their pixels: the 1x1
+    layers behind the first convolution run once on the clean image and on the CHANGED rows of each copy
+    (UNetModel._sparse_prepare, csrc/sparse_rows.hip).  Same bits as the dense forward (CLX_SPARSE_NOISE=0), on one
+    stream and on two, with one and two input channels, in 2-D and 3-D; a plan whose 1x1 layers are fused pairs has no
+    such prefix and a noise level that changes most rows takes the dense path — the results do not move."""
+    oracle, model, raw = _make(name, device, seed=6)
+    n_it = 4
+    noise = torch.rand(raw.shape[0], 2 * n_it, *raw.shape[1:], generator=torch.Generator().manual_seed(2))
+    x = raw.to(device)
+    monkeypatch.setenv("CLX_STREAMS_MIN_GFLOP", "0")
+    model.max_infer_batch = 4
+    for p_noise in (0.008, 0.6):
+        model.set_infer(p_salt_pepper=p_noise, num_infer_iterations=n_it, device=device)
+        monkeypatch.setenv("CLX_SPARSE_NOISE", "0")
+        dense = model.infer_on_device(x, noise=noise).clone()
+        monkeypatch.delenv("CLX_SPARSE_NOISE", raising=False)
+        plan = next(iter(model._plans.values()))
+        calls = []
+        real = type(plan)._pointwise_on_rows
+        monkeypatch.setattr(type(plan), "_pointwise_on_rows",
+                            lambda self, *a, **k: (calls.append(int(a[2]["n"])), real(self, *a, **k))[1])
+        sparse2 = model.infer_on_device(x, noise=noise).clone()
+        monkeypatch.setenv("CLX_INFER_STREAMS", "1")
+        sparse1 = model.infer_on_device(x, noise=noise).clone()
+        monkeypatch.delenv("CLX_INFER_STREAMS", raising=False)
+        monkeypatch.setattr(type(plan), "_pointwise_on_rows", real)
+        assert torch.equal(dense, sparse2) and torch.equal(dense, sparse1)
+        used = name != "2d_chain64" and p_noise < 0.1
+        assert bool(calls) == used, (name, p_noise, calls)
+        if used:
+            first = plan.pointwise_prefix()[0]
+            npix = first.out_shape[0] * first.out_shape[1] * first.out_shape[2]
+            assert 0 < max(calls) < 0.6 * 4 * npix
+    oracle.set_infer(0.6, n_it)
+    with torch.no_grad():
+        ref = oracle(raw, noise=noise)
+    assert (sparse2.cpu() - ref).abs().max().item() < 1e-4
+
+
+def test_changed_rows_gather_scatter_broadcast_through_the_c_abi(device):
+    """clx_changed_rows against a numpy restatement (window-dilated difference of each copy from the clean image, per
+    chunk, any order), and the three row movers."""
+    import numpy as np
+
+    from cellulus_amd import _clx
+
+    rng = np.random.default_rng(0)
+    T, C, D, H, W, chunk = 5, 2, 3, 9, 150, 2
+    kd, kh, kw = 2, 3, 3
+    clean = rng.random((C, D, H, W), dtype=np.float32)
+    noisy = np.repeat(clean[None], T, axis=0)
+    hits = rng.random(noisy.shape) < 0.02
+    noisy[hits] = 0.5
+    od, oh, ow = D - kd + 1, H - kh + 1, W - kw + 1
+    diff = (noisy != clean[None]).any(axis=1)                                    # (T, D, H, W)
+    want = np.zeros((T, od, oh, ow), bool)
+    for dz in range(kd):
+        for dy in range(kh):
+            for dx in range(kw):
+                want |= diff[:, dz:dz + od, dy:dy + oh, dx:dx + ow]
+    npix = od * oh * ow
+    nchunks = (T + chunk - 1) // chunk
+    cap = chunk * npix
+    rows = torch.full((nchunks * cap,), -1, dtype=torch.int32, device=device)
+    counts = torch.empty(nchunks, dtype=torch.int32, device=device)
+    st = _clx.stream_ptr(device)
+    c_d, n_d = torch.from_numpy(clean).to(device), torch.from_numpy(noisy).to(device)
+    ws = torch.empty(int(_clx.load().clx_changed_rows_workspace(T, D, H, W)), dtype=torch.uint8, device=device)
+    _clx.call("clx_changed_rows", _clx.ptr(c_d), _clx.ptr(n_d), T, C, D, H, W, kd, kh, kw, chunk, _clx.ptr(rows),
+              _clx.ptr(counts), cap, _clx.ptr(ws), st)
+    counts_h, rows_h = counts.cpu().numpy(), rows.cpu().numpy()
+    for c in range(nchunks):
+        ref = np.flatnonzero(want[c * chunk:(c + 1) * chunk].reshape(-1))
+        got = np.sort(rows_h[c * cap:c * cap + counts_h[c]])
+        np.testing.assert_array_equal(got, ref)
+        assert (rows_h[c * cap + counts_h[c]:(c + 1) * cap] == -1).all()
+    # a capacity below the count: the count is still the true one, nothing is written past the capacity
+    rows.fill_(-1)
+    _clx.call("clx_changed_rows", _clx.ptr(c_d), _clx.ptr(n_d), T, C, D, H, W, kd, kh, kw, chunk, _clx.ptr(rows),
+              _clx.ptr(counts), 3, _clx.ptr(ws), st)
+    assert counts.cpu().numpy().tolist() == counts_h.tolist()
+    assert (rows.cpu().numpy()[3 * nchunks:] == -1).all()
+    # gather / scatter / broadcast
+    src = torch.from_numpy(rng.random((50, 12), dtype=np.float32)).to(device)
+    idx = torch.from_numpy(rng.permutation(50)[:17].astype(np.int32)).to(device)
+    dst = torch.zeros((17, 8), dtype=torch.float32, device=device)
+    _clx.call("clx_gather_rows", _clx.ptr(src), 12, _clx.ptr(idx), 17, 8, _clx.ptr(dst), 8, st)
+    assert torch.equal(dst, src[idx.long(), :8])
+    back = torch.zeros((50, 12), dtype=torch.float32, device=device)
+    _clx.call("clx_scatter_rows", _clx.ptr(dst), 8, _clx.ptr(idx), 17, 8, _clx.ptr(back), 12, st)
+    ref = torch.zeros_like(back)
+    ref[idx.long(), :8] = dst
+    assert torch.equal(back, ref)
+    out = torch.empty((3, 50, 12), dtype=torch.float32, device=device)
+    _clx.call("clx_broadcast_rows", _clx.ptr(src), src.numel(), _clx.ptr(out), 3, st)
+    assert torch.equal(out, src[None].expand(3, -1, -1))
+    with pytest.raises(_clx.ClxError, match="multiples of 4"):
+        _clx.call("clx_gather_rows", _clx.ptr(src), 12, _clx.ptr(idx), 17, 6, _clx.ptr(dst), 8, st)
+
+
 @pytest.mark.parametrize("name", ["2d_small", "3d_small"])
 def test_head_forward_matches_reference_head(name, device):
     """UNetModel.head_forward (unet.py:65-67) = head(backbone_output), values and all gradients."""
