@@ -418,6 +418,20 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     t_embed_s, _emb_s, prof_s, t_one_s, streams_s = both_passes(256)
     t_detect_s, t_segment_s, (_l, centers_s, _s, ncomp_s), _inputs = post_stages(device, 256, reps)
     t_embed, emb, prof, t_one, streams = both_passes(size)
+    changed = dict(getattr(model, "_last_changed_rows", None) or {})
+    if changed.get("used"):
+        # the same tile with every 1x1 layer dense on every copy (CLX_SPARSE_NOISE=0): what the changed-rows form saves
+        os.environ["CLX_SPARSE_NOISE"] = "0"
+        try:
+            t_dense, emb_dense, _p = embed_stage(model, device, size, n_it, reps)
+        finally:
+            del os.environ["CLX_SPARSE_NOISE"]
+        changed.update(embed_ms=round(t_embed * 1e3, 2), embed_ms_dense=round(t_dense * 1e3, 2),
+                       what="the 1x1 layers straight behind the first convolution run once on the clean tile and "
+                            "again on the rows of each noisy copy that differ from it (the window-dilated noise "
+                            "pixels); bit-identical to the dense forward (tests/test_gpu_unet.py); "
+                            "CLX_SPARSE_NOISE=0 switches it off")
+        changed["fraction"] = round(changed["fraction"], 4)
     t_detect, t_segment, (labels, centers, seg, ncomp), (mean, std, mean_d, std_d) = post_stages(device, size, reps)
 
     # mean-shift at full density (reduction_probability 1.0: every foreground pixel is a seed —
@@ -475,6 +489,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
+        "changed_rows": changed,
         "roofline": roofline_of(prof, t_one, t_embed, streams, model.infer_chunk(2 * n_it, (size + 16, size + 16))),
         "at_256": {
             "metric": "infer Mpixels/s (embed + mean-shift detect + segment), 2D 256x256 (one 272^2 tile), 1 GPU",

@@ -389,6 +389,8 @@ class UNetModel(nn.Module):  # type: ignore
         clean_rows = one.forward_prefix(clean, params, len(tail))
         copied.synchronize()
         n = host[:nchunks].tolist()
+        self._last_changed_rows = dict(fraction=sum(n) / float(T * npix_out), layers=[op.name for op in tail],
+                                       window=tuple(first.kernel), used=max(n) <= cap)
         if max(n) > cap:
             return None
         return [dict(clean_rows=clean_rows, rows=rows[j * cap:j * cap + n[j]], n=n[j]) for j in range(nchunks)]
