@@ -17,7 +17,7 @@ import torch.nn as nn
 
 import ctypes
 
-from .. import _clx
+from .. import _clx, parallel
 from .._clx import ClxConvDesc, ClxSrc
 from .plan import DualPlan, UNetPlan, build_topology, dual_stream_wanted, forward_flops, pad4
 
@@ -362,6 +362,12 @@ class UNetModel(nn.Module):  # type: ignore
         nchunks = T // step
         cap = max(1, int(float(os.environ.get("CLX_SPARSE_NOISE_MAX", "0.3")) * step * npix_out))
         dev = noisy.device
+        if getattr(self, "_clean_plan", None) is None or self._clean_plan[0] is not plan:
+            # room for the one-image plan and the compact rows (per stream) beside everything else, with a margin
+            one_image = sum(t.numel() * t.element_size() for t in plan.buf.values()) // max(step, 1)
+            compact = 3 * cap * 4 * max(pad4(op.cout) for op in [first] + tail)
+            if parallel.free_device_memory(dev) < 1.5 * (one_image + 2 * compact):
+                return None
         rows = torch.empty(nchunks * cap, dtype=torch.int32, device=dev)
         counts = torch.empty(nchunks, dtype=torch.int32, device=dev)
         noisy = noisy.contiguous()
@@ -435,8 +441,7 @@ class UNetModel(nn.Module):  # type: ignore
             need = sum(t.numel() * t.element_size() for t in plan.buf.values())
             if plan.workspace is not None:
                 need += plan.workspace.numel() * plan.workspace.element_size()
-            free = torch.cuda.mem_get_info(noisy.device)[0] + torch.cuda.memory_reserved(noisy.device) \
-                - torch.cuda.memory_allocated(noisy.device)
+            free = parallel.free_device_memory(noisy.device)
             nstreams = min(nstreams, 1 + int(free // (1.25 * need)))
             if nstreams < 2:
                 return plain_loop()

@@ -40,6 +40,26 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def ranks_sharing_device():
+    """Ranks that run on THIS rank's device: 1, or — under the test hook CLX_LOCAL_DEVICE, which pins every rank of the
+    host to one device (the 8-rank dress rehearsal of BASELINE configs[2] on one GPU) — the ranks on this host."""
+    if "CLX_LOCAL_DEVICE" not in os.environ:
+        return 1
+    return max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))
+
+
+def free_device_memory(device):
+    """Bytes this process may still take on `device`: what the device has free plus what torch's allocator holds
+    unused, capped by the rank's share of the device where several ranks run on it (they start together: what is free
+    NOW says nothing about what the others are about to take)."""
+    free = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    share = ranks_sharing_device()
+    if share > 1:
+        total = torch.cuda.get_device_properties(device).total_memory
+        free = min(free, total // share - torch.cuda.memory_allocated(device))
+    return max(0, free)
+
+
 def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 

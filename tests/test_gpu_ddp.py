@@ -43,6 +43,8 @@ for step in range(2):
     r = torch.from_numpy(data[f"r{step}"][rank * per:(rank + 1) * per])
     loss, _, _ = train_iteration((raw, a, r), model, crit, opt, dev)
     losses.append(loss)
+    if step == 0:
+        grad0 = model._flat_grad.clone()            # the all-reduced gradient of the first step (same weights everywhere)
 from cellulus_amd.models.plan import DualPlan
 assert isinstance(next(iter(model._plans.values())), DualPlan) == (os.environ["CLX_STREAMS_MIN_GFLOP"] == "0")
 # every rank issued the same gradient ranges in the same order (they depend on the plan only) ...
@@ -56,7 +58,8 @@ mine = model._flat.clone()
 parallel.broadcast_(mine, src=0)
 assert torch.equal(mine, model._flat), "ranks diverged"
 if rank == 0:
-    np.savez(sys.argv[3], flat=model._flat.cpu().numpy(), losses=np.array(losses), nbuckets=len(ranges[0]))
+    np.savez(sys.argv[3], flat=model._flat.cpu().numpy(), losses=np.array(losses), nbuckets=len(ranges[0]),
+             grad0=grad0.cpu().numpy())
 torch.distributed.barrier()
 """
 
@@ -122,9 +125,26 @@ def test_ranks_equal_one_process_at_global_batch(tmp_path, device, world, bucket
         batch = tuple(torch.from_numpy(data[f"{k}{step}"]) for k in ("raw", "a", "r"))
         loss, _, _ = train_iteration(batch, model, crit, opt, device)
         losses.append(loss)
+        if step == 0:
+            grad0 = model._flat_grad.cpu().numpy().copy()
     # the loss is a SUM over pairs: the all-reduced loss equals the global-batch loss
     np.testing.assert_allclose(got["losses"], losses, rtol=1e-5)
-    np.testing.assert_allclose(got["flat"], model._flat.cpu().numpy(), atol=2e-5)
+    # the all-reduced gradient of the first step IS the global batch's gradient (sums of the same terms in another order)
+    scale = np.abs(grad0).max()
+    np.testing.assert_allclose(got["grad0"] / scale, grad0 / scale, atol=1e-4)
+    # ... and two Adam steps later the parameters are the one-process parameters.  Adam's first steps move a parameter by
+    # lr * g / (|g| + eps) ~ +-lr whatever |g| is, so where a gradient element is smaller than the float noise of its
+    # sum (terms of 1e3 cancelling) the ORDER of the additions decides its sign — atomics: it changes from run to run,
+    # about one run in twenty lands 1 % of the elements on the other side (|difference| = 2.8 lr, evidence kept below).
+    # The bar: nearly all elements to 2e-5, none further than the steps can move them apart.
+    ref_flat = model._flat.cpu().numpy()
+    far = np.abs(got["flat"] - ref_flat) > 2e-5
+    if far.any():                                                  # keep the evidence
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        np.savez(os.path.join(ROOT, "gpurun_out", f"ddp_mismatch_w{world}_b{bucket_mb}_{int(dual)}.npz"),
+                 ranks=got["flat"], one=ref_flat, grad_ranks=got["grad0"], grad_one=grad0)
+    assert far.mean() < 0.03, far.mean()
+    assert np.abs(got["flat"] - ref_flat).max() < 2 * 2 * 1e-3 * 1.05
 
 
 def test_bench_starts_eight_ranks(tmp_path):
