@@ -976,3 +976,33 @@ def test_fused_1x1_pairs_need_exclusive_tensors():
     # a Winograd layer is never half of a pair
     wino = dict(direct, **{"head.0": 2})
     assert ("head.0", "head.2") not in [(a.name, b.name) for a, b in P.find_chain_pairs(topo, wino, 2)]
+
+
+def test_infer_chunk_sizes_and_shared_device_rule(monkeypatch):
+    """UNetModel.infer_chunk: copies per forward by pixel count (eight 528^2 tiles' worth, a divisor of the copies; all of
+    them for small tiles; max_infer_batch overrides).  parallel.ranks_sharing_device: 1 unless the test hook
+    CLX_LOCAL_DEVICE pins the host's ranks to one device."""
+    from cellulus_amd import parallel
+    from cellulus_amd.models import get_model
+
+    m = get_model(in_channels=1, out_channels=2, num_fmaps=8, fmap_inc_factor=2, features_in_last_layer=8,
+                  downsampling_factors=[(2, 2)], num_spatial_dims=2)
+    assert m.infer_chunk(32, (528, 528)) == 8
+    assert m.infer_chunk(32, (272, 272)) == 16
+    assert m.infer_chunk(32, (1040, 1040)) == 2
+    assert m.infer_chunk(32, (4000, 4000)) == 1
+    assert m.infer_chunk(4, (56, 56)) == 4
+    assert m.infer_chunk(6, (400, 400)) == 6
+    assert m.infer_chunk(32, (64, 64, 64)) == 8
+    assert m.infer_chunk(30, (528, 528)) == 6            # a divisor of the copies
+    m.max_infer_batch = 3
+    assert m.infer_chunk(32, (528, 528)) == 3 and m.infer_chunk(2, (16, 16)) == 2
+    for k in ("CLX_LOCAL_DEVICE", "LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert parallel.ranks_sharing_device() == 1
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert parallel.ranks_sharing_device() == 1          # eight ranks, eight devices
+    monkeypatch.setenv("CLX_LOCAL_DEVICE", "0")
+    assert parallel.ranks_sharing_device() == 8
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
+    assert parallel.ranks_sharing_device() == 4
