@@ -489,6 +489,10 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         "stage_ms": {"embed": round(t_embed * 1e3, 2), "detect": round(t_detect * 1e3, 3),
                      "segment": round(t_segment * 1e3, 3)},
         "embed_tflops": round(2 * n_it * fwd_flops / t_embed / 1e12, 2),
+        "embed_tflops_note": "direct-form FLOPs of the 32 dense forwards / embedding time: a work rate, NOT a utilisation "
+                             "(the Winograd layers execute 1/4 of their direct multiplies, the changed-rows form of the "
+                             "first level's 1x1 layers a tenth of theirs); utilisation is roofline.frac / step_mfma_frac, "
+                             "from the FLOPs the kernels execute",
         "changed_rows": changed,
         "roofline": roofline_of(prof, t_one, t_embed, streams, model.infer_chunk(2 * n_it, (size + 16, size + 16))),
         "at_256": {

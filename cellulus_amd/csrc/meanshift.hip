@@ -45,20 +45,57 @@ __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ s
   constexpr int PXL = Vec16<TIn>::N;
   constexpr int WT = 64 * G * PXL;
   const int lane = threadIdx.x & 63;
-  for (int wt = blockIdx.x * 4 + (threadIdx.x >> 6); wt < nwt; wt += gridDim.x * 4) {
-    const long long base = (long long)wt * WT;
-    unsigned int b = 0u;
-    if (vec && base + WT <= npix) {
-      // whole tile inside the image (wave-uniform): unconditional loads — behind per-lane conditions the compiler's
-      // wait-count pass puts a wait behind every load and the kernel ran at half the rate of minmax_kernel
-      V sv[G];
+  // the tile's G * PXL = 16 ballot words leave as ONE 128-byte store (lane k keeps word k), not as sixteen single-lane stores
+  auto emit = [&](int wt, unsigned int b) {
+    int total = 0;
+    unsigned long long mine = 0ull;
 #pragma unroll
-      for (int g = 0; g < G; ++g) sv[g] = *reinterpret_cast<const V*>(sd + base + (long long)(g * 64 + lane) * PXL);
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int e = 0; e < PXL; ++e) {
+        const unsigned long long w = __ballot((b >> (g * PXL + e)) & 1u);
+        if (lane == g * PXL + e) mine = w;
+        total += __popcll(w);
+      }
+    if (lane < G * PXL) flags[(long long)wt * (G * PXL) + lane] = mine;
+    if (lane == 0) counts[wt] = total;
+  };
+  const int stride = gridDim.x * 4;
+  int wt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // whole tiles (wave-uniform): unconditional loads — behind per-lane conditions the compiler's wait-count pass puts a
+  // wait behind every load —, and the NEXT tile's loads are issued before this tile's ballots: a wavefront
+  // that takes two tiles no longer waits out two load latencies one after the other
+  const int nfull = vec ? (int)(npix / WT) : 0;
+  if (wt < nfull) {
+    V cur[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) cur[g] = *reinterpret_cast<const V*>(sd + (long long)wt * WT + (long long)(g * 64 + lane) * PXL);
+    auto bits = [&](const V (&x)[G]) {
+      unsigned int b = 0u;
 #pragma unroll
       for (int g = 0; g < G; ++g)
 #pragma unroll
-        for (int e = 0; e < PXL; ++e) b |= ((double)sv[g][e] < thr ? 1u : 0u) << (g * PXL + e);
-    } else if (vec) {
+        for (int e = 0; e < PXL; ++e) b |= ((double)x[g][e] < thr ? 1u : 0u) << (g * PXL + e);
+      return b;
+    };
+    while (wt + stride < nfull) {                        // (the last tile is peeled: no conditional prefetch)
+      V nxt[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g)
+        nxt[g] = *reinterpret_cast<const V*>(sd + (long long)(wt + stride) * WT + (long long)(g * 64 + lane) * PXL);
+      emit(wt, bits(cur));
+#pragma unroll
+      for (int g = 0; g < G; ++g) cur[g] = nxt[g];
+      wt += stride;
+    }
+    emit(wt, bits(cur));
+    wt += stride;
+  }
+  // the ragged last tile, tiles of an unaligned image
+  for (; wt < nwt; wt += stride) {
+    const long long base = (long long)wt * WT;
+    unsigned int b = 0u;
+    if (vec) {
       V sv[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -82,20 +119,7 @@ __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ s
           if (i + e < npix) b |= ((double)sd[i + e] < thr ? 1u : 0u) << (g * PXL + e);
       }
     }
-    // the G * PXL = 16 ballot words of the tile leave as ONE 128-byte store (lane k keeps word k), not as sixteen
-    // single-lane stores
-    int total = 0;
-    unsigned long long mine = 0ull;
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int e = 0; e < PXL; ++e) {
-        const unsigned long long w = __ballot((b >> (g * PXL + e)) & 1u);
-        if (lane == g * PXL + e) mine = w;
-        total += __popcll(w);
-      }
-    if (lane < G * PXL) flags[(long long)wt * (G * PXL) + lane] = mine;
-    if (lane == 0) counts[wt] = total;
+    emit(wt, b);
   }
 }
 
