@@ -335,6 +335,7 @@ def embed_stage(model, device, size, n_it, reps):
     rng = np.random.default_rng(0)
     raw = torch.from_numpy(np.pad(rng.random((1, 1, size, size), dtype=np.float32),
                                   [(0, 0), (0, 0), (8, 8), (8, 8)], mode="reflect")).to(device)
+    torch.manual_seed(1000 + size)                                  # the same noise in every call: results are comparable
     noise = torch.rand(1, 2 * n_it, 1, crop, crop, device=device)
     model.infer_on_device(raw, noise=noise)                       # warm-up (plan + packing)
     _clx.call("clx_profile_enable", 2)
@@ -427,6 +428,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         finally:
             del os.environ["CLX_SPARSE_NOISE"]
         changed.update(embed_ms=round(t_embed * 1e3, 2), embed_ms_dense=round(t_dense * 1e3, 2),
+                       identical_to_dense=bool(torch.equal(emb, emb_dense)),
                        what="the 1x1 layers straight behind the first convolution run once on the clean tile and "
                             "again on the rows of each noisy copy that differ from it (the window-dilated noise "
                             "pixels); bit-identical to the dense forward (tests/test_gpu_unet.py); "

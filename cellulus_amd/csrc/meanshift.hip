@@ -13,20 +13,22 @@ namespace {
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
-// Coordinate add + stable (raster-order) compaction of the foreground pixels [mean_shift.py:15-32,83-90] as THREE
-// plain streaming launches — no ticket, no look-back, no persistent blocks, no barrier, no state in the workspace.
+// Coordinate add + stable (raster-order) compaction of the foreground pixels [mean_shift.py:15-32,83-90] as TWO
+// plain streaming launches — no ticket, no look-back, no persistent blocks, no grid barrier, no state in the workspace.
 // The unit is a WAVE-TILE: 1024 consecutive pixels, lane l of the wavefront owning the 16-byte groups g * 64 + l.
 //   ms_flags_kernel    reads the std plane once: per wave-tile the foreground flags as the wavefront's ballot words (1 bit
 //                      per pixel, in the (group, pixel-of-group) order the scatter pass reads them back in) and the count;
-//   ms_tile_scan       exclusive prefix of the wave-tile counts (one block; a 4096^2 image is 16 K counts), total -> nfg;
-//   ms_scatter_kernel  per wave-tile: positions from the ballot words (popcounts), the embedding values — all of the
-//                      tile's loads in flight at once —, coordinates added (in place for float64), points and raster
-//                      indices written.
+//                      a block takes a contiguous chunk of tiles and also leaves the chunk's count;
+//   ms_scatter_kernel  per wave-tile: the points in front of it = the chunks in front of its chunk (<= 2048 values, summed
+//                      by the block) + the tiles of its chunk in front of it (summed by the wavefront) — these loads go
+//                      out with the tile's embedding loads, all in flight at once —, positions from the ballot words
+//                      (popcounts), coordinates added (in place for float64), points and raster indices written.
+// (Until the end of round 4 a one-block scan of the 16 K tile counts stood between the two: 7 us + a launch boundary.)
 // History: rounds 2-3 did this in ONE launch — persistent blocks taking tiles by an atomic ticket, counts
 // published and prefixes obtained by decoupled look-back.  At 4096^2 that form lost 15 us to the ticket word (one word
 // serves ~88 returning atomics per microsecond) and 40 us to the look-back (a hop is a round trip to the memory side)
 // of its 175 us; batching tickets serialised the look-back (13 ms), super-tiles with a 256-wide look-back halved the
-// bytes in flight (219 us).  Three launches cost two boundaries (~2 us each): 147 us, 0.63 of the HBM peak.
+// bytes in flight (219 us).  Three launches (flags, scan, scatter): 147-160 us; two: 140-146 us.
 // TIn = double: the reference's float64 arrays, coordinates added IN PLACE (WB).  TIn = float: the network's float32
 // output handed over in device memory by infer()'s fused predict -> detect path — the float64 values the staged path
 // reads back from the `embeddings` dataset are these floats widened (cellulus/predict.py:104-112), so widening in
@@ -39,13 +41,14 @@ template <> struct Vec16<float> { typedef f32x4 type; static constexpr int N = 4
 
 template <typename TIn, int G>
 __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ sd, double thr, long long npix, int vec,
-                                                       int nwt, unsigned long long* __restrict__ flags,
-                                                       int* __restrict__ counts) {
+                                                       int nwt, int tiles_per_block, unsigned long long* __restrict__ flags,
+                                                       int* __restrict__ counts, int* __restrict__ chunk_counts) {
   using V = typename Vec16<TIn>::type;
   constexpr int PXL = Vec16<TIn>::N;
   constexpr int WT = 64 * G * PXL;
   const int lane = threadIdx.x & 63;
   // the tile's G * PXL = 16 ballot words leave as ONE 128-byte store (lane k keeps word k), not as sixteen single-lane stores
+  __shared__ int wave_total[4];
   auto emit = [&](int wt, unsigned int b) {
     int total = 0;
     unsigned long long mine = 0ull;
@@ -59,13 +62,19 @@ __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ s
       }
     if (lane < G * PXL) flags[(long long)wt * (G * PXL) + lane] = mine;
     if (lane == 0) counts[wt] = total;
+    return total;
   };
-  const int stride = gridDim.x * 4;
-  int wt = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // block k takes the CONTIGUOUS chunk of tiles [k * tiles_per_block, ...) — wavefront w every fourth of them — and
+  // leaves the chunk's total: the scatter pass adds up the chunks in front of its own (<= 2048 values) and the tiles of
+  // its chunk in front of its tile, and no scan launch stands between the two passes
+  constexpr int stride = 4;
+  const int chunk_end = min(nwt, ((int)blockIdx.x + 1) * tiles_per_block);
+  int wt = blockIdx.x * tiles_per_block + (threadIdx.x >> 6);
+  int mine_total = 0;
   // whole tiles (wave-uniform): unconditional loads — behind per-lane conditions the compiler's wait-count pass puts a
   // wait behind every load —, and the NEXT tile's loads are issued before this tile's ballots: a wavefront
   // that takes two tiles no longer waits out two load latencies one after the other
-  const int nfull = vec ? (int)(npix / WT) : 0;
+  const int nfull = min(chunk_end, vec ? (int)(npix / WT) : 0);
   if (wt < nfull) {
     V cur[G];
 #pragma unroll
@@ -83,16 +92,16 @@ __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ s
 #pragma unroll
       for (int g = 0; g < G; ++g)
         nxt[g] = *reinterpret_cast<const V*>(sd + (long long)(wt + stride) * WT + (long long)(g * 64 + lane) * PXL);
-      emit(wt, bits(cur));
+      mine_total += emit(wt, bits(cur));
 #pragma unroll
       for (int g = 0; g < G; ++g) cur[g] = nxt[g];
       wt += stride;
     }
-    emit(wt, bits(cur));
+    mine_total += emit(wt, bits(cur));
     wt += stride;
   }
   // the ragged last tile, tiles of an unaligned image
-  for (; wt < nwt; wt += stride) {
+  for (; wt < chunk_end; wt += stride) {
     const long long base = (long long)wt * WT;
     unsigned int b = 0u;
     if (vec) {
@@ -119,51 +128,24 @@ __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ s
           if (i + e < npix) b |= ((double)sd[i + e] < thr ? 1u : 0u) << (g * PXL + e);
       }
     }
-    emit(wt, b);
+    mine_total += emit(wt, b);
   }
+  if (lane == 0) wave_total[threadIdx.x >> 6] = mine_total;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_counts[blockIdx.x] = wave_total[0] + wave_total[1] + wave_total[2] + wave_total[3];
 }
 
-// exclusive scan of counts[0..n) into prefix[0..n) (n a multiple of 4: whole groups of four wave-tiles, 16-byte accesses),
-// total -> *nfg_out.  One block; a thread takes consecutive groups of four (a 4096^2 image: 16 K counts, four groups each).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(1024) void ms_tile_scan(const int* __restrict__ counts, int n4, int* __restrict__ prefix,
-                                                     int* __restrict__ nfg_out) {
-  __shared__ int part[1024];
-  const int tid = threadIdx.x;
-  const i32x4* c4 = reinterpret_cast<const i32x4*>(counts);
-  i32x4* p4 = reinterpret_cast<i32x4*>(prefix);
-  const int per = (n4 + 1023) / 1024;
-  const int lo = min(tid * per, n4), hi = min(lo + per, n4);
-  int s = 0;
-  for (int i = lo; i < hi; ++i) {
-    const i32x4 c = c4[i];
-    s += c[0] + c[1] + c[2] + c[3];
-  }
-  part[tid] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = (tid >= o) ? part[tid - o] : 0;
-    __syncthreads();
-    part[tid] += v;
-    __syncthreads();
-  }
-  int run = (tid == 0) ? 0 : part[tid - 1];
-  for (int i = lo; i < hi; ++i) {
-    const i32x4 c = c4[i];
-    i32x4 p;
-    p[0] = run; p[1] = run + c[0]; p[2] = p[1] + c[1]; p[3] = p[2] + c[2];
-    p4[i] = p;
-    run = p[3] + c[3];
-  }
-  if (tid == 1023) *nfg_out = part[1023];
-}
 
 template <int ND, typename TIn, int G, bool WB, int BLOCKS>
 __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict__ emb, FastDiv dX, FastDiv dY, int Y, int X,
                                                                  long long npix, int vec, int nwt,
                                                                  const unsigned long long* __restrict__ flags,
-                                                                 const int* __restrict__ prefix,
-                                                                 double* __restrict__ Xout, int* __restrict__ index) {
+                                                                 const int* __restrict__ counts,
+                                                                 const int* __restrict__ chunk_counts, int tiles_per_chunk,
+                                                                 double* __restrict__ Xout, int* __restrict__ index,
+                                                                 int* __restrict__ nfg_out) {
+  __shared__ int part[4];
   using V = typename Vec16<TIn>::type;
   constexpr int PXL = Vec16<TIn>::N;
   constexpr int WT = 64 * G * PXL;
@@ -171,6 +153,15 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
   const unsigned long long lower = (1ull << lane) - 1ull;
   for (int wt = blockIdx.x * 4 + (threadIdx.x >> 6); wt < nwt; wt += gridDim.x * 4) {
     const long long base = (long long)wt * WT;
+    // points in front of this tile = the chunks of the flags pass in front of its chunk (summed by the block) + the
+    // tiles of its chunk in front of it (summed by the wavefront); the loads go out first, the sums are taken below
+    const int chunk = wt / tiles_per_chunk, chunk_first = chunk * tiles_per_chunk;
+    // (the chunks by the block, the tiles by the wavefront; every wavefront summing the chunks for itself — no barriers
+    //  — measured the same for float64 and 10 % slower for float32 input: 51 against 46 us)
+    int before = 0;
+    for (int j = threadIdx.x; j < chunk; j += 256) before += chunk_counts[j];
+    int inside = 0;
+    for (int t = chunk_first + lane; t < wt; t += 64) inside += counts[t];
     const unsigned long long* tf = flags + (long long)wt * G * PXL;
     unsigned long long B[G][PXL];            // wave-uniform: this tile's ballot words
 #pragma unroll
@@ -197,7 +188,15 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
         }
       }
     }
-    int run = prefix[wt];                     // points before group g of this tile
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      before += __shfl_xor(before, o, 64);
+      inside += __shfl_xor(inside, o, 64);
+    }
+    __syncthreads();                          // (nwt and tiles_per_chunk are multiples of four: the block's four
+    if (lane == 0) part[threadIdx.x >> 6] = before;   //  wavefronts run the same trips and sit in one chunk)
+    __syncthreads();
+    int run = part[0] + part[1] + part[2] + part[3] + inside;     // points before group g of this tile
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const long long i = base + (long long)(g * 64 + lane) * PXL;
@@ -248,6 +247,7 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
       }
       run += cnt;
     }
+    if (wt == nwt - 1 && lane == 0) *nfg_out = run;
   }
 }
 
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void ms_assign_cells_kernel(
 
 }  // namespace
 
-// workspace of the compaction: [flags: one bit per pixel, whole wave-tiles][counts: nwt ints][prefix: nwt + 1 ints]
+// workspace of the compaction: [flags: one bit per pixel, whole wave-tiles][counts: nwt ints][chunk counts of the flags pass: <= nwt / 4 ints]
 static long long wave_tiles(long long npix) { return (npix + 4095) / 4096 * 4; }      // whole groups of four
 
 extern "C" size_t clx_ms_prepare_workspace(long long npix) {
@@ -690,19 +690,22 @@ static void launch_prepare(TIn* emb, const TIn* std, double threshold, int Z, in
   const int nwt = (int)wave_tiles(npix);
   unsigned long long* flags = (unsigned long long*)workspace;
   int* counts = (int*)(flags + (size_t)nwt * 16);          // 16-byte aligned: nwt is a multiple of 4
-  int* prefix = counts + nwt;
+  int* chunk_counts = counts + nwt;                         // one per block of the flags pass (<= nwt / 4)
   // every channel plane starts at a multiple of npix elements: 16-byte accesses need npix % PXL == 0 and aligned bases
   const int vec = (npix % PXL == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
   const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
   static const int g1cap = getenv("CLX_MS_FLAGS_GRID") ? atoi(getenv("CLX_MS_FLAGS_GRID")) : 2048;        // (sweeps)
   static const int g3cap = getenv("CLX_MS_SCATTER_GRID") ? atoi(getenv("CLX_MS_SCATTER_GRID")) : 1 << 20;
+  // the flags pass in at most g1cap blocks of contiguous chunks, a multiple of four tiles each
+  int tiles_per_block = (nwt + g1cap - 1) / (g1cap > 0 ? g1cap : 1);
+  tiles_per_block = (tiles_per_block + 3) / 4 * 4;
+  const int g1 = (nwt + tiles_per_block - 1) / tiles_per_block;
   const int nb = (nwt + 3) / 4;
-  const int g1 = nb < g1cap ? nb : g1cap, g3 = nb < g3cap ? nb : g3cap;
+  const int g3 = nb < g3cap ? nb : g3cap;
   CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_flags_kernel<TIn, G>), dim3(g1), dim3(256), 0, st, std, threshold, npix, vec,
-                  nwt, flags, counts);
-  CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, ms_tile_scan, dim3(1), dim3(1024), 0, st, counts, nwt / 4, prefix, nfg_out);
+                  nwt, tiles_per_block, flags, counts, chunk_counts);
   CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_scatter_kernel<ND, TIn, G, WB, BLOCKS>), dim3(g3), dim3(256), 0, st, emb, dX, dY,
-                  Y, X, npix, vec, nwt, flags, prefix, Xout, index);
+                  Y, X, npix, vec, nwt, flags, counts, chunk_counts, tiles_per_block, Xout, index, nfg_out);
 }
 
 extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,

@@ -62,6 +62,32 @@ def test_inference_chunk_of_eight_528_tiles_equals_its_halves_bit_for_bit(model,
             assert torch.equal(half, full[lo:lo + 4]), f"copies {lo}..{lo + 3}"
 
 
+def test_benchmark_tile_through_changed_rows_equals_the_dense_forward_bit_for_bit(model, device, monkeypatch):
+    """The benchmark's inference tile (528^2, 256 feature maps, 32 noisy copies at 1 % salt / pepper, chunks of eight on
+    two streams): the 1x1 layers of the first level on the clean tile + the changed rows of each copy
+    against every layer densely on every copy (CLX_SPARSE_NOISE=0) — the kernels and tile shapes the bench line is
+    measured on — torch.equal on mean and std; 8-9 % of the rows are recomputed."""
+    model.eval()
+    model.set_infer(p_salt_pepper=0.01, num_infer_iterations=16, device=device)
+    torch.manual_seed(7)
+    raw = torch.rand(1, 1, 528, 528, device=device)
+    noise = torch.rand(1, 32, 1, 528, 528, device=device)
+    try:
+        monkeypatch.setenv("CLX_SPARSE_NOISE", "0")
+        dense = model.infer_on_device(raw, noise=noise).clone()
+        monkeypatch.delenv("CLX_SPARSE_NOISE", raising=False)
+        model._last_changed_rows = None
+        sparse = model.infer_on_device(raw, noise=noise).clone()
+        info = model._last_changed_rows
+        assert info is not None and info["used"] and 0.07 < info["fraction"] < 0.10, info
+        assert torch.equal(dense, sparse)
+        monkeypatch.setenv("CLX_INFER_STREAMS", "1")
+        assert torch.equal(dense, model.infer_on_device(raw, noise=noise))
+    finally:
+        model.train()
+        model.mode = "train"
+
+
 def test_translation_equivariance_at_multiples_of_the_downsampling(model, device):
     """crop_to_factor makes the valid U-Net equivariant to shifts that are multiples of the
     cumulative downsampling factor: shifting the input window by 4 px shifts the output by 4 px."""
