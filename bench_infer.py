@@ -430,10 +430,14 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         changed.update(embed_ms=round(t_embed * 1e3, 2), embed_ms_dense=round(t_dense * 1e3, 2),
                        identical_to_dense=bool(torch.equal(emb, emb_dense)),
                        what="the 1x1 layers straight behind the first convolution run once on the clean tile and "
-                            "again on the rows of each noisy copy that differ from it (the window-dilated noise "
-                            "pixels); bit-identical to the dense forward (tests/test_gpu_unet.py); "
-                            "CLX_SPARSE_NOISE=0 switches it off")
+                            "again on the rows of each noisy copy that differ from it (`fraction`: the window-dilated "
+                            "noise pixels), the Winograd layer behind them on the output tiles whose input window holds "
+                            "such a row (`tile_fraction`); every copy's full tensors exist with the dense forward's "
+                            "bits (identical_to_dense; tests/test_gpu_unet.py, test_gpu_fullsize.py); "
+                            "CLX_SPARSE_NOISE=0 / CLX_SPARSE_TILES=0 switch the two off")
         changed["fraction"] = round(changed["fraction"], 4)
+        if "tile_fraction" in changed:
+            changed["tile_fraction"] = round(changed["tile_fraction"], 4)
     t_detect, t_segment, (labels, centers, seg, ncomp), (mean, std, mean_d, std_d) = post_stages(device, size, reps)
 
     # mean-shift at full density (reduction_probability 1.0: every foreground pixel is a seed —

@@ -86,6 +86,8 @@ class ClxConvDesc(Structure):
         ("adjoint", c_int),
         ("pool_out", c_void_p),
         ("ld_pool", c_int),
+        ("tile_list", c_void_p),
+        ("tile_count", c_int),
     ]
 
 
@@ -120,6 +122,7 @@ PROTOTYPES = {
     "clx_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_changed_rows_workspace": (c_size_t, [_I, _I, _I, _I]),
     "clx_changed_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _LL, _P, _P]),
+    "clx_changed_tiles": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _LL, _P]),
     "clx_gather_rows": (_I, [_P, _I, _P, _LL, _I, _P, _I, _P]),
     "clx_scatter_rows": (_I, [_P, _I, _P, _LL, _I, _P, _I, _P]),
     "clx_broadcast_rows": (_I, [_P, _LL, _P, _I, _P]),

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void diff_bits_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void dilate_rows_kernel(const unsigned long long* __restrict__ bits, int T, int IH,
                                                           int nw, long long nwords_copy, int KD, int KH, int KW, int OD,
                                                           int OH, int OW, int onw, int chunk, int* __restrict__ rows,
-                                                          int* __restrict__ counts, long long cap) {
+                                                          int* __restrict__ counts, long long cap,
+                                                          unsigned long long* __restrict__ row_bits) {
   const long long npix_out = (long long)OD * OH * OW;
   const long long per_copy = (long long)OD * OH * onw, total = (long long)T * per_copy;
   const int lane = threadIdx.x & 63;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(256) void dilate_rows_kernel(const unsigned long lo
         }
       const int left = OW - wd * 64;                              // output pixels of this word inside the row
       if (left < 64) acc &= (1ull << left) - 1ull;
+      row_bits[i] = acc;                                          // [copy][oz * OH + oy][word]: clx_changed_tiles reads these
     }
     const int n = __popcll(acc);
     int pending = n > 0 ? t / chunk : -1;
@@ -97,6 +99,56 @@ __global__ __launch_bounds__(256) void dilate_rows_kernel(const unsigned long lo
       long long pos = base;
       for (unsigned long long m = acc; m != 0ull; m &= m - 1ull, ++pos)
         if (pos < cap) rows[(long long)ck * cap + pos] = (int)(first + __builtin_ctzll(m));
+    }
+  }
+}
+
+// Output tiles (tile x tile, 2-D) of a (WH, WW) valid convolution over the rows whose bits dilate_rows_kernel left: a
+// tile is CHANGED if any row of its (tile + WH - 1) x (tile + WW - 1) window is.  One thread per (copy, ty, tx); the
+// chunk's list takes ((copy inside the chunk) * th + ty) * tw + tx, in no particular order.
+__global__ __launch_bounds__(256) void changed_tiles_kernel(const unsigned long long* __restrict__ row_bits, int T, int OH,
+                                                            int OW, int onw, int WH, int WW, int tile, int th, int tw,
+                                                            int chunk, int* __restrict__ tiles, int* __restrict__ counts,
+                                                            long long cap) {
+  const long long per_copy = (long long)th * tw, total = (long long)T * per_copy;
+  const int lane = threadIdx.x & 63;
+  const long long rounded = (total + 63) / 64 * 64;              // every lane reaches the ballots
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (long long)gridDim.x * blockDim.x) {
+    bool changed = false;
+    int t = 0;
+    long long r = 0;
+    if (i < total) {
+      t = (int)(i / per_copy);
+      r = i - (long long)t * per_copy;
+      const int ty = (int)(r / tw), tx = (int)(r - (long long)ty * tw);
+      const int y0 = ty * tile, y1 = min(y0 + tile + WH - 1, OH);
+      const int x0 = tx * tile, nbits = min(x0 + tile + WW - 1, OW) - x0;        // (<= 64: checked by the launcher)
+      const int wd = x0 >> 6, sh = x0 & 63;
+      const unsigned long long mask = nbits >= 64 ? ~0ull : (1ull << nbits) - 1ull;
+      unsigned long long any = 0ull;
+      for (int y = y0; y < y1; ++y) {
+        const unsigned long long* row = row_bits + ((long long)t * OH + y) * onw;
+        unsigned long long v = row[wd] >> sh;
+        if (sh != 0 && wd + 1 < onw) v |= row[wd + 1] << (64 - sh);
+        any |= v & mask;
+      }
+      changed = any != 0ull;
+    }
+    int pending = changed ? t / chunk : -1;
+    while (true) {                                                // (a wavefront's tiles may straddle two chunks)
+      const unsigned long long want = __ballot(pending >= 0);
+      if (want == 0ull) break;
+      const int leader = __builtin_ctzll(want);
+      const int cur = __shfl(pending, leader, 64);
+      const unsigned long long mine = __ballot(pending == cur);
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&counts[cur], __popcll(mine));
+      base = __shfl(base, leader, 64);
+      if (pending == cur) {
+        const long long pos = base + __popcll(mine & ((1ull << lane) - 1ull));
+        if (pos < cap) tiles[(long long)cur * cap + pos] = (int)((long long)(t - cur * chunk) * per_copy + r);
+        pending = -1;
+      }
     }
   }
 }
@@ -143,8 +195,10 @@ inline int rows_grid(long long total) {
 
 }  // namespace
 
+// workspace: [one bit per input pixel and copy][one bit per output row and copy, at most as many]
+static size_t input_bit_words(int T, int ID, int IH, int IW) { return (size_t)T * ID * IH * ((IW + 63) / 64); }
 extern "C" size_t clx_changed_rows_workspace(int T, int ID, int IH, int IW) {
-  return (size_t)T * ID * IH * ((IW + 63) / 64) * sizeof(unsigned long long);
+  return 2 * input_bit_words(T, ID, IH, IW) * sizeof(unsigned long long);
 }
 
 extern "C" int clx_changed_rows(const float* clean, const float* noisy, int T, int C, int ID, int IH, int IW, int KD,
@@ -167,8 +221,30 @@ extern "C" int clx_changed_rows(const float* clean, const float* noisy, int T, i
   diff_bits_kernel<<<rows_grid(total_words * 64), 256, 0, st>>>(clean, noisy, C, (long long)ID * IH * IW, IW, nw, nwords_copy,
                                                                 total_words, bits);
   dilate_rows_kernel<<<rows_grid((long long)T * OD * OH * onw), 256, 0, st>>>(bits, T, IH, nw, nwords_copy, KD, KH, KW, OD, OH,
-                                                                            OW, onw, chunk, rows, counts, cap);
+                                                                            OW, onw, chunk, rows, counts, cap,
+                                                                            bits + input_bit_words(T, ID, IH, IW));
   CLX_CHECK_LAUNCH("clx_changed_rows");
+  return CLX_OK;
+}
+
+extern "C" int clx_changed_tiles(const void* workspace, int T, int ID, int IH, int IW, int KD, int KH, int KW, int WH,
+                                 int WW, int tile, int chunk, int* tiles, int* counts, long long cap, clx_stream stream) {
+  CLX_REQUIRE(workspace && tiles && counts, "clx_changed_tiles: null pointer");
+  CLX_REQUIRE(T > 0 && ID > 0 && IH > 0 && IW > 0 && KD >= 1 && KH >= 1 && KW >= 1, "clx_changed_tiles: bad extents");
+  const int OD = ID - KD + 1, OH = IH - KH + 1, OW = IW - KW + 1;
+  CLX_REQUIRE(OD == 1, "clx_changed_tiles: 2-D layers only (one output plane)");
+  CLX_REQUIRE(WH >= 1 && WW >= 1 && WH <= OH && WW <= OW && tile >= 1 && tile + WW - 1 <= 64,
+              "clx_changed_tiles: bad window / tile");
+  CLX_REQUIRE(chunk >= 1 && cap >= 1, "clx_changed_tiles: bad chunk / capacity");
+  const int th = (OH - WH + 1 + tile - 1) / tile, tw = (OW - WW + 1 + tile - 1) / tile;
+  CLX_REQUIRE((long long)chunk * th * tw < (1ll << 31), "clx_changed_tiles: a chunk's tiles must fit 31 bits");
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunks = (T + chunk - 1) / chunk;
+  CLX_REQUIRE(hipMemsetAsync(counts, 0, sizeof(int) * nchunks, st) == hipSuccess, "clx_changed_tiles: hipMemsetAsync failed");
+  const unsigned long long* row_bits = (const unsigned long long*)workspace + input_bit_words(T, ID, IH, IW);
+  changed_tiles_kernel<<<rows_grid((long long)T * th * tw), 256, 0, st>>>(row_bits, T, OH, OW, (OW + 63) / 64, WH, WW, tile, th,
+                                                                          tw, chunk, tiles, counts, cap);
+  CLX_CHECK_LAUNCH("clx_changed_tiles");
   return CLX_OK;
 }
 

@@ -87,17 +87,20 @@ __device__ __forceinline__ void axpy(V& acc, bool& first, float coef, const V& v
 // V[xi][t][c] = (B^T d B)[xi] for the A x A input patch of tile t (stride MT)
 template <int MT, int R>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4, Geom g,
-                                                         float* __restrict__ V, long long total) {
+                                                         float* __restrict__ V, long long total,
+                                                         const int* __restrict__ tile_list = nullptr, long long Tc = 0) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   const int C = C4 * 4;
-  const long long plane = g.T * C;
+  // (tile_list: only the listed tiles, stored compactly — V[xi][i][c] for the i-th listed tile)
+  const long long plane = (tile_list ? Tc : g.T) * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
-    long long t = i / C4;
-    const int tx = (int)(t % g.tw);
-    const long long q = t / g.tw;
+    const long long t = i / C4;
+    const long long tg = tile_list ? (long long)tile_list[t] : t;
+    const int tx = (int)(tg % g.tw);
+    const long long q = tg / g.tw;
     const int ty = (int)(q % g.th);
     const int b = (int)(q / g.th);
     const int bb = b / g.ID, bz = b - bb * g.ID;
@@ -152,21 +155,23 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           int accumulate, unsigned int* __restrict__ gate_out,
                                                           int ld_gate, const unsigned int* __restrict__ mask_bits,
                                                           int ld_mask_bits, float* __restrict__ pool_out, int ld_pool,
-                                                          long long total) {
+                                                          long long total, const int* __restrict__ tile_list = nullptr,
+                                                          long long Tc = 0) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   constexpr int MP = MT / 2;          // 2 x 2 pooling windows per tile side (MT = 2 or 4: windows never straddle tiles)
   const int N = N4 * 4;
-  const long long plane = g.T * N;
+  const long long plane = (tile_list ? Tc : g.T) * N;
   // gate bits (N4 % 8 == 0, checked by the launcher): the 8 lanes i .. i + 7, i % 8 == 0, are the 32
   // channels of one word of one tile, and they take every branch below together
   const int sub = threadIdx.x & 7;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i % N4) * 4;
-    long long t = i / N4;
-    const int tx = (int)(t % g.tw);
-    const long long q = t / g.tw;
+    const long long t = i / N4;
+    const long long tg = tile_list ? (long long)tile_list[t] : t;
+    const int tx = (int)(tg % g.tw);
+    const long long q = tg / g.tw;
     const int ty = (int)(q % g.th);
     const int b = (int)(q / g.th);
     const float* src = M + t * N + n;
@@ -760,17 +765,31 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   const clx_src& S = d->src[0];
   const int C = S.C, Np = pad4(d->N);
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
-  float* M = (float*)d->workspace + AA * gin.T * C;
+  const int* list = d->tile_list;
+  if (list != nullptr) {
+    CLX_REQUIRE(d->KD == 1 && d->ID == 1 && d->PH == 0 && d->vcache == nullptr && !d->accumulate && d->tile_count >= 0 &&
+                    d->tile_count <= gin.T && gin.T == gout.T,
+                "clx_conv_fwd(winograd): tile_list needs a 2-D valid convolution without vcache / accumulate and at most "
+                "th * tw * B tiles");
+    if (d->tile_count == 0) return CLX_OK;
+  }
+  // (with a tile list the transforms and the products see tile_count tiles, stored compactly)
+  const long long Tin = list ? d->tile_count : gin.T, Tout = list ? d->tile_count : gout.T;
+  float* M = (float*)d->workspace + AA * Tin * C;
   if (!(d->vcache && d->vcache_valid)) {     // (a weight-gradient call may have left V: dy_vcache)
-    const long long tot_in = gin.T * (C / 4);
-    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
+    const long long tot_in = Tin * (C / 4);
+    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in, list, Tin);
   }
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
+  if (list) {                                // the listed tiles as one row of tiles of one image
+    gd.B = 1;
+    gd.src[0].W = gd.IW = (int)Tin;
+  }
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
   gd.precision = d->precision;
-  const int rc = clx_igemm_launch(&gd, AA, gin.T * C, (long long)Np * d->KD * C, gout.T * Np, st);
+  const int rc = clx_igemm_launch(&gd, AA, Tin * C, (long long)Np * d->KD * C, Tout * Np, st);
   if (rc) return rc;
-  const long long tot_out = gout.T * (Np / 4);
+  const long long tot_out = Tout * (Np / 4);
   // the bit forms need whole words per lane group: channel count a multiple of 32
   CLX_REQUIRE((d->gate_out == nullptr && d->mask_bits == nullptr) || Np % 32 == 0,
               "clx_conv_fwd(winograd): gate_out / mask_bits need a channel count that is a multiple of 32");
@@ -785,7 +804,8 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, gout, d->bias, d->relu, d->mask,
                                                                       d->ld_mask, d->out, d->ld_out, d->N, d->accumulate,
                                                                       d->gate_out, d->ld_gate, d->mask_bits,
-                                                                      d->ld_mask_bits, d->pool_out, d->ld_pool, tot_out);
+                                                                      d->ld_mask_bits, d->pool_out, d->ld_pool, tot_out,
+                                                                      list, Tout);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }

@@ -1171,6 +1171,27 @@ class UNetPlan:
             src = op.out
         return (first, tail) if tail else None
 
+    def tiled_layer_behind_prefix(self):
+        """The 2-D Winograd layer that reads the last 1x1 layer of pointwise_prefix (conv_pass.6 of the first level), or
+        None: its output tiles can be computed for a list of tiles only (clx_conv_desc.tile_list)."""
+        prefix = self.pointwise_prefix()
+        if prefix is None:
+            return None
+        first, tail = prefix
+        ops = self.topo.fwd_order
+        k = 1 + len(tail)
+        if k >= len(ops) or not isinstance(ops[k], ConvLayer):
+            return None
+        op = ops[k]
+        code = self.algo[op.name]["fwd"]
+        if (not code or op.kernel[0] != 1 or op.in_shape[0] != 1 or op.name in self.subpixel or op.name in self.chains
+                or op.name in self.chain_second or len(op.sources) != 1):
+            return None
+        s = op.sources[0]
+        if s.tensor != tail[-1].out or tuple(s.crop) != (0, 0, 0) or tuple(s.factor) != (1, 1, 1):
+            return None
+        return op, WINO_TILE[code]
+
     def _compact(self, slot, rows, width):
         """grow-only scratch for `rows` compact rows of `width` floats"""
         bufs = self.__dict__.setdefault("_compact_bufs", {})
@@ -1180,8 +1201,9 @@ class UNetPlan:
         return b
 
     def forward_prefix(self, raw, params, nlayers):
-        """the first convolution and the `nlayers` 1x1 layers behind it on `raw` -> the last one's output rows
-        (B * pixels, padded channels), in this plan's buffer"""
+        """the first convolution and the `nlayers` layers behind it on `raw` -> the last one's output rows
+        (B * pixels, padded channels), in this plan's buffer (a Winograd layer with a fused pooling also leaves the
+        pooled tensor in its buffer)"""
         t = self.topo
         st = _clx.stream_ptr(self.device)
         npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
@@ -1192,8 +1214,9 @@ class UNetPlan:
             self._conv_forward(op, params, st)
         return self.buf[t.fwd_order[nlayers].out]
 
-    def _conv_forward(self, op, params, st):
-        """one plain convolution layer of the forward pass"""
+    def _conv_forward(self, op, params, st, tiles=None):
+        """one plain convolution layer of the forward pass (tiles = (int32 tensor, count): a Winograd layer computes the
+        listed output tiles only)"""
         d = self._desc(op)
         d.N = op.cout
         d.wpack = self.wpack_fwd[op.name].data_ptr()
@@ -1215,7 +1238,27 @@ class UNetPlan:
             if pool is not None:
                 d.pool_out = self.buf[pool.out].data_ptr()
                 d.ld_pool = pad4(pool.channels)
+        if tiles is not None:
+            d.tile_list = tiles[0].data_ptr()
+            d.tile_count = int(tiles[1])
         _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+
+    def _tiles_forward(self, op, params, sparse, st):
+        """The Winograd layer behind the 1x1 layers for a chunk of noisy copies: the clean image's output (and pooled
+        output) under every copy, then the CHANGED tiles of each copy — those whose input window holds a changed row —
+        through the transforms and the batched products (clx_conv_desc.tile_list).  A tile's output depends on its own
+        input window alone: the dense computation's bits."""
+        dense = self.buf[op.out]
+        clean = sparse["clean_tile_rows"]
+        assert clean.shape[1] == dense.shape[1] and clean.shape[0] * self.B == dense.shape[0]
+        _clx.call("clx_broadcast_rows", _clx.ptr(clean), clean.numel(), _clx.ptr(dense), self.B, st)
+        pool = self.fused_pool.get(op.name)
+        if pool is not None:
+            pooled, clean_pooled = self.buf[pool.out], sparse["clean_pool_rows"]
+            assert clean_pooled.shape[0] * self.B == pooled.shape[0]
+            _clx.call("clx_broadcast_rows", _clx.ptr(clean_pooled), clean_pooled.numel(), _clx.ptr(pooled), self.B, st)
+        if int(sparse["ntiles"]) > 0:
+            self._conv_forward(op, params, st, tiles=(sparse["tiles"], sparse["ntiles"]))
 
     def _pointwise_on_rows(self, tail, params, sparse, st):
         """The 1x1 layers `tail` for a chunk of noisy copies: once on the clean image (done by the caller: sparse
@@ -1289,6 +1332,9 @@ class UNetPlan:
                 self._pointwise_on_rows(sparse_tail, params, sparse, st)
             elif isinstance(op, ConvLayer) and sparse_tail and any(op is q for q in sparse_tail):
                 continue                                    # computed with the first 1x1 layer of the prefix
+            elif isinstance(op, ConvLayer) and sparse is not None and sparse.get("tiles") is not None \
+                    and op is sparse["tile_op"]:
+                self._tiles_forward(op, params, sparse, st)
             elif isinstance(op, ConvLayer):
                 self._conv_forward(op, params, st)
             elif any(p is op for p in self.fused_pool.values()):

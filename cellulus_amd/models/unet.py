@@ -369,7 +369,15 @@ class UNetModel(nn.Module):  # type: ignore
             if parallel.free_device_memory(dev) < 1.5 * (one_image + 2 * compact):
                 return None
         rows = torch.empty(nchunks * cap, dtype=torch.int32, device=dev)
-        counts = torch.empty(nchunks, dtype=torch.int32, device=dev)
+        counts = torch.empty(2 * nchunks, dtype=torch.int32, device=dev)       # changed rows, changed tiles per chunk
+        # the Winograd layer behind the 1x1 layers: its output tiles whose input window holds a changed row
+        tiled = plan.tiled_layer_behind_prefix() if os.environ.get("CLX_SPARSE_TILES", "1") != "0" else None
+        tiles = None
+        if tiled is not None:
+            top, tile = tiled
+            th, tw = -(-top.out_shape[1] // tile), -(-top.out_shape[2] // tile)
+            cap_t = max(1, int(float(os.environ.get("CLX_SPARSE_TILES_MAX", "0.7")) * step * th * tw))
+            tiles = torch.empty(nchunks * cap_t, dtype=torch.int32, device=dev)
         noisy = noisy.contiguous()
         clean = clean.contiguous()
         st = _clx.stream_ptr(dev)
@@ -379,9 +387,12 @@ class UNetModel(nn.Module):  # type: ignore
         # the counts size the launches: they leave for pinned memory now and the host waits for THAT copy only, after
         # it has enqueued the clean image's pass (the device works on it meanwhile)
         host = getattr(self, "_counts_host", None)
-        if host is None or host.numel() < nchunks:
-            host = self._counts_host = torch.empty(max(nchunks, 64), dtype=torch.int32).pin_memory()
-        host[:nchunks].copy_(counts, non_blocking=True)
+        if host is None or host.numel() < 2 * nchunks:
+            host = self._counts_host = torch.empty(max(2 * nchunks, 64), dtype=torch.int32).pin_memory()
+        if tiles is not None:
+            _clx.call("clx_changed_tiles", _clx.ptr(ws), T, *first.in_shape, *first.kernel, top.kernel[1], top.kernel[2],
+                      tile, step, _clx.ptr(tiles), _clx.ptr(counts[nchunks:]), cap_t, st)
+        host[:2 * nchunks].copy_(counts, non_blocking=True)
         copied = torch.cuda.Event()
         copied.record()
         # the clean image through the prefix, on a one-image plan that reads the chunk plan's packed weights
@@ -392,14 +403,30 @@ class UNetModel(nn.Module):  # type: ignore
             cp = self._clean_plan = (plan, one)
         one = cp[1]
         one.wpack_fwd = plan.wpack_fwd
-        clean_rows = one.forward_prefix(clean, params, len(tail))
+        clean_rows = one.forward_prefix(clean, params, len(tail) + (1 if tiles is not None else 0))
+        clean_tile_rows = clean_pool_rows = None
+        if tiles is not None:
+            assert one.algo[top.name] == plan.algo[top.name] and bool(one.fused_pool.get(top.name)) == \
+                bool(plan.fused_pool.get(top.name))
+            clean_tile_rows, clean_rows = clean_rows, one.buf[tail[-1].out]
+            if one.fused_pool.get(top.name) is not None:
+                clean_pool_rows = one.buf[one.fused_pool[top.name].out]
         copied.synchronize()
         n = host[:nchunks].tolist()
+        nt = host[nchunks:2 * nchunks].tolist() if tiles is not None else None
+        if nt is not None and max(nt) > cap_t:
+            tiles = None                                           # most tiles changed: that layer densely
         self._last_changed_rows = dict(fraction=sum(n) / float(T * npix_out), layers=[op.name for op in tail],
                                        window=tuple(first.kernel), used=max(n) <= cap)
         if max(n) > cap:
             return None
-        return [dict(clean_rows=clean_rows, rows=rows[j * cap:j * cap + n[j]], n=n[j]) for j in range(nchunks)]
+        out = [dict(clean_rows=clean_rows, rows=rows[j * cap:j * cap + n[j]], n=n[j]) for j in range(nchunks)]
+        if tiles is not None:
+            self._last_changed_rows.update(tile_layer=top.name, tile_fraction=sum(nt) / float(T * th * tw))
+            for j, dct in enumerate(out):
+                dct.update(tile_op=top, tiles=tiles[j * cap_t:j * cap_t + nt[j]], ntiles=nt[j],
+                           clean_tile_rows=clean_tile_rows, clean_pool_rows=clean_pool_rows)
+        return out
 
     def _forward_chunks(self, noisy, step, clean=None):
         """The network on `noisy` (T, C, *spatial) in chunks of `step` copies -> (T, out_channels, *out_spatial).

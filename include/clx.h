@@ -166,6 +166,14 @@ typedef struct clx_conv_desc {
    * Output height and width must be even; ld_pool % 4 == 0; the same values clx_maxpool_fwd(out, 1, 2, 2) writes. */
   float* pool_out;
   int ld_pool;
+  /* clx_conv_fwd, Winograd algorithms on 2-D layers (KD = 1) only, optional: compute ONLY the output tiles listed —
+   * tile_list[i] = (b * th + ty) * tw + tx with th x tw = ceil(OH / tile) x ceil(OW / tile) tiles per image — and leave
+   * every other element of `out` (and `pool_out`) untouched: the noisy copies of one image differ from it in some
+   * tiles only (the caller has put the clean image's output under every copy).  The transforms and the
+   * batched products see tile_count tiles; each listed tile gets the bits the full computation gives it.  No
+   * vcache / accumulate with a list. */
+  const int* tile_list;
+  int tile_count;
 } clx_conv_desc;
 
 enum clx_conv_algo {
@@ -435,11 +443,18 @@ int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long lo
  * The copies are taken in chunks of `chunk`; chunk c's changed rows are written to rows[c * cap ...] as
  * (t - c * chunk) * npix_out + output pixel (any order), their number to counts[c] (which may exceed cap: rows beyond
  * cap are not written — the caller then takes the dense path).  counts: ceil(T / chunk) ints.
- * workspace: clx_changed_rows_workspace(T, ID, IH, IW) bytes of scratch (one bit per input pixel and copy), 8-byte
- * aligned.  KW < 64. */
+ * workspace: clx_changed_rows_workspace(T, ID, IH, IW) bytes of scratch (a bit per input pixel and per output row of
+ * every copy), 8-byte aligned.  KW < 64. */
 size_t clx_changed_rows_workspace(int T, int ID, int IH, int IW);
 int clx_changed_rows(const float* clean, const float* noisy, int T, int C, int ID, int IH, int IW, int KD, int KH,
                      int KW, int chunk, int* rows, int* counts, long long cap, void* workspace, clx_stream stream);
+/* After clx_changed_rows (same T, extents and window; 2-D: one output plane), from the row bits it left in `workspace`:
+ * the output TILES (tile x tile) of a (WH, WW) valid convolution over those rows that see a changed row in their
+ * (tile + WH - 1) x (tile + WW - 1) window — what clx_conv_desc.tile_list takes for the Winograd layer behind the 1 x 1
+ * layers.  Chunk c's tiles go to tiles[c * cap ...] as ((t - c * chunk) * th + ty) * tw + tx (any order), their number to
+ * counts[c] (may exceed cap; tiles beyond cap are not written).  tile + WW - 1 <= 64. */
+int clx_changed_tiles(const void* workspace, int T, int ID, int IH, int IW, int KD, int KH, int KW, int WH, int WW,
+                      int tile, int chunk, int* tiles, int* counts, long long cap, clx_stream stream);
 /* dst[r][0..width) = src[rows[r]][0..width) for r < n (row strides ld_src / ld_dst floats; width, strides % 4 == 0,
  * 16-byte aligned bases). */
 int clx_gather_rows(const float* src, int ld_src, const int* rows, long long n, int width, float* dst, int ld_dst,

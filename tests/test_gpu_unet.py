@@ -54,6 +54,11 @@ CONFIGS = {
     "3d_chain64": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=64, fmap_inc_factor=2,
                                 features_in_last_layer=64, downsampling_factors=[[2, 2, 2]],
                                 num_spatial_dims=3), spatial=(24, 20, 20), batch=1),
+    # 96 channels at the top level: its 1x1 layers run one by one (no fused pairs) and its last 3x3 layer as Winograd
+    # with the pooling written by the output transform — the infer-mode prefix of changed rows AND changed tiles
+    "2d_96": dict(cfg=dict(in_channels=1, out_channels=2, num_fmaps=96, fmap_inc_factor=2,
+                           features_in_last_layer=32, downsampling_factors=[[2, 2]],
+                           num_spatial_dims=2), spatial=(76, 92), batch=1),
     "3d_small": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=8, fmap_inc_factor=2,
                               features_in_last_layer=16, downsampling_factors=[[2, 2, 2]],
                               num_spatial_dims=3), spatial=(28, 24, 32), batch=2),
@@ -288,7 +293,7 @@ def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, 
     assert torch.equal(model.infer_on_device(x, noise=noise), one_b)
 
 
-@pytest.mark.parametrize("name", ["2d_wide", "2d_odd_channels", "3d_small", "2d_chain64"])
+@pytest.mark.parametrize("name", ["2d_wide", "2d_odd_channels", "3d_small", "2d_chain64", "2d_96"])
 def test_noisy_copies_through_changed_rows_equal_the_dense_forward_bit_for_bit(name, device, monkeypatch):
     """The noisy copies of infer mode (unet.py:73-100) differ from the image in p_salt_pepper of their pixels: the 1x1
     layers behind the first convolution run once on the clean image and on the CHANGED rows of each copy
@@ -323,6 +328,16 @@ def test_noisy_copies_through_changed_rows_equal_the_dense_forward_bit_for_bit(n
             first = plan.pointwise_prefix()[0]
             npix = first.out_shape[0] * first.out_shape[1] * first.out_shape[2]
             assert 0 < max(calls) < 0.6 * 4 * npix
+            info = model._last_changed_rows
+            # the Winograd layer behind the 1x1 layers takes a tile list where there is one (2d_96) ...
+            assert ("tile_fraction" in info) == (name == "2d_96"), info
+            if name == "2d_96":
+                assert plan.tiled_layer_behind_prefix()[1] == 4 and 0.0 < info["tile_fraction"] < 0.7
+                # ... and CLX_SPARSE_TILES=0 keeps that layer dense: the same bits again
+                monkeypatch.setenv("CLX_SPARSE_TILES", "0")
+                assert torch.equal(dense, model.infer_on_device(x, noise=noise))
+                assert "tile_fraction" not in model._last_changed_rows
+                monkeypatch.delenv("CLX_SPARSE_TILES", raising=False)
     oracle.set_infer(0.6, n_it)
     with torch.no_grad():
         ref = oracle(raw, noise=noise)
@@ -372,6 +387,37 @@ def test_changed_rows_gather_scatter_broadcast_through_the_c_abi(device):
               _clx.ptr(counts), 3, _clx.ptr(ws), st)
     assert counts.cpu().numpy().tolist() == counts_h.tolist()
     assert (rows.cpu().numpy()[3 * nchunks:] == -1).all()
+    # changed TILES of a (3, 3) convolution over those rows, 4 x 4 output tiles (2-D: one plane)
+    T2, C2, H2, W2 = 3, 1, 21, 150
+    clean2 = rng.random((C2, 1, H2, W2), dtype=np.float32)
+    noisy2 = np.repeat(clean2[None], T2, axis=0)
+    noisy2[rng.random(noisy2.shape) < 0.004] = 0.25
+    oh2, ow2 = H2 - 2, W2 - 2
+    diff2 = (noisy2 != clean2[None]).any(axis=1)[:, 0]
+    rowchg = np.zeros((T2, oh2, ow2), bool)
+    for dy in range(3):
+        for dx in range(3):
+            rowchg |= diff2[:, dy:dy + oh2, dx:dx + ow2]
+    th, tw = -(-(oh2 - 2) // 4), -(-(ow2 - 2) // 4)
+    want_t = np.zeros((T2, th, tw), bool)
+    for ty in range(th):
+        for tx in range(tw):
+            want_t[:, ty, tx] = rowchg[:, 4 * ty:4 * ty + 6, 4 * tx:4 * tx + 6].any(axis=(1, 2))
+    ws2 = torch.empty(int(_clx.load().clx_changed_rows_workspace(T2, 1, H2, W2)), dtype=torch.uint8, device=device)
+    rows2 = torch.empty(2 * 2 * oh2 * ow2, dtype=torch.int32, device=device)
+    cnt2 = torch.empty(4, dtype=torch.int32, device=device)
+    c2_d, n2_d = torch.from_numpy(clean2).to(device), torch.from_numpy(noisy2).to(device)
+    _clx.call("clx_changed_rows", _clx.ptr(c2_d), _clx.ptr(n2_d), T2, C2, 1, H2, W2, 1, 3, 3, 2, _clx.ptr(rows2),
+              _clx.ptr(cnt2), 2 * oh2 * ow2, _clx.ptr(ws2), st)
+    capt = 2 * th * tw
+    tiles = torch.full((2 * capt,), -1, dtype=torch.int32, device=device)
+    _clx.call("clx_changed_tiles", _clx.ptr(ws2), T2, 1, H2, W2, 1, 3, 3, 3, 3, 4, 2, _clx.ptr(tiles), _clx.ptr(cnt2[2:]),
+              capt, st)
+    tc, tl = cnt2.cpu().numpy()[2:], tiles.cpu().numpy()
+    assert 0 < tc.sum() < T2 * th * tw
+    for c in range(2):
+        ref_t = np.flatnonzero(want_t[c * 2:(c + 1) * 2].reshape(-1))
+        np.testing.assert_array_equal(np.sort(tl[c * capt:c * capt + tc[c]]), ref_t)
     # gather / scatter / broadcast
     src = torch.from_numpy(rng.random((50, 12), dtype=np.float32)).to(device)
     idx = torch.from_numpy(rng.permutation(50)[:17].astype(np.int32)).to(device)
