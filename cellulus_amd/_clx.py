@@ -123,6 +123,7 @@ PROTOTYPES = {
     "clx_changed_rows_workspace": (c_size_t, [_I, _I, _I, _I]),
     "clx_changed_rows": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _LL, _P, _P]),
     "clx_changed_tiles": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _LL, _P]),
+    "clx_grey_rows": (_I, [_P, _I, _I, _I, _I, _I, _P, _LL, _P, _P, _I, _I, _P, _I, _P]),
     "clx_gather_rows": (_I, [_P, _I, _P, _LL, _I, _P, _I, _P]),
     "clx_scatter_rows": (_I, [_P, _I, _P, _LL, _I, _P, _I, _P]),
     "clx_broadcast_rows": (_I, [_P, _LL, _P, _I, _P]),

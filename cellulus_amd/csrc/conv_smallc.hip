@@ -429,6 +429,55 @@ __global__ __launch_bounds__(256) void conv_grey_wgrad_kernel(const SmallP p) {
 }
 
 // grey kernels apply: one real channel, valid 3x3 or 3x3x3 kernel, channel quads stored whole
+// conv_grey_fwd_kernel's arithmetic for a LIST of output pixels of a planar one-channel image batch (the changed
+// rows of the noisy copies of infer mode): out[r][n] = act(bias[n] + sum over the taps in the order
+// t = (dz * 3 + dy) * 3 + dx of x[...] * w[n][t]) with the same fused multiply-adds in the same order — the bits
+// conv_grey_fwd_kernel writes for that pixel (tests/test_gpu_unet.py compares them).  lane = (px, cq): four listed
+// pixels per wavefront, channel quad cq of the 64 channels of blockIdx.y.
+template <int KD>
+__global__ __launch_bounds__(256) void conv_grey_rows_kernel(const float* __restrict__ x, int D, int H, int W, int OD,
+                                                             int OH, int OW, const int* __restrict__ rows, long long n,
+                                                             const float* __restrict__ wpack,
+                                                             const float* __restrict__ bias, int relu, int N,
+                                                             float* __restrict__ out, int ld_out) {
+  constexpr int R = KD * 3, TAPS = R * 3;
+  const int lane = threadIdx.x & 63, px = lane >> 4, cq = lane & 15;
+  const int nn = blockIdx.y * 64 + cq * 4;
+  const bool live_n = nn < N;
+  f32x4 w[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[t][e] = live_n ? wpack[((size_t)(nn + e) * TAPS + t) * 4] : 0.f;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && live_n) bv = *reinterpret_cast<const f32x4*>(bias + nn);
+  const long long npo = (long long)OD * OH * OW;
+  const long long groups = (n + 3) / 4;
+  for (long long g = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += (long long)gridDim.x * 4) {
+    const long long r = g * 4 + px;
+    const bool live = r < n;
+    const long long row = rows[live ? r : n - 1];
+    const long long b = row / npo, pix = row - b * npo;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), oz = (int)(pix / ((long long)OW * OH));
+    const float* src = x + ((b * D + oz) * H + oy) * (long long)W + ox;
+    float xv[TAPS];
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) xv[rr * 3 + tx] = src[((long long)(rr / 3) * H + (rr % 3)) * W + tx];
+    f32x4 acc = bv;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) acc += xv[rr * 3 + tx] * w[rr * 3 + tx];
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    if (live && live_n) *reinterpret_cast<f32x4*>(out + (size_t)r * ld_out + nn) = acc;
+  }
+}
+
 bool grey_applicable(const clx_conv_desc* d, int ld_act) {
   return d->c_real == 1 && d->KH == 3 && d->KW == 3 && (d->KD == 1 || d->KD == 3) && d->PD == 0 &&
          d->PH == 0 && d->PW == 0 && d->N % 4 == 0 && ld_act % 4 == 0;
@@ -530,5 +579,26 @@ int clx_smallc_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
     case 32: conv_smallc_wgrad_stream_kernel<32><<<grid, 256, lds, st>>>(p); break;
     default: conv_smallc_wgrad_stream_kernel<64><<<grid, 256, lds, st>>>(p); break;
   }
+  return CLX_OK;
+}
+
+extern "C" int clx_grey_rows(const float* x, int B, int ID, int IH, int IW, int KD, const int* rows, long long n,
+                             const float* wpack, const float* bias, int relu, int N, float* out, int ld_out,
+                             clx_stream stream) {
+  CLX_REQUIRE(n >= 0, "clx_grey_rows: bad count");
+  if (n == 0) return CLX_OK;
+  CLX_REQUIRE(x && rows && wpack && out, "clx_grey_rows: null pointer");
+  CLX_REQUIRE(B > 0 && (KD == 1 || KD == 3) && ID >= KD && IH >= 3 && IW >= 3, "clx_grey_rows: a 3x3 or 3x3x3 window");
+  CLX_REQUIRE(N > 0 && N % 4 == 0 && ld_out % 4 == 0 && ld_out >= N && ((uintptr_t)out & 15) == 0 &&
+                  (!bias || ((uintptr_t)bias & 15) == 0),
+              "clx_grey_rows: N, ld_out multiples of 4, aligned out / bias");
+  const int OD = ID - KD + 1, OH = IH - 2, OW = IW - 2;
+  long long gx = (n + 15) / 16;
+  if (gx > 4096) gx = 4096;
+  const dim3 grid((unsigned)gx, (unsigned)((N + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (KD == 1) conv_grey_rows_kernel<1><<<grid, 256, 0, st>>>(x, ID, IH, IW, OD, OH, OW, rows, n, wpack, bias, relu, N, out, ld_out);
+  else conv_grey_rows_kernel<3><<<grid, 256, 0, st>>>(x, ID, IH, IW, OD, OH, OW, rows, n, wpack, bias, relu, N, out, ld_out);
+  CLX_CHECK_LAUNCH("clx_grey_rows");
   return CLX_OK;
 }

@@ -1171,6 +1171,16 @@ class UNetPlan:
             src = op.out
         return (first, tail) if tail else None
 
+    def first_layer_on_rows(self):
+        """True if the first layer of pointwise_prefix can be computed for a list of output pixels by clx_grey_rows: a
+        one-channel image under a 3 x 3 (x 3) kernel — the layers clx_conv_fwd gives to conv_grey_fwd_kernel."""
+        prefix = self.pointwise_prefix()
+        if prefix is None or os.environ.get("CLX_SPARSE_FIRST", "1") == "0":
+            return False
+        first = prefix[0]
+        return (self.topo.in_channels == 1 and tuple(first.kernel) in ((1, 3, 3), (3, 3, 3)) and first.cout % 4 == 0
+                and first.in_shape[0] >= first.kernel[0] and self.precision == 0)
+
     def tiled_layer_behind_prefix(self):
         """The 2-D Winograd layer that reads the last 1x1 layer of pointwise_prefix (conv_pass.6 of the first level), or
         None: its output tiles can be computed for a list of tiles only (clx_conv_desc.tile_list)."""
@@ -1271,7 +1281,16 @@ class UNetPlan:
         cur = None
         if n > 0:
             cur = self._compact(0, n, width)
-            _clx.call("clx_gather_rows", _clx.ptr(src), width, _clx.ptr(rows), n, width, _clx.ptr(cur), width, st)
+            if sparse.get("noisy") is not None:
+                # one-channel image: the first layer itself on the changed rows (clx_grey_rows: the dense kernel's
+                # arithmetic) — the dense first-layer tensor of the copies is never written
+                first = self.topo.fwd_order[0]
+                b = params[2 * first.param_index + 1]
+                _clx.call("clx_grey_rows", _clx.ptr(sparse["noisy"]), self.B, *first.in_shape, first.kernel[0],
+                          _clx.ptr(rows), n, _clx.ptr(self.wpack_fwd[first.name]), _clx.ptr(b) if b is not None else None,
+                          1 if first.relu else 0, first.cout, _clx.ptr(cur), width, st)
+            else:
+                _clx.call("clx_gather_rows", _clx.ptr(src), width, _clx.ptr(rows), n, width, _clx.ptr(cur), width, st)
             for k, op in enumerate(tail):
                 y = self._compact(1 + k % 2, n, pad4(op.cout))
                 d = ClxConvDesc()
@@ -1317,11 +1336,17 @@ class UNetPlan:
         self._vcache_fresh = set()      # Winograd layers whose V this forward left in self.vcache
         npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
         raw = raw.contiguous()
-        _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
-                  t.in_channels, npix_in, pad4(t.in_channels), st)
+        rows_only_first = sparse is not None and self.first_layer_on_rows()
+        if rows_only_first:
+            sparse = dict(sparse, noisy=raw)                # the first layer runs on the changed rows only
+        else:
+            _clx.call("clx_planar_to_pixel", _clx.ptr(raw), _clx.ptr(self.buf["raw"]), self.B,
+                      t.in_channels, npix_in, pad4(t.in_channels), st)
         for op_index, op in enumerate(t.fwd_order):
             if on_op is not None and op_index > 0:
                 on_op(op_index - 1)
+            if op_index == 0 and rows_only_first:
+                continue
             if isinstance(op, ConvLayer) and op.name in self.chain_second:
                 continue                                    # computed with its predecessor
             if isinstance(op, ConvLayer) and op.name in self.chains:

@@ -455,6 +455,12 @@ int clx_changed_rows(const float* clean, const float* noisy, int T, int C, int I
  * counts[c] (may exceed cap; tiles beyond cap are not written).  tile + WW - 1 <= 64. */
 int clx_changed_tiles(const void* workspace, int T, int ID, int IH, int IW, int KD, int KH, int KW, int WH, int WW,
                       int tile, int chunk, int* tiles, int* counts, long long cap, clx_stream stream);
+/* The first layer of a ONE-channel image (3 x 3 or 3 x 3 x 3, valid; what clx_conv_fwd runs for c_real == 1) for a LIST of
+ * output pixels: x planar (B, ID, IH, IW), rows[r] = b * (output pixels per image) + output pixel, wpack / bias as for
+ * clx_conv_fwd of that layer; out[r][0..N) — the same fused multiply-adds in the same order as the dense kernel, so the
+ * same bits (the changed rows of noisy copies never pass through a dense first-layer tensor). */
+int clx_grey_rows(const float* x, int B, int ID, int IH, int IW, int KD, const int* rows, long long n, const float* wpack,
+                  const float* bias, int relu, int N, float* out, int ld_out, clx_stream stream);
 /* dst[r][0..width) = src[rows[r]][0..width) for r < n (row strides ld_src / ld_dst floats; width, strides % 4 == 0,
  * 16-byte aligned bases). */
 int clx_gather_rows(const float* src, int ld_src, const int* rows, long long n, int width, float* dst, int ld_dst,

@@ -329,6 +329,13 @@ def test_noisy_copies_through_changed_rows_equal_the_dense_forward_bit_for_bit(n
             npix = first.out_shape[0] * first.out_shape[1] * first.out_shape[2]
             assert 0 < max(calls) < 0.6 * 4 * npix
             info = model._last_changed_rows
+            # one-channel images: the first layer itself runs on the changed rows (clx_grey_rows, the dense kernel's
+            # arithmetic); two channels, or CLX_SPARSE_FIRST=0: densely, and its changed rows are gathered
+            assert plan.first_layer_on_rows() == (name != "2d_odd_channels")
+            monkeypatch.setenv("CLX_SPARSE_FIRST", "0")
+            assert not plan.first_layer_on_rows()
+            assert torch.equal(dense, model.infer_on_device(x, noise=noise))
+            monkeypatch.delenv("CLX_SPARSE_FIRST", raising=False)
             # the Winograd layer behind the 1x1 layers takes a tile list where there is one (2d_96) ...
             assert ("tile_fraction" in info) == (name == "2d_96"), info
             if name == "2d_96":
