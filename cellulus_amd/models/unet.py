@@ -346,9 +346,11 @@ class UNetModel(nn.Module):  # type: ignore
     def _sparse_prepare(self, plan, noisy, clean, step, params):
         """Noisy copies of ONE image (`clean`, (1, C, *spatial)): per chunk of `step` copies the rows of the first
         convolution's output that differ from the clean image's, and the clean image's rows behind the 1x1 layers that
-        follow (plan.pointwise_prefix) -> a list of per-chunk dicts for UNetPlan.forward(sparse=...), or None where the
-        dense path is the better one: no such prefix, CLX_SPARSE_NOISE=0, or more than CLX_SPARSE_NOISE_MAX (default
-        0.3) of the rows changed.  One host synchronisation (the row counts size the launches)."""
+        follow (plan.pointwise_prefix) — and, where a 2-D Winograd layer reads those, its output tiles whose input window
+        holds such a row, with the clean image's output of that layer — -> a list of per-chunk dicts for UNetPlan.forward
+        (sparse=...), or None where the dense path is the better one: no such prefix, CLX_SPARSE_NOISE=0, or more than
+        CLX_SPARSE_NOISE_MAX (default 0.3) of the rows changed.  One host synchronisation (the counts size the launches);
+        DESIGN.md 3.1f."""
         if clean is None or os.environ.get("CLX_SPARSE_NOISE", "1") == "0":
             return None
         prefix = plan.pointwise_prefix()
@@ -399,15 +401,20 @@ class UNetModel(nn.Module):  # type: ignore
         cp = getattr(self, "_clean_plan", None)
         if cp is None or cp[0] is not plan:
             one = UNetPlan(plan.topo, 1, dev, False)
-            assert all(one.algo[op.name] == plan.algo[op.name] for op in [first] + tail)
-            cp = self._clean_plan = (plan, one)
+            # (the one-image plan must run these layers the way the chunk plan does: it reads that plan's packed weights)
+            same = all(one.algo[op.name] == plan.algo[op.name] for op in [first] + tail)
+            same_tiles = tiled is not None and one.algo[tiled[0].name] == plan.algo[tiled[0].name] and \
+                bool(one.fused_pool.get(tiled[0].name)) == bool(plan.fused_pool.get(tiled[0].name))
+            cp = self._clean_plan = (plan, one if same else None, same_tiles)
         one = cp[1]
+        if one is None:
+            return None
+        if tiles is not None and not cp[2]:
+            tiles = None
         one.wpack_fwd = plan.wpack_fwd
         clean_rows = one.forward_prefix(clean, params, len(tail) + (1 if tiles is not None else 0))
         clean_tile_rows = clean_pool_rows = None
         if tiles is not None:
-            assert one.algo[top.name] == plan.algo[top.name] and bool(one.fused_pool.get(top.name)) == \
-                bool(plan.fused_pool.get(top.name))
             clean_tile_rows, clean_rows = clean_rows, one.buf[tail[-1].out]
             if one.fused_pool.get(top.name) is not None:
                 clean_pool_rows = one.buf[one.fused_pool[top.name].out]
@@ -438,8 +445,8 @@ class UNetModel(nn.Module):  # type: ignore
         set of packed weights: the HBM-bound Winograd transforms of one chunk run under the GEMMs of the other, as in
         plan.DualPlan.  Same kernels on the same rows: bit-identical to the plain loop (tests/test_gpu_unet.py).  Measured at
         the benchmark tile (8 copies of 528 x 528 per chunk): embedding stage 199.7 -> 189.5 ms (round 4, with the second
-        stream started behind the first chunk's second layer; 204 -> 198 in round 3's form).  CLX_INFER_STREAMS=1: the
-        plain loop."""
+        stream started behind the first chunk's second layer; 204 -> 198 in round 3's form); with the first level on the
+        changed rows / tiles of the copies (`clean`): 171 -> 163 ms.  CLX_INFER_STREAMS=1: the plain loop."""
         T = noisy.shape[0]
         nstreams = min(int(os.environ.get("CLX_INFER_STREAMS", "2") or 2), 4, T // max(step, 1))
         if T % step:
