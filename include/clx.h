@@ -483,8 +483,8 @@ int clx_broadcast_rows(const float* src, long long nfloats, float* dst, int copi
  *   X:    (nfg, ND) f64 out,  index: (nfg) int32 raster index of each fg pixel
  *   nfg_out: device int32, number of foreground pixels
  * workspace: clx_ms_prepare_workspace(npix) bytes of plain scratch (16-byte aligned; no contents are expected and none
- * are kept: the foreground flags as one bit per pixel + the per-tile counts and their prefix).  Three launches: flags +
- * counts from the std plane, a scan of the counts, the scatter pass. */
+ * are kept: the foreground flags as one bit per pixel + the counts per tile and per chunk of tiles).  Two launches: flags
+ * + counts from the std plane; the scatter pass, which sums the counts in front of each tile itself. */
 size_t clx_ms_prepare_workspace(long long npix);
 int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
                    int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
