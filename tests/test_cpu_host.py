@@ -49,6 +49,17 @@ def test_argument_validation_without_gpu():
         _clx.call("clx_conv_fwd", ctypes.byref(d), None)
     assert lib.clx_maxpool_fwd(None, None, 1, 1, 4, 4, 4, 1, 2, 2, None) == -1
     assert lib.clx_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
+    # the row / tile movers of the infer-mode prefix
+    assert lib.clx_changed_rows(None, None, 4, 1, 1, 16, 16, 1, 3, 3, 2, None, None, 8, None, None) == -1
+    assert b"null pointer" in lib.clx_last_error()
+    assert lib.clx_changed_tiles(None, 4, 1, 16, 16, 1, 3, 3, 3, 3, 4, 2, None, None, 8, None) == -1
+    assert lib.clx_gather_rows(None, 8, None, 0, 8, None, 8, None) == 0          # nothing to move
+    assert lib.clx_gather_rows(None, 8, None, 3, 8, None, 8, None) == -1
+    assert lib.clx_scatter_rows(None, 8, None, -1, 8, None, 8, None) == -1
+    assert lib.clx_broadcast_rows(None, 16, None, 2, None) == -1
+    assert lib.clx_grey_rows(None, 1, 1, 16, 16, 1, None, 0, None, None, 1, 8, None, 8, None) == 0
+    assert lib.clx_grey_rows(None, 1, 1, 16, 16, 1, None, 5, None, None, 1, 8, None, 8, None) == -1
+    assert lib.clx_changed_rows_workspace(4, 1, 16, 130) == 2 * 4 * 16 * 3 * 8
 
 
 def test_product_fails_loudly_without_hip_device():
