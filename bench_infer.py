@@ -414,7 +414,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
                 del os.environ["CLX_INFER_STREAMS"]
             else:
                 os.environ["CLX_INFER_STREAMS"] = keep
-        return t_default, emb_, prof_one, t_one, (2 if two else 1)
+        return t_default, emb_, prof_one, t_one, (len(model._infer_pair[2]) if two else 1)
 
     t_embed_s, _emb_s, prof_s, t_one_s, streams_s = both_passes(256)
     t_detect_s, t_segment_s, (_l, centers_s, _s, ncomp_s), _inputs = post_stages(device, 256, reps)

@@ -172,8 +172,13 @@ def test_cfg3_dress_rehearsal_eight_ranks_at_the_real_workload(tmp_path, device)
     refuses several ranks per device — the collective semantics, the bucket ranges of the 38.5-MB gradient, the loader
     policy and the control flow are what is under test, not the wire).  The line must carry both halves of the metric
     (train crops/s, infer Mpixels/s through the sharded infer()) and the real train() with per-rank loader processes."""
+    import gc
+
     import bench
 
+    # the eight ranks need the device's memory: give back what this process's earlier tests left in torch's allocator
+    gc.collect()
+    torch.cuda.empty_cache()
     env = dict(os.environ, CLX_DIST_BACKEND="gloo", CLX_LOCAL_DEVICE="0", OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "CLX_STREAMS",
               "CLX_GRAD_BUCKET_MB", "CLX_DEVICE_PAIRS"):

@@ -16,7 +16,7 @@ model.eval()
 model.set_infer(p_salt_pepper=0.01, num_infer_iterations=16, device=dev)
 ref = None
 for rep in range(2):
-  for streams, off in (("2", "-1"), ("2", "0"), ("2", "1"), ("2", "2"), ("2", "3"), ("2", "4"), ("2", "5"), ("3", "1"), ("3", "3")):
+  for streams, off in (("2", "1"), ("3", "1"), ("4", "1"), ("2", "2"), ("3", "2"), ("2", "0"), ("2", "-1")):
     for mb in (8,):
         os.environ["CLX_INFER_OFFSET_OP"] = off
         os.environ["CLX_INFER_STREAMS"] = streams
