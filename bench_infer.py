@@ -205,7 +205,7 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
                 kernels=out)
 
 
-def e2e_infer(device, samples=16, size=512, rank=0, world=1):
+def e2e_infer(device, samples=32, size=512, rank=0, world=1):
     """The product's infer() on a synthetic zarr: S x size^2 raw images in, embeddings / detection /
     binary-segmentation / centered-embeddings / segmentation out, default inference settings
     (16 noise iterations, reduction_probability 0.1, cell post-processing).

@@ -446,11 +446,12 @@ class UNetModel(nn.Module):  # type: ignore
         plan.DualPlan.  Same kernels on the same rows: bit-identical to the plain loop (tests/test_gpu_unet.py).  Measured at
         the benchmark tile (8 copies of 528 x 528 per chunk): embedding stage 199.7 -> 189.5 ms (round 4, with the second
         stream started behind the first chunk's second layer; 204 -> 198 in round 3's form); with the first level on the
-        changed rows / tiles of the copies (`clean`): 171 -> 163 ms; on FOUR streams (the default where four sets of
-        activations fit the rank's share of the device — all chunks of a tile in flight): 161-162 -> 158-159 ms (three:
-        162-166).  CLX_INFER_STREAMS=1: the plain loop."""
+        changed rows / tiles of the copies (`clean`): 171 -> 163 ms.  FOUR streams (all chunks of a tile in flight) bring the
+        stage to 158-159 ms (three: 162-166) but infer() end to end from 165.3 to 168.8 ms per sample — the post-processing of
+        the previous sample shares the device with four busy queues instead of two — so two stay the default
+        (CLX_INFER_STREAMS=4 for the kernel-level figure).  CLX_INFER_STREAMS=1: the plain loop."""
         T = noisy.shape[0]
-        nstreams = min(int(os.environ.get("CLX_INFER_STREAMS", "4") or 4), 4, T // max(step, 1))
+        nstreams = min(int(os.environ.get("CLX_INFER_STREAMS", "2") or 2), 4, T // max(step, 1))
         if T % step:
             preds = [self._forward_nograd(noisy[i:i + step].contiguous()) for i in range(0, T, step)]
             return torch.cat(preds, dim=0) if len(preds) > 1 else preds[0]
