@@ -339,7 +339,7 @@ def run_workload(wl_key, args, rank, world, device):
 
     lib = _clx.load()
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-             3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels"}
+             3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
 
     def read_clock(reset=True):
         """MHz the MFMA kernels ran at since the last reset (clx_profile_clock), None if nothing was recorded"""

@@ -321,7 +321,7 @@ def infer_sharded(device, rank, world, samples_per_rank=16):
 
 
 MFMA_KINDS = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-              3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels"}
+              3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
 
 
 def embed_stage(model, device, size, n_it, reps):

@@ -113,6 +113,8 @@ PROTOTYPES = {
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
+    "clx_conv_fused_applicable": (_I, [POINTER(ClxConvDesc)]),
+    "clx_conv_fused_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc)]),
     "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_pixel_to_planar": (_I, [_P, _P, _I, _I, _LL, _I, _P]),
     "clx_depth_to_space": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

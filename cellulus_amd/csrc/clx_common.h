@@ -84,6 +84,9 @@ int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dw
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad, int tile,
                   int ksize, int kd, hipStream_t st);
 
+// Winograd F(4x4) with the transforms inside the product kernel (wino_fused.hip)
+int clx_wino_fused_fwd(const clx_conv_desc* d, hipStream_t st);
+
 // in-library kernel timing (clx_core.hip); kinds match enum clx_profile_kind in clx.h
 bool clx_prof_enabled();
 void clx_prof_events(int kind, double flops, hipEvent_t* e0, hipEvent_t* e1);

@@ -602,9 +602,15 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
               "clx_conv_fwd: gate_out needs relu, ld_out %% 32 == 0 and ld_gate >= ld_out / 32");
   CLX_REQUIRE(d->mask_bits == nullptr || (d->mask == nullptr && d->ld_mask_bits * 32 >= d->N),
               "clx_conv_fwd: mask_bits replaces mask and needs ld_mask_bits >= ceil(N / 32)");
-  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
+  CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4 ||
+                  d->algo == CLX_ALGO_WINOGRAD4_FUSED,
               "clx_conv_fwd: bad algo");
+  if (d->algo == CLX_ALGO_WINOGRAD4_FUSED) return clx_wino_fused_fwd(d, (hipStream_t)stream);
   if (d->algo != CLX_ALGO_DIRECT) return clx_wino_fwd(d, (hipStream_t)stream);
+  // pool_out / tile_list / adjoint are honoured by the Winograd paths only: a caller whose plan and dispatch disagree
+  // would otherwise be left with a pooled buffer nobody wrote, or a dense recomputation, and no error
+  CLX_REQUIRE(d->pool_out == nullptr && d->tile_list == nullptr && !d->adjoint,
+              "clx_conv_fwd: pool_out / tile_list / adjoint need a Winograd algorithm (algo = %d)", d->algo);
   // the small-channel kernels know neither ReLU-gate form (float mask, gate bits in or out): a
   // layer that asks for one — e.g. a NON-first layer with 4 input channels whose output feeds a
   // bit-gated data gradient — stays on the implicit-GEMM kernel, which writes / applies them

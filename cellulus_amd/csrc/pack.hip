@@ -167,6 +167,14 @@ extern "C" int clx_pack_weights(const float* w, float* wp, int cout, int cin, in
     CLX_CHECK_LAUNCH("clx_pack_weights(winograd adjoint)");
     return CLX_OK;
   }
+  if (mode == CLX_PACK_WINO4_FUSED) {
+    CLX_REQUIRE((taps == 9 || taps == 4) && cout_pad % 64 == 0 && cin_pad % 8 == 0,
+                "clx_pack_weights: the fused Winograd layout exists for 2-D 3x3 / 2x2 kernels with cout_pad %% 64 == 0 and "
+                "cin_pad %% 8 == 0");
+    clx_wino_pack(w, wp, cout, cin, cin_pad, cout_pad, 3, 4, taps == 9 ? 3 : 2, 1, (hipStream_t)stream);
+    CLX_CHECK_LAUNCH("clx_pack_weights(winograd fused)");
+    return CLX_OK;
+  }
   if (mode == CLX_PACK_WINO_FWD || mode == CLX_PACK_WINO_DGRAD || mode == CLX_PACK_WINO4_FWD ||
       mode == CLX_PACK_WINO4_DGRAD) {
     const bool four = mode == CLX_PACK_WINO4_FWD || mode == CLX_PACK_WINO4_DGRAD;

@@ -15,6 +15,7 @@
 // Replaces the same reference calls as conv_igemm.hip / conv_wgrad.hip (nn.Conv2d 3x3 and
 // its autograd backward, cellulus/models/unet.py:24-51, cellulus/train.py:178).
 #include "clx_common.h"
+#include "wino_tables.h"
 
 namespace {
 
@@ -36,53 +37,6 @@ struct Geom {
   int OH, OW, th, tw;      // output extent, tiles per image
   long long T;             // B * th * tw
 };
-
-// Transform matrices of F(MT x MT, 3 x 3) (Cook-Toom, y = A^T [(G g) o (B^T d)]), A = MT + 2.
-//   MT = 2: points {0, 1, -1, inf}
-//   MT = 4: points {0, 1, -1, 1/2, -2, inf} — measured on a 768-channel layer in f32 (max abs
-//           error / max|y|): 4.7e-6, against 1.1e-5 for the textbook {0, +-1, +-2}, 7e-7 for
-//           MT = 2 and 3.5e-7 for the direct convolution (tools/wino_numerics.py).
-// All entries of A^T and B^T are dyadic, i.e. exact in f32; G is applied in double.
-template <int MT, int R> struct WT;
-template <> struct WT<2, 3> {
-  static constexpr int A = 4;
-  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
-  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
-  static constexpr double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-};
-template <> struct WT<4, 3> {
-  static constexpr int A = 6;
-  static constexpr float BT[6][6] = {{1, -1.5f, -2, 1.5f, 1, 0},  {0, -1, 0.5f, 2.5f, 1, 0}, {0, 1, -2.5f, 0.5f, 1, 0},
-                                     {0, -2, -1, 2, 1, 0},        {0, 0.5f, -1, -0.5f, 1, 0}, {0, 1, -1.5f, -2, 1.5f, 1}};
-  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, -2, 0}, {0, 1, 1, 0.25f, 4, 0}, {0, 1, -1, 0.125f, -8, 1}};
-  static constexpr double G[6][3] = {{1, 0, 0},
-                                     {1.0 / 3, 1.0 / 3, 1.0 / 3},
-                                     {-1.0 / 3, 1.0 / 3, -1.0 / 3},
-                                     {-16.0 / 15, -8.0 / 15, -4.0 / 15},
-                                     {1.0 / 15, -2.0 / 15, 4.0 / 15},
-                                     {0, 0, 1}};
-};
-
-// F(4x4, 2x2) — the 2x2 convolution over the low-resolution tensor in the sub-pixel form of the
-// upsample convolution (plan.py): points {0, 1, -1, 1/2, inf}, 25 multiplications per 4x4 outputs
-// instead of 64; every |A^T| entry <= 1.
-template <> struct WT<4, 2> {
-  static constexpr int A = 5;
-  static constexpr float BT[5][5] = {{0.5f, -1, -0.5f, 1, 0}, {0, -0.5f, 0.5f, 1, 0}, {0, 0.5f, -1.5f, 1, 0},
-                                     {0, -1, 0, 1, 0},        {0, 0.5f, -1, -0.5f, 1}};
-  static constexpr float AT[4][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 0.5f, 0}, {0, 1, 1, 0.25f, 0}, {0, 1, -1, 0.125f, 1}};
-  static constexpr double G[5][2] = {{2, 0}, {1, 1}, {-1.0 / 3, 1.0 / 3}, {-8.0 / 3, -4.0 / 3}, {0, 1}};
-};
-
-// acc (+)= coef * v with the coefficient known at compile time: zeros vanish, +-1 become add/sub
-template <typename V>
-__device__ __forceinline__ void axpy(V& acc, bool& first, float coef, const V& v) {
-  if (coef == 0.f) return;
-  if (first) { acc = (coef == 1.f) ? v : (coef == -1.f) ? -v : coef * v; first = false; }
-  else if (coef == 1.f) acc += v;
-  else if (coef == -1.f) acc -= v;
-  else acc += coef * v;
-}
 
 // V[xi][t][c] = (B^T d B)[xi] for the A x A input patch of tile t (stride MT)
 template <int MT, int R>
@@ -572,10 +526,11 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
 // mode FWD:   g = w[n][c][:, :]            rows n < rows_pad (cout_pad), cols c < cin_pad
 // mode DGRAD: g = flip(w[n][c]) transposed roles: U[xi][c][n]
 // mode 2 (adjoint form): g = w[n][c] as it is, transposed roles: U[xi][c][n] = the forward transform, transposed
+// fused (with mode FWD, 2-D): the same values in the fragment layout of the fused kernel (wino_fused_index)
 template <int MT, int R>
 __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, float* __restrict__ U, int cout, int cin,
                                                  int rows, int cols, int kdt, int dgrad, long long total,
-                                                 long long first, long long step) {
+                                                 long long first, long long step, bool fused = false) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   // U[xi][row][dz][col]: the batched GEMM sees kdt "taps" along z (1 for 2-D layers)
@@ -619,16 +574,17 @@ __device__ __forceinline__ void wino_filter_body(const float* __restrict__ w, fl
         double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) acc += tt[r][k] * W::G[qq][k];
-        U[(r * A + qq) * plane + i] = (float)acc;
+        if (fused) U[wino_fused_index(r * A + qq, row, col, cols, A * A)] = (float)acc;
+        else U[(r * A + qq) * plane + i] = (float)acc;
       }
   }
 }
 
 template <int MT, int R>
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int cout,
-                                   int cin, int rows, int cols, int kdt, int dgrad, long long total) {
+                                   int cin, int rows, int cols, int kdt, int dgrad, long long total, bool fused) {
   wino_filter_body<MT, R>(w, U, cout, cin, rows, cols, kdt, dgrad, total,
-                          (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+                          (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, fused);
 }
 
 // every packing of a step in one launch: blockIdx.y = job (clx_pack_weights_batch)
@@ -655,14 +611,15 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const clx_pack_job* __r
     }
     return;
   }
-  const bool four = j.mode == CLX_PACK_WINO4_FWD || j.mode == CLX_PACK_WINO4_DGRAD || j.mode == CLX_PACK_WINO4_ADJOINT;
+  const bool fused = j.mode == CLX_PACK_WINO4_FUSED;
+  const bool four = j.mode == CLX_PACK_WINO4_FWD || j.mode == CLX_PACK_WINO4_DGRAD || j.mode == CLX_PACK_WINO4_ADJOINT || fused;
   const int dgrad = (j.mode == CLX_PACK_WINO_DGRAD || j.mode == CLX_PACK_WINO4_DGRAD) ? 1
                     : j.mode == CLX_PACK_WINO4_ADJOINT                               ? 2 : 0;
   const int ksize = (j.taps == 9 || j.taps == 27) ? 3 : 2, kd = (j.taps == 27 || j.taps == 8) ? ksize : 1;
   const int rows = dgrad ? j.cin_pad : j.cout_pad, cols = dgrad ? j.cout_pad : j.cin_pad;
   const long long total = (long long)rows * kd * cols;
-  if (ksize == 2) wino_filter_body<4, 2>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step);
-  else if (four) wino_filter_body<4, 3>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step);
+  if (ksize == 2) wino_filter_body<4, 2>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step, fused);
+  else if (four) wino_filter_body<4, 3>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step, fused);
   else wino_filter_body<2, 3>(j.w, j.wp, j.cout, j.cin, rows, cols, kd, dgrad, total, first, step);
 }
 
@@ -935,14 +892,17 @@ int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dw
                          : wino_wgrad_t<2, 3>(d, dy, ld_dy, dwpack, dbias, st);
 }
 
+// dgrad: 0 forward, 1 flipped filter, 2 adjoint form, 3 forward in the fused kernel's fragment layout
 int clx_wino_pack(const float* w, float* wp, int cout, int cin, int cin_pad, int cout_pad, int dgrad,
                   int tile, int ksize, int kd, hipStream_t st) {
+  const bool fused = dgrad == 3;
+  if (fused) dgrad = 0;
   const int rows = dgrad ? cin_pad : cout_pad, cols = dgrad ? cout_pad : cin_pad;
   const long long total = (long long)rows * kd * cols;
   const int grid = grid_for(total, 256);
-  if (ksize == 2) wino_filter_kernel<4, 2><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
-  else if (tile == 4) wino_filter_kernel<4, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
-  else wino_filter_kernel<2, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total);
+  if (ksize == 2) wino_filter_kernel<4, 2><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total, fused);
+  else if (tile == 4) wino_filter_kernel<4, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total, fused);
+  else wino_filter_kernel<2, 3><<<grid, 256, 0, st>>>(w, wp, cout, cin, rows, cols, kd, dgrad, total, fused);
   return CLX_OK;
 }
 

@@ -35,10 +35,11 @@ def pad4(c: int) -> int:
 # layer) or F(4x4, 3x3) (4x fewer, ~5e-6; the direct kernel: ~4e-7).
 WINO_MIN_CHANNELS = int(os.environ.get("CLX_WINOGRAD_MIN_CHANNELS", "64"))
 # per-layer algorithm code = clx_conv_algo: 0 direct, 1 Winograd F(2x2), 2 Winograd F(4x4)
-WINO_TAPS = {1: 16, 2: 36}
-WINO_PACK_FWD = {1: 2, 2: 4}        # clx_pack_mode
+# (3 = F(4x4) with the transforms inside the product kernel, forward only: clx_conv_algo CLX_ALGO_WINOGRAD4_FUSED)
+WINO_TAPS = {1: 16, 2: 36, 3: 36}
+WINO_PACK_FWD = {1: 2, 2: 4, 3: 7}  # clx_pack_mode
 WINO_PACK_DGRAD = {1: 3, 2: 5}
-WINO_TILE = {1: 2, 2: 4}
+WINO_TILE = {1: 2, 2: 4, 3: 4}
 
 
 # 3-D layers (F(4x4) in (y, x) per z plane, the z taps inside the batched GEMMs): K = 3 * C per GEMM, so
@@ -72,6 +73,27 @@ def precision_code() -> int:
 
 def winograd_enabled() -> bool:
     return os.environ.get("CLX_WINOGRAD", "1") != "0"
+
+
+# The fused forms keep the products' results on chip: 36 x 32 x 64 accumulators per workgroup, i.e. 10.7 FLOP per
+# byte of operands from L2 where the 128 x 128 tiles of the batched GEMMs have 32 — they top out near 110 TFLOP/s.  That
+# beats the three-launch form where ITS GEMMs are short (K = C <= 256: 78-90 TFLOP/s with the transforms) or narrow
+# (N = 64: HBM-bound on V and M), and loses at C = 768 (113 TFLOP/s with the transforms; tools/exp/fused_bench.py,
+# DESIGN.md 3.1g).
+FUSED_MAX_CHANNELS = int(os.environ.get("CLX_WINO_FUSED_MAX_CHANNELS", "256"))
+
+
+def fused_pays(cin_pad: int, cout: int) -> bool:
+    return cout <= 64 or cin_pad <= FUSED_MAX_CHANNELS
+
+
+def fused_wanted(keep_activations: bool) -> bool:
+    """2-D F(4x4) forward layers as ONE launch each (csrc/wino_fused.hip: the transformed tensors never reach HBM).
+    CLX_WINO_FUSED=0 keeps the three-launch form everywhere; the training plans (which keep the transformed input for
+    the weight gradient) take it with CLX_WINO_FUSED_TRAIN=1 only."""
+    if os.environ.get("CLX_WINO_FUSED", "1") == "0":
+        return False
+    return (not keep_activations) or os.environ.get("CLX_WINO_FUSED_TRAIN", "0") == "1"
 
 
 @dataclass
@@ -305,6 +327,7 @@ class UNetPlan:
         self.device = device
         self.keep = keep_activations
         self.precision = precision_code()
+        self.fused = fused_wanted(keep_activations) and self.precision == 0
         # opt-in: run-to-run reproducible training (CLX_DETERMINISTIC=1; the reference's CPU autograd is
         # deterministic, cellulus/train.py:177-179).  Weight-gradient slices add in a fixed order, bias
         # gradients come from ordered column sums, the first layer takes the generic kernel and the fused
@@ -337,6 +360,10 @@ class UNetPlan:
                 nf = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 0))
                 if nf:
                     a["fwd"], ws_bytes = code, max(ws_bytes, nf)
+                    if (code == 2 and self.fused and layer.cout == pad4(layer.cout) and fused_pays(layer.cin_pad, layer.cout)
+                            and int(lib.clx_conv_fused_applicable(ctypes.byref(d)))):
+                        a["fwd"] = 3
+                        ws_bytes = max(ws_bytes, int(lib.clx_conv_fused_workspace_bytes(ctypes.byref(d))))
                 d.N = pad4(layer.cout)
                 nw = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 1))
                 if nw and self.keep:
@@ -358,6 +385,7 @@ class UNetPlan:
                 self.buf[sp["zname"]] = torch.zeros((n, sp["P"] * sp["N"]), dtype=torch.float32, device=self.device)
                 # the 2x2 convolution over the low-res tensor as Winograd F(4x4, 2x2)
                 sp["wino"] = 0
+                sp["fused_z"] = sp["fused_skip"] = False    # forward halves in the one-launch form (wino_fused.hip)
                 if (winograd_enabled() and winograd_code() == 2 and sp["zk"] in ((1, 2, 2), (2, 2, 2))
                         and min(sp["C1p"], sp["P"] * sp["N"]) >= wino_min_channels(sp["zk"])):
                     lib = _clx.load()
@@ -372,6 +400,10 @@ class UNetPlan:
                     if all(need):
                         sp["wino"] = 2
                         ws_bytes = max([ws_bytes] + need)
+                        sp["fused_z"] = bool(self.fused and fused_pays(sp["C1p"], sp["P"] * sp["N"])
+                                             and int(lib.clx_conv_fused_applicable(ctypes.byref(dz))))
+                        if sp["fused_z"]:
+                            ws_bytes = max(ws_bytes, int(lib.clx_conv_fused_workspace_bytes(ctypes.byref(dz))))
                 # ... and the 3x3 convolution over the skip tensor as F(4x4, 3x3), forward and weight
                 # gradient only: its data gradient has K = N (64 at the benchmark config), too short
                 # a contraction for the batched GEMMs to pay
@@ -391,6 +423,9 @@ class UNetPlan:
                     if all(need):
                         sp["wino_skip"] = 2
                         ws_bytes = max([ws_bytes] + need)
+                        ds.N = conv0.cout
+                        sp["fused_skip"] = bool(self.fused and conv0.cout == sp["N"] and fused_pays(sp["C0p"], conv0.cout)
+                                                and int(lib.clx_conv_fused_applicable(ctypes.byref(ds))))
                 # its data gradient contracts over z taps x output channels: long enough only in 3-D
                 sp["wino_skip_dgrad"] = 0
                 if sp["wino_skip"] and self.keep and sp["N"] * conv0.kernel[0] >= WINO_MIN_CHANNELS:
@@ -496,11 +531,11 @@ class UNetPlan:
                 sp["g_skip"] = torch.empty(layer.cout * sp["C0"] * layer.taps, dtype=torch.float32, device=self.device)
                 sp["g_z"] = torch.empty(sp["P"] * sp["N"] * sp["C1"] * sp["ztaps"], dtype=torch.float32,
                                         device=self.device)
-                if sp["wino_skip"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
+                if sp["wino_skip"] and not sp["fused_skip"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     tiles = self.B * layer.in_shape[0] * -(-layer.out_shape[1] // 4) * -(-layer.out_shape[2] // 4)
                     sp["vcache_skip"] = torch.empty(36 * tiles * sp["C0p"], dtype=torch.float32, device=self.device)
                 sp["_dw_z_n"] = ztaps * sp["P"] * sp["N"] * sp["C1p"]
-                if sp["wino"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
+                if sp["wino"] and not sp["fused_z"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     zs = sp["zshape"]
                     tiles = self.B * (zs[0] + sp["zk"][0] - 1) * -(-zs[1] // 4) * -(-zs[2] // 4)
                     sp["vcache"] = torch.empty(25 * tiles * sp["C1p"], dtype=torch.float32, device=self.device)
@@ -713,6 +748,13 @@ class UNetPlan:
             d.relu = 0
         return dz, ds
 
+    @staticmethod
+    def _sp_pack_mode(sp, half):
+        """clx_pack_mode of a sub-pixel layer's forward weights: plain, F(4x4), or F(4x4) in the fused kernel's layout"""
+        if half == "skip":
+            return 7 if sp["fused_skip"] else 4 if sp["wino_skip"] else 0
+        return 7 if sp["fused_z"] else 4 if sp["wino"] else 0
+
     def _sp_pack(self, layer, sp, w, need_dgrad, st):
         # one launch: the skip half's weights and the phase-summed weights of the upsampled half
         # (_phase_weights is the same algebra in torch ops, kept as the CPU-testable statement)
@@ -723,9 +765,9 @@ class UNetPlan:
         _clx.call("clx_subpixel_split_weights", _clx.ptr(wv), _clx.ptr(w_skip), _clx.ptr(weff), layer.cout,
                   layer.cin, sp["C0"], sp["N"], *layer.kernel, *sp["fac"], st)
         _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_fwd"]), layer.cout, sp["C0"],
-                  layer.taps, sp["C0p"], sp["N"], 4 if sp["wino_skip"] else 0, st)
+                  layer.taps, sp["C0p"], sp["N"], self._sp_pack_mode(sp, "skip"), st)
         _clx.call("clx_pack_weights", _clx.ptr(weff), _clx.ptr(sp["wp_z_fwd"]), sp["P"] * sp["N"], sp["C1"],
-                  sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], 4 if sp["wino"] else 0, st)
+                  sp["ztaps"], sp["C1p"], sp["P"] * sp["N"], self._sp_pack_mode(sp, "z"), st)
         if need_dgrad:
             _clx.call("clx_pack_weights", _clx.ptr(w_skip), _clx.ptr(sp["wp_skip_dgrad"]), layer.cout, sp["C0"],
                       layer.taps, sp["C0p"], sp["N"], 5 if sp["wino_skip_dgrad"] else 1, st)
@@ -739,7 +781,9 @@ class UNetPlan:
         dz.out = zbuf.data_ptr()
         dz.ld_out = sp["P"] * sp["N"]
         sp["_v_fresh"] = False
-        if sp["wino"]:
+        if sp["fused_z"]:
+            self._use_workspace(dz, 3)
+        elif sp["wino"]:
             self._use_workspace(dz, sp["wino"])
             if self.keep and "vcache" in sp:
                 dz.vcache = sp["vcache"].data_ptr()
@@ -759,7 +803,9 @@ class UNetPlan:
         if layer.relu and self.keep:
             self._set_gate_out(ds, layer.out)
         sp["_vskip_fresh"] = False
-        if sp["wino_skip"]:
+        if sp["fused_skip"]:
+            self._use_workspace(ds, 3)
+        elif sp["wino_skip"]:
             self._use_workspace(ds, sp["wino_skip"])
             if self.keep and "vcache_skip" in sp:
                 ds.vcache = sp["vcache_skip"].data_ptr()
@@ -925,6 +971,8 @@ class UNetPlan:
 
     def _use_workspace(self, d, code):
         d.algo = code
+        if self.workspace is None:      # (only one-launch fused layers: nothing needs scratch)
+            return
         d.workspace = self.workspace.data_ptr()
         d.workspace_bytes = self.workspace.numel() * 4
 
@@ -1076,6 +1124,8 @@ class UNetPlan:
                 jobs.append(ClxPackJob(src.data_ptr(), dst.data_ptr(), cout, cin, taps, cin_pad, cout_pad, mode))
                 if mode in (0, 1):
                     return (cout if mode == 0 else cin_pad) * taps * (cin_pad if mode == 0 else cout_pad)
+                if mode == 7:
+                    return cout_pad * cin_pad
                 rows, cols = (cin_pad, cout_pad) if mode in (3, 5, 6) else (cout_pad, cin_pad)
                 return rows * (3 if taps == 27 else 2 if taps == 8 else 1) * cols
 
@@ -1086,9 +1136,9 @@ class UNetPlan:
                     sp = self.subpixel[layer.name]
                     PN = sp["P"] * sp["N"]
                     biggest = max(biggest, job(sp["w_skip"], sp["wp_skip_fwd"], layer.cout, sp["C0"], layer.taps,
-                                               sp["C0p"], sp["N"], 4 if sp["wino_skip"] else 0),
+                                               sp["C0p"], sp["N"], self._sp_pack_mode(sp, "skip")),
                                   job(sp["weff"], sp["wp_z_fwd"], PN, sp["C1"], sp["ztaps"], sp["C1p"], PN,
-                                      4 if sp["wino"] else 0))
+                                      self._sp_pack_mode(sp, "z")))
                     if need_dgrad:
                         biggest = max(biggest, job(sp["w_skip"], sp["wp_skip_dgrad"], layer.cout, sp["C0"], layer.taps,
                                                    sp["C0p"], sp["N"], 5 if sp["wino_skip_dgrad"] else 1),

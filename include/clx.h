@@ -61,7 +61,8 @@ enum clx_profile_kind {
   CLX_PROF_GROW_SHRINK = 10, /* every kernel of clx_grow_shrink */
   CLX_PROF_MINMAX = 11,      /* minmax_init + minmax_kernel */
   CLX_PROF_HISTOGRAM = 12,   /* histogram_kernel */
-  CLX_PROF_NOISE_STATS = 13  /* noise_stats kernels */
+  CLX_PROF_NOISE_STATS = 13, /* noise_stats kernels */
+  CLX_PROF_WINO_FUSED = 14   /* wino_fused_kernel (CLX_ALGO_WINOGRAD4_FUSED; FLOPs = 2 * a^2 * tiles * N * C executed) */
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);
@@ -193,8 +194,27 @@ enum clx_conv_algo {
    * and 3-D layers with cubic kernels (3x3x3, 2x2x2; PD = PH): the transform is applied in
    * (y, x) per z plane and the z taps stay a contraction inside the batched GEMMs
    * (K = KD * C), i.e. 4x / 2.56x fewer multiplications in 3-D as well. */
-  CLX_ALGO_WINOGRAD4 = 2
+  CLX_ALGO_WINOGRAD4 = 2,
+  /* The same F(4x4, 3x3) / F(4x4, 2x2) arithmetic for 2-D valid layers in ONE launch and without workspace: a
+   * workgroup owns 32 output tiles x 64 output channels and ALL 36 (25) transform-domain products of them — the input
+   * transform of 8 channels at a time goes through LDS into the MFMA A operand, the 36 x 32 x 64 accumulators live
+   * in the registers of 8 waves, the weights arrive as ready-made B fragments (CLX_PACK_WINO4_FUSED), the output
+   * transform + bias / ReLU / accumulate / gate bits / 2 x 2 pooling runs on the accumulators through LDS.  The
+   * transformed tensors V and M (2.25x the activation each, written and read once by CLX_ALGO_WINOGRAD4) never
+   * exist in HBM.  Layers with N > 64 given clx_conv_fused_workspace_bytes(d) of workspace run as TWO launches instead
+   * (input transform once, then products + output transform: only M stays on chip).  Requires
+   * clx_conv_fused_applicable(d); honours tile_list / pool_out / gate_out / accumulate, knows neither mask / mask_bits
+   * nor vcache (forward form only). */
+  CLX_ALGO_WINOGRAD4_FUSED = 3
 };
+/* 1 if clx_conv_fwd accepts `d` with algo = CLX_ALGO_WINOGRAD4_FUSED (2-D valid 3x3 or 2x2 layer, one plain source with
+ * C % 8 == 0 and a tensor below 4 GB, N % 64 == 0), else 0. */
+int clx_conv_fused_applicable(const clx_conv_desc* d);
+/* Scratch bytes CLX_ALGO_WINOGRAD4_FUSED wants in clx_conv_desc.workspace (0 = none: N = 64, everything in one launch).
+ * With it (N > 64) the input is transformed ONCE by a launch of its own into the workspace, in the MFMA-fragment order
+ * the product kernel loads straight into registers, and only the products' results M stay on chip; without it the
+ * one-launch form runs (every block of 64 output channels transforms its input again). */
+size_t clx_conv_fused_workspace_bytes(const clx_conv_desc* d);
 enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
 enum clx_conv_precision { CLX_PREC_F32 = 0, CLX_PREC_F32X3BF16 = 1 };
 /* Scratch bytes clx_conv_fwd (pass FWD; also the dgrad form) / clx_conv_wgrad (pass WGRAD)
@@ -255,8 +275,11 @@ enum clx_pack_mode {
   CLX_PACK_WINO4_FWD = 4,  /* F(4x4): taps 9 -> U[36][cout_pad][cin_pad], taps 4 (2x2) -> U[25][..],
                             * taps 27 / 8 (3-D) -> U[36 | 25][cout_pad][kd][cin_pad]            */
   CLX_PACK_WINO4_DGRAD = 5, /* the same for the flipped filter: U[a*a][cin_pad][kd][cout_pad]    */
-  CLX_PACK_WINO4_ADJOINT = 6 /* F(4x4, 3x3[x3]): the FORWARD filter transform stored transposed (z taps reversed),
-                              * U[36][cin_pad][kd][cout_pad] (clx_conv_desc.adjoint) */
+  CLX_PACK_WINO4_ADJOINT = 6, /* F(4x4, 3x3[x3]): the FORWARD filter transform stored transposed (z taps reversed),
+                               * U[36][cin_pad][kd][cout_pad] (clx_conv_desc.adjoint) */
+  CLX_PACK_WINO4_FUSED = 7    /* 2-D F(4x4, 3x3) / F(4x4, 2x2) for CLX_ALGO_WINOGRAD4_FUSED: the values of _WINO4_FWD in the
+                               * MFMA-fragment order the fused kernel's waves load straight into registers,
+                               * [cout_pad / 64][cin_pad / 8][36 | 25][2][64 lanes][4]; cout_pad % 64 == 0, cin_pad % 8 == 0 */
 };
 /* Repack torch-layout conv weights w (Cout, Cin, taps) for clx_conv_fwd.
  * cin_pad/cout_pad >= real extents (multiples of 4), padding is zero-filled.

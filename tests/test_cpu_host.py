@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/clx.h but not exported"
     assert sorted(_clx.PROTOTYPES) == declared, "ctypes prototypes and clx.h disagree"
-    assert _clx.load().clx_abi_version() == 11
+    assert _clx.load().clx_abi_version() == 12
 
 
 def test_argument_validation_without_gpu():
