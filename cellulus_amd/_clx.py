@@ -185,6 +185,7 @@ PROTOTYPES = {
 
 MINMAX_DOUBLES = 2 + 2 * 512            # CLX_MINMAX_DOUBLES (include/clx.h): results + per-block partials
 NOISE_MINMAX_FLOATS = 2 + 2 * 1024      # CLX_NOISE_MINMAX_FLOATS
+NOISE_MINMAX_MAX_T = 64                 # clx_noise_stats_minmax: predictions per pixel it keeps in registers
 
 _lib = None
 

@@ -143,7 +143,10 @@ class PredictScan:
         minimum and maximum of the std channel — or None where the tiles overlap (a later tile overwrites part of an
         earlier one, whose values must not count)."""
         mm = None
-        if want_std_minmax and self.tiles_partition:
+        # (the statistics kernel folds the range into its pass for up to 64 predictions per pixel, i.e. 32 noise
+        #  iterations — the reference bounds num_infer_iterations nowhere: beyond that, no range here and the Otsu
+        #  threshold finds it with a pass of its own, minmax_on_device)
+        if want_std_minmax and self.tiles_partition and 2 * int(self.model.num_infer_iterations) <= _clx.NOISE_MINMAX_MAX_T:
             mm = torch.empty(_clx.NOISE_MINMAX_FLOATS, dtype=torch.float32, device=self.device)     # [0..1] + partials
         first = True
         raw = raw.astype(np.float32) * np.float32(self.factor)             # gp.Normalize

@@ -83,6 +83,11 @@ def threshold_otsu(image, nbins=256, minmax=None):
         lo, hi = (float(v) for v in minmax[:2].cpu().tolist())   # float32 -> Python float: exact
     else:
         lo, hi = float(minmax[0]), float(minmax[1])
+    if not (np.isfinite(lo) and np.isfinite(hi)):
+        # numpy's histogram (skimage.filters.threshold_otsu -> np.histogram) refuses such an image too; the two range
+        # paths treat a NaN differently (fmin / fmax drop it, the bit-pattern maximum of clx_noise_stats_minmax exposes
+        # it), so neither may go on silently
+        raise ValueError(f"threshold_otsu: the image's range [{lo}, {hi}] is not finite")
     if lo == hi:                 # min == max: every pixel equals the first one
         return lo
     counts, edges = histogram_on_device(image, nbins, minmax=(lo, hi))

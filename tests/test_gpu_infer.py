@@ -661,8 +661,12 @@ def test_fused_infer_writes_the_same_datasets_as_the_staged_path(device, tmp_pat
     # (72, 80): the last tile of an axis is shifted back inside the image (tiles overlap: the Otsu range of the std channel
     # comes from its own pass); (80, 120): 2 x 3 tiles of 40 partition the image (the range is folded over the tiles' mean /
     # std launches, clx_noise_stats_minmax)
-    for post, shape in (("cell", (2, 1, 72, 80)), ("nucleus", (2, 1, 72, 80)), ("cell", (2, 1, 80, 120))):
-        tag = f"{post}_{shape[2]}x{shape[3]}"
+    # ... and the same partition with 33 noise iterations: 66 predictions per pixel are more than the statistics kernel
+    # folds a range over (64) — the reference bounds num_infer_iterations nowhere (inference_config.py), the fused path
+    # must then take the range from its own pass like the staged one
+    for post, shape, n_it in (("cell", (2, 1, 72, 80), 2), ("nucleus", (2, 1, 72, 80), 2), ("cell", (2, 1, 80, 120), 2),
+                              ("cell", (1, 1, 80, 120), 33)):
+        tag = f"{post}_{shape[2]}x{shape[3]}_{n_it}"
         for fused in ("1", "0"):
             container = str(tmp_path / f"data_{tag}_{fused}.zarr")
             _write_raw(container, 2, shape=shape)
@@ -676,7 +680,7 @@ def test_fused_infer_writes_the_same_datasets_as_the_staged_path(device, tmp_pat
                                                   secondary_dataset_name="embeddings"),
                     segmentation_dataset_config=dict(container_path=container, dataset_name="segmentation",
                                                      secondary_dataset_name="detection"),
-                    crop_size=[56, 56], num_infer_iterations=2, p_salt_pepper=0.05, num_bandwidths=2,
+                    crop_size=[56, 56], num_infer_iterations=n_it, p_salt_pepper=0.05, num_bandwidths=2,
                     reduction_probability=0.5, min_size=6, grow_distance=2, shrink_distance=3,
                     post_processing=post, device="cuda:0"))
             monkeypatch.setenv("CLX_FUSED_INFER", fused)
