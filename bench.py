@@ -43,7 +43,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA; the opt-in f32x3bf16 form spends six bf16 products per f32 product
 
 WORKLOADS = {
     "train2d": dict(
@@ -339,7 +338,7 @@ def run_workload(wl_key, args, rank, world, device):
 
     lib = _clx.load()
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-             3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
+             6: "chain64_kernels", 14: "wino_fused_kernels"}
 
     def read_clock(reset=True):
         """MHz the MFMA kernels ran at since the last reset (clx_profile_clock), None if nothing was recorded"""
@@ -444,7 +443,7 @@ def run_workload(wl_key, args, rank, world, device):
     # HIP-event durations (events recorded inside libclx around the kernel launch itself)
     dom_name, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    peak = BF16_MFMA_PEAK_TFLOPS / 6 if dom_name in ("gemm_x3_kernel", "wgrad_x3_kernel") else F32_MFMA_PEAK_TFLOPS
+    peak = F32_MFMA_PEAK_TFLOPS
     mfma_ms = sum(v[1] for v in prof.values())
     mfma_fl = sum(v[2] for v in prof.values())
     plan_algo = getattr(plan, "algo", {})
@@ -729,10 +728,6 @@ def main():
                     help="0 (default): the product's default, two half batches on two streams per GPU (CLX_STREAMS "
                          "unset).  1: one stream — every kernel alone on the device, the run the roofline numbers and "
                          "the PMC profiles are taken from")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3bf16"],
-                    help="f32 (default, the headline): float32 MFMA.  f32x3bf16: ALSO time the 2-D workload with the "
-                         "opt-in precision (plain GEMMs on the bf16 matrix cores, three-way exact split of the float32 "
-                         "operands) and report it as the extra object `train2d_f32x3bf16`; never the headline value")
     args = ap.parse_args()
     if args.streams:
         os.environ["CLX_STREAMS"] = str(args.streams)
@@ -752,21 +747,7 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    env_precision = os.environ.get("CLX_PRECISION", "f32") or "f32"
     res = run_workload(args.workload, args, rank, world, device)
-    res_x3 = infer_x3 = None
-    if args.precision == "f32x3bf16":
-        os.environ["CLX_PRECISION"] = "f32x3bf16"
-        torch.cuda.empty_cache()
-        try:
-            res_x3 = run_workload(args.workload, args, rank, world, device)
-            if world == 1 and not args.no_infer:
-                from bench_infer import infer_bench
-
-                torch.cuda.empty_cache()
-                infer_x3 = infer_bench(device, with_cpu=False, with_e2e=False, with_streaming=False)
-        finally:
-            os.environ["CLX_PRECISION"] = env_precision
     res3d = None
     if args.workload == "train2d" and not args.no_train3d:
         torch.cuda.empty_cache()
@@ -804,18 +785,6 @@ def main():
         "data": "synthetic",
     }
     out.update({k: v for k, v in res.items() if k not in out})
-    if env_precision != "f32":
-        # (profiling runs of the opt-in precision set CLX_PRECISION outside; such a line is never the headline)
-        out["dtype"] = env_precision
-        out["note"] = f"CLX_PRECISION={env_precision} was set in the environment: every number of this line is the opt-in precision's"
-    if res_x3 is not None:
-        out["train2d_f32x3bf16"] = dict(
-            metric="train crops/sec with the OPT-IN precision f32x3bf16 (not the headline; dtype of the results is "
-                   "still float32: six exact bf16 products per f32 product on the plain GEMMs, the rest unchanged)",
-            steps=args.steps, warmup=args.warmup, **res_x3)
-    if infer_x3 is not None:
-        out["infer_f32x3bf16"] = dict(infer_x3, metric=infer_x3["metric"] + " with the OPT-IN precision f32x3bf16 "
-                                      "on the embedding network (not the headline)")
     if res3d is not None:
         out["train3d"] = dict(metric="train crops/sec, BASELINE configs[3]", steps=args.steps, warmup=args.warmup,
                               **res3d)

@@ -25,7 +25,6 @@ import torch
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3
-BF16_MFMA_PEAK_TFLOPS = 2516.6
 
 
 def _sync_time(fn, reps):
@@ -321,7 +320,7 @@ def infer_sharded(device, rank, world, samples_per_rank=16):
 
 
 MFMA_KINDS = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-              3: "gemm_x3_kernel", 4: "wgrad_x3_kernel", 5: "gemm_t_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
+              6: "chain64_kernels", 14: "wino_fused_kernels"}
 
 
 def embed_stage(model, device, size, n_it, reps):
@@ -459,8 +458,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     def roofline_of(prof, t_embed_tile, t_value_pass, nstreams, plan_batch):
         dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # (the opt-in precision prices its kernel against bf16 MFMA / 6)
-        peak = BF16_MFMA_PEAK_TFLOPS / 6 if dom == "gemm_x3_kernel" else F32_MFMA_PEAK_TFLOPS
+        peak = F32_MFMA_PEAK_TFLOPS
         mfma_ms = sum(v[1] for v in prof.values())
         mfma_fl = sum(v[2] for v in prof.values())
         traffic, traffic_source = traffic_lookup(dom, "infer")

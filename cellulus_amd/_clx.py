@@ -77,7 +77,6 @@ class ClxConvDesc(Structure):
         ("vcache_valid", c_int),
         ("c_real", c_int),
         ("dy_vcache", c_void_p),
-        ("precision", c_int),
         ("gate_out", c_void_p),
         ("ld_gate", c_int),
         ("mask_bits", c_void_p),

@@ -69,14 +69,6 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
                      long long bs_out, hipStream_t st);
 int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
                      int batch, long long bs_x, long long bs_dy, long long bs_out, hipStream_t st);
-// plain products with the weights as the MFMA's A operand (gemm_t.hip)
-bool clx_gemmt_applicable(const clx_conv_desc* d);
-int clx_gemmt_launch(const clx_conv_desc* d, int batch, long long bs_in, long long bs_w, long long bs_out,
-                     hipStream_t st);
-// opt-in precision f32x3bf16 for the plain GEMMs (gemm_x3.hip)
-bool clx_x3_applicable(const clx_conv_desc* d);
-int clx_x3_launch(const clx_conv_desc* d, int batch, long long bs_in, long long bs_w, long long bs_out,
-                  hipStream_t st);
 // Winograd F(2x2, 3x3) / F(4x4, 3x3) path (wino.hip)
 int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st);
 int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,

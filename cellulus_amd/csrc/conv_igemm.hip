@@ -629,8 +629,6 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
 // wpack + b*bs_w and writes out + b*bs_out (mask is not batched).  Used by the Winograd path.
 int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long long bs_w,
                      long long bs_out, hipStream_t st) {
-  if (clx_x3_applicable(d)) return clx_x3_launch(d, batch, bs_in, bs_w, bs_out, st);
-  if (clx_gemmt_applicable(d)) return clx_gemmt_launch(d, batch, bs_in, bs_w, bs_out, st);
   ConvP p;
   fill_params(d, p);
   p.zeros = zero_buffer();

@@ -332,168 +332,6 @@ __global__ __launch_bounds__(256, (BMN == 128 && BNC == 128) ? 3 : 2) void conv_
 }
 
 
-// ---------------------------------------------------------------------------------------------------------
-// OPT-IN precision f32x3bf16 (gemm_x3.hip explains the arithmetic): the plain weight-gradient products
-//   dw[n][c] += sum_p dy[p][n] * x[p][c]      (1x1(x1) layers and the per-xi products of the Winograd layers)
-// on the bf16 matrix cores.  Both operands are pixel-major, the bf16 MFMA wants eight consecutive k (= pixels)
-// of one channel per lane: a staging thread loads a block of 8 pixels x 4 channels (eight 16-byte loads),
-// splits every value exactly into three bf16 pieces and stores, per channel and piece, the eight pixels as one
-// 16-byte LDS word — image [piece][pixel group][channel][8], the four channel words of a thread XOR-swizzled so
-// that the 8-lane groups of ds_write_b128 and the 16-lane groups of the fragment reads are conflict-free.
-// Threads 0-127 stage dy, 128-255 stage x.  One accumulator set (164 VGPRs, three blocks per CU): the
-// accumulation bias of the bf16 MFMA, which gemm_x3.hip cancels between two accumulators because a weight
-// gradient sums its outputs coherently over the pixels, ends here in single weight-gradient elements that
-// nothing sums — 1e-7 of their size.  Slices, tail split and the float-atomic combine are those of
-// conv_wgrad_kernel.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int X3_BKP = 32;                       // pixels per chunk: two k-steps of 16
-constexpr int X3_PIECE = 4 * 128 * 8;            // bf16 elements per piece image (8 KB)
-
-__global__ __launch_bounds__(256, 3) void wgrad_x3_kernel(const WgradP p) {
-  __shared__ __attribute__((aligned(16))) unsigned short Ys[3 * X3_PIECE];
-  __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * X3_PIECE];
-
-  const int T = p.tiles_n * p.tiles_c;
-  const bool tail = (int)blockIdx.x >= p.n_main;
-  const int ns = tail ? p.nslices_tail : p.nslices;
-  const int cps = tail ? p.chunks_per_slice_tail : p.chunks_per_slice;
-  const int u = tail ? xcd_remap((int)blockIdx.x - p.n_main, (int)gridDim.x - p.n_main) : xcd_remap((int)blockIdx.x, p.n_main);
-  const int per_batch = T * ns;
-  const int batch = u / per_batch + (tail ? p.batch_split : 0);
-  const int v = u % per_batch;
-  const int slice = v / T;
-  const int t = v - slice * T;
-  const int tile_c = t % p.tiles_c, tile_n = t / p.tiles_c;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int li = lane & 31, lh = lane >> 5;
-
-  // ---- staging role of this thread
-  const int op = tid >> 7, tt = tid & 127, cg = tt & 31, pg = tt >> 5;
-  const float* base = op == 0 ? p.dy + batch * p.bs_dy + tile_n * 128 + 4 * cg
-                              : p.src[0].ptr + batch * p.bs_x + tile_c * 128 + 4 * cg;
-  const long long ld = op == 0 ? p.ld_dy : p.src[0].ld;
-  unsigned short* img = (op == 0 ? Ys : Xs) + (pg * 128 + 4 * cg) * 8;
-  const int esw = (cg >> 1) & 3;
-
-  const int chunk0 = slice * cps;
-  int nchunks = (p.M + X3_BKP - 1) / X3_BKP - chunk0;
-  if (nchunks > cps) nchunks = cps;
-  const bool do_bias = (p.dbias != nullptr) && tile_c == 0 && batch == 0 && op == 0;
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-
-  f32x4 g[8];
-  auto load_chunk = [&](int chunk) {
-    const int p0 = (chunk0 + chunk) * X3_BKP + 8 * pg;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      g[i] = *reinterpret_cast<const f32x4*>(p0 + i < p.M ? base + (long long)(p0 + i) * ld : p.zeros);
-  };
-  auto store_chunk = [&]() {
-    if (do_bias) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bsum += g[i];
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {                // one channel at a time: 24 piece registers live, not 96
-      unsigned int h[3][8];                      // [piece][pixel]: the piece in the upper half of the word
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float x0 = g[i][e];
-        h[0][i] = __float_as_uint(x0);
-        const float r1 = x0 - __uint_as_float(h[0][i] & 0xffff0000u);
-        h[1][i] = __float_as_uint(r1);
-        const float r2 = r1 - __uint_as_float(h[1][i] & 0xffff0000u);
-        h[2][i] = __float_as_uint(r2);
-      }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        u32x4 w;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w[k] = __builtin_amdgcn_perm(h[q][2 * k + 1], h[q][2 * k], 0x07060302u);
-        *reinterpret_cast<u32x4*>(img + q * X3_PIECE + (e ^ esw) * 8) = w;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // fragment word of channel ch: slot 4 (ch >> 2) + ((ch & 3) ^ ((ch >> 3) & 3))
-  int fa[2], fb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int ca = wm * 64 + i * 32 + li, cb = wn * 64 + i * 32 + li;
-    fa[i] = ((ca & ~3) + ((ca & 3) ^ ((ca >> 3) & 3))) * 8;
-    fb[i] = ((cb & ~3) + ((cb & 3) ^ ((cb >> 3) & 3))) * 8;
-  }
-
-  if (nchunks > 0) load_chunk(0);
-  for (int ch = 0; ch < nchunks; ++ch) {
-    __syncthreads();
-    store_chunk();
-    __syncthreads();
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int kg = (2 * ks + lh) * 128 * 8;
-      bf16x8 a[2][3], b[2][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          a[i][q] = *reinterpret_cast<const bf16x8*>(Ys + q * X3_PIECE + kg + fa[i]);
-          b[i][q] = *reinterpret_cast<const bf16x8*>(Xs + q * X3_PIECE + kg + fb[i]);
-        }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);    // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
-          acc[i][j] = c;
-        }
-    }
-  }
-
-  // ---- combine: float atomics into dw[n][c]
-  float* dst = p.dwp + batch * p.bs_out;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = tile_c * 128 + (wn * 2 + j) * 32 + li;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = tile_n * 128 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        atomicAdd(dst + (size_t)n * p.Ctot + c, acc[i][j][r]);
-      }
-    }
-
-  // ---- bias gradient: column sums of the dy rows this block staged (four pixel groups per channel group)
-  if (p.dbias != nullptr && tile_c == 0 && batch == 0) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(Ys);   // [4][128]
-    if (op == 0) *reinterpret_cast<f32x4*>(red + pg * 128 + 4 * cg) = bsum;
-    __syncthreads();
-    if (tid < 128) atomicAdd(p.dbias + tile_n * 128 + tid, red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid]);
-  }
-}
-
 }  // namespace
 
 // co-resident blocks of a kernel on the current device = CUs x blocks per CU (cached)
@@ -524,16 +362,6 @@ static const float* wgrad_zero_buffer() {
     cache[dev] = (const float*)ptr;
   }
   return cache[dev];
-}
-
-// the opt-in precision covers plain products with whole 128 x 128 tiles
-static bool wgrad_x3_applicable(const clx_conv_desc* d) {
-  if (d->precision != CLX_PREC_F32X3BF16 || d->nsrc != 1) return false;
-  if (d->KD != 1 || d->KH != 1 || d->KW != 1 || d->PD || d->PH || d->PW) return false;
-  const clx_src& S = d->src[0];
-  if (S.fz != 1 || S.fy != 1 || S.fx != 1 || S.oz || S.oy || S.ox) return false;
-  if (S.D != d->ID || S.H != d->IH || S.W != d->IW) return false;
-  return d->N % 128 == 0 && S.C % 128 == 0;
 }
 
 // tiles of one batch element of the weight-gradient launch (n tiles x c tiles x taps)
@@ -592,17 +420,15 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   p.tiles_c = cdiv(p.Ctot, bnc);
   const int T = p.tiles_n * p.tiles_c * p.taps;
   const int Tall = T * batch;
-  const bool x3 = wgrad_x3_applicable(d) && d->det_turns == nullptr;
   if (p.turns != nullptr && hipMemsetAsync(p.turns, 0, (size_t)Tall * sizeof(int), st) != hipSuccess) {
     clx_set_error("clx_conv_wgrad: clearing the turn counters failed");
     return CLX_ERR_LAUNCH;
   }
-  const int BKP = x3 ? X3_BKP : big_n && big_c ? bkp<128, 128>() : 32;
+  const int BKP = big_n && big_c ? bkp<128, 128>() : 32;
   const int total_chunks = cdiv(p.M, BKP);
   // Split-K so that the grid is a whole number of "rounds" of co-resident blocks: a grid of
   // 4 rounds + a few blocks would run 5 rounds (the tail alone costs 20 %).
-  const void* fn = x3             ? (const void*)wgrad_x3_kernel
-                   : big_n && big_c ? (const void*)conv_wgrad_kernel<128, 128, 2, 2>
+  const void* fn = big_n && big_c ? (const void*)conv_wgrad_kernel<128, 128, 2, 2>
                    : big_n        ? (const void*)conv_wgrad_kernel<128, 64, 4, 1>
                    : big_c        ? (const void*)conv_wgrad_kernel<64, 128, 1, 4>
                                   : (const void*)conv_wgrad_kernel<64, 64, 2, 2>;
@@ -645,11 +471,7 @@ int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* 
   const dim3 grid(p.n_main + T * p.nslices_tail * (batch - p.batch_split)), block(256);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled())
-    clx_prof_events(x3 ? CLX_PROF_WGRAD_X3 : CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, &e0, &e1);
-  if (x3) {
-    CLX_LAUNCH_TIMED(wgrad_x3_kernel, grid, block, st, e0, e1, p);
-    return CLX_OK;
-  }
+    clx_prof_events(CLX_PROF_WGRAD, 2.0 * p.M * p.N * p.Ctot * p.taps * batch, &e0, &e1);
 #define CLX_WG(BMN_, BNC_, WM_, WN_)                                                                           \
   do {                                                                                                         \
     if (lin_mode == 1) CLX_LAUNCH_TIMED((conv_wgrad_kernel<BMN_, BNC_, WM_, WN_, 1, 1>), grid, block, st, e0, e1, p);      \

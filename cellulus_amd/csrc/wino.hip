@@ -743,7 +743,6 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
     gd.src[0].W = gd.IW = (int)Tin;
   }
   gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
-  gd.precision = d->precision;
   const int rc = clx_igemm_launch(&gd, AA, Tin * C, (long long)Np * d->KD * C, Tout * Np, st);
   if (rc) return rc;
   const long long tot_out = Tout * (Np / 4);
@@ -801,7 +800,6 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
   }
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = N;
-  gd.precision = d->precision;
   gd.det_turns = d->det_turns;            // reproducible mode: the xi products add their slices in order
   const int rc = clx_wgrad_launch(&gd, Md, N, dwpack, nullptr, AA, gin.T * C, gout.T * N,
                                   (long long)d->KD * N * C, st);
@@ -853,7 +851,6 @@ static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
   gd.B = d->B; gd.ID = planes_dy; gd.IH = 1; gd.IW = th * tw;
   gd.KD = d->KD; gd.KH = gd.KW = 1; gd.PD = d->PD;
   gd.N = Cp; gd.wpack = d->wpack; gd.out = P; gd.ld_out = Cp;
-  gd.precision = d->precision;
   const int rc = clx_igemm_launch(&gd, 36, Tdy * Nf, (long long)Cp * d->KD * Nf, Tdx * Cp, st);
   if (rc) return rc;
   const int IH = OHf + 2, IW = OWf + 2;

@@ -60,17 +60,6 @@ def wino_min_channels(kernel):
     return WINO_MIN_CHANNELS_3D if kernel[0] > 1 else WINO_MIN_CHANNELS
 
 
-def precision_code() -> int:
-    """clx_conv_precision for the forward / data-gradient GEMMs: 0 = float32 MFMA (default); CLX_PRECISION=
-    f32x3bf16 opts into the three-way bfloat16 split of the float32 operands (csrc/gemm_x3.hip)."""
-    name = os.environ.get("CLX_PRECISION", "f32")
-    if name in ("f32", ""):
-        return 0
-    if name == "f32x3bf16":
-        return 1
-    raise ValueError(f"CLX_PRECISION must be 'f32' or 'f32x3bf16', got {name!r}")
-
-
 def winograd_enabled() -> bool:
     return os.environ.get("CLX_WINOGRAD", "1") != "0"
 
@@ -326,15 +315,12 @@ class UNetPlan:
         self.B = int(batch)
         self.device = device
         self.keep = keep_activations
-        self.precision = precision_code()
-        self.fused = fused_wanted(keep_activations) and self.precision == 0
+        self.fused = fused_wanted(keep_activations)
         # opt-in: run-to-run reproducible training (CLX_DETERMINISTIC=1; the reference's CPU autograd is
         # deterministic, cellulus/train.py:177-179).  Weight-gradient slices add in a fixed order, bias
         # gradients come from ordered column sums, the first layer takes the generic kernel and the fused
         # 1x1 pairs are off (their block sums meet in float atomics); train._fused_step switches the loss.
         self.deterministic = os.environ.get("CLX_DETERMINISTIC", "0") == "1"
-        if self.deterministic and self.precision != 0:
-            raise ValueError("CLX_DETERMINISTIC=1 is implemented for the default precision (float32 MFMA) only")
         self.buf = {}
         self._alloc()
 
@@ -496,7 +482,7 @@ class UNetPlan:
         head.2) that run as ONE launch each way (csrc/chain64.hip: the intermediate tensor is written once
         and never read back, its gradient never exists in HBM).  CLX_CHAIN64=0 keeps the layer-by-layer path."""
         self.chains, self.chain_second = {}, {}
-        if os.environ.get("CLX_CHAIN64", "1") == "0" or self.precision != 0 or self.deterministic:
+        if os.environ.get("CLX_CHAIN64", "1") == "0" or self.deterministic:
             return
         for a, b in find_chain_pairs(self.topo, {n: v["fwd"] for n, v in self.algo.items()}, self.B):
             self.chains[a.name] = (a, b)
@@ -737,7 +723,6 @@ class UNetPlan:
         ds.KD, ds.KH, ds.KW = layer.kernel
         ds.PD = ds.PH = ds.PW = 0
         for d in (dz, ds):
-            d.precision = self.precision
             d.algo = 0
             d.accumulate = 0
             d.workspace = None
@@ -911,7 +896,6 @@ class UNetPlan:
         dl.algo = 0
         dl.workspace = None
         dl.workspace_bytes = 0
-        dl.precision = self.precision
         if dzbuf is not None:
             self._set_mask(dl, up_s.tensor)                 # ReLU gate of the low-res tensor
         else:                                               # geometry-only query
@@ -946,7 +930,6 @@ class UNetPlan:
         d.workspace_bytes = 0
         # a raw image with 1-3 channels is stored padded to 4: tell the first-layer kernels
         d.c_real = layer.sources[0].channels if len(layer.sources) == 1 else 0
-        d.precision = self.precision
         return d
 
     def _set_gate_out(self, d, name):
@@ -999,7 +982,6 @@ class UNetPlan:
         dd.algo = 0
         dd.workspace = None
         dd.workspace_bytes = 0
-        dd.precision = self.precision
         return dd
 
     def _expand_cin(self, layer, w):
@@ -1229,7 +1211,7 @@ class UNetPlan:
             return False
         first = prefix[0]
         return (self.topo.in_channels == 1 and tuple(first.kernel) in ((1, 3, 3), (3, 3, 3)) and first.cout % 4 == 0
-                and first.in_shape[0] >= first.kernel[0] and self.precision == 0)
+                and first.in_shape[0] >= first.kernel[0])
 
     def tiled_layer_behind_prefix(self):
         """The 2-D Winograd layer that reads the last 1x1 layer of pointwise_prefix (conv_pass.6 of the first level), or
@@ -1363,7 +1345,6 @@ class UNetPlan:
                 d.relu = 1 if op.relu else 0
                 d.out = y.data_ptr()
                 d.ld_out = y.shape[1]
-                d.precision = self.precision
                 _clx.call("clx_conv_fwd", ctypes.byref(d), st)
                 cur = y
         dense = self.buf[tail[-1].out]
@@ -1643,7 +1624,7 @@ class DualPlan:
         self._shared = False
         self.buf = _Rows(self.parts, "buf")
 
-    def __getattr__(self, name):            # algo, chains, subpixel, gate, precision, ... : the halves agree
+    def __getattr__(self, name):            # algo, chains, subpixel, gate, ... : the halves agree
         if name in ("parts", "streams"):
             raise AttributeError(name)
         if name == "gbuf":

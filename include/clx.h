@@ -50,9 +50,7 @@ enum clx_profile_kind {
   CLX_PROF_IGEMM_WIDE = 0,   /* conv_igemm_kernel<128,128> */
   CLX_PROF_IGEMM_NARROW = 1, /* conv_igemm_kernel<128,64>  */
   CLX_PROF_WGRAD = 2,        /* conv_wgrad_kernel<...>     */
-  CLX_PROF_GEMM_X3 = 3,      /* gemm_x3_kernel (opt-in precision f32x3bf16; FLOPs = f32-equivalent 2*M*N*K) */
-  CLX_PROF_WGRAD_X3 = 4,     /* wgrad_x3_kernel (weight gradient of the opt-in precision) */
-  CLX_PROF_GEMM_T = 5,       /* gemm_t_kernel (plain products, weights as the MFMA's A operand) */
+  /* (3, 4, 5: the opt-in f32x3bf16 GEMMs and the transposed-operand GEMM of rounds 2-4, removed in round 5) */
   CLX_PROF_CHAIN64 = 6,      /* chain64_fwd / _bwd kernels (fused pairs of 64-channel 1x1 layers) */
   /* the HBM-bound kernels of detect / segment (no FLOPs: total_flops of these kinds is 0; the caller prices them by bytes) */
   CLX_PROF_MS_PREPARE = 7,   /* ms_prepare_kernel */
@@ -128,15 +126,6 @@ typedef struct clx_conv_desc {
    * transforms; the following clx_conv_fwd (data-gradient form) then sets vcache = this buffer and
    * vcache_valid = 1 and skips its own input transform.  dY must be dense (ld_dy == N). */
   void* dy_vcache;
-  /* clx_conv_precision: 0 = float32 MFMA (default, the reference's arithmetic).  1 = opt-in
-   * "f32x3bf16": where the convolution is a plain matrix product (1x1 layers, the batched GEMMs of
-   * the 2-D Winograd layers; clx_conv_fwd incl. its data-gradient form: N % 128 == 0, K % 32 == 0;
-   * clx_conv_wgrad: N % 128 == 0 and C % 128 == 0) every float32 operand is split exactly into
-   * three bfloat16 pieces and six exact products are accumulated in float32 on the bf16 matrix
-   * cores, the accumulation bias of that instruction cancelled between two accumulators (error ~
-   * one float32 rounding per product, measured below the float32 MFMA's); everything else stays on
-   * the default path. */
-  int precision;
   /* ReLU gates as bits (optional, both may be NULL).  gate_out: with relu = 1, also write
    * bit (n & 31) of word gate_out[m * ld_gate + (n >> 5)] = (out[m][n] > 0); requires ld_out % 32 == 0
    * (whole words per pixel; bits of channels >= N are written as 0).  mask_bits: the same layout
@@ -216,7 +205,6 @@ int clx_conv_fused_applicable(const clx_conv_desc* d);
  * one-launch form runs (every block of 64 output channels transforms its input again). */
 size_t clx_conv_fused_workspace_bytes(const clx_conv_desc* d);
 enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
-enum clx_conv_precision { CLX_PREC_F32 = 0, CLX_PREC_F32X3BF16 = 1 };
 /* Scratch bytes clx_conv_fwd (pass FWD; also the dgrad form) / clx_conv_wgrad (pass WGRAD)
  * need for descriptor `d` with algo = CLX_ALGO_WINOGRAD / _WINOGRAD4; 0 if Winograd does not apply to
  * the geometry (the caller must then use CLX_ALGO_DIRECT). */

@@ -59,10 +59,9 @@ def _planar(plan, name, nd):
     return t[:, :, 0] if nd == 2 else t
 
 
-@pytest.mark.parametrize("name,cfg,crop,precision,head_scale", [
-    ("cfg2", CFG2, (256, 256), "f32", 1.0), ("cfg4", CFG4, (64, 64, 64), "f32", 1.0),
-    ("cfg2", CFG2, (256, 256), "f32x3bf16", 1.0), ("cfg2-trained-scale", CFG2, (256, 256), "f32", 0.0)])
-def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, precision, head_scale, device, monkeypatch):
+@pytest.mark.parametrize("name,cfg,crop,head_scale", [
+    ("cfg2", CFG2, (256, 256), 1.0), ("cfg4", CFG4, (64, 64, 64), 1.0), ("cfg2-trained-scale", CFG2, (256, 256), 0.0)])
+def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, head_scale, device, monkeypatch):
     """Forward: < 1e-4 against the float32 AND the float64 oracle.  head_scale 0 = "trained scale": a Kaiming network
     emits offsets of range ~0.3, a trained one offsets of O(object_size / 2) pixels — the head's last layer is scaled
     so that the output range is 15 (the offsets of object_size 30), where the same RELATIVE error is 50x the absolute one.
@@ -75,10 +74,6 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, preci
     against the free-running float64 oracle no farther than the float32 CPU oracle is."""
     import torch.nn.functional as F
 
-    # "f32x3bf16": the opt-in precision (plain GEMMs on the bf16 matrix cores, float32 operands split
-    # exactly into three bfloat16 pieces, six exact products) is held to the SAME bars as the default
-    monkeypatch.setenv("CLX_PRECISION", precision)
-    name = f"{name}/{precision}"
     nd = len(crop)
     torch.manual_seed(0)
     oracle = O.OracleUNetModel(**cfg)
@@ -100,7 +95,6 @@ def test_full_size_forward_and_gradients_match_the_oracle(name, cfg, crop, preci
     # the default plan at this size is the one the benchmark runs
     got = model(raw.to(device))
     plan = next(iter(model._plans.values()))
-    assert plan.precision == (1 if precision == "f32x3bf16" else 0)
     assert sum(1 for a in plan.algo.values() if a["fwd"] == 2) >= 3, "Winograd F(4x4) expected on the wide layers"
     assert plan.subpixel, "the sub-pixel form of the upsample convolution is expected here"
     torch.manual_seed(2)

@@ -562,53 +562,6 @@ def test_gate_bits_and_dual_dy_transform_change_nothing(device, monkeypatch):
             assert torch.allclose(g, r, rtol=1e-4, atol=1e-5 * r.abs().max().item()), key
 
 
-def test_opt_in_precision_f32x3bf16_matches_the_oracle_and_is_used(device, monkeypatch):
-    """CLX_PRECISION=f32x3bf16: the plain GEMMs (1x1 layers, Winograd batched GEMMs; N % 128 == 0, K % 32 == 0)
-    run gemm_x3_kernel — seen through the in-library launch profile — and forward / gradients keep the
-    default path's bars against the float64 oracle; layers the kernel does not cover fall back to float32."""
-    import ctypes
-
-    from cellulus_amd import _clx
-
-    cfg = dict(in_channels=1, out_channels=2, num_fmaps=128, fmap_inc_factor=2, features_in_last_layer=64,
-               downsampling_factors=[[2, 2]], num_spatial_dims=2)
-    monkeypatch.setenv("CLX_PRECISION", "f32x3bf16")
-    torch.manual_seed(0)
-    oracle = OracleUNetModel(**cfg)
-    for _n, layer in oracle.named_modules():
-        if isinstance(layer, torch.nn.modules.conv._ConvNd):
-            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
-    model = get_model(**cfg)
-    model.load_state_dict(oracle.state_dict(), strict=True)
-    model = model.to(device)
-    raw = torch.rand(2, 1, 92, 100)
-    _clx.call("clx_profile_enable", 2)
-    got = model(raw.to(device))
-    torch.manual_seed(2)
-    dout = torch.randn(got.shape)
-    got.backward(dout.to(device))
-    n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-    _clx.load().clx_profile_read(3, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
-    n_w = ctypes.c_double()
-    _clx.load().clx_profile_read(4, ctypes.byref(n_w), ctypes.byref(ms_l), ctypes.byref(fl_l))
-    _clx.call("clx_profile_enable", 0)
-    assert n_w.value >= 4, "the weight gradients of the wide layers were expected on wgrad_x3_kernel"
-    assert n_l.value >= 8, "gemm_x3_kernel was not launched"
-    o64 = oracle.double()
-    ref = o64(raw.double())
-    ref.backward(dout.double())
-    assert (got.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4
-    # gradients against the FREE-RUNNING float64 oracle: at 2e7 activations a handful of ReLU decisions differ
-    # between any float32-grade forward pass and the float64 one (tests/test_gpu_fullsize_oracle.py holds this
-    # precision to 1e-4 on the same decisions at the benchmark size); here: the same order as the default path
-    for (n, po), (_n2, pm) in zip(o64.named_parameters(), model.named_parameters()):
-        l2 = ((pm.grad.cpu().double() - po.grad).norm() / (po.grad.norm() + 1e-30)).item()
-        assert l2 < 5e-3, (n, l2)
-    monkeypatch.setenv("CLX_PRECISION", "fp8")
-    with pytest.raises(ValueError, match="CLX_PRECISION"):
-        get_model(**cfg).to(device)(raw.to(device))
-
-
 def test_rejects_cpu_tensors():
     from cellulus_amd._clx import ClxError
 
@@ -965,115 +918,3 @@ def test_adjoint_winograd_data_gradient_through_the_c_abi(kd, mask_kind, device)
     dd.relu = 1
     with pytest.raises(_clx.ClxError):
         _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
-
-
-@pytest.mark.parametrize("N,C,M", [(128, 128, 5000), (256, 384, 33333), (128, 256, 31)])
-def test_opt_in_precision_weight_gradient_kernel_vs_f64(N, C, M, device):
-    """wgrad_x3_kernel (clx_conv_wgrad on a plain 1x1 product with precision = CLX_PREC_F32X3BF16): weight and bias
-    gradient against float64, ragged pixel counts (zero-filled last chunk, many slices), accumulation into a
-    non-zero buffer; the same call in the default precision for scale."""
-    import ctypes
-
-    from cellulus_amd import _clx
-    from cellulus_amd._clx import ClxConvDesc, ClxSrc
-
-    torch.manual_seed(N + C + M)
-    x = torch.relu(torch.randn(M, C))
-    dy = torch.randn(M, N)
-    ref = dy.double().t() @ x.double()
-    refb = dy.double().sum(0)
-    x_d, dy_d = x.to(device), dy.to(device)
-    errs = {}
-    for prec in (0, 1):
-        dw = torch.ones(N * C, device=device)
-        db = torch.ones(N, device=device)
-        d = ClxConvDesc()
-        d.nsrc = 1
-        s = ClxSrc()
-        s.ptr, s.C, s.ld = x_d.data_ptr(), C, C
-        s.D, s.H, s.W = 1, 1, M
-        s.fz = s.fy = s.fx = 1
-        d.src[0] = s
-        d.B, d.ID, d.IH, d.IW = 1, 1, 1, M
-        d.KD = d.KH = d.KW = 1
-        d.N = N
-        d.precision = prec
-        _clx.call("clx_profile_enable", 2)
-        _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy_d), N, _clx.ptr(dw), _clx.ptr(db), _clx.stream_ptr(device))
-        n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        _clx.load().clx_profile_read(4, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
-        _clx.call("clx_profile_enable", 0)
-        assert n_l.value == prec, "wgrad_x3_kernel runs exactly when the descriptor asks for the opt-in precision"
-        got = dw.view(N, C).cpu().double() - 1.0
-        errs[prec] = ((got - ref).norm() / ref.norm()).item()
-        assert errs[prec] < 2e-6, (prec, errs)
-        assert ((db.cpu().double() - 1.0 - refb).abs().max() / refb.abs().max()).item() < 1e-5
-    print(f"wgrad N={N} C={C} M={M}: rel L2 vs f64: f32 {errs[0]:.2e}, f32x3bf16 {errs[1]:.2e}")
-
-
-@pytest.mark.parametrize("C,N,M", [(32, 128, 1000), (256, 256, 4099), (96, 128, 130)])
-def test_opt_in_precision_gemm_kernel_epilogues_vs_f64(C, N, M, device):
-    """gemm_x3_kernel straight through clx_conv_fwd (1x1 product, precision = CLX_PREC_F32X3BF16): plain,
-    bias + ReLU + gate bits, ReLU-gate mask as floats and as bits, accumulate — against float64, ragged row counts."""
-    import ctypes
-
-    from cellulus_amd import _clx
-    from cellulus_amd._clx import ClxConvDesc, ClxSrc
-
-    torch.manual_seed(C + N + M)
-    x = torch.randn(M, C)
-    w = torch.randn(N, C) * 0.2
-    bias = torch.randn(N)
-    ref = x.double() @ w.double().t()
-    x_d, w_d, b_d = x.to(device), w.to(device), bias.to(device)
-    gate = torch.randn(M, N)
-    gate_d = gate.to(device).contiguous()
-    packed = torch.zeros(M, N // 32, dtype=torch.int64)
-    for c in range(N):
-        packed[:, c // 32] |= (gate[:, c] > 0).long() << (c % 32)
-    bits = torch.where(packed >= (1 << 31), packed - (1 << 32), packed).to(torch.int32).to(device)
-    prev = torch.randn(M, N)
-    st = _clx.stream_ptr(device)
-    _clx.call("clx_profile_enable", 2)
-    for mode in ("plain", "bias_relu_gate", "mask", "mask_bits", "accumulate"):
-        out = prev.to(device).clone().contiguous() if mode == "accumulate" else torch.full((M, N), float("nan"), device=device)
-        d = ClxConvDesc()
-        d.nsrc = 1
-        s = ClxSrc()
-        s.ptr, s.C, s.ld = x_d.data_ptr(), C, C
-        s.D, s.H, s.W = 1, 1, M
-        s.fz = s.fy = s.fx = 1
-        d.src[0] = s
-        d.B, d.ID, d.IH, d.IW = 1, 1, 1, M
-        d.KD = d.KH = d.KW = 1
-        d.N = N
-        d.wpack = w_d.data_ptr()
-        d.out, d.ld_out = out.data_ptr(), N
-        d.precision = 1
-        want, gate_out = ref, None
-        if mode == "bias_relu_gate":
-            d.bias, d.relu = b_d.data_ptr(), 1
-            want = torch.relu(ref + bias.double())
-            gate_out = torch.zeros(M, N // 32, dtype=torch.int32, device=device)
-            d.gate_out, d.ld_gate = gate_out.data_ptr(), N // 32
-        elif mode == "mask":
-            d.mask, d.ld_mask = gate_d.data_ptr(), N
-            want = ref * (gate > 0)
-        elif mode == "mask_bits":
-            d.mask_bits, d.ld_mask_bits = bits.data_ptr(), N // 32
-            want = ref * (gate > 0)
-        elif mode == "accumulate":
-            d.accumulate = 1
-            want = ref + prev.double()
-        _clx.call("clx_conv_fwd", ctypes.byref(d), st)
-        got = out.cpu().double()
-        assert torch.isfinite(got).all(), mode
-        assert ((got - want).abs().max() / want.abs().max()).item() < 2e-6, mode
-        if gate_out is not None:
-            g = gate_out.cpu().long() & 0xFFFFFFFF
-            for c in range(0, N, 7):
-                assert torch.equal(((g[:, c // 32] >> (c % 32)) & 1).bool(), got[:, c] > 0), (mode, c)
-    n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-    _clx.load().clx_profile_read(3, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
-    _clx.call("clx_profile_enable", 0)
-    assert n_l.value == 5, "gemm_x3_kernel was expected to run these products"

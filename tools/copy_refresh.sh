@@ -3,27 +3,22 @@
 set -e
 P=${1:-r02}; R=gpurun_out/refresh
 cp $R/bench_default.json profiles/${P}_bench_default.json
-cp $R/bench_f32x3bf16.json profiles/${P}_bench_f32x3bf16.json
 cp $R/bench_under_rocprof.json profiles/${P}_train2d_bench_under_rocprof.json
 cp $R/bench3d_under_rocprof.json profiles/${P}_train3d_bench_under_rocprof.json
-cp $R/bench_x3_under_rocprof.json profiles/${P}_train2d_f32x3bf16_bench_under_rocprof.json
 cp $R/prof_kernel_stats.csv profiles/${P}_train2d_kernel_stats.csv
 cp $R/prof3d_kernel_stats.csv profiles/${P}_train3d_kernel_stats.csv
-cp $R/prof_x3_kernel_stats.csv profiles/${P}_train2d_f32x3bf16_kernel_stats.csv
 cp $R/prof_stream_kernel_stats.csv profiles/${P}_streaming_kernel_stats.csv
 cp $R/per_layer.txt profiles/${P}_train2d_per_layer.txt
 cp $R/per_layer_3d.txt profiles/${P}_train3d_per_layer.txt
 cp $R/pmc_conv_kernels.txt profiles/${P}_pmc_conv_kernels.txt
 cp $R/pmc_conv_kernels_3d.txt profiles/${P}_pmc_conv_kernels_3d.txt
 cp $R/pmc_wino_kernels.txt profiles/${P}_pmc_wino_kernels.txt
-cp $R/pmc_x3_kernels.txt profiles/${P}_pmc_x3_kernels.txt
 cp $R/streaming_kernels.txt profiles/${P}_streaming_kernels.txt
 cp $R/hbm_traffic_train2d.txt profiles/${P}_hbm_traffic_train2d.txt
 cp $R/hbm_traffic_train3d.txt profiles/${P}_hbm_traffic_train3d.txt
 cp $R/hbm_traffic_streaming.txt profiles/${P}_hbm_traffic_streaming.txt
 cp $R/hbm_traffic_train2d.json $R/hbm_traffic_train3d.json $R/hbm_traffic_streaming.json profiles/
 cp $R/pmc_lds_conflicts_f32.txt profiles/${P}_pmc_lds_conflicts_f32.txt
-cp $R/pmc_lds_conflicts_f32x3bf16.txt profiles/${P}_pmc_lds_conflicts_f32x3bf16.txt
 [ -f $R/streaming_kernels_4096.txt ] && cp $R/streaming_kernels_4096.txt profiles/${P}_streaming_kernels_4096.txt
 [ -f $R/prof_stream4k_kernel_stats.csv ] && cp $R/prof_stream4k_kernel_stats.csv profiles/${P}_streaming_4096_kernel_stats.csv
 [ -f $R/bench_one_stream.json ] && cp $R/bench_one_stream.json profiles/${P}_bench_one_stream.json

@@ -13,61 +13,52 @@ python bench.py --streams 1 --no-infer --no-cpu-baseline --no-train-e2e > $O/ben
 CLX_BENCH_DETAIL=1 python bench.py --steps 6 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e > $O/per_layer.txt 2>&1
 # kernel statistics, 2-D (+ the 3-D workload the default line also times): ONE stream (--streams 1: every kernel alone on
 # the device — the pass bench.py takes its roofline numbers from; average durations must agree with roofline.avg_launch_ms)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python3 bench.py --streams 1 --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof3d -o t -- python3 bench.py --streams 1 --workload train3d --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e > $O/bench3d_under_rocprof.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o t -- python3 bench.py --streams 1 --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > $O/bench_under_rocprof.json 2>/dev/null
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof3d -o t -- python3 bench.py --streams 1 --workload train3d --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e > $O/bench3d_under_rocprof.json 2>/dev/null
 # ... and the default command (two half batches on two streams; the trace holds both of bench.py's passes) with what
 # shares the device when: tools/step_overlap.sh
 bash tools/step_overlap.sh train2d > $O/overlap_train2d.txt 2>&1
 bash tools/step_overlap.sh train3d > $O/overlap_train3d.txt 2>&1
 export CLX_STREAMS=1      # every PMC pass and per-layer table below: kernels alone on the device
 # matrix-pipe busy per kernel
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
 python3 tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels.txt
 python3 tools/pmc_digest.py $O/pmc chain64 >> $O/pmc_conv_kernels.txt
 python3 tools/pmc_digest.py $O/pmc wino_ > $O/pmc_wino_kernels.txt
 rm -rf $O/pmc
 # HBM bytes per launch: training kernels ...
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
 python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train2d.json conv_ wino_ chain64 > $O/hbm_traffic_train2d.txt
 rm -rf $O/pmc_rd $O/pmc_wr
 # ... the 3-D workload ...
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
 CLX_TRAFFIC_CMD="bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e" python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train3d.json conv_ wino_ chain64 > $O/hbm_traffic_train3d.txt
 rm -rf $O/pmc_rd $O/pmc_wr
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --workload train3d --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --workload train3d --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
 python3 tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels_3d.txt
 python3 tools/pmc_digest.py $O/pmc chain64 >> $O/pmc_conv_kernels_3d.txt
 rm -rf $O/pmc
 CLX_BENCH_DETAIL=1 python bench.py --workload train3d --steps 6 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e > $O/per_layer_3d.txt 2>&1
 # ... and the streaming kernels of detect / segment (one 8192^2 image = 256 samples of 512^2 per launch)
 python tools/bench_stream.py 4096 > $O/streaming_kernels_4096.txt 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream4k -o t -- python3 tools/bench_stream.py 4096 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream4k -o t -- python3 tools/bench_stream.py 4096 > /dev/null 2>&1
 python tools/bench_stream.py 8192 > $O/streaming_kernels.txt 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 tools/bench_stream.py 8192 > /dev/null 2>&1
 CLX_TRAFFIC_CMD="tools/bench_stream.py 8192" python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_streaming.json ms_ cc_ gs_ grow_shrink bucket_ histogram_kernel minmax_kernel noise_stats > $O/hbm_traffic_streaming.txt
 rm -rf $O/pmc_rd $O/pmc_wr
-# ... and the opt-in precision f32x3bf16 (its own bench object; kernel statistics and matrix-pipe busy of that step)
-unset CLX_STREAMS
-python bench.py --precision f32x3bf16 > $O/bench_f32x3bf16.json 2> $O/bench_f32x3bf16.err
-export CLX_STREAMS=1
-CLX_PRECISION=f32x3bf16 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_x3 -o t -- python3 bench.py --steps 4 --warmup 2 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > $O/bench_x3_under_rocprof.json 2>/dev/null
-CLX_PRECISION=f32x3bf16 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
-python3 tools/pmc_digest.py $O/pmc _x3 > $O/pmc_x3_kernels.txt
-rm -rf $O/pmc
-for d in prof prof3d prof_stream prof_stream4k prof_x3; do
+for d in prof prof3d prof_stream prof_stream4k; do
   f=$(find $O/$d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $O/${d}_kernel_stats.csv
 done
-rm -rf $O/prof $O/prof3d $O/prof_stream $O/prof_stream4k $O/prof_x3
-# LDS bank conflicts / wait counters of the MFMA kernels, both precisions
-for prec in f32 f32x3bf16; do
-  CLX_PRECISION=$prec bash tools/pmc_issue_counters.sh > /dev/null 2>&1
-  cat gpurun_out/pmc_$prec/set1.txt gpurun_out/pmc_$prec/set1_f32.txt | grep -v "grey\|smallc" > $O/pmc_lds_conflicts_$prec.txt
-done
+rm -rf $O/prof $O/prof3d $O/prof_stream $O/prof_stream4k
+# LDS bank conflicts / wait counters of the MFMA kernels
+export CLX_STREAMS=1
+bash tools/pmc_issue_counters.sh > /dev/null 2>&1
+cat gpurun_out/pmc_f32/set1_f32.txt | grep -v "grey\|smallc" > $O/pmc_lds_conflicts_f32.txt
 unset CLX_STREAMS
 CLX_DETERMINISTIC=1 python bench.py --steps 10 --warmup 3 --no-infer --no-cpu-baseline --no-train-e2e > $O/bench_deterministic.json 2>/dev/null
 ls -la $O

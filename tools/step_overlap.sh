@@ -11,7 +11,7 @@ O = sys.argv[1]
 f = glob.glob(O + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-MFMA = ('conv_igemm_kernel', 'conv_wgrad_kernel', 'chain64', 'gemm_x3', 'wgrad_x3', 'gemm_t')
+MFMA = ('conv_igemm_kernel', 'conv_wgrad_kernel', 'chain64', 'wino_fused_kernel', 'wino_pre_kernel')
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 # the two-stream pass is the first K steps after the warm-up: take the step between the 3rd and 4th Adam launch
 if len(idx) < 4:
