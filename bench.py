@@ -28,6 +28,8 @@ Extra objects on that line:
                  rank with its own loader processes (train.loader_policy), whole-job crops/s.
   cpu_baseline — the oracle's CPU train step (plain PyTorch, host cores) on
                  a bounded sample of the same workload; baseline only (1 GPU).
+  gpu_library_baseline — the same plain-PyTorch model moved to the GPU (what the reference does with device = "cuda:0":
+                 MIOpen convolutions + autograd): train step and one infer-mode tile; baseline only (1 GPU).
   ranks_seen, per_rank_ms_per_step, allreduce_ms_exposed — what the data-parallel run saw.
 """
 
@@ -711,6 +713,68 @@ def cpu_baseline(workload, device, seed, budget_s=90.0):
                 loss_rel_diff=float(np.abs(l_cpu - l_gpu) / max(abs(l_cpu), 1e-12)))
 
 
+def gpu_library_baseline(workload, device, seed=0, steps=3, with_infer=True):
+    """What the REFERENCE does on this GPU with ``device = "cuda:0"`` (cellulus/train.py:60-62: the model is moved to the
+    device and every ``nn.ConvNd`` runs in the vendor library — MIOpen on ROCm): the oracle's plain-PyTorch model
+    (oracle/unet_oracle.py: nn.Conv2d / MaxPool / Upsample / autograd / torch.optim.Adam) moved to the device, one
+    warm-up and ``steps`` timed train steps on the workload's batch, and one infer-mode tile (the 2 x 16 noisy forwards
+    of cellulus/models/unet.py:73-100 at 512^2).  A baseline like ``cpu_baseline``: measured beside the product, never
+    inside it and never inside the timed region of ``value``."""
+    import torch
+
+    from oracle import unet_oracle as O
+
+    torch.manual_seed(seed)
+    model = O.OracleUNetModel(**workload["model"])
+    for _n, layer in model.named_modules():
+        if isinstance(layer, torch.nn.modules.conv._ConvNd):
+            torch.nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+    model = model.to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=4e-5, weight_decay=0.01)
+    full = int(workload["batch"])
+    raw = synthetic_raw(full, workload["crop"], seed).to(device)
+    anchor, reference = (t.to(device) for t in sample_pairs(full, workload["crop"], workload["kappa"], workload["density"], seed))
+
+    def step():
+        return O.train_step(model, opt, raw, anchor, reference, 10.0, 1e-5)
+
+    t0 = time.perf_counter()
+    loss0 = step()[0]
+    torch.cuda.synchronize(device)
+    t_warm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    out = dict(value=round(full / dt, 3), unit="crops/s", ms_per_step=round(dt * 1e3, 2), steps=steps,
+               warmup_s=round(t_warm, 2), first_loss=round(float(loss0), 4), kind="reference arithmetic in the vendor library",
+               what=f"oracle/unet_oracle.py (plain nn.Conv{len(workload['crop'])}d model, autograd, torch.optim.Adam) on {torch.cuda.get_device_name(device)}: "
+                    f"torch {torch.__version__}, MIOpen convolutions (float32), batch {full}, the same synthetic crops and pairs; "
+                    "solver / kernel names: profiles/r05_gpu_library_baseline_kernels.txt")
+    if with_infer and len(workload["crop"]) == 2:
+        del opt
+        model.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        size, n_it = 512, 16
+        model.eval()
+        model.set_infer(0.01, n_it)
+        tile = torch.rand(1, 1, size + 16, size + 16, device=device)
+        noise = torch.rand(1, 2 * n_it, 1, size + 16, size + 16, device=device)
+        with torch.no_grad():
+            model(tile, noise=noise)                      # warm-up
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            emb = model(tile, noise=noise)
+            torch.cuda.synchronize(device)
+        t_tile = time.perf_counter() - t0
+        assert tuple(emb.shape) == (1, 3, size, size)
+        out["infer_tile"] = dict(value=round(size * size / t_tile / 1e6, 4), unit="Mpixels/s (embedding stage only)",
+                                 ms_per_tile=round(t_tile * 1e3, 1),
+                                 what=f"one {size}^2 tile: 2 x {n_it} batch-1 forwards + std_mean, as cellulus/models/unet.py:73-100 runs them")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -718,6 +782,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="train2d", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-library-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-train3d", action="store_true")
     ap.add_argument("--no-train-e2e", action="store_true")
@@ -815,6 +880,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(WORKLOADS[args.workload], device, seed=0)
         except Exception as e:
             out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    # (--no-cpu-baseline switches BOTH baselines off: the profiling scripts pass it to keep foreign kernels out of their traces)
+    if world == 1 and not args.no_gpu_library_baseline and not args.no_cpu_baseline and args.workload in ("train2d", "train3d"):
+        try:
+            torch.cuda.empty_cache()
+            out["gpu_library_baseline"] = gpu_library_baseline(WORKLOADS[args.workload], device)
+        except Exception as e:
+            out["gpu_library_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

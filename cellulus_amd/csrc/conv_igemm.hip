@@ -87,6 +87,7 @@ struct ConvP {
   int relu, ld_mask, ld_out, accumulate;
   int nbm, nbn;
   long long bs_in, bs_w, bs_out;   // per-batch strides in floats (gridDim.y batches; 0 = none)
+  int flush_every;                 // chunks of 32 products per fresh accumulator (two-level summation over K); 0 = never
 };
 
 // FAST: no zero rows exist (no padding; channel counts are multiples of the 32-wide K chunk) and every offset fits 32 bits:
@@ -269,13 +270,22 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     return true;
   };
 
-  f32x16 acc[TM][TN];
+  // Two-level summation over K: `acc` holds the products of ONE chunk of 32, `tot` the chunks before it.  One
+  // accumulator walking the whole contraction rounds every product against a partial sum that keeps growing when the
+  // terms are coherent — post-ReLU activations are non-negative —: measured on the benchmark network at a trained
+  // network's output scale, 1.6x (K = 256) to 3.1x (K = 2304) the rms error of the reference's CPU path (oneDNN blocks
+  // its contraction), and the whole of the network's excess distance from the float64 oracle (tools/exp/
+  // layer_profile_error.py).  With a fresh accumulator per chunk the error of a K = 256 layer is 0.45x
+  // the single chain's (emulated in float64 on real activations).  The adds of a tile's 16 registers are issued in
+  // front of the tile's first MFMA of the next chunk, which starts from zero: they read results that completed three
+  // MFMAs ago and hide under the MFMAs around them.
+  f32x16 acc[TM][TN], tot[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; tot[a][b][r] = 0.f; }
 
   const int li = lane & 31, lh = lane >> 5;
   // bias of this lane's accumulator columns: fetched here, used in the epilogue
@@ -318,6 +328,35 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
         for (int c = 0; c < TN; ++c)
           acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a][e], bf[slot][c][e], acc[a][c], 0, 0, 0);
   };
+  // the first group of a chunk: every tile's previous chunk goes into `tot` and the tile restarts from zero, IN PLACE —
+  // spelled as instructions: written as `tot += acc; acc = mfma(a, b, 0)` the compiler rotated the adds to the bottom of
+  // the loop behind a COPY of the 64 accumulator registers (a third set: 338 registers wanted, 82 spilled, 124 -> 69
+  // TFLOP/s).  The tile's 32 instructions sit in front of its first MFMA and under the MFMAs of the tiles around it.
+  // CLX_IGEMM_FLUSH (read once, default 2): chunks per fresh accumulator — 1: every 32 products; 2: every 64 (half the
+  // flush instructions, the same error on real activations: emulation 2.1e-8 / 2.5e-8 rms against 4.6e-8 for one
+  // chain at K = 256); 0: one chain over all of K (rounds 1-4)
+  int since_flush = 0;
+  auto mfma_group_first = [&](int slot) {
+    const bool flush = p.flush_every > 0 && ++since_flush >= p.flush_every;
+    if (flush) since_flush = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int c = 0; c < TN; ++c) {
+          if (e == 0 && flush) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              float t = tot[a][c][r], x = acc[a][c][r];
+              asm volatile("v_add_f32 %0, %0, %1\n\tv_mov_b32 %1, 0" : "+v"(t), "+v"(x));
+              tot[a][c][r] = t;
+              acc[a][c][r] = x;
+            }
+          }
+          acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a][e], bf[slot][c][e], acc[a][c], 0, 0, 0);
+        }
+  };
   // Per chunk: 4 groups of 4*TM*TN MFMAs.  Everything else is slotted between the
   // groups so the matrix pipe never waits for a long non-MFMA stretch: global loads of
   // the next chunk before groups 0/1, their LDS stores (other buffer) before group 3,
@@ -335,7 +374,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
     load_a();
     load_frags(buf, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(0);
+    mfma_group_first(0);
     __builtin_amdgcn_sched_barrier(0);
     load_b();
     load_frags(buf, 2, 0);
@@ -366,7 +405,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   }
   load_frags(buf, 1, 1);
   __builtin_amdgcn_sched_barrier(0);
-  mfma_group(0);
+  mfma_group_first(0);
   __builtin_amdgcn_sched_barrier(0);
   load_frags(buf, 2, 0);
   __builtin_amdgcn_sched_barrier(0);
@@ -377,6 +416,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   mfma_group(0);
   __builtin_amdgcn_sched_barrier(0);
   mfma_group(1);
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] += tot[a][b];
 
   STAMP(2);
 #ifdef IG_STAMP
@@ -585,6 +628,7 @@ static void fill_params(const clx_conv_desc* d, ConvP& p) {
   p.relu = d->relu; p.ld_mask = d->ld_mask; p.ld_out = d->ld_out;
   p.accumulate = d->accumulate;
   p.bs_in = p.bs_w = p.bs_out = 0;
+  p.flush_every = 0;
 }
 
 extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
@@ -634,6 +678,8 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   p.zeros = zero_buffer();
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_fwd: cannot resolve the device zero buffer");
   p.bs_in = bs_in; p.bs_w = bs_w; p.bs_out = bs_out;
+  static const int flush_env = getenv("CLX_IGEMM_FLUSH") ? atoi(getenv("CLX_IGEMM_FLUSH")) : 2;
+  p.flush_every = flush_env;
   // 128-wide N tiles unless padding N up to a multiple of 128 wastes > 20 % of the MFMAs
   const bool wide = d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2;
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -130,6 +130,7 @@ def train(experiment_config):
         drop_last=True,
         num_workers=policy["loader_procs"],
         pin_memory=True,
+        collate_fn=_collate_narrow if max(train_config.crop_size) < 32768 else None,
     )
 
     # set model
@@ -235,6 +236,17 @@ def train(experiment_config):
         logger.plot(force=True)
 
 
+def _collate_narrow(samples):
+    """The DataLoader's batch assembly with the pair coordinates as int16: they index a crop (< 32768 per axis), and
+    at the benchmark configuration the two int64 arrays are 38 of the 40 MB a batch moves through the loader
+    processes' shared memory, the pinning thread and the H2D copy.  ``_DevicePrefetcher`` widens them on the device:
+    ``train_iteration`` sees the reference's int64 tensors (``cellulus/train.py:166-173``)."""
+    raw = torch.from_numpy(np.stack([s[0] for s in samples]))
+    anchor = torch.from_numpy(np.stack([s[1] for s in samples]).astype(np.int16))
+    reference = torch.from_numpy(np.stack([s[2] for s in samples]).astype(np.int16))
+    return raw, anchor, reference
+
+
 class _DevicePrefetcher:
     """Stages batch i+1 (pinned host memory -> HBM, 40 MB at the 2-D configuration: raw plus two
     int64 coordinate arrays) on a copy stream while step i computes, so that the transfer is off
@@ -262,7 +274,9 @@ class _DevicePrefetcher:
                 anchor, reference = self.pair_sampler.sample(raw.shape[0], self.step)
                 self.next = (raw, anchor, reference)
             else:
-                self.next = tuple(t.to(self.device, non_blocking=True) for t in batch)
+                staged = [t.to(self.device, non_blocking=True) for t in batch]
+                # (the loader narrowed the coordinates for the trip: _collate_narrow)
+                self.next = tuple(t.to(torch.int64) if t.dtype == torch.int16 else t for t in staged)
             self.step += 1
 
     def __iter__(self):

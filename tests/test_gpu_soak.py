@@ -1,6 +1,6 @@
 """GPU: nothing grows while the drivers run at benchmark size (promoted from tests/diag/soak_memory.py).
 
-300 iterations of the real ``train()`` at BASELINE configs[1] (loader processes with the default elastic
+180 iterations (CLX_SOAK_ITERATIONS; 300 and more for a long soak) of the real ``train()`` at BASELINE configs[1] (loader processes with the default elastic
 augmentation and the np.random pair stream, device prefetcher, logging) and two passes of ``infer()`` over a
 512^2 container: device memory and host RSS after the start-up must be flat."""
 
@@ -31,7 +31,7 @@ def test_train_loop_holds_its_memory_at_benchmark_size(device, tmp_path, monkeyp
     f = zarr_io.open("data.zarr")
     f["train/raw"] = np.concatenate([synthetic_raw(1, (384, 384), s).numpy() for s in range(8)])
     f["train/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
-    iters = 300
+    iters = max(140, int(os.environ.get("CLX_SOAK_ITERATIONS", "180")))    # (under -m gpu: the suite has a time limit)
     cfg = ExperimentConfig(
         normalization_factor=1.0, model_config=dict(num_fmaps=256, fmap_inc_factor=3),
         train_config=dict(crop_size=[256, 256], batch_size=8, max_iterations=iters, num_workers=8,

@@ -37,6 +37,23 @@ def _blobs(crop, seed):
 
 
 def test_trained_network_label_maps_equal_the_all_oracle_chain(device, tmp_path, monkeypatch):
+    _train_infer_compare(dict(MODEL), "cfg-1", int(os.environ.get("CLX_TEST_TRAIN_ITERATIONS", "400")), 1e-3,
+                         tmp_path, monkeypatch, min_instances=20)
+
+
+def test_trained_benchmark_width_network_at_the_benchmark_tile(device, tmp_path, monkeypatch):
+    """The same chain with the BENCHMARK network (BASELINE configs[1] / [4]: 256 feature maps, factor 3 — the network
+    whose wide layers run as Winograd F(4x4), three-launch and fused, and whose 1x1 layers contract over 256 / 768
+    channels) trained for 200 iterations on the GPU, then ``infer()`` on a 512^2 sample as ONE 528^2 tile at the default
+    16 noise iterations (32 forwards in four chunks of eight on two streams, the first level on changed rows / tiles:
+    what bench.py times) against the oracle's scan — 55 TFLOP on the CPU side, about a minute — and the all-oracle
+    chain behind it.  (Until round 5 this tile was compared on Kaiming weights, where offsets are 0.3 px.)"""
+    _train_infer_compare(dict(num_fmaps=256, fmap_inc_factor=3, features_in_last_layer=64, downsampling_factors=[[2, 2]]),
+                         "cfg-2 width", int(os.environ.get("CLX_TEST_TRAIN_ITERATIONS_WIDE", "200")), 2e-4,
+                         tmp_path, monkeypatch, min_instances=10)
+
+
+def _train_infer_compare(MODEL, tag, iterations, lr, tmp_path, monkeypatch, min_instances):
     from cellulus_amd.configs import ExperimentConfig
     from cellulus_amd.infer import infer
     from cellulus_amd.train import train
@@ -51,13 +68,12 @@ def test_trained_network_label_maps_equal_the_all_oracle_chain(device, tmp_path,
     raw = _blobs((512, 512), seed=11)
     f["test/raw"] = raw
     f["test/raw"].attrs["axis_names"] = ["s", "c", "y", "x"]
-    iterations = int(os.environ.get("CLX_TEST_TRAIN_ITERATIONS", "400"))
     torch.manual_seed(0)
     np.random.seed(0)
     train(ExperimentConfig(
         normalization_factor=1.0, object_size=30, model_config=dict(MODEL),
         train_config=dict(crop_size=[256, 256], batch_size=8, max_iterations=iterations, num_workers=0,
-                          elastic_deform=False, initial_learning_rate=1e-3, device="cuda:0",
+                          elastic_deform=False, initial_learning_rate=lr, device="cuda:0",
                           save_model_every=10 ** 6, save_best_model_every=10 ** 6, save_snapshot_every=10 ** 6,
                           train_data_config=dict(container_path=container, dataset_name="train/raw"))))
     ckpt = os.path.join("models", f"{iterations - 1:06d}.pth")          # train.py:188-191: the last iteration is saved
@@ -91,7 +107,10 @@ def test_trained_network_label_maps_equal_the_all_oracle_chain(device, tmp_path,
     torch.manual_seed(42)
     np.random.seed(42)
     O.OracleUNetModel(**ocfg)                                              # the draws of infer()'s model construction
+    threads_before = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))          # (the CPU oracle is fastest at 32 threads on the pool's hosts)
     ref_emb = O.predict_scan(oracle, raw, [528, 528], p, n_it, 1.0, literal_dry_run=False)
+    torch.set_num_threads(threads_before)
     err = np.abs(emb - ref_emb).max()
     rng_mean = np.abs(ref_emb[0, :2]).max()
     _mask, _cen, ref_labels = IO.detect_sample(ref_emb[0], bw, 1, min_size, rp)
@@ -106,13 +125,13 @@ def test_trained_network_label_maps_equal_the_all_oracle_chain(device, tmp_path,
     area_g = joint.sum(axis=0)[ids_g != 0][None, :]
     iou = jp / np.maximum(area_p + area_g - jp, 1)
     f1 = float(IO.compute_F1(iou)[0]) if n_obj and n_ref else float("nan")
-    print(f"trained cfg-1 network ({iterations} iterations"
+    print(f"trained {tag} network ({iterations} iterations"
           + (f", loss {losses[0]:.1f} -> {losses[-1]:.1f}" if losses is not None and len(losses) else "")
           + f"): offsets up to {rng_mean:.2f} px, |embeddings - oracle| {err:.2e}; {n_obj} instances (oracle chain {n_ref}); "
           f"pixels that differ from the all-oracle chain: {differ} of {seg[0, 0].size}; F1 against it {f1}")
-    assert n_ref >= 20, "the trained network should separate the blobs (the test image holds ~100)"
-    # embeddings: the north-star tolerance, relative to the magnitude a trained network emits
-    assert err < 1e-4 * max(1.0, rng_mean), err
+    assert n_ref >= min_instances, "the trained network should separate the blobs (the test image holds ~100)"
+    # embeddings: the north-star tolerance, ABSOLUTE up to offsets of 15 px (object_size 30), relative beyond
+    assert err < 1e-4 * max(1.0, rng_mean / 15.0), (err, rng_mean)
     # label maps: bit-identical; a tie pixel (equidistant from two modes within rounding) may flip — then at most
     # 1e-4 of the pixels and every instance still matched one to one
     if differ:

@@ -93,23 +93,52 @@ def test_forward_matches_oracle(name, device):
 
 @pytest.mark.parametrize("name", list(CONFIGS))
 def test_backward_matches_oracle(name, device):
+    """Every parameter gradient against the float64 oracle evaluated on the HIP forward pass's own ReLU gates and
+    max-pool winners (oracle.unet_oracle.forced_decisions: a pre-activation within rounding distance of zero may take
+    either side in any float32 forward pass, and ONE flipped gate moves a gradient by a whole term — 4.6e-3 of a
+    first-layer gradient when the summation order of the GEMM kernel changed in round 5 and this test compared with the
+    free-running oracle); the free-running distance is bounded too, by what single flips can do."""
+    import torch.nn.functional as F
+
     oracle, model, raw = _make(name, device, seed=1)
     oracle = oracle.double()
-    ref = oracle(raw.double())
-    torch.manual_seed(2)
-    dout = torch.randn_like(ref).float()
-    ref.backward(dout.double())
     got = model(raw.to(device))
     assert got.requires_grad
+    torch.manual_seed(2)
+    dout = torch.randn(got.shape)
     got.backward(dout.to(device))
-    for (n, po), (n2, pm) in zip(oracle.named_parameters(), model.named_parameters()):
+    plan = next(iter(model._plans.values()))
+    nd = plan.topo.nd
+
+    def planar(tensor_name):
+        shape, c = plan.topo.shapes[tensor_name]
+        t = plan.buf[tensor_name].view((plan.B,) + tuple(shape) + (-1,))[..., :c].permute(0, 4, 1, 2, 3).contiguous().cpu()
+        return t[:, :, 0] if nd == 2 else t
+
+    masks = [planar(layer.out) > 0 for layer in plan.topo.convs if layer.relu]
+    pool = F.max_pool2d if nd == 2 else F.max_pool3d
+    winners = [pool(planar(p.src), p.factor[3 - nd:], stride=p.factor[3 - nd:], return_indices=True)[1]
+               for p in plan.topo.pools]
+    from oracle.unet_oracle import forced_decisions
+
+    with forced_decisions(oracle, masks, winners):
+        ref = oracle(raw.double())
+        ref.backward(dout.double())
+    assert (got.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4
+    forced = [p.grad.clone() for p in oracle.parameters()]
+    for p in oracle.parameters():
+        p.grad = None
+    oracle(raw.double()).backward(dout.double())
+    for (n, po), (n2, pm), g_ref in zip(oracle.named_parameters(), model.named_parameters(), forced):
         assert n == n2
-        g_ref, g = po.grad, pm.grad.cpu().double()
+        g = pm.grad.cpu().double()
         scale = g_ref.abs().max().item() + 1e-12
         err = (g - g_ref).abs().max().item() / scale
         l2 = ((g - g_ref).norm() / (g_ref.norm() + 1e-12)).item()
         assert err < 1e-3, f"{name}: grad of {n}: max rel err {err} (scale {scale})"
         assert l2 < 1e-4, f"{name}: grad of {n}: rel L2 err {l2}"
+        free = ((g - po.grad).norm() / (po.grad.norm() + 1e-12)).item()
+        assert free < 2e-2, f"{name}: grad of {n}: rel L2 err {free} against the free-running float64 oracle"
 
 
 @pytest.mark.parametrize("name", ["2d_chain64", "3d_chain64"])
@@ -128,7 +157,9 @@ def test_fused_1x1_pairs_are_used_and_equal_the_layer_by_layer_path(name, device
     grads = [p.grad.clone() for p in model.parameters()]
     with torch.no_grad():
         inf = model(x).clone()
-    assert torch.allclose(inf, got.detach(), atol=1e-6)
+    # (the inference plan may run a layer in another form than the training plan — the fused Winograd kernels, whose
+    #  contraction is one chain where the implicit-GEMM kernel restarts its accumulators every 64 products)
+    assert torch.allclose(inf, got.detach(), atol=1e-5)
     monkeypatch.setenv("CLX_CHAIN64", "0")
     _o, plain, _r = _make(name, device, seed=4)
     ref = plain(x)
