@@ -50,6 +50,10 @@ extern "C" int clx_profile_clock(double* shader_ticks, double* wall_ticks_100mhz
   return CLX_OK;
 }
 
+#ifndef CLX_FLUSH_FORM
+#define CLX_FLUSH_FORM 0
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -347,12 +351,22 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
         for (int c = 0; c < TN; ++c) {
           if (e == 0 && flush) {
 #pragma unroll
+#if CLX_FLUSH_FORM == 1        // four 32-bit instructions per pair (the first version of this flush)
             for (int r = 0; r < 16; ++r) {
               float t = tot[a][c][r], x = acc[a][c][r];
               asm volatile("v_add_f32 %0, %0, %1\n\tv_mov_b32 %1, 0" : "+v"(t), "+v"(x));
               tot[a][c][r] = t;
               acc[a][c][r] = x;
             }
+#else                          // one packed add + one 64-bit move per pair
+            for (int r = 0; r < 16; r += 2) {
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              f32x2 t = {tot[a][c][r], tot[a][c][r + 1]}, x = {acc[a][c][r], acc[a][c][r + 1]};
+              asm volatile("v_pk_add_f32 %0, %0, %1\n\tv_mov_b64 %1, 0" : "+v"(t), "+v"(x));
+              tot[a][c][r] = t[0]; tot[a][c][r + 1] = t[1];
+              acc[a][c][r] = x[0]; acc[a][c][r + 1] = x[1];
+            }
+#endif
           }
           acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][a][e], bf[slot][c][e], acc[a][c], 0, 0, 0);
         }

@@ -1,14 +1,12 @@
-mkdir -p gpurun_out/r05k
-for f in 0 1 2 4; do
-  echo "=== CLX_IGEMM_FLUSH=$f"
-  CLX_IGEMM_FLUSH=$f timeout 600 python tools/parity_trained_scale.py 2d 2>&1 | grep -v amdgpu | grep "default\|three-launch\|from 128"
-  CLX_IGEMM_FLUSH=$f timeout 600 python bench.py --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > gpurun_out/r05k/bench_$f.json 2> gpurun_out/r05k/bench_$f.err; python - $f <<'PY'
-import json, sys
-d=json.load(open(f'gpurun_out/r05k/bench_{sys.argv[1]}.json'))
-print(d['value'], d['ms_per_step'], d['roofline']['per_kernel']['conv_igemm_kernel<128,128,2,2>'])
-PY
-done > gpurun_out/r05k/flush.txt 2>&1
-cat gpurun_out/r05k/flush.txt
-echo "=== fused only for N = 64 (inference plan), flush 2"
-CLX_WINO_FUSED_MAX_CHANNELS=0 timeout 600 python tools/parity_trained_scale.py 2d 2>&1 | grep -v amdgpu | grep "default"
-timeout 900 python -m pytest tests/test_gpu_unet.py tests/test_gpu_chain.py tests/test_gpu_fastpath.py tests/test_gpu_wino_fused.py tests/test_gpu_train.py tests/test_gpu_fuzz.py -q 2>&1 | tail -4
+mkdir -p gpurun_out/r05n
+for rep in 1 2; do
+for lib in cellulus_amd/libclx.so cellulus_amd/libclx.so.scalarflush; do
+  for f in 2 0; do
+  CLX_IGEMM_FLUSH=$f python tools/bench_with_lib.py $lib --no-infer --no-cpu-baseline --no-train-e2e --no-train3d 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$lib flush=$f', d['value'], d['ms_per_step'], d['roofline']['per_kernel']['conv_igemm_kernel<128,128,2,2>']['tflops'])"
+  done
+done
+done
+CLX_IGEMM_FLUSH=2 timeout 300 python tools/parity_trained_scale.py 2d 2>&1 | grep "default"
