@@ -1192,12 +1192,19 @@ class UNetPlan:
         first = ops[0]
         if special(first) or len(first.sources) != 1 or first.sources[0].tensor != "raw":
             return None
+        # On the changed-rows path the copies' tensors between `first` and the LAST layer of the tail are never written
+        # (only the last one is rebuilt by broadcast + scatter): every tensor in between must have the next layer of the
+        # prefix as its ONLY reader — a topology in which one of them is also a skip connection or pooled would read
+        # stale rows (today's build_topology never makes one; find_chain_pairs guards its pairs the same way)
+        readers = tensor_consumers(self.topo)
         tail, src = [], first.out
         for op in ops[1:]:
             if not isinstance(op, ConvLayer) or op.taps != 1 or special(op) or self.algo[op.name]["fwd"]:
                 break
             s = op.sources[0]
             if len(op.sources) != 1 or s.tensor != src or tuple(s.crop) != (0, 0, 0) or tuple(s.factor) != (1, 1, 1):
+                break
+            if readers.get(src, 0) != 1:
                 break
             tail.append(op)
             src = op.out

@@ -44,6 +44,12 @@ def main():
           "frac of 8 TB/s", round(n * n * 8 / t_k / 8e12, 3), "ncomp", int(ncomp.item()))
     ref_path = "/tmp/cc_ref_%d.npy" % n
     if not os.path.exists(ref_path):
+        # (never from a profiled process: the child would inherit the profiler's preload, start from a process that has
+        #  initialised the GPU, and its CLX_CC_LABELS=0 kernels would land in the same counter files — cc_pmc.sh writes
+        #  the reference first, outside the profiler)
+        if any(k.startswith("ROCPROF") or k == "ROCP_TOOL_LIBRARIES" for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            print("   (no reference dump and running under the profiler: comparison skipped)")
+            return
         env = dict(os.environ, CLX_CC_LABELS="0")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", ref_path], env=env, check=True)
     ref = np.load(ref_path)
