@@ -31,5 +31,11 @@ cp $R/pmc_lds_conflicts_f32.txt profiles/${P}_pmc_lds_conflicts_f32.txt
 [ -f $R/hbm_traffic_infer.json ] && cp $R/hbm_traffic_infer.json profiles/hbm_traffic_infer.json
 [ -f $R/hbm_traffic_infer.txt ] && cp $R/hbm_traffic_infer.txt profiles/${P}_hbm_traffic_infer.txt
 [ -f $R/pmc_infer_kernels.txt ] && cp $R/pmc_infer_kernels.txt profiles/${P}_pmc_infer_kernels.txt
+[ -f $R/gpu_library_baseline_kernels.txt ] && cp $R/gpu_library_baseline_kernels.txt profiles/${P}_gpu_library_baseline_kernels.txt
+[ -f $R/gpu_library_baseline_miopen_cmds.txt ] && cp $R/gpu_library_baseline_miopen_cmds.txt profiles/${P}_gpu_library_baseline_miopen_cmds.txt
+[ -f $R/gpu_library_baseline_line.json ] && cp $R/gpu_library_baseline_line.json profiles/${P}_gpu_library_baseline_line.json
+[ -f $R/wino_fused_layers.txt ] && cp $R/wino_fused_layers.txt profiles/${P}_wino_fused_layers.txt
+[ -f $R/parity_trained_scale_2d.txt ] && cp $R/parity_trained_scale_2d.txt profiles/${P}_parity_trained_scale_2d.txt
+[ -f $R/parity_trained_scale_3d.txt ] && cp $R/parity_trained_scale_3d.txt profiles/${P}_parity_trained_scale_3d.txt
 
 true

@@ -66,4 +66,12 @@ echo refresh done
 # the inference tile (one stream: every kernel alone): kernel statistics, per-kernel table of one tile, HBM traffic, matrix-pipe busy
 bash tools/infer_profile.sh > $O/infer_profile.log 2>&1
 cp gpurun_out/infer_prof/* $O/ 2>/dev/null
+# the reference's own GPU path (PyTorch + MIOpen) and the fused Winograd layer table
+bash tools/gpu_library_kernels.sh > $O/gpu_library.log 2>&1
+cp gpurun_out/gpu_library/kernels.txt $O/gpu_library_baseline_kernels.txt 2>/dev/null
+cp gpurun_out/gpu_library/miopen_cmds.txt $O/gpu_library_baseline_miopen_cmds.txt 2>/dev/null
+cp gpurun_out/gpu_library/line.json $O/gpu_library_baseline_line.json 2>/dev/null
+timeout 300 python tools/exp/fused_bench.py 2>/dev/null | grep "^{" > $O/wino_fused_layers.txt
+timeout 300 python tools/parity_trained_scale.py 2d 2>/dev/null | grep -v amdgpu > $O/parity_trained_scale_2d.txt
+timeout 300 python tools/parity_trained_scale.py 3d 2>/dev/null | grep -v amdgpu > $O/parity_trained_scale_3d.txt
 echo refresh complete
