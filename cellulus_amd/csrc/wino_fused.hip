@@ -201,9 +201,7 @@ __device__ __forceinline__ void fused_epilogue(const FusedP& p, f32x16 (&acc)[Fu
   }
 }
 
-// VAR: diagnostic variants (CLX_FUSED_VARIANT, tools/exp/fused_bench.py --variant): bit 0 = the weights are fetched once,
-// bit 1 = no transform, bit 2 = the patches are fetched once, bit 3 = no MFMAs.  0 = the product.
-template <int R, int VAR = 0>
+template <int R>
 __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const FusedP p) {
   using G = FusedGeom<R>;
   using W = WT<4, R>;
@@ -251,13 +249,11 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const FusedP p) {
   constexpr int NRG = (NRAW + 1) / 2;
   f32x4 ra[NRG];
   auto load_raw_group = [&](int chunk, int grp) {
-    if ((VAR & 4) && chunk > 1) return;
 #pragma unroll
     for (int j = grp * NRG; j < (grp ? NRAW : NRG); ++j)
       ra[j - grp * NRG] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)roff[j], chunk * (FK * 4), 0));
   };
   auto store_raw_group = [&](int rb, int grp) {
-    if (VAR & 2) return;
 #pragma unroll
     for (int j = grp * NRG; j < (grp ? NRAW : NRG); ++j) {
       if (lane + 64 * j < G::RAW_ITEMS) *reinterpret_cast<f32x4*>(raw_w + rb * (FT * RAW_TILE) + 256 * j) = ra[j - grp * NRG];
@@ -285,12 +281,10 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const FusedP p) {
   // rows: V[r][q] = sum_l w[r][l] BT[q][l]
   float dd[NPASS][A];
   auto read_pass = [&](int rb, int q) {            // both passes read the same addresses (raw, then Wt)
-    if (VAR & 2) return;
 #pragma unroll
     for (int k = 0; k < A; ++k) dd[q][k] = raw[rb * (FT * RAW_TILE) + s_col[q] + k * A * 8];
   };
   auto col_out = [&](int rb, int q, int r) {
-    if (VAR & 2) return;
     float acc1 = 0.f;
     bool first = true;
 #pragma unroll
@@ -298,7 +292,6 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const FusedP p) {
     if (s_live[q]) raw[rb * (FT * RAW_TILE) + s_row[q] + r * 8] = acc1;
   };
   auto row_out = [&](int buf, int q, int qq) {
-    if (VAR & 2) return;
     float acc1 = 0.f;
     bool first = true;
 #pragma unroll
@@ -372,13 +365,13 @@ __global__ __launch_bounds__(512, 1) void wino_fused_kernel(const FusedP p) {
       constexpr int m = decltype(mc)::value;
       constexpr int j = m / 4, e = m % 4;
       if constexpr (e == 0 && j + 1 < XIW) load_af(PAR, j + 1);
-      if (!(VAR & 8) && xi_live(j))
+      if (xi_live(j))
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j & 1][e], bfr[j][e], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!LAST) {
         tslot(mc, std::integral_constant<int, PAR ^ 1>{}, c_raw);
         if constexpr (e == 3) {                    // xi_j's last MFMA is issued: its fragment for the next chunk
-          if (!(VAR & 1)) load_b(c_next, j);
+          load_b(c_next, j);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -657,21 +650,6 @@ int clx_wino_fused_fwd(const clx_conv_desc* d, hipStream_t st) {
     if (d->KH == 3) CLX_LAUNCH_TIMED((wino_pre_kernel<3>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p);
     else CLX_LAUNCH_TIMED((wino_pre_kernel<2>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p);
     CLX_CHECK_LAUNCH("clx_conv_fwd(winograd fused, two launches)");
-    return CLX_OK;
-  }
-  static const int variant = getenv("CLX_FUSED_VARIANT") ? atoi(getenv("CLX_FUSED_VARIANT")) : 0;
-  if (variant && d->KH == 3) {
-    switch (variant) {
-      case 1: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 1>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      case 2: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 2>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      case 4: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 4>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      case 6: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 6>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      case 7: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 7>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      case 8: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 8>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      case 9: CLX_LAUNCH_TIMED((wino_fused_kernel<3, 9>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p); break;
-      default: CLX_REQUIRE(false, "CLX_FUSED_VARIANT: unknown variant %d", variant);
-    }
-    CLX_CHECK_LAUNCH("clx_conv_fwd(winograd fused, variant)");
     return CLX_OK;
   }
   if (d->KH == 3) CLX_LAUNCH_TIMED((wino_fused_kernel<3>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p);
