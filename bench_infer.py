@@ -163,8 +163,17 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     t = _kernel_time(lambda: _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(idx), n_fg, _clx.ptr(cc_sorted),
                                        len(centers), 2, _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, 15.0,
                                        gx, gy, gz, _clx.ptr(labels), st), PROF_KIND["ms_assign"])
-    row("ms_assign", t, n_fg * (16 + 4 + 4), "per foreground pixel 20 B read + 4 B label written",
-        centres=len(centers))
+    row("ms_assign_scatter", t, n_fg * (16 + 4 + 4), "per foreground pixel 20 B read + 4 B label written through the raster "
+        "index (rounds 1-4's form: the zero fill of the map it scatters into is NOT in this row)", centres=len(centers))
+    # the form the product runs: the whole label map in one pass over the compaction's tiles (flags from `ws`)
+    dense = torch.empty(npix, dtype=torch.int32, device=device)
+    t = _kernel_time(lambda: _clx.call("clx_ms_assign_dense", _clx.ptr(pts), _clx.ptr(cc_sorted), len(centers), 2,
+                                       _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, 15.0, gx, gy, gz, _clx.ptr(ws), 0,
+                                       1, Y, X, _clx.ptr(dense), st), PROF_KIND["ms_assign"])
+    assert torch.equal(dense, labels)
+    row("ms_assign", t, n_fg * 16 + npix * 4 + npix // 8, "per foreground pixel 16 B read, per pixel 4 B label written "
+        "(background included: no zero fill, no raster index) + 1 flag bit read", centres=len(centers))
+    del dense
     if only_mean_shift:
         return dict(pixels_per_launch=npix, samples_of_512x512_per_launch=npix // (512 * 512), kernels=out)
     seg = labels.view(Y, X).clone()

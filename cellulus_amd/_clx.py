@@ -144,6 +144,9 @@ PROTOTYPES = {
     "clx_adam_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P]),
     "clx_adam_step_guarded": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _P, _P]),
     "clx_noise_stats": (_I, [_P, _P, _I, _I, _LL, _P]),
+    "clx_noise_inject": (_I, [_P, _P, _P, _I, _I, _LL, ctypes.c_float, _P]),
+    "clx_zero_many": (_I, [POINTER(_P), POINTER(_LL), _I, _P]),
+    "clx_gather_rows_f64": (_I, [_P, _P, _LL, _I, _P, _P]),
     "clx_noise_stats_minmax": (_I, [_P, _P, _I, _I, _LL, _P, _I, _P]),
     "clx_ms_prepare_workspace": (c_size_t, [_LL]),
     "clx_ms_prepare": (_I, [_P, _P, _D, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
@@ -154,6 +157,7 @@ PROTOTYPES = {
     "clx_ms_assign": (_I, [_P, _P, _I, _P, _I, _I, _P, _P]),
     "clx_ms_assign_grid": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _P]),
     "clx_ms_assign_cells": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _P]),
+    "clx_ms_assign_dense": (_I, [_P, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
     "clx_ms_bucket_workspace": (c_size_t, [_I, _LL]),
     "clx_ms_bucket": (_I, [_P, _I, _I, POINTER(c_double), _D, _I, _I, _I, _P, _P, _P, _P]),
     "clx_offset_magnitude": (_I, [_P, _P, _I, _LL, _P]),
@@ -224,6 +228,19 @@ def ptr(t):
     if t is None:
         return c_void_p(0)
     return c_void_p(t.data_ptr())
+
+
+def zero_many(*tensors):
+    """Zero fills of contiguous device tensors on the current stream of their device, eight buffers per launch
+    (clx_zero_many): the accumulators a step adds into, without one torch fill kernel each."""
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    if not ts:
+        return
+    for t in ts:
+        assert t.is_cuda and t.is_contiguous() and t.element_size() % 4 == 0, "zero_many: contiguous 4/8-byte device tensors"
+    ptrs = (_P * len(ts))(*[t.data_ptr() for t in ts])
+    sizes = (_LL * len(ts))(*[t.numel() * t.element_size() for t in ts])
+    call("clx_zero_many", ptrs, sizes, len(ts), stream_ptr(ts[0].device))
 
 
 def require_device(t, name="tensor"):

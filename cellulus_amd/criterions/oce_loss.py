@@ -52,7 +52,8 @@ class _GatherAdd(torch.autograd.Function):
         coordinates = coordinates.contiguous()
         P = coordinates.shape[1]
         sel = torch.empty((B, P, ND), dtype=torch.float32, device=outputs.device)
-        oob = torch.zeros(1, dtype=torch.int32, device=outputs.device)
+        oob = torch.empty(1, dtype=torch.int32, device=outputs.device)
+        _clx.zero_many(oob)
         _clx.call("clx_gather_add_fwd", _clx.ptr(outputs), _clx.ptr(coordinates), _clx.ptr(sel),
                   B, P, ND, Z, Y, X, _clx.ptr(oob), _clx.stream_ptr(outputs.device))
         raise_on_bad_coordinates(int(oob.item()), (Z, Y, X)[3 - ND:])
@@ -68,7 +69,8 @@ class _GatherAdd(torch.autograd.Function):
         B, ND = shape[0], shape[1]
         Z, Y, X = (1, shape[2], shape[3]) if nd == 2 else shape[2:]
         dsel = dsel.contiguous()
-        dout = torch.zeros(shape, dtype=torch.float32, device=dsel.device)
+        dout = torch.empty(shape, dtype=torch.float32, device=dsel.device)
+        _clx.zero_many(dout)
         _clx.call("clx_gather_add_bwd", _clx.ptr(dsel), _clx.ptr(coordinates), _clx.ptr(dout),
                   B, coordinates.shape[1], ND, Z, Y, X, None, _clx.stream_ptr(dsel.device))
         return dout, None
@@ -89,7 +91,8 @@ class _OCE(torch.autograd.Function):
         a = anchor.contiguous()
         r = reference.contiguous()
         npairs = a.numel() // nd
-        sums = torch.zeros(3, dtype=torch.float64, device=a.device)
+        sums = torch.empty(3, dtype=torch.float64, device=a.device)
+        _clx.zero_many(sums)
         need_grad = anchor.requires_grad
         da = torch.empty_like(a) if need_grad else None
         _clx.call("clx_oce_loss_fwd_bwd", _clx.ptr(a), _clx.ptr(r), _clx.ptr(da), _clx.ptr(sums),

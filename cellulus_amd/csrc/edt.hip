@@ -431,14 +431,16 @@ __global__ __launch_bounds__(256) void gs_rows_kernel(int* __restrict__ seg, con
     }
     clear &= wm;                                  // only foreground pixels hold anything to clear
     if (!interior) clear = 0;
-    // ---- apply: one row per iteration, the wavefront's lanes are the 64 pixels of the word
-    unsigned long long rows = __ballot(clear != 0);
-    while (rows) {
-      const int src = __builtin_ctzll(rows);
-      rows &= rows - 1;
-      const unsigned long long m = shfl_u64(clear, src);
-      const int yy = ty * rows_per_wave - H + src;
-      if ((m >> lane) & 1ull) seg[(long long)yy * X + wx * 64 + lane] = 0;
+    // ---- apply: every lane walks the set bits of ITS row's word (a rim of ~10 pixels per row that crosses objects: as many
+    // trips, all rows at once; the round-4 form took one trip — two shuffles and a store of a few lanes — per ROW with
+    // anything to clear, ~50 per wavefront)
+    if (clear) {
+      int* rowp = seg + (long long)y * X + wx * 64;
+      do {
+        const int b = __builtin_ctzll(clear);
+        clear &= clear - 1;
+        rowp[b] = 0;
+      } while (clear);
     }
   }
 }

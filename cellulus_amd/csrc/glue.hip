@@ -365,6 +365,114 @@ extern "C" int clx_noise_stats_minmax(const float* preds, float* out, int T, int
   return CLX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The launches PyTorch used to stand in for on the hot path (round 5): salt / pepper injection, the zero fills of the
+// accumulators a step adds into, the row gather of the mean-shift subsample.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// out[t][i] = rnd[t][i] <= p ? (t < n_half ? 0.5 : 1.0) : raw[i]      [cellulus/models/unet.py:75-88]
+template <int V>
+__global__ __launch_bounds__(256) void noise_inject_kernel(const float* __restrict__ rnd, const float* __restrict__ raw,
+                                                           float* __restrict__ out, int T, int n_half, long long nv,
+                                                           float p) {
+  typedef float vec __attribute__((ext_vector_type(V)));
+  const long long total = (long long)T * nv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int t = (int)(i / nv);
+    const long long j = i - (long long)t * nv;
+    const float val = t < n_half ? 0.5f : 1.0f;
+    const vec r = *reinterpret_cast<const vec*>(rnd + i * V);
+    vec x = *reinterpret_cast<const vec*>(raw + j * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e)
+      if (r[e] <= p) x[e] = val;
+    *reinterpret_cast<vec*>(out + i * V) = x;
+  }
+}
+
+struct ZeroManyP {
+  unsigned long long base[8];
+  unsigned long long first16[9];   // prefix of the buffers' 16-byte units
+  unsigned int tail_words[8];      // 4-byte words behind a buffer's last whole unit
+  int count;
+};
+
+__global__ __launch_bounds__(256) void zero_many_kernel(ZeroManyP p) {
+  const unsigned long long total = p.first16[p.count];
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * 256) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < 8; ++q) k += (q < p.count && i >= p.first16[q]) ? 1 : 0;
+    reinterpret_cast<f32x4*>(p.base[k])[i - p.first16[k]] = z;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 32) {
+    const int k = threadIdx.x >> 2, w = threadIdx.x & 3;
+    if (k < p.count && (unsigned int)w < p.tail_words[k])
+      reinterpret_cast<float*>(p.base[k])[(p.first16[k + 1] - p.first16[k]) * 4 + w] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double* __restrict__ src, const int* __restrict__ sel,
+                                                              long long n, int nd, double* __restrict__ dst) {
+  const long long total = n * nd;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / nd;
+    dst[i] = src[(long long)sel[r] * nd + (i - r * nd)];
+  }
+}
+
+}  // namespace
+
+extern "C" int clx_noise_inject(const float* rnd, const float* raw, float* out, int T, int n_half, long long n,
+                                float p, clx_stream stream) {
+  CLX_REQUIRE(rnd && raw && out && T > 0 && n > 0 && n_half >= 0 && n_half <= T, "clx_noise_inject: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = n % 4 == 0 && ((((uintptr_t)rnd | (uintptr_t)raw | (uintptr_t)out) & 15) == 0);
+  if (vec)
+    noise_inject_kernel<4><<<grid_for((long long)T * (n / 4), 256), 256, 0, st>>>(rnd, raw, out, T, n_half, n / 4, p);
+  else
+    noise_inject_kernel<1><<<grid_for((long long)T * n, 256), 256, 0, st>>>(rnd, raw, out, T, n_half, n, p);
+  CLX_CHECK_LAUNCH("clx_noise_inject");
+  return CLX_OK;
+}
+
+extern "C" int clx_zero_many(void* const* buffers, const long long* nbytes, int count, clx_stream stream) {
+  CLX_REQUIRE(count >= 0 && (count == 0 || (buffers && nbytes)), "clx_zero_many: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int first = 0; first < count; first += 8) {
+    ZeroManyP p;
+    p.count = 0;
+    p.first16[0] = 0;
+    for (int k = first; k < count && k < first + 8; ++k) {
+      CLX_REQUIRE(nbytes[k] >= 0 && nbytes[k] % 4 == 0, "clx_zero_many: sizes are multiples of 4 bytes");
+      if (nbytes[k] == 0) continue;
+      CLX_REQUIRE(buffers[k] && ((uintptr_t)buffers[k] & 15) == 0, "clx_zero_many: buffers are 16-byte aligned");
+      const int q = p.count++;
+      p.base[q] = (unsigned long long)(uintptr_t)buffers[k];
+      p.first16[q + 1] = p.first16[q] + (unsigned long long)nbytes[k] / 16;
+      p.tail_words[q] = (unsigned int)(nbytes[k] % 16) / 4;
+    }
+    if (p.count == 0) continue;
+    for (int q = p.count; q < 8; ++q) { p.base[q] = 0; p.first16[q + 1] = p.first16[p.count]; p.tail_words[q] = 0; }
+    long long g = (long long)((p.first16[p.count] + 255) / 256);
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    zero_many_kernel<<<(int)g, 256, 0, st>>>(p);
+  }
+  CLX_CHECK_LAUNCH("clx_zero_many");
+  return CLX_OK;
+}
+
+extern "C" int clx_gather_rows_f64(const double* src, const int* rows, long long n, int width, double* dst,
+                                   clx_stream stream) {
+  CLX_REQUIRE(n >= 0 && width > 0 && (n == 0 || (src && rows && dst)), "clx_gather_rows_f64: bad arguments");
+  if (n == 0) return CLX_OK;
+  gather_rows_f64_kernel<<<grid_for(n * width, 256), 256, 0, (hipStream_t)stream>>>(src, rows, n, width, dst);
+  CLX_CHECK_LAUNCH("clx_gather_rows_f64");
+  return CLX_OK;
+}
+
 static int subpixel_launch(bool to_space, const float* src, float* dst, int ld_lo, int ld_hi, int B,
                            int D, int H, int W, int N, int fz, int fy, int fx, hipStream_t st,
                            const char* who) {

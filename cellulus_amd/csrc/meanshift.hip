@@ -136,6 +136,7 @@ __global__ __launch_bounds__(256) void ms_flags_kernel(const TIn* __restrict__ s
 }
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 template <int ND, typename TIn, int G, bool WB, int BLOCKS>
 __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict__ emb, FastDiv dX, FastDiv dY, int Y, int X,
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
                                                                  const int* __restrict__ counts,
                                                                  const int* __restrict__ chunk_counts, int tiles_per_chunk,
                                                                  double* __restrict__ Xout, int* __restrict__ index,
-                                                                 int* __restrict__ nfg_out) {
+                                                                 int* __restrict__ nfg_out, int* __restrict__ tile_start) {
   __shared__ int part[4];
   using V = typename Vec16<TIn>::type;
   constexpr int PXL = Vec16<TIn>::N;
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
     if (lane == 0) part[threadIdx.x >> 6] = before;   //  wavefronts run the same trips and sit in one chunk)
     __syncthreads();
     int run = part[0] + part[1] + part[2] + part[3] + inside;     // points before group g of this tile
+    if (lane == 0) tile_start[wt] = run;                           // (kept for clx_ms_assign_dense)
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const long long i = base + (long long)(g * 64 + lane) * PXL;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
           if ((gb >> e) & 1u) {
 #pragma unroll
             for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = val[c];
-            index[pos] = (int)(i + e);
+            if (index) index[pos] = (int)(i + e);
             ++pos;
           }
           if (++cx == X) { cx = 0; if (++cy == Y) { cy = 0; ++cz; } }
@@ -593,83 +595,319 @@ __global__ __launch_bounds__(256) void ms_assign_grid_kernel(
 // from a contiguous range instead of order[j] -> centers[order[j]] (two dependent trips to L2), and in 2-D the
 // (up to three) rows' ranges are fetched together before any centre — five dependent memory levels per pixel
 // instead of ten.  Same arithmetic and the same tie rule (smaller centre id) as ms_assign_grid_kernel.
+// One candidate of the search: the centre cs[j] (cell order) with id order[j]; the winner is the minimum under the total
+// order (squared distance, centre id), so the visiting order does not matter.
 template <int ND>
-__global__ __launch_bounds__(256) void ms_assign_cells_kernel(
-    const double* __restrict__ X, const int* __restrict__ index, int nfg, const double* __restrict__ cs,
-    const int* __restrict__ order, const int* __restrict__ cell_start, double ox, double oy,
-    double oz, double h, int nx, int ny, int nz, int* __restrict__ labels) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nfg) return;
-  double x[ND];
+__device__ __forceinline__ void ms_candidate(const double (&x)[ND], const double* __restrict__ cs,
+                                             const int* __restrict__ order, int j, double& best, int& arg) {
+  double c[ND];
   if (ND == 2) {
-    const f64x2 p = *reinterpret_cast<const f64x2*>(X + (long long)i * 2);
-    x[0] = p[0]; x[1] = p[1];
+    const f64x2 q = *reinterpret_cast<const f64x2*>(cs + (long long)j * 2);
+    c[0] = q[0]; c[1] = q[1];
   } else {
 #pragma unroll
-    for (int c = 0; c < ND; ++c) x[c] = X[(long long)i * ND + c];
+    for (int e = 0; e < ND; ++e) c[e] = cs[(long long)j * ND + e];
   }
-  const int dst = index[i];
-  const double inv = 1.0 / h;
-  const int cx = min(max((int)floor((x[0] - ox) * inv), 0), nx - 1);
-  const int cy = min(max((int)floor((x[1] - oy) * inv), 0), ny - 1);
-  const int cz = (ND == 3) ? min(max((int)floor((x[2] - oz) * inv), 0), nz - 1) : 0;
+  const int k = order[j];
+  double d2 = 0.0;
+#pragma unroll
+  for (int e = 0; e < ND; ++e) {
+    const double df = x[e] - c[e];
+    d2 += df * df;
+  }
+  if (arg < 0 || d2 < best || (d2 == best && k < arg)) { best = d2; arg = k; }
+}
+
+// The block of cells within r of the pixel's own, r = r0, 2 r0, ...: every centre outside it is at least r h away, so
+// a winner closer than that (strictly) is the nearest centre; otherwise the block doubles until it is the whole grid.
+template <int ND>
+__device__ int ms_ring_search(const double (&x)[ND], int cx, int cy, int cz, int r0, const double* __restrict__ cs,
+                              const int* __restrict__ order, const int* __restrict__ cell_start, double h, int nx,
+                              int ny, int nz) {
   double best = 0.0;
   int arg = -1;
-  auto candidate = [&](int j) {
-    double c[ND];
-    if (ND == 2) {
-      const f64x2 q = *reinterpret_cast<const f64x2*>(cs + (long long)j * 2);
-      c[0] = q[0]; c[1] = q[1];
-    } else {
-#pragma unroll
-      for (int e = 0; e < ND; ++e) c[e] = cs[(long long)j * ND + e];
-    }
-    const int k = order[j];
-    double d2 = 0.0;
-#pragma unroll
-    for (int e = 0; e < ND; ++e) {
-      const double df = x[e] - c[e];
-      d2 += df * df;
-    }
-    if (arg < 0 || d2 < best || (d2 == best && k < arg)) { best = d2; arg = k; }
-  };
-  for (int r = 1;; r *= 2) {
+  for (int r = r0;; r *= 2) {
     const int x0 = max(cx - r, 0), x1 = min(cx + r, nx - 1);
     const int y0 = max(cy - r, 0), y1 = min(cy + r, ny - 1);
     const int z0 = (ND == 3) ? max(cz - r, 0) : 0, z1 = (ND == 3) ? min(cz + r, nz - 1) : 0;
     arg = -1;
-    if (ND == 2 && r == 1) {
-      int lo[3], hi[3];
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int yy = y0 + t;
-        const bool ok = yy <= y1;
-        const long long row = (long long)(ok ? yy : y0) * nx;
-        const int a = cell_start[row + x0], b = cell_start[row + x1 + 1];
-        lo[t] = a;
-        hi[t] = ok ? b : a;
+    for (int zz = z0; zz <= z1; ++zz)
+      for (int yy = y0; yy <= y1; ++yy) {
+        const long long row = ((long long)zz * ny + yy) * nx;
+        const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];
+        for (int j = lo; j < hi; ++j) ms_candidate<ND>(x, cs, order, j, best, arg);
       }
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-        for (int j = lo[t]; j < hi[t]; ++j) candidate(j);
-    } else {
-      for (int zz = z0; zz <= z1; ++zz)
-        for (int yy = y0; yy <= y1; ++yy) {
-          const long long row = ((long long)zz * ny + yy) * nx;
-          const int lo = cell_start[row + x0], hi = cell_start[row + x1 + 1];
-          for (int j = lo; j < hi; ++j) candidate(j);
-        }
-    }
     const bool whole = x0 == 0 && x1 == nx - 1 && y0 == 0 && y1 == ny - 1 && z0 == 0 && z1 == nz - 1;
     const double reach = (double)r * h;
     if (whole || (arg >= 0 && best < reach * reach)) break;
   }
-  labels[dst] = arg + 1;
+  return arg;
 }
 
-// (Two pixels per thread — both points, both pixels' row ranges, then the candidates — measured the same: 22.4
-// against 21.7 us at 4096^2, 97.6 against 97.8 at 8192^2.  At full occupancy the kernel moves 3.9 TB/s of real traffic:
-// points, indices, and label runs of ~24 pixels that fill their 128-byte lines partly.)
+template <int ND>
+__global__ __launch_bounds__(256) void ms_assign_cells_kernel(
+    const double* __restrict__ X, const int* __restrict__ index, int nfg, const double* __restrict__ cs,
+    const int* __restrict__ order, const int* __restrict__ cell_start, double ox, double oy,
+    double oz, double h, double inv, int nx, int ny, int nz, int* __restrict__ labels) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nfg) return;
+  double x[ND];
+#pragma unroll
+  for (int c = 0; c < ND; ++c) x[c] = X[(long long)i * ND + c];
+  const int cx = min(max((int)floor((x[0] - ox) * inv), 0), nx - 1);
+  const int cy = min(max((int)floor((x[1] - oy) * inv), 0), ny - 1);
+  const int cz = (ND == 3) ? min(max((int)floor((x[2] - oz) * inv), 0), nz - 1) : 0;
+  labels[index[i]] = ms_ring_search<ND>(x, cx, cy, cz, 1, cs, order, cell_start, h, nx, ny, nz) + 1;
+}
+
+// 2-D search, the common case — the 3 x 3 block holds the winner — as one straight line: the six row-range words of the
+// block together; then the block's candidates as ONE sequence (the three rows' ranges end to end), two per trip, instead
+// of a loop per row (a wavefront holds pixels of ~3 objects, whose centres sit in different rows of their blocks).
+// Offsets are 32-bit (the grid has < 2^31 cells, the host checks), inv = 1 / h comes from the host (the same IEEE
+// quotient).  A pixel whose block does not decide (rare: embeddings cluster around their centre) goes on with
+// ms_ring_search at r = 2.  Returns the centre id (-1: no centre at all).
+__device__ __forceinline__ int ms_search_2d(const double (&x)[2], const double* __restrict__ cs,
+                                            const int* __restrict__ order, const int* __restrict__ cell_start, double ox,
+                                            double oy, double h, double inv, int nx, int ny) {
+  const int cx = min(max((int)floor((x[0] - ox) * inv), 0), nx - 1);
+  const int cy = min(max((int)floor((x[1] - oy) * inv), 0), ny - 1);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, nx - 1);
+  const int y0 = max(cy - 1, 0), y1 = min(cy + 1, ny - 1);
+  // (byte offsets in 32 bits off the uniform base: one address register per load; selects, not branches)
+  const char* csb = reinterpret_cast<const char*>(cell_start);
+  int a[3], n[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const bool ok = y0 + t <= y1;
+    const unsigned int row = (unsigned int)(ok ? y0 + t : y0) * (unsigned int)nx;
+    const int lo = *reinterpret_cast<const int*>(csb + ((row + (unsigned int)x0) << 2));
+    const int hi = *reinterpret_cast<const int*>(csb + ((row + (unsigned int)x1 + 1u) << 2));
+    a[t] = lo;
+    n[t] = ok ? hi - lo : 0;
+  }
+  const int n01 = n[0] + n[1], total = n01 + n[2];
+  const int a1 = a[1] - n[0], a2 = a[2] - n01;      // candidate s of the sequence: row 0, then row 1, then row 2
+  const char* cb = reinterpret_cast<const char*>(cs);
+  const char* ob = reinterpret_cast<const char*>(order);
+  double best = 0.0;
+  int arg = -1;
+  for (int s = 0; s < total; s += 2) {
+    f64x2 q[2];
+    int k[2];
+    bool valid[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      valid[u] = s + u < total;
+      const int sc = valid[u] ? s + u : s;            // (a lane without a second candidate reads its first again)
+      int j = a2 + sc;
+      j = sc < n01 ? a1 + sc : j;
+      j = sc < n[0] ? a[0] + sc : j;
+      q[u] = *reinterpret_cast<const f64x2*>(cb + ((unsigned int)j << 4));
+      k[u] = *reinterpret_cast<const int*>(ob + ((unsigned int)j << 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);                // both candidates' loads go out before the first is looked at
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const double d0 = x[0] - q[u][0], d1 = x[1] - q[u][1];
+      double d2 = 0.0;
+      d2 += d0 * d0;
+      d2 += d1 * d1;
+      const bool take = valid[u] & ((arg < 0) | (d2 < best) | ((d2 == best) & (k[u] < arg)));
+      best = take ? d2 : best;
+      arg = take ? k[u] : arg;
+    }
+  }
+  const bool whole = x0 == 0 && x1 == nx - 1 && y0 == 0 && y1 == ny - 1;
+  if (!(whole || (arg >= 0 && best < h * h))) arg = ms_ring_search<2>(x, cx, cy, 0, 2, cs, order, cell_start, h, nx, ny, 1);
+  return arg;
+}
+
+__global__ __launch_bounds__(256) void ms_assign_cells2d_kernel(
+    const double* __restrict__ X, const int* __restrict__ index, int nfg, const double* __restrict__ cs,
+    const int* __restrict__ order, const int* __restrict__ cell_start, double ox, double oy, double h, double inv,
+    int nx, int ny, int* __restrict__ labels) {
+  const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned int)nfg) return;
+  const f64x2 p = *reinterpret_cast<const f64x2*>(X + (size_t)i * 2);
+  const int dst = index[i];
+  const double x[2] = {p[0], p[1]};
+  labels[dst] = ms_search_2d(x, cs, order, cell_start, ox, oy, h, inv, nx, ny) + 1;
+}
+
+// The assignment that writes the WHOLE label map (round 5).  The form above scatters one 4-byte label per foreground
+// pixel into a map somebody zeroed before: at 8192^2 the scatter alone is a third of its time (93 us; 61 us with the
+// store taken out, 65 us with the labels stored densely in point order — partial 32-byte sectors at both ends of
+// every run of foreground pixels) and the zero fill of the map is another 268 MB that no row of the table counted.
+// Here a wavefront (a block of its own: no barrier between wavefronts) takes one wave-tile (1024 pixels) of the compaction
+// and the points the compaction made of it, which are contiguous in X: phase 1 — a lane per POINT (all lanes busy, the
+// search above, U points of a lane together) leaves the label in LDS; phase 2 — a lane per 16-byte group of PIXELS looks
+// its pixels' bits up in the compaction's flag words
+// (still in the workspace clx_ms_prepare filled, with the points in front of every tile), takes the labels of the set
+// ones from LDS in order and stores the group: every pixel of the map is written once, in full lines, background as 0;
+// no raster index is read, no map is zeroed.
+// U points of one thread searched TOGETHER: their six row-range words go out at once, then one candidate of each per
+// trip — the dependent trips to memory of one search serve U of them (a block of the dense form below has ~3 points per
+// thread and would otherwise walk the chain three times between its two barriers).  Same arithmetic, same order of
+// candidates, same tie rule as ms_search_2d; slots that are not `live` cost loads of valid addresses and nothing else.
+template <int U>
+__device__ __forceinline__ void ms_search_2d_multi(const double (&x)[U][2], const bool (&live)[U],
+                                                   const double* __restrict__ cs, int ncenters,
+                                                   const int* __restrict__ order, const int* __restrict__ cell_start,
+                                                   double ox, double oy, double h, double inv, int nx, int ny,
+                                                   int (&arg)[U]) {
+  const char* csb = reinterpret_cast<const char*>(cell_start);
+  const char* cb = reinterpret_cast<const char*>(cs);
+  const char* ob = reinterpret_cast<const char*>(order);
+  int cx[U], cy[U], a0[U], a1[U], a2[U], n0[U], n01[U], total[U];
+  bool whole[U];
+  int lo[U][3], hi[U][3];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    cx[u] = min(max((int)floor((x[u][0] - ox) * inv), 0), nx - 1);
+    cy[u] = min(max((int)floor((x[u][1] - oy) * inv), 0), ny - 1);
+    const int x0 = max(cx[u] - 1, 0), x1 = min(cx[u] + 1, nx - 1);
+    const int y0 = max(cy[u] - 1, 0), y1 = min(cy[u] + 1, ny - 1);
+    whole[u] = x0 == 0 && x1 == nx - 1 && y0 == 0 && y1 == ny - 1;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const bool ok = y0 + t <= y1;
+      const unsigned int row = (unsigned int)(ok ? y0 + t : y0) * (unsigned int)nx;
+      lo[u][t] = *reinterpret_cast<const int*>(csb + ((row + (unsigned int)x0) << 2));
+      hi[u][t] = *reinterpret_cast<const int*>(csb + ((row + (unsigned int)x1 + 1u) << 2));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);                  // every point's row ranges are on their way before one is used
+  int smax = 0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int y0 = max(cy[u] - 1, 0), y1 = min(cy[u] + 1, ny - 1);
+    int n[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) n[t] = (y0 + t <= y1) ? hi[u][t] - lo[u][t] : 0;
+    n0[u] = n[0];
+    n01[u] = n[0] + n[1];
+    total[u] = live[u] ? n01[u] + n[2] : 0;
+    a0[u] = lo[u][0];
+    a1[u] = lo[u][1] - n0[u];
+    a2[u] = lo[u][2] - n01[u];
+    smax = max(smax, total[u]);
+  }
+  double best[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) { best[u] = 0.0; arg[u] = -1; }
+  for (int s = 0; s < smax; ++s) {
+    f64x2 q[U];
+    int k[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sc = s < total[u] ? s : 0;
+      int j = a2[u] + sc;
+      j = sc < n01[u] ? a1[u] + sc : j;
+      j = sc < n0[u] ? a0[u] + sc : j;
+      j = min(j, ncenters - 1);                       // (a slot without candidates: any valid address)
+      q[u] = *reinterpret_cast<const f64x2*>(cb + ((unsigned int)j << 4));
+      k[u] = *reinterpret_cast<const int*>(ob + ((unsigned int)j << 2));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double d0 = x[u][0] - q[u][0], d1 = x[u][1] - q[u][1];
+      double d2 = 0.0;
+      d2 += d0 * d0;
+      d2 += d1 * d1;
+      const bool take = (s < total[u]) & ((arg[u] < 0) | (d2 < best[u]) | ((d2 == best[u]) & (k[u] < arg[u])));
+      best[u] = take ? d2 : best[u];
+      arg[u] = take ? k[u] : arg[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (live[u] && !(whole[u] || (arg[u] >= 0 && best[u] < h * h)))
+      arg[u] = ms_ring_search<2>(x[u], cx[u], cy[u], 0, 2, cs, order, cell_start, h, nx, ny, 1);
+}
+
+template <int ND, int PXL, int G, int U>
+__global__ __launch_bounds__(64) void ms_assign_dense_kernel(
+    const double* __restrict__ X, const double* __restrict__ cs, int ncenters, const int* __restrict__ order,
+    const int* __restrict__ cell_start, double ox, double oy, double oz, double h, double inv, int nx, int ny, int nz,
+    const unsigned long long* __restrict__ flags, const int* __restrict__ counts, const int* __restrict__ tile_start,
+    long long npix, int vec, int* __restrict__ labels) {
+  constexpr int WT = 64 * G * PXL;
+  __shared__ int lab[WT];
+  const int lane = threadIdx.x;
+  const int wt = blockIdx.x;
+  // wave-uniform words first: the tile's points, its flag words (scalar loads, in flight under phase 1)
+  const int p0 = tile_start[wt];
+  const int total = counts[wt];
+  int run = 0;
+  const unsigned long long* tf = flags + (long long)wt * G * PXL;
+  unsigned long long B[G][PXL];
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < PXL; ++e) B[g][e] = tf[g * PXL + e];
+  if (ND == 2) {
+    for (int q0 = 0; q0 < total; q0 += 64 * U) {
+      double x[U][2];
+      bool live[U];
+      int arg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + u * 64 + lane;
+        live[u] = q < total;
+        const f64x2 p = *reinterpret_cast<const f64x2*>(X + (size_t)(p0 + (live[u] ? q : 0)) * 2);
+        x[u][0] = p[0]; x[u][1] = p[1];
+      }
+      ms_search_2d_multi<U>(x, live, cs, ncenters, order, cell_start, ox, oy, h, inv, nx, ny, arg);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (live[u]) lab[q0 + u * 64 + lane] = arg[u] + 1;
+    }
+  } else {
+    for (int q = lane; q < total; q += 64) {
+      double x[ND];
+#pragma unroll
+      for (int c = 0; c < ND; ++c) x[c] = X[(size_t)(p0 + q) * ND + c];
+      const int cx = min(max((int)floor((x[0] - ox) * inv), 0), nx - 1);
+      const int cy = min(max((int)floor((x[1] - oy) * inv), 0), ny - 1);
+      const int cz = min(max((int)floor((x[ND - 1] - oz) * inv), 0), nz - 1);
+      lab[q] = ms_ring_search<ND>(x, cx, cy, cz, 1, cs, order, cell_start, h, nx, ny, nz) + 1;
+    }
+  }
+  __syncthreads();
+  const long long base = (long long)wt * WT;
+  if (base >= npix) return;
+  const unsigned long long lower = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    int bef = 0, cnt = 0;
+#pragma unroll
+    for (int e = 0; e < PXL; ++e) {
+      bef += __popcll(B[g][e] & lower);
+      cnt += __popcll(B[g][e]);
+    }
+    int pos = run + bef;
+    int out[PXL];
+#pragma unroll
+    for (int e = 0; e < PXL; ++e) {
+      const bool fg = (B[g][e] >> lane) & 1ull;
+      out[e] = fg ? lab[fg ? pos : 0] : 0;
+      pos += fg ? 1 : 0;
+    }
+    const long long i = base + (long long)(g * 64 + lane) * PXL;
+    if (vec) {
+      if (i < npix) {
+        if constexpr (PXL == 4) *reinterpret_cast<i32x4*>(labels + i) = i32x4{out[0], out[1], out[2], out[3]};
+        else *reinterpret_cast<i32x2*>(labels + i) = i32x2{out[0], out[1]};
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < PXL; ++e)
+        if (i + e < npix) labels[i + e] = out[e];
+    }
+    run += cnt;
+  }
+}
 
 }  // namespace
 
@@ -678,7 +916,7 @@ static long long wave_tiles(long long npix) { return (npix + 4095) / 4096 * 4; }
 
 extern "C" size_t clx_ms_prepare_workspace(long long npix) {
   const long long nwt = wave_tiles(npix);
-  return (size_t)nwt * 128 + (size_t)(2 * nwt + 2) * sizeof(int) + 64;
+  return (size_t)nwt * 128 + (size_t)(3 * nwt + 2) * sizeof(int) + 64;
 }
 
 template <int ND, typename TIn, int G, bool WB, int BLOCKS>
@@ -691,6 +929,7 @@ static void launch_prepare(TIn* emb, const TIn* std, double threshold, int Z, in
   unsigned long long* flags = (unsigned long long*)workspace;
   int* counts = (int*)(flags + (size_t)nwt * 16);          // 16-byte aligned: nwt is a multiple of 4
   int* chunk_counts = counts + nwt;                         // one per block of the flags pass (<= nwt / 4)
+  int* tile_start = counts + 2 * nwt;                       // the points in front of every tile
   // every channel plane starts at a multiple of npix elements: 16-byte accesses need npix % PXL == 0 and aligned bases
   const int vec = (npix % PXL == 0) && (((uintptr_t)emb | (uintptr_t)std) & 15) == 0 ? 1 : 0;
   const FastDiv dX = make_fastdiv((uint32_t)X), dY = make_fastdiv((uint32_t)Y);
@@ -705,13 +944,13 @@ static void launch_prepare(TIn* emb, const TIn* std, double threshold, int Z, in
   CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_flags_kernel<TIn, G>), dim3(g1), dim3(256), 0, st, std, threshold, npix, vec,
                   nwt, tiles_per_block, flags, counts, chunk_counts);
   CLX_LAUNCH_KIND(CLX_PROF_MS_PREPARE, (ms_scatter_kernel<ND, TIn, G, WB, BLOCKS>), dim3(g3), dim3(256), 0, st, emb, dX, dY,
-                  Y, X, npix, vec, nwt, flags, counts, chunk_counts, tiles_per_block, Xout, index, nfg_out);
+                  Y, X, npix, vec, nwt, flags, counts, chunk_counts, tiles_per_block, Xout, index, nfg_out, tile_start);
 }
 
 extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
                               int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
                               void* workspace, clx_stream stream) {
-  CLX_REQUIRE(emb && std && Xout && index && nfg_out && workspace, "clx_ms_prepare: null pointer");
+  CLX_REQUIRE(emb && std && Xout && nfg_out && workspace, "clx_ms_prepare: null pointer");
   CLX_REQUIRE((ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0, "clx_ms_prepare: bad extents");
   CLX_REQUIRE(ND == 3 || Z == 1, "clx_ms_prepare: Z must be 1 for 2-D data");
   CLX_REQUIRE(((uintptr_t)workspace & 15) == 0, "clx_ms_prepare: workspace must be 16-byte aligned");
@@ -727,7 +966,7 @@ extern "C" int clx_ms_prepare(double* emb, const double* std, double threshold, 
 extern "C" int clx_ms_prepare_f32(const float* emb, const float* std, double threshold, int ND,
                                   int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
                                   void* workspace, clx_stream stream) {
-  CLX_REQUIRE(emb && std && Xout && index && nfg_out && workspace, "clx_ms_prepare_f32: null pointer");
+  CLX_REQUIRE(emb && std && Xout && nfg_out && workspace, "clx_ms_prepare_f32: null pointer");
   CLX_REQUIRE((ND == 2 || ND == 3) && Z > 0 && Y > 0 && X > 0, "clx_ms_prepare_f32: bad extents");
   CLX_REQUIRE(ND == 3 || Z == 1, "clx_ms_prepare_f32: Z must be 1 for 2-D data");
   CLX_REQUIRE(((uintptr_t)workspace & 15) == 0, "clx_ms_prepare_f32: workspace must be 16-byte aligned");
@@ -828,17 +1067,62 @@ extern "C" int clx_ms_assign_cells(const double* X, const int* index, int nfg, c
   CLX_REQUIRE(X && index && centers_sorted && labels && order && cell_start && origin, "clx_ms_assign_cells: null pointer");
   CLX_REQUIRE((ND == 2 || ND == 3) && nfg >= 0 && ncenters > 0, "clx_ms_assign_cells: bad extents");
   CLX_REQUIRE(cell > 0.0 && nx > 0 && ny > 0 && nz > 0 && (ND == 3 || nz == 1), "clx_ms_assign_cells: bad grid");
+  CLX_REQUIRE((long long)nx * ny * nz < (1ll << 31) - 1, "clx_ms_assign_cells: more than 2^31 cells");
   CLX_REQUIRE(ND == 3 || ((((uintptr_t)X | (uintptr_t)centers_sorted) & 15) == 0), "clx_ms_assign_cells: 16-byte alignment");
   if (nfg == 0) return CLX_OK;
   const int grid = (nfg + 255) / 256;
   hipStream_t st = (hipStream_t)stream;
+  const double inv = 1.0 / cell;
   if (ND == 2)
-    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_cells_kernel<2>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers_sorted, order, cell_start, origin[0],
-                                                     origin[1], 0.0, cell, nx, ny, nz, labels);
+    CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, ms_assign_cells2d_kernel, dim3(grid), dim3(256), 0, st, X, index, nfg, centers_sorted, order, cell_start,
+                    origin[0], origin[1], cell, inv, nx, ny, labels);
   else
     CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_cells_kernel<3>), dim3(grid), dim3(256), 0, st, X, index, nfg, centers_sorted, order, cell_start, origin[0],
-                                                     origin[1], origin[2], cell, nx, ny, nz, labels);
+                                                     origin[1], origin[2], cell, inv, nx, ny, nz, labels);
   CLX_CHECK_LAUNCH("clx_ms_assign_cells");
+  return CLX_OK;
+}
+
+template <int ND, int PXL, int G>
+static void launch_assign_dense(const double* X, const double* cs, int ncenters, const int* order, const int* cell_start,
+                                const double* origin, double cell, int nx, int ny, int nz, const void* workspace,
+                                long long npix, int* labels, hipStream_t st) {
+  const int nwt = (int)wave_tiles(npix);
+  const unsigned long long* flags = (const unsigned long long*)workspace;
+  const int* counts = (const int*)(flags + (size_t)nwt * 16);
+  const int* tile_start = counts + 2 * nwt;
+  const int vec = (npix % PXL == 0) && (((uintptr_t)labels) & 15) == 0 ? 1 : 0;
+  static const int u = getenv("CLX_MS_DENSE_U") ? atoi(getenv("CLX_MS_DENSE_U")) : 2;      // (sweep: 104 us at 8192^2; 1: 128, 3: 117, 4: 127)
+#define CLX_DENSE(UU) CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_dense_kernel<ND, PXL, G, UU>), dim3(nwt), dim3(64), 0, st, X, cs, ncenters, order, \
+                  cell_start, origin[0], origin[1], ND == 3 ? origin[2] : 0.0, cell, 1.0 / cell, nx, ny, nz, flags, counts, \
+                  tile_start, npix, vec, labels)
+  if (ND == 2 && u == 1) CLX_DENSE(1); else if (ND == 2 && u == 2) CLX_DENSE(2); else if (ND == 2 && u == 3) CLX_DENSE(3); else if (ND == 2 && u == 4) CLX_DENSE(4); else CLX_DENSE(2);
+#undef CLX_DENSE
+}
+
+extern "C" int clx_ms_assign_dense(const double* X, const double* centers_sorted, int ncenters, int ND, const int* order,
+                                   const int* cell_start, const double* origin, double cell, int nx, int ny, int nz,
+                                   const void* prepare_workspace, int prepared_from_f32, int Z, int Y, int Xdim,
+                                   int* labels, clx_stream stream) {
+  CLX_REQUIRE(X && centers_sorted && labels && order && cell_start && origin && prepare_workspace,
+              "clx_ms_assign_dense: null pointer");
+  CLX_REQUIRE((ND == 2 || ND == 3) && ncenters > 0 && Z > 0 && Y > 0 && Xdim > 0 && (ND == 3 || Z == 1),
+              "clx_ms_assign_dense: bad extents");
+  CLX_REQUIRE(cell > 0.0 && nx > 0 && ny > 0 && nz > 0 && (ND == 3 || nz == 1), "clx_ms_assign_dense: bad grid");
+  CLX_REQUIRE((long long)nx * ny * nz < (1ll << 31) - 1, "clx_ms_assign_dense: more than 2^31 cells");
+  CLX_REQUIRE(ND == 3 || ((((uintptr_t)X | (uintptr_t)centers_sorted) & 15) == 0), "clx_ms_assign_dense: 16-byte alignment");
+  CLX_REQUIRE(((uintptr_t)prepare_workspace & 15) == 0, "clx_ms_assign_dense: workspace must be 16-byte aligned");
+  const long long npix = (long long)Z * Y * Xdim;
+  CLX_REQUIRE(npix < (1ll << 31), "clx_ms_assign_dense: too many pixels");
+  hipStream_t st = (hipStream_t)stream;
+  if (prepared_from_f32) {
+    if (ND == 2) launch_assign_dense<2, 4, 4>(X, centers_sorted, ncenters, order, cell_start, origin, cell, nx, ny, nz, prepare_workspace, npix, labels, st);
+    else launch_assign_dense<3, 4, 4>(X, centers_sorted, ncenters, order, cell_start, origin, cell, nx, ny, nz, prepare_workspace, npix, labels, st);
+  } else {
+    if (ND == 2) launch_assign_dense<2, 2, 8>(X, centers_sorted, ncenters, order, cell_start, origin, cell, nx, ny, nz, prepare_workspace, npix, labels, st);
+    else launch_assign_dense<3, 2, 8>(X, centers_sorted, ncenters, order, cell_start, origin, cell, nx, ny, nz, prepare_workspace, npix, labels, st);
+  }
+  CLX_CHECK_LAUNCH("clx_ms_assign_dense");
   return CLX_OK;
 }
 

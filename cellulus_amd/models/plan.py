@@ -1443,10 +1443,10 @@ class UNetPlan:
 
     def zero_gradients(self, grads, flat_grad=None):
         """The accumulators the backward kernels add into: packed weight gradients and bias gradients."""
-        self.dwpack.zero_()
-        if flat_grad is not None:          # `grads` tile this buffer: one fill instead of one per bias
-            flat_grad.zero_()
+        if flat_grad is not None:          # `grads` tile this buffer: ONE launch for both accumulators
+            _clx.zero_many(self.dwpack, flat_grad)
         else:
+            _clx.zero_many(self.dwpack)
             for g in grads[1::2]:
                 if g is not None:
                     g.zero_()

@@ -557,12 +557,7 @@ class UNetModel(nn.Module):  # type: ignore
             else:
                 rnd = noise[sample]
             rnd = rnd.to(raw.device, non_blocking=True)
-            key = (n_it, raw.device)
-            if getattr(self, "_noise_vals_key", None) != key:    # built once: a host list -> device copy synchronises
-                self._noise_vals = torch.tensor([0.5] * n_it + [1.0] * n_it, dtype=torch.float32, device=raw.device)
-                self._noise_vals_key = key
-            vals = self._noise_vals.view((T,) + (1,) * (raw_sample.ndim - 1))
-            noisy = torch.where(rnd <= self.p_salt_pepper, vals, raw_sample.expand_as(rnd))
+            noisy = self._inject_noise(rnd, raw_sample, n_it)
             step = self.infer_chunk(T, raw_sample.shape[2:])
             preds = self._forward_chunks(noisy, step, clean=raw_sample)
             C = preds.shape[1]
@@ -576,6 +571,19 @@ class UNetModel(nn.Module):  # type: ignore
                           1 if (reset and sample == 0) else 0, st)
             embeddings.append(out)
         return torch.stack(embeddings, dim=0)
+
+    def _inject_noise(self, rnd, raw_sample, n_it):
+        """The 2 * n_it noisy copies of one sample (unet.py:75-88: `noisy[rnd <= p] = 0.5` for the first n_it draws, 1.0
+        for the rest) in one launch (clx_noise_inject); rnd: (T, C, *spatial) float32 on the device."""
+        if rnd.dtype != torch.float32 or raw_sample.dtype != torch.float32 or not rnd.is_contiguous():
+            vals = torch.tensor([0.5] * n_it + [1.0] * n_it, dtype=raw_sample.dtype, device=raw_sample.device)
+            return torch.where(rnd <= self.p_salt_pepper, vals.view((-1,) + (1,) * (raw_sample.ndim - 1)),
+                               raw_sample.expand_as(rnd))
+        noisy = torch.empty_like(rnd)
+        clean = raw_sample.contiguous()
+        _clx.call("clx_noise_inject", _clx.ptr(rnd), _clx.ptr(clean), _clx.ptr(noisy), rnd.shape[0], n_it,
+                  clean.numel(), float(self.p_salt_pepper), _clx.stream_ptr(rnd.device))
+        return noisy
 
     def infer_chunk(self, T, spatial):
         """Noisy copies per forward of the infer-mode loop (unet.py:75-88 runs them one by one).  ``max_infer_batch`` if

@@ -355,7 +355,8 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
     if anchor.ndim != 3 or anchor.shape != reference.shape or anchor.shape[0] != B or anchor.shape[2] != ND:
         raise ValueError(f"coordinates must be (B={B}, P, {ND}); got {tuple(anchor.shape)} and "
                          f"{tuple(reference.shape)}")
-    sums = torch.zeros(4, dtype=torch.float64, device=device)     # loss, oce, reg, bad-coordinate count
+    sums = torch.empty(4, dtype=torch.float64, device=device)     # loss, oce, reg, bad-coordinate count
+    _clx.zero_many(sums)
     geometry = []
 
     def loss_fn(offsets, lo, hi):
@@ -376,7 +377,8 @@ def _fused_step(model, criterion, optimizer, raw, anchor, reference):
                       float(criterion.temperature), float(criterion.regularization_weight), _clx.ptr(scratch),
                       _clx.stream_ptr(device))
         else:
-            doffsets = torch.zeros_like(offsets)
+            doffsets = torch.empty_like(offsets)
+            _clx.zero_many(doffsets)
             _clx.call("clx_oce_pairs_fused", _clx.ptr(offsets), _clx.ptr(a), _clx.ptr(r),
                       _clx.ptr(doffsets), _clx.ptr(sums), hi - lo, a.shape[1], ND, Z, Y, X,
                       float(criterion.temperature), float(criterion.regularization_weight),

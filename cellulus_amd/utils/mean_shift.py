@@ -134,17 +134,23 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     ws = _prepare_workspace(int(lib.clx_ms_prepare_workspace(npix)), dev)
     pts = torch.empty((npix, nd), dtype=torch.float64, device=dev)
     index = torch.empty(npix, dtype=torch.int32, device=dev)
-    nfg_d = torch.zeros(1, dtype=torch.int32, device=dev)
+    nfg_d = torch.empty(1, dtype=torch.int32, device=dev)
+    labels = torch.empty(spatial, dtype=torch.int32, device=dev)      # written in full by clx_ms_assign_dense
+    _clx.zero_many(nfg_d)
     _clx.call(prepare, _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
               _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
-    labels = torch.zeros(spatial, dtype=torch.int32, device=dev)
     nfg = int(nfg_d.item())
     if nfg == 0:      # mean_shift.py:83-84,92-93 -> all -1, +1 -> 0
+        _clx.zero_many(labels)
         return labels, np.zeros((0, nd))
     pts = pts[:nfg]
     if reduction_probability < 1.0:
         keep = np.random.rand(nfg) < reduction_probability      # mean_shift.py:69
-        fit = pts[torch.from_numpy(keep).to(dev)].contiguous()
+        # the host drew the mask, so it knows the rows: a gather of known size, not a masked select that has to
+        # report its size back
+        rows = torch.from_numpy(np.flatnonzero(keep).astype(np.int32)).to(dev, non_blocking=True)
+        fit = torch.empty((rows.shape[0], nd), dtype=torch.float64, device=dev)
+        _clx.call("clx_gather_rows_f64", _clx.ptr(pts), _clx.ptr(rows), rows.shape[0], nd, _clx.ptr(fit), st)
     else:
         fit = pts
     if fit.shape[0] == 0:
@@ -188,9 +194,13 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
         cstart_d = torch.from_numpy(cstart).to(dev)
         corigin_c = (ctypes.c_double * nd)(*corigin.tolist())
         cc_sorted = torch.from_numpy(np.ascontiguousarray(cluster_centers[order])).to(dev)      # centres in cell order
-        _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc_sorted), ncc, nd,
-                  _clx.ptr(order_d), _clx.ptr(cstart_d), corigin_c, cell, gx, gy, gz, _clx.ptr(labels), st)
+        # the whole label map in one pass over the compaction's tiles (their flags are still in `ws`): no zero fill,
+        # no scatter through the raster index
+        _clx.call("clx_ms_assign_dense", _clx.ptr(pts), _clx.ptr(cc_sorted), ncc, nd, _clx.ptr(order_d),
+                  _clx.ptr(cstart_d), corigin_c, cell, gx, gy, gz, _clx.ptr(ws), 0 if emb.dtype == torch.float64 else 1,
+                  Z, Y, X, _clx.ptr(labels), st)
     else:
+        _clx.zero_many(labels)
         _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,
                   _clx.ptr(labels), st)
     return labels, cluster_centers

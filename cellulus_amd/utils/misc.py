@@ -19,7 +19,8 @@ def label_on_device(seg, min_size=1):
     lib = _clx.load()
     ws = torch.empty(int(lib.clx_cc_workspace(npix)), dtype=torch.uint8, device=seg.device)
     out = torch.empty_like(seg)
-    ncomp = torch.zeros(1, dtype=torch.int32, device=seg.device)
+    ncomp = torch.empty(1, dtype=torch.int32, device=seg.device)
+    _clx.zero_many(ncomp)
     _clx.call("clx_cc_label_filter", _clx.ptr(seg), _clx.ptr(out), Z, Y, X, int(min_size),
               _clx.ptr(ncomp), _clx.ptr(ws), _clx.stream_ptr(seg.device))
     return out, ncomp

@@ -42,7 +42,8 @@ def histogram_on_device(x, nbins=256, minmax=None):
         lo, hi = lo - 0.5, hi + 0.5
     edges = np.linspace(lo, hi, nbins + 1, endpoint=True, dtype=np.float64)
     edges_d = torch.from_numpy(edges).to(x.device)
-    counts = torch.zeros(nbins, dtype=torch.int64, device=x.device)
+    counts = torch.empty(nbins, dtype=torch.int64, device=x.device)
+    _clx.zero_many(counts)
     _clx.call("clx_histogram_f64" if x.dtype == torch.float64 else "clx_histogram_f32", _clx.ptr(x), x.numel(),
               _clx.ptr(edges_d), nbins, _clx.ptr(counts), st)
     return counts.cpu().numpy(), edges

@@ -443,6 +443,20 @@ int clx_noise_stats(const float* preds, float* out, int T, int C, long long n,
 int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long long n, float* std_minmax,
                            int init, clx_stream stream);
 
+/* Salt / pepper noise of the infer-mode forward (cellulus/models/unet.py:75-88: `noisy[rnd <= p] = 0.5`, then 1.0):
+ * rnd (T, n) uniform randoms, raw (n) the clean tile, out (T, n): out[t][i] = rnd[t][i] <= p ? (t < n_half ? 0.5 : 1.0)
+ * : raw[i], the comparison in float32 as torch compares a float32 tensor with a Python scalar.  One launch in place
+ * of torch's compare + where. */
+int clx_noise_inject(const float* rnd, const float* raw, float* out, int T, int n_half, long long n, float p,
+                     clx_stream stream);
+/* Zero fills of `count` device buffers (16-byte aligned, sizes multiples of 4 bytes) in one launch per eight: the
+ * accumulators a training step adds into (packed weight gradients, bias gradients, the scatter target of the loss). */
+int clx_zero_many(void* const* buffers, const long long* nbytes, int count, clx_stream stream);
+/* dst[i][:] = src[rows[i]][:] for float64 rows of `width` values: the random subsample MeanShift is fitted on
+ * (cellulus/utils/mean_shift.py:69-70, `X[np.random.rand(len(X)) < p]`; the host draws the mask and sends the row
+ * numbers, so the device-side size is known without a synchronising masked select). */
+int clx_gather_rows_f64(const double* src, const int* rows, long long n, int width, double* dst, clx_stream stream);
+
 /* The noisy copies of one tile (cellulus/models/unet.py:75-88: 2 * num_infer_iterations forwards of the same image
  * with salt / pepper noise in p_salt_pepper of its pixels) differ from the clean image only around those pixels.  Behind
  * the first k x k convolution the changed output pixels are the window-dilated set, and 1 x 1 layers keep it; a row of a
@@ -493,9 +507,10 @@ int clx_broadcast_rows(const float* src, long long nfloats, float* dst, int copi
  *   emb:  (ND, [Z,] Y, X) f64, channel 0 += x, 1 += y, 2 += z
  *   X:    (nfg, ND) f64 out,  index: (nfg) int32 raster index of each fg pixel
  *   nfg_out: device int32, number of foreground pixels
- * workspace: clx_ms_prepare_workspace(npix) bytes of plain scratch (16-byte aligned; no contents are expected and none
- * are kept: the foreground flags as one bit per pixel + the counts per tile and per chunk of tiles).  Two launches: flags
- * + counts from the std plane; the scatter pass, which sums the counts in front of each tile itself. */
+ * workspace: clx_ms_prepare_workspace(npix) bytes of scratch (16-byte aligned; no contents are expected; what the call
+ * leaves — the foreground flags as one bit per pixel, the counts per tile and per chunk of tiles, the points in front of
+ * every tile — is what clx_ms_assign_dense reads back).  Two launches: flags + counts from the std plane; the scatter
+ * pass, which sums the counts in front of each tile itself.  index may be NULL (clx_ms_assign_dense does not need it). */
 size_t clx_ms_prepare_workspace(long long npix);
 int clx_ms_prepare(double* emb, const double* std, double threshold, int ND,
                    int Z, int Y, int X, double* Xout, int* index, int* nfg_out,
@@ -554,6 +569,17 @@ int clx_ms_assign_grid(const double* X, const int* index, int nfg, const double*
 int clx_ms_assign_cells(const double* X, const int* index, int nfg, const double* centers_sorted,
                         int ncenters, int ND, const int* order, const int* cell_start,
                         const double* origin, double cell, int nx, int ny, int nz, int* labels,
+                        clx_stream stream);
+/* The same assignment writing the WHOLE label map — every pixel once, in full lines, background as 0 — instead of
+ * scattering one label per foreground pixel into a map the caller zeroed.  It reads the compaction's flag words and
+ * per-tile point counts back from `prepare_workspace`: the workspace the clx_ms_prepare (prepared_from_f32 = 0) or
+ * clx_ms_prepare_f32 (= 1) call that produced X for this (Z, Y, X) image left behind, untouched since (the ONE piece of
+ * state between two calls of this library; the raster index is not read and may have been left out of that call).
+ * labels: (Z, Y, X) int32, no initial contents expected.  Same labels as clx_ms_assign_cells + a zero fill
+ * (cellulus/utils/mean_shift.py:93-104 with the `-1 -> 0` of :29-32). */
+int clx_ms_assign_dense(const double* X, const double* centers_sorted, int ncenters, int ND, const int* order,
+                        const int* cell_start, const double* origin, double cell, int nx, int ny, int nz,
+                        const void* prepare_workspace, int prepared_from_f32, int Z, int Y, int Xdim, int* labels,
                         clx_stream stream);
 
 /* Seeds for use_seeds = true (cellulus/detect.py:128-132), float64, the libraries' operation order:

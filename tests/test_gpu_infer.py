@@ -882,3 +882,140 @@ def test_noise_stats_emits_the_std_range(device):
     # reset
     _clx.call("clx_noise_stats_minmax", _clx.ptr(preds), _clx.ptr(out), T, C, n, _clx.ptr(mm), 1, st)
     assert mm[:2].cpu().tolist() == [float(ref[C].min().item()), float(ref[C].max().item())]
+
+
+@pytest.mark.parametrize("K,extent,bw", [(3000, 400.0, 25.0), (40, 30.0, 25.0), (1, 10.0, 5.0), (700, 2000.0, 3.0)])
+def test_assign_cells_candidate_sequence_dense_cells_and_tiny_grids(K, extent, bw, device):
+    """The 2-D form of clx_ms_assign_cells walks the 3 x 3 block's candidates as one sequence, two per trip: blocks holding
+    many centres (odd and even counts), grids of one or two cells per axis (clamped rows), blocks that hold none (the
+    doubling search takes over) — all equal to the plain loop over every centre."""
+    import ctypes
+
+    from cellulus_amd import _clx
+    from cellulus_amd.utils import mean_shift as MS
+
+    rng = np.random.default_rng(K)
+    centers = rng.uniform(0, extent, size=(K, 2))
+    pts = np.concatenate([rng.uniform(-0.2 * extent, 1.2 * extent, size=(30000, 2)),
+                          centers[rng.integers(0, K, size=5000)] + rng.normal(0, 0.3 * bw, size=(5000, 2))])
+    n = len(pts)
+    X = torch.from_numpy(pts).to(device)
+    index = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(device)
+    st = _clx.stream_ptr(device)
+    ref = torch.zeros(n, dtype=torch.int32, device=device)
+    cc = torch.from_numpy(centers).to(device)
+    _clx.call("clx_ms_assign", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc), K, 2, _clx.ptr(ref), st)
+    order, cstart, origin, (gx, gy, gz) = MS._center_grid(centers, bw)
+    got = torch.zeros(n, dtype=torch.int32, device=device)
+    order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)
+    cc_sorted = torch.from_numpy(np.ascontiguousarray(centers[order])).to(device)
+    _clx.call("clx_ms_assign_cells", _clx.ptr(X), _clx.ptr(index), n, _clx.ptr(cc_sorted), K, 2, _clx.ptr(order_d),
+              _clx.ptr(cstart_d), (ctypes.c_double * 2)(*origin.tolist()), bw, gx, gy, gz, _clx.ptr(got), st)
+    assert torch.equal(got, ref)
+    d2 = ((pts[:, None, :] - centers[None]) ** 2).sum(-1)
+    want = np.zeros(n, dtype=np.int32)
+    want[index.cpu().numpy()] = d2.argmin(1) + 1
+    np.testing.assert_array_equal(ref.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 64), (2, 33, 47), (1, 7, 9, 11)])
+def test_noise_inject_equals_the_torch_expression(shape, device):
+    """clx_noise_inject == torch.where(rnd <= p, [0.5] * n + [1.0] * n, raw) — the comparison in float32 like torch's
+    (p = 0.1 rounds UP in float32: a draw of exactly float32(0.1) counts as noise)."""
+    from cellulus_amd import _clx
+
+    torch.manual_seed(5)
+    n_it = 3
+    T = 2 * n_it
+    raw = torch.rand((1,) + shape, device=device)
+    rnd = torch.rand((T,) + shape, device=device)
+    for p in (0.01, 0.1, 0.5):
+        rnd.view(-1)[::7] = float(np.float32(p))
+        vals = torch.tensor([0.5] * n_it + [1.0] * n_it, device=device).view((T,) + (1,) * len(shape))
+        want = torch.where(rnd <= p, vals, raw.expand_as(rnd))
+        got = torch.empty_like(rnd)
+        _clx.call("clx_noise_inject", _clx.ptr(rnd), _clx.ptr(raw), _clx.ptr(got), T, n_it, raw.numel(), p,
+                  _clx.stream_ptr(device))
+        assert torch.equal(got, want)
+        assert (got != raw.expand_as(rnd)).any()
+
+
+def test_zero_many_and_row_gather(device):
+    from cellulus_amd import _clx
+
+    sizes = [1, 3, 4, 5, 1024, 4099, 1 << 20, 7, 2, 65537, 12]          # more than eight buffers: two launches
+    bufs = [torch.full((s,), 7.0, dtype=torch.float32, device=device) for s in sizes]
+    guard = [torch.full((s + 8,), 3.0, dtype=torch.float32, device=device) for s in sizes]
+    views = [g[4:4 + s] for g, s in zip(guard, sizes)]                     # 16-byte aligned views inside a guard band
+    i64 = torch.full((257,), 9, dtype=torch.int64, device=device)
+    _clx.zero_many(*bufs, None, i64, *views)
+    for b in bufs + views + [i64]:
+        assert int(torch.count_nonzero(b).item()) == 0
+    for g, s in zip(guard, sizes):
+        assert g[:4].eq(3.0).all() and g[4 + s:].eq(3.0).all()
+    rng = np.random.default_rng(0)
+    for nd in (2, 3):
+        src = torch.from_numpy(rng.normal(size=(5000, nd))).to(device)
+        rows = torch.from_numpy(np.flatnonzero(rng.random(5000) < 0.1).astype(np.int32)).to(device)
+        dst = torch.empty((rows.shape[0], nd), dtype=torch.float64, device=device)
+        _clx.call("clx_gather_rows_f64", _clx.ptr(src), _clx.ptr(rows), rows.shape[0], nd, _clx.ptr(dst),
+                  _clx.stream_ptr(device))
+        assert torch.equal(dst, src[rows.long()])
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (97, 33), (5, 301), (130, 1024), (1000, 1030), (9, 20, 31), (16, 64, 64)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_dense_assignment_equals_scatter_into_a_zeroed_map(shape, f32, device):
+    """clx_ms_assign_dense (whole label map from the compaction's tiles, read back from the prepare workspace) ==
+    zero fill + clx_ms_assign_cells through the raster index: odd image sizes (ragged last tile, unaligned rows), tiles
+    without foreground, tiles that are all foreground, both prepare forms, with and without the raster index."""
+    import ctypes
+
+    from cellulus_amd import _clx
+    from cellulus_amd.utils import mean_shift as MS
+
+    nd = len(shape)
+    rng = np.random.default_rng(sum(shape) + int(f32))
+    npix = int(np.prod(shape))
+    Z, Y, X = (1,) * (3 - nd) + tuple(shape)
+    emb_np = rng.normal(0, 3.0, size=(nd,) + tuple(shape))
+    std_np = rng.uniform(0, 1, size=shape)
+    std_np.reshape(-1)[: min(npix, 2500)] = 0.9            # leading tiles without foreground ...
+    std_np.reshape(-1)[npix // 2: npix // 2 + min(npix // 4, 3000)] = 0.1        # ... and a stretch that is all foreground
+    dt = torch.float32 if f32 else torch.float64
+    emb = torch.from_numpy(emb_np).to(device=device, dtype=dt)
+    std = torch.from_numpy(std_np).to(device=device, dtype=dt)
+    lib = _clx.load()
+    st = _clx.stream_ptr(device)
+    ws = torch.empty(int(lib.clx_ms_prepare_workspace(npix)), dtype=torch.uint8, device=device)
+    pts = torch.empty((npix, nd), dtype=torch.float64, device=device)
+    index = torch.empty(npix, dtype=torch.int32, device=device)
+    nfg_d = torch.zeros(1, dtype=torch.int32, device=device)
+    prepare = "clx_ms_prepare_f32" if f32 else "clx_ms_prepare"
+    _clx.call(prepare, _clx.ptr(emb.clone()), _clx.ptr(std), 0.5, nd, Z, Y, X, _clx.ptr(pts), _clx.ptr(index),
+              _clx.ptr(nfg_d), _clx.ptr(ws), st)
+    nfg = int(nfg_d.item())
+    assert 0 < nfg < npix
+    K, bw = 60, 4.0
+    centers = np.stack([rng.uniform(0, s, size=K) for s in shape[::-1]], axis=1)
+    order, cstart, origin, (gx, gy, gz) = MS._center_grid(centers, bw)
+    order_d, cstart_d = torch.from_numpy(order).to(device), torch.from_numpy(cstart).to(device)
+    cc_sorted = torch.from_numpy(np.ascontiguousarray(centers[order])).to(device)
+    origin_c = (ctypes.c_double * nd)(*origin.tolist())
+    want = torch.zeros(shape, dtype=torch.int32, device=device)
+    _clx.call("clx_ms_assign_cells", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc_sorted), K, nd, _clx.ptr(order_d),
+              _clx.ptr(cstart_d), origin_c, bw, gx, gy, gz, _clx.ptr(want), st)
+    got = torch.full(shape, -7, dtype=torch.int32, device=device)
+    _clx.call("clx_ms_assign_dense", _clx.ptr(pts), _clx.ptr(cc_sorted), K, nd, _clx.ptr(order_d), _clx.ptr(cstart_d),
+              origin_c, bw, gx, gy, gz, _clx.ptr(ws), 1 if f32 else 0, Z, Y, X, _clx.ptr(got), st)
+    assert torch.equal(got, want)
+    assert int((want > 0).sum().item()) == nfg
+    # the compaction without the raster index leaves the same points and the same workspace
+    pts2 = torch.empty_like(pts)
+    _clx.call(prepare, _clx.ptr(emb.clone()), _clx.ptr(std), 0.5, nd, Z, Y, X, _clx.ptr(pts2), None,
+              _clx.ptr(nfg_d), _clx.ptr(ws), st)
+    assert int(nfg_d.item()) == nfg and torch.equal(pts2[:nfg], pts[:nfg])
+    got.fill_(-7)
+    _clx.call("clx_ms_assign_dense", _clx.ptr(pts2), _clx.ptr(cc_sorted), K, nd, _clx.ptr(order_d), _clx.ptr(cstart_d),
+              origin_c, bw, gx, gy, gz, _clx.ptr(ws), 1 if f32 else 0, Z, Y, X, _clx.ptr(got), st)
+    assert torch.equal(got, want)
