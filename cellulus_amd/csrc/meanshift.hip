@@ -1126,6 +1126,137 @@ extern "C" int clx_ms_assign_dense(const double* X, const double* centers_sorted
   return CLX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// HOST: sklearn MeanShift.fit's post-processing of the converged seeds (_mean_shift.py: center_intensity_dict ->
+// sorted by (count, centre) descending -> greedy removal of every centre within `bandwidth` of a kept one), the step
+// between clx_ms_iterate* and clx_ms_assign* [cellulus/utils/mean_shift.py:62-74 -> MeanShift.fit].  Sequential by
+// definition; in numpy it was the largest single cost of the detect stage per 512^2 sample (a Python trip per kept
+// centre over all ~4 500 seeds).  Here: two sorts and the greedy pass over a hash grid of edge `bandwidth`.
+// ---------------------------------------------------------------------------------------------
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+extern "C" int clx_ms_dedup_centers(const double* centers, const int* counts, int n, int ND, double bandwidth,
+                                    double* out, int* n_out) {
+  CLX_REQUIRE(n_out != nullptr && n >= 0 && (ND == 2 || ND == 3) && (n == 0 || (centers && counts && out)),
+              "clx_ms_dedup_centers: bad arguments");
+  CLX_REQUIRE(bandwidth > 0.0, "clx_ms_dedup_centers: bandwidth must be positive");
+  auto at = [&](int i, int d) { return centers[(size_t)i * ND + d]; };
+  // dict semantics: identical centre tuples are one key (first occurrence), the LAST count wins
+  struct Item { double c[3]; int src; int count; };
+  std::vector<Item> items;
+  items.reserve(n);
+  for (int i = 0; i < n; ++i)
+    if (counts[i] > 0) {
+      Item it;
+      for (int d = 0; d < 3; ++d) it.c[d] = d < ND ? at(i, d) : 0.0;
+      it.src = i;
+      it.count = counts[i];
+      items.push_back(it);
+    }
+  std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+    for (int d = 0; d < 3; ++d) {
+      if (a.c[d] < b.c[d]) return true;
+      if (a.c[d] > b.c[d]) return false;
+    }
+    return a.src < b.src;
+  });
+  struct Key { int src; int count; double c[3]; };
+  std::vector<Key> keys;
+  keys.reserve(items.size());
+  for (size_t k = 0; k < items.size();) {
+    size_t e = k + 1;
+    while (e < items.size() && items[k].c[0] == items[e].c[0] && items[k].c[1] == items[e].c[1] && items[k].c[2] == items[e].c[2]) ++e;
+    Key key;
+    key.src = items[k].src;                               // (ties in the tuple are ordered by index: first, last)
+    key.count = items[e - 1].count;
+    for (int d = 0; d < 3; ++d) key.c[d] = items[k].c[d];
+    keys.push_back(key);
+    k = e;
+  }
+  // sorted(items, key = (count, centre tuple), reverse = True)
+  std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+    if (a.count != b.count) return a.count > b.count;
+    for (int d = 0; d < 3; ++d) {
+      if (a.c[d] > b.c[d]) return true;
+      if (a.c[d] < b.c[d]) return false;
+    }
+    return false;
+  });
+  const int m = (int)keys.size();
+  const double bw2 = bandwidth * bandwidth;
+  auto within = [&](int a, int b) {
+    double d2 = 0.0;
+    for (int d = 0; d < ND; ++d) {
+      const double df = keys[a].c[d] - keys[b].c[d];
+      d2 += df * df;
+    }
+    return d2 <= bw2;
+  };
+  std::vector<char> unique((size_t)m, 1);
+  // grid of edge `bandwidth`: everything within the radius of a centre sits in the 3^ND cells around its own
+  double lo[3] = {0, 0, 0};
+  bool grid_ok = m > 64;
+  for (int d = 0; d < ND && grid_ok; ++d) {
+    double mn = at(keys[0].src, d), mx = mn;
+    for (int k = 0; k < m; ++k) {
+      const double v = at(keys[k].src, d);
+      if (!std::isfinite(v)) grid_ok = false;
+      mn = std::min(mn, v);
+      mx = std::max(mx, v);
+    }
+    lo[d] = mn;
+    if (!((mx - mn) / bandwidth < 2097152.0)) grid_ok = false;      // 21 bits per axis in the cell key
+  }
+  if (grid_ok) {
+    auto cell_of = [&](int k, long long (&c)[3]) {
+      c[0] = c[1] = c[2] = 0;
+      for (int d = 0; d < ND; ++d) c[d] = (long long)std::floor((at(keys[k].src, d) - lo[d]) / bandwidth);
+    };
+    auto key_of = [](long long x, long long y, long long z) { return (unsigned long long)((z << 42) | (y << 21) | x); };
+    std::vector<std::pair<unsigned long long, int>> cells((size_t)m);        // (cell key, centre), sorted by key
+    for (int k = 0; k < m; ++k) {
+      long long c[3];
+      cell_of(k, c);
+      cells[k] = std::make_pair(key_of(c[0], c[1], c[2]), k);
+    }
+    std::sort(cells.begin(), cells.end());
+    for (int i = 0; i < m; ++i) {
+      if (!unique[i]) continue;
+      long long c[3];
+      cell_of(i, c);
+      for (long long dz = (ND == 3 ? -1 : 0); dz <= (ND == 3 ? 1 : 0); ++dz)
+        for (long long dy = -1; dy <= 1; ++dy) {
+          const long long y = c[1] + dy, z = c[2] + dz;
+          if (y < 0 || z < 0) continue;
+          // the three cells of a row of the block are consecutive keys
+          const long long x0 = c[0] > 0 ? c[0] - 1 : 0;
+          auto it = std::lower_bound(cells.begin(), cells.end(), std::make_pair(key_of(x0, y, z), -1));
+          const unsigned long long last = key_of(c[0] + 1, y, z);
+          for (; it != cells.end() && it->first <= last; ++it)
+            if (within(it->second, i)) unique[it->second] = 0;
+        }
+      unique[i] = 1;
+    }
+  } else {
+    for (int i = 0; i < m; ++i) {
+      if (!unique[i]) continue;
+      for (int j = 0; j < m; ++j)
+        if (within(j, i)) unique[j] = 0;
+      unique[i] = 1;
+    }
+  }
+  int kept = 0;
+  for (int k = 0; k < m; ++k)
+    if (unique[k]) {
+      for (int d = 0; d < ND; ++d) out[(size_t)kept * ND + d] = at(keys[k].src, d);
+      ++kept;
+    }
+  *n_out = kept;
+  return CLX_OK;
+}
+
 extern "C" size_t clx_ms_bucket_workspace(int n, long long ncells) {
   return (size_t)(2 * (long long)n + ncells + 4) * sizeof(int);
 }

@@ -65,8 +65,26 @@ def _center_grid(centers, cell):
 
 
 def dedup_centers(centers, counts, bandwidth):
-    """sklearn MeanShift.fit post-processing (_mean_shift.py: center_intensity_dict,
-    sort by (count, centre) descending, greedy removal of centres within `bandwidth`)."""
+    """sklearn MeanShift.fit post-processing (_mean_shift.py: center_intensity_dict, sort by (count, centre) descending,
+    greedy removal of centres within `bandwidth`) — libclx's host function clx_ms_dedup_centers (two sorts + the greedy
+    pass over a hash grid); `_dedup_centers_numpy` below is the same in numpy, kept as the tests' second opinion."""
+    import ctypes
+
+    centers = np.ascontiguousarray(centers, dtype=np.float64)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n, nd = centers.shape
+    out = np.empty((max(n, 1), nd), dtype=np.float64)
+    kept = ctypes.c_int(0)
+    _clx.call("clx_ms_dedup_centers", centers.ctypes.data_as(ctypes.c_void_p), counts.ctypes.data_as(ctypes.c_void_p),
+              n, nd, float(bandwidth), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(kept))
+    if kept.value == 0:
+        raise ValueError(
+            "No point was within bandwidth=%f of any seed. Try a different seeding strategy "
+            "or increase the bandwidth." % bandwidth)
+    return out[:kept.value].copy()
+
+
+def _dedup_centers_numpy(centers, counts, bandwidth):
     centers = np.asarray(centers, dtype=np.float64)
     counts = np.asarray(counts)
     keep = counts > 0

@@ -549,6 +549,14 @@ size_t clx_ms_bucket_workspace(int n, long long ncells);
 int clx_ms_bucket(const double* fit, int n, int ND, const double* origin, double cell, int nx,
                   int ny, int nz, double* fit_sorted, int* cell_start, void* workspace,
                   clx_stream stream);
+/* HOST function (host pointers, no stream): sklearn MeanShift.fit's post-processing of the converged seeds —
+ * identical centre tuples collapse (the last count wins), sort by (count, centre) descending, greedy removal of every
+ * centre within `bandwidth` (squared distance <= bandwidth^2) of a kept one
+ * [cellulus/utils/mean_shift.py:62-74 -> sklearn/cluster/_mean_shift.py MeanShift.fit].  centers (n, ND) and counts (n)
+ * are what clx_ms_iterate* produced, copied to the host; out: room for n centres; *n_out: the kept ones, in sklearn's
+ * order (0 when no seed had a neighbour — sklearn raises there, and so does the Python caller). */
+int clx_ms_dedup_centers(const double* centers, const int* counts, int n, int ND, double bandwidth,
+                         double* out, int* n_out);
 /* labels[index[i]] = 1 + argmin_k |X[i] - centers[k]|  (first minimum);
  * labels (npix) int32 must be zero-filled by the caller (background = 0). */
 int clx_ms_assign(const double* X, const int* index, int nfg,

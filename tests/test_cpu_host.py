@@ -276,6 +276,21 @@ def test_dedup_centers_equals_oracle_dict_sort_dedup():
     with pytest.raises(ValueError, match="bandwidth"):
         dedup_centers(centers, np.zeros(400, dtype=np.int32), 15.0)
     assert IO is not None
+    # libclx's host function (sorts + hash grid) against the numpy form, 2-D and 3-D, signed zeros, one-cell and wide grids
+    from cellulus_amd.utils.mean_shift import _dedup_centers_numpy
+    for trial in range(40):
+        nd = 2 + trial % 2
+        n, k = int(rng.integers(1, 2500)), int(rng.integers(1, 150))
+        modes = rng.uniform(-100, 500, size=(k, nd))
+        c = modes[rng.integers(0, k, size=n)] + rng.normal(0, rng.choice([1e-3, 0.5, 5.0]), size=(n, nd))
+        if n > 20:
+            c[5:15] = c[5]
+            c[16] = -0.0
+            c[17] = 0.0
+        cnt = rng.integers(0, 5, size=n).astype(np.int32)
+        cnt[0] = max(cnt[0], 1)
+        bw = float(rng.choice([3.0, 15.0, 60.0, 1e4]))
+        np.testing.assert_array_equal(dedup_centers(c, cnt, bw), _dedup_centers_numpy(c, cnt, bw))
 
 
 # -------------------------------------------------------------- evaluation
