@@ -147,6 +147,7 @@ PROTOTYPES = {
     "clx_noise_inject": (_I, [_P, _P, _P, _I, _I, _LL, ctypes.c_float, _P]),
     "clx_zero_many": (_I, [POINTER(_P), POINTER(_LL), _I, _P]),
     "clx_gather_rows_f64": (_I, [_P, _P, _LL, _I, _P, _P]),
+    "clx_rows_extent_f64": (_I, [_P, _LL, _I, _P, _P]),
     "clx_noise_stats_minmax": (_I, [_P, _P, _I, _I, _LL, _P, _I, _P]),
     "clx_ms_prepare_workspace": (c_size_t, [_LL]),
     "clx_ms_prepare": (_I, [_P, _P, _D, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
@@ -189,6 +190,7 @@ PROTOTYPES = {
 
 MINMAX_DOUBLES = 2 + 2 * 512            # CLX_MINMAX_DOUBLES (include/clx.h): results + per-block partials
 NOISE_MINMAX_FLOATS = 2 + 2 * 1024      # CLX_NOISE_MINMAX_FLOATS
+ROWS_EXTENT_DOUBLES = 6 * (1 + 256)     # CLX_ROWS_EXTENT_DOUBLES
 NOISE_MINMAX_MAX_T = 64                 # clx_noise_stats_minmax: predictions per pixel it keeps in registers
 
 _lib = None

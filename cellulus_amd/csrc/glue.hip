@@ -425,6 +425,68 @@ __global__ __launch_bounds__(256) void gather_rows_f64_kernel(const double* __re
 
 }  // namespace
 
+namespace {
+constexpr int EXTENT_BLOCKS = 256;
+
+// per-column minimum and maximum of a (n, ND) float64 array: block partials [block][2 * ND], then one block over them
+template <int ND>
+__global__ __launch_bounds__(256) void rows_extent_kernel(const double* __restrict__ src, long long n, double* __restrict__ partial) {
+  __shared__ double red[4][2 * ND];
+  double lo[ND], hi[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d) { lo[d] = __builtin_huge_val(); hi[d] = -__builtin_huge_val(); }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+      const double v = src[i * ND + d];
+      lo[d] = fmin(lo[d], v);
+      hi[d] = fmax(hi[d], v);
+    }
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[d] = fmin(lo[d], __shfl_xor(lo[d], o, 64));
+      hi[d] = fmax(hi[d], __shfl_xor(hi[d], o, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int d = 0; d < ND; ++d) { red[threadIdx.x >> 6][d] = lo[d]; red[threadIdx.x >> 6][ND + d] = hi[d]; }
+  __syncthreads();
+  if (threadIdx.x < 2 * ND) {
+    const int d = threadIdx.x;
+    double v = red[0][d];
+    for (int w = 1; w < 4; ++w) v = d < ND ? fmin(v, red[w][d]) : fmax(v, red[w][d]);
+    partial[(size_t)blockIdx.x * 2 * ND + d] = v;
+  }
+}
+
+template <int ND>
+__global__ __launch_bounds__(64) void rows_extent_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+  const int d = threadIdx.x;
+  if (d >= 2 * ND) return;
+  double v = partial[d];
+  for (int b = 1; b < nblocks; ++b) v = d < ND ? fmin(v, partial[(size_t)b * 2 * ND + d]) : fmax(v, partial[(size_t)b * 2 * ND + d]);
+  out[d] = v;
+}
+}  // namespace
+
+extern "C" int clx_rows_extent_f64(const double* src, long long n, int width, double* extent, clx_stream stream) {
+  CLX_REQUIRE(src && extent && n > 0 && (width == 2 || width == 3), "clx_rows_extent_f64: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  long long g = (n + 255) / 256;
+  g = g > EXTENT_BLOCKS ? EXTENT_BLOCKS : g;
+  // one block: its partial IS the result
+  double* partial = g == 1 ? extent : extent + 2 * width;
+  if (width == 2) rows_extent_kernel<2><<<(int)g, 256, 0, st>>>(src, n, partial);
+  else rows_extent_kernel<3><<<(int)g, 256, 0, st>>>(src, n, partial);
+  if (g > 1) {
+    if (width == 2) rows_extent_final<2><<<1, 64, 0, st>>>(partial, (int)g, extent);
+    else rows_extent_final<3><<<1, 64, 0, st>>>(partial, (int)g, extent);
+  }
+  CLX_CHECK_LAUNCH("clx_rows_extent_f64");
+  return CLX_OK;
+}
+
 extern "C" int clx_noise_inject(const float* rnd, const float* raw, float* out, int T, int n_half, long long n,
                                 float p, clx_stream stream) {
   CLX_REQUIRE(rnd && raw && out && T > 0 && n > 0 && n_half >= 0 && n_half <= T, "clx_noise_inject: bad arguments");

@@ -28,10 +28,10 @@ def _bucket(fit, bandwidth):
 
     n, nd = fit.shape
     cell = float(bandwidth) * (1.0 + 1e-9)        # strictly larger than the query radius
-    lo = fit.amin(dim=0)
-    hi = fit.amax(dim=0)
-    ext = torch.stack([lo, hi]).cpu().numpy().astype(np.float64)      # one small D2H copy
-    origin = ext[0]
+    ext_d = torch.empty(_clx.ROWS_EXTENT_DOUBLES, dtype=torch.float64, device=fit.device)
+    _clx.call("clx_rows_extent_f64", _clx.ptr(fit), n, nd, _clx.ptr(ext_d), _clx.stream_ptr(fit.device))
+    ext = ext_d[:2 * nd].cpu().numpy().reshape(2, nd)                  # one small D2H copy
+    origin = ext[0].copy()
     dims = np.floor((ext[1] - origin) / cell).astype(np.int64) + 1
     nx, ny = int(dims[0]), int(dims[1])
     nz = int(dims[2]) if nd == 3 else 1
@@ -181,9 +181,11 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
         if seeds_d.ndim != 2 or seeds_d.shape[1] != nd:
             raise ValueError(f"seeds must have shape (n, {nd})")
     ns = seeds_d.shape[0]
-    centers = torch.empty((ns, nd), dtype=torch.float64, device=dev)
-    counts = torch.empty(ns, dtype=torch.int32, device=dev)
-    iters = torch.empty(ns, dtype=torch.int32, device=dev)
+    # converged seeds and their neighbour counts in ONE allocation: one copy to the host instead of two
+    res = torch.empty(ns * (nd * 8 + 8), dtype=torch.uint8, device=dev)
+    centers = res[:ns * nd * 8].view(torch.float64).view(ns, nd)
+    counts = res[ns * nd * 8: ns * nd * 8 + ns * 4].view(torch.int32)
+    iters = res[ns * nd * 8 + ns * 4:].view(torch.int32)
     if fit.shape[0] >= GRID_MIN_POINTS:
         import ctypes
 
@@ -197,9 +199,10 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     else:
         _clx.call("clx_ms_iterate", _clx.ptr(fit), fit.shape[0], _clx.ptr(seeds_d), ns, nd,
                   float(bandwidth), MAX_ITER, _clx.ptr(centers), _clx.ptr(counts), _clx.ptr(iters), st)
-    cluster_centers = dedup_centers(centers.cpu().numpy(), counts.cpu().numpy(), float(bandwidth))
-    cc = torch.from_numpy(np.ascontiguousarray(cluster_centers)).to(dev)
-    ncc = cc.shape[0]
+    res_h = res.cpu().numpy()
+    cluster_centers = dedup_centers(res_h[:ns * nd * 8].view(np.float64).reshape(ns, nd),
+                                    res_h[ns * nd * 8: ns * nd * 8 + ns * 4].view(np.int32), float(bandwidth))
+    ncc = cluster_centers.shape[0]
     grid_cells = 0
     if ncc >= ASSIGN_GRID_MIN_CENTERS:
         cell = float(bandwidth)
@@ -208,10 +211,17 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     if ncc >= ASSIGN_GRID_MIN_CENTERS and grid_cells <= 1 << 26:
         import ctypes
 
-        order_d = torch.from_numpy(order).to(dev)
-        cstart_d = torch.from_numpy(cstart).to(dev)
         corigin_c = (ctypes.c_double * nd)(*corigin.tolist())
-        cc_sorted = torch.from_numpy(np.ascontiguousarray(cluster_centers[order])).to(dev)      # centres in cell order
+        # centres in cell order | their ids | the cells' offsets: one buffer, one upload
+        nb_c, nb_o = ncc * nd * 8, ncc * 4
+        tables = np.empty(nb_c + nb_o + cstart.nbytes, dtype=np.uint8)
+        tables[:nb_c].view(np.float64)[:] = cluster_centers[order].reshape(-1)
+        tables[nb_c:nb_c + nb_o].view(np.int32)[:] = order
+        tables[nb_c + nb_o:].view(np.int32)[:] = cstart
+        tables_d = torch.from_numpy(tables).to(dev)
+        cc_sorted = tables_d[:nb_c].view(torch.float64).view(ncc, nd)
+        order_d = tables_d[nb_c:nb_c + nb_o].view(torch.int32)
+        cstart_d = tables_d[nb_c + nb_o:].view(torch.int32)
         # the whole label map in one pass over the compaction's tiles (their flags are still in `ws`): no zero fill,
         # no scatter through the raster index
         _clx.call("clx_ms_assign_dense", _clx.ptr(pts), _clx.ptr(cc_sorted), ncc, nd, _clx.ptr(order_d),
@@ -219,6 +229,7 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
                   Z, Y, X, _clx.ptr(labels), st)
     else:
         _clx.zero_many(labels)
+        cc = torch.from_numpy(np.ascontiguousarray(cluster_centers)).to(dev)
         _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,
                   _clx.ptr(labels), st)
     return labels, cluster_centers

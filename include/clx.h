@@ -449,6 +449,12 @@ int clx_noise_stats_minmax(const float* preds, float* out, int T, int C, long lo
  * of torch's compare + where. */
 int clx_noise_inject(const float* rnd, const float* raw, float* out, int T, int n_half, long long n, float p,
                      clx_stream stream);
+/* Per-column minimum and maximum of a (n, width) float64 array, width 2 or 3: extent[0..width) = minima,
+ * extent[width..2 width) = maxima — the bounding box the uniform grid of the mean-shift fit points is laid over
+ * (sklearn builds a KD-tree there; cellulus/utils/mean_shift.py:62-74).  extent: CLX_ROWS_EXTENT_DOUBLES doubles (the
+ * results + room for the block partials).  One launch up to 256 rows x 256, two above. */
+#define CLX_ROWS_EXTENT_DOUBLES (6 * (1 + 256))
+int clx_rows_extent_f64(const double* src, long long n, int width, double* extent, clx_stream stream);
 /* Zero fills of `count` device buffers (16-byte aligned, sizes multiples of 4 bytes) in one launch per eight: the
  * accumulators a training step adds into (packed weight gradients, bias gradients, the scatter target of the loss). */
 int clx_zero_many(void* const* buffers, const long long* nbytes, int count, clx_stream stream);

@@ -1019,3 +1019,16 @@ def test_dense_assignment_equals_scatter_into_a_zeroed_map(shape, f32, device):
     _clx.call("clx_ms_assign_dense", _clx.ptr(pts2), _clx.ptr(cc_sorted), K, nd, _clx.ptr(order_d), _clx.ptr(cstart_d),
               origin_c, bw, gx, gy, gz, _clx.ptr(ws), 1 if f32 else 0, Z, Y, X, _clx.ptr(got), st)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("n,nd", [(1, 2), (255, 2), (4500, 2), (70000, 2), (300000, 3), (17, 3)])
+def test_rows_extent_equals_numpy_min_max(n, nd, device):
+    from cellulus_amd import _clx
+
+    rng = np.random.default_rng(n)
+    src_np = rng.normal(0, 100, size=(n, nd))
+    src = torch.from_numpy(src_np).to(device)
+    ext = torch.full((_clx.ROWS_EXTENT_DOUBLES,), float("nan"), dtype=torch.float64, device=device)
+    _clx.call("clx_rows_extent_f64", _clx.ptr(src), n, nd, _clx.ptr(ext), _clx.stream_ptr(device))
+    got = ext[:2 * nd].cpu().numpy().reshape(2, nd)
+    np.testing.assert_array_equal(got, np.stack([src_np.min(axis=0), src_np.max(axis=0)]))
