@@ -132,18 +132,19 @@ def streaming_rooflines(device, size=4096, only_mean_shift=False):
     idx = torch.empty(npix, dtype=torch.int32, device=device)
     nfg = torch.zeros(1, dtype=torch.int32, device=device)
     emb = emb0.clone()
+    # (as the product calls it since round 5: without the raster index — clx_ms_assign_dense does not read one)
     t = _kernel_time(lambda: _clx.call("clx_ms_prepare", _clx.ptr(emb), _clx.ptr(sd), 0.5, 2, 1, Y, X, _clx.ptr(pts),
-                                       _clx.ptr(idx), _clx.ptr(nfg), _clx.ptr(ws), st), PROF_KIND["ms_prepare"])
+                                       None, _clx.ptr(nfg), _clx.ptr(ws), st), PROF_KIND["ms_prepare"])
     n_fg = int(nfg.item())
-    row("ms_prepare", t, npix * (3 * 8 + 2 * 8) + n_fg * (2 * 8 + 4),
-        "per pixel 24 B read + 16 B written, per foreground pixel 20 B more", nfg=n_fg)
+    row("ms_prepare", t, npix * (3 * 8 + 2 * 8) + n_fg * (2 * 8),
+        "per pixel 24 B read + 16 B written, per foreground pixel 16 B more (the point; no raster index)", nfg=n_fg)
     # the fused path's form: the network's float32 planes in, widened in registers, nothing written per background pixel
     emb32, sd32 = emb0.float(), sd.float()
     t = _kernel_time(lambda: _clx.call("clx_ms_prepare_f32", _clx.ptr(emb32), _clx.ptr(sd32), 0.5, 2, 1, Y, X, _clx.ptr(pts),
-                                       _clx.ptr(idx), _clx.ptr(nfg), _clx.ptr(ws), st), PROF_KIND["ms_prepare"])
+                                       None, _clx.ptr(nfg), _clx.ptr(ws), st), PROF_KIND["ms_prepare"])
     assert int(nfg.item()) == n_fg
-    row("ms_prepare_f32", t, npix * 4 + n_fg * (2 * 4 + 2 * 8 + 4),
-        "per pixel 4 B read (std), per foreground pixel 8 B read + 20 B written (infer()'s fused hand-over)", nfg=n_fg)
+    row("ms_prepare_f32", t, npix * 4 + n_fg * (2 * 4 + 2 * 8),
+        "per pixel 4 B read (std), per foreground pixel 8 B read + 16 B written (infer()'s fused hand-over)", nfg=n_fg)
     del emb32
     # centres: one per object (their true centres), assignment of all foreground pixels
     emb = emb0.clone()

@@ -46,8 +46,6 @@ def _bucket(fit, bandwidth):
     return fit_sorted, cell_start, origin, cell, (nx, ny, nz)
 
 
-ASSIGN_GRID_MIN_CENTERS = 32      # below this the plain loop over the (LDS-resident) centres is as fast
-
 
 def _center_grid(centers, cell):
     """Host side of clx_ms_assign_grid: the (few hundred) centres sorted by uniform-grid cell."""
@@ -151,12 +149,11 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     lib = _clx.load()
     ws = _prepare_workspace(int(lib.clx_ms_prepare_workspace(npix)), dev)
     pts = torch.empty((npix, nd), dtype=torch.float64, device=dev)
-    index = torch.empty(npix, dtype=torch.int32, device=dev)
     nfg_d = torch.empty(1, dtype=torch.int32, device=dev)
     labels = torch.empty(spatial, dtype=torch.int32, device=dev)      # written in full by clx_ms_assign_dense
     _clx.zero_many(nfg_d)
     _clx.call(prepare, _clx.ptr(emb), _clx.ptr(std), float(threshold), nd, Z, Y, X,
-              _clx.ptr(pts), _clx.ptr(index), _clx.ptr(nfg_d), _clx.ptr(ws), st)
+              _clx.ptr(pts), None, _clx.ptr(nfg_d), _clx.ptr(ws), st)
     nfg = int(nfg_d.item())
     if nfg == 0:      # mean_shift.py:83-84,92-93 -> all -1, +1 -> 0
         _clx.zero_many(labels)
@@ -203,35 +200,32 @@ def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, 
     cluster_centers = dedup_centers(res_h[:ns * nd * 8].view(np.float64).reshape(ns, nd),
                                     res_h[ns * nd * 8: ns * nd * 8 + ns * 4].view(np.int32), float(bandwidth))
     ncc = cluster_centers.shape[0]
-    grid_cells = 0
-    if ncc >= ASSIGN_GRID_MIN_CENTERS:
-        cell = float(bandwidth)
-        order, cstart, corigin, (gx, gy, gz) = _center_grid(cluster_centers, cell)
-        grid_cells = gx * gy * gz
-    if ncc >= ASSIGN_GRID_MIN_CENTERS and grid_cells <= 1 << 26:
-        import ctypes
+    import ctypes
 
-        corigin_c = (ctypes.c_double * nd)(*corigin.tolist())
-        # centres in cell order | their ids | the cells' offsets: one buffer, one upload
-        nb_c, nb_o = ncc * nd * 8, ncc * 4
-        tables = np.empty(nb_c + nb_o + cstart.nbytes, dtype=np.uint8)
-        tables[:nb_c].view(np.float64)[:] = cluster_centers[order].reshape(-1)
-        tables[nb_c:nb_c + nb_o].view(np.int32)[:] = order
-        tables[nb_c + nb_o:].view(np.int32)[:] = cstart
-        tables_d = torch.from_numpy(tables).to(dev)
-        cc_sorted = tables_d[:nb_c].view(torch.float64).view(ncc, nd)
-        order_d = tables_d[nb_c:nb_c + nb_o].view(torch.int32)
-        cstart_d = tables_d[nb_c + nb_o:].view(torch.int32)
-        # the whole label map in one pass over the compaction's tiles (their flags are still in `ws`): no zero fill,
-        # no scatter through the raster index
-        _clx.call("clx_ms_assign_dense", _clx.ptr(pts), _clx.ptr(cc_sorted), ncc, nd, _clx.ptr(order_d),
-                  _clx.ptr(cstart_d), corigin_c, cell, gx, gy, gz, _clx.ptr(ws), 0 if emb.dtype == torch.float64 else 1,
-                  Z, Y, X, _clx.ptr(labels), st)
-    else:
-        _clx.zero_many(labels)
-        cc = torch.from_numpy(np.ascontiguousarray(cluster_centers)).to(dev)
-        _clx.call("clx_ms_assign", _clx.ptr(pts), _clx.ptr(index), nfg, _clx.ptr(cc), ncc, nd,
-                  _clx.ptr(labels), st)
+    # nearest centre of every foreground pixel: the centres in a uniform grid (any edge gives the exact nearest centre —
+    # the search widens its block until the winner is closer than the block's reach; the bandwidth is the edge at which
+    # a pixel's own 3^ND block decides; doubled while stray centres would make the grid larger than 2^26 cells)
+    cell = float(bandwidth)
+    order, cstart, corigin, (gx, gy, gz) = _center_grid(cluster_centers, cell)
+    while gx * gy * gz > 1 << 26:
+        cell *= 2.0
+        order, cstart, corigin, (gx, gy, gz) = _center_grid(cluster_centers, cell)
+    corigin_c = (ctypes.c_double * nd)(*corigin.tolist())
+    # centres in cell order | their ids | the cells' offsets: one buffer, one upload
+    nb_c, nb_o = ncc * nd * 8, ncc * 4
+    tables = np.empty(nb_c + nb_o + cstart.nbytes, dtype=np.uint8)
+    tables[:nb_c].view(np.float64)[:] = cluster_centers[order].reshape(-1)
+    tables[nb_c:nb_c + nb_o].view(np.int32)[:] = order
+    tables[nb_c + nb_o:].view(np.int32)[:] = cstart
+    tables_d = torch.from_numpy(tables).to(dev)
+    cc_sorted = tables_d[:nb_c].view(torch.float64).view(ncc, nd)
+    order_d = tables_d[nb_c:nb_c + nb_o].view(torch.int32)
+    cstart_d = tables_d[nb_c + nb_o:].view(torch.int32)
+    # the whole label map in one pass over the compaction's tiles (their flags are still in `ws`): no zero fill, no
+    # scatter through a raster index (which clx_ms_prepare was not asked for)
+    _clx.call("clx_ms_assign_dense", _clx.ptr(pts), _clx.ptr(cc_sorted), ncc, nd, _clx.ptr(order_d),
+              _clx.ptr(cstart_d), corigin_c, cell, gx, gy, gz, _clx.ptr(ws), 0 if emb.dtype == torch.float64 else 1,
+              Z, Y, X, _clx.ptr(labels), st)
     return labels, cluster_centers
 
 
