@@ -160,6 +160,7 @@ PROTOTYPES = {
     "clx_ms_assign_cells": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _P]),
     "clx_ms_assign_dense": (_I, [_P, _P, _I, _I, _P, _P, POINTER(c_double), _D, _I, _I, _I, _P, _I, _I, _I, _I, _P, _P]),
     "clx_ms_dedup_centers": (_I, [_P, _P, _I, _I, _D, _P, POINTER(_I)]),
+    "clx_sample_offsets_mt19937": (_I, [_P, POINTER(_I), _I, _I, _LL, _P, POINTER(_I)]),
     "clx_ms_bucket_workspace": (c_size_t, [_I, _LL]),
     "clx_ms_bucket": (_I, [_P, _I, _I, POINTER(c_double), _D, _I, _I, _I, _P, _P, _P, _P]),
     "clx_offset_magnitude": (_I, [_P, _P, _I, _LL, _P]),

@@ -13,6 +13,7 @@ zarr_dataset.py:177-251 call for call on the global numpy RNG, so seeding
 """
 
 import math
+import os
 import random
 from typing import Tuple
 
@@ -174,6 +175,28 @@ class ZarrDataset(IterableDataset):  # type: ignore
 
     # ------------------------------------------------------------ pair sampler
     def sample_offsets_within_radius(self, radius, number_offsets):
+        """zarr_dataset.py:185-198.  Same offsets and the same state of numpy's global generator afterwards as the
+        reference's code; drawn by libclx's host function (MT19937 + numpy's masked rejection restated in C: 20 -> 4 ms
+        for a 256^2 crop's 196 850 pairs) when that generator is the legacy MT19937 and the radius an integer, by numpy
+        (`_sample_offsets_numpy`) otherwise."""
+        nd = self.num_spatial_dims
+        if os.environ.get("CLX_NATIVE_PAIR_SAMPLER", "1") != "0" and float(radius).is_integer() and 1 <= radius < 16384:
+            state = np.random.get_state(legacy=True)
+            if state[0] == "MT19937":
+                import ctypes
+
+                from .. import _clx
+
+                key = np.ascontiguousarray(state[1], dtype=np.uint32).copy()
+                pos = ctypes.c_int(int(state[2]))
+                offsets = np.empty((number_offsets, nd), dtype=np.int64)
+                _clx.call("clx_sample_offsets_mt19937", key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos),
+                          int(radius), nd, int(number_offsets), offsets.ctypes.data_as(ctypes.c_void_p), None)
+                np.random.set_state(("MT19937", key, pos.value, state[3], state[4]))
+                return offsets
+        return self._sample_offsets_numpy(radius, number_offsets)
+
+    def _sample_offsets_numpy(self, radius, number_offsets):
         # (the reference stacks the draws, filters twice with temporaries of the full size and slices: 19 of the 31 ms
         #  a 256^2 crop's pairs cost; the same draws in the same order, one combined mask, the survivors gathered once)
         nd = self.num_spatial_dims
@@ -183,7 +206,7 @@ class ZarrDataset(IterableDataset):  # type: ignore
             sq += d * d
         keep = np.flatnonzero((sq < radius ** 2) & (sq > 0))     # (integers: |o|_1 > 0 <=> |o|^2 > 0)
         if len(keep) < number_offsets:
-            return self.sample_offsets_within_radius(radius, number_offsets)
+            return self._sample_offsets_numpy(radius, number_offsets)
         keep = keep[:number_offsets]
         offsets = np.empty((number_offsets, nd), dtype=draws[0].dtype)
         for d in range(nd):

@@ -555,6 +555,15 @@ size_t clx_ms_bucket_workspace(int n, long long ncells);
 int clx_ms_bucket(const double* fit, int n, int ND, const double* origin, double cell, int nx,
                   int ny, int nz, double* fit_sorted, int* cell_start, void* workspace,
                   clx_stream stream);
+/* HOST function: the offsets of the reference's pair sampler (cellulus/datasets/zarr_dataset.py:185-198,
+ * sample_offsets_within_radius) drawn from numpy's LEGACY global generator — MT19937, 32-bit outputs, masked rejection,
+ * i.e. what `np.random.randint(-radius, radius + 1, size = ND * number_offsets)` called ND times produces — filtered
+ * (0 < |o|^2 < radius^2) and cut to number_offsets rows, redrawn like the reference when too few survive.  key[624],
+ * *pos: the generator's state (np.random.get_state()[1:3]), advanced exactly as numpy would have; offsets:
+ * (number_offsets, ND) int64 out; *rounds (may be NULL): how many times everything was drawn.  Same values, same
+ * final state as the numpy form (tests/test_cpu_host.py), a fifth of its time. */
+int clx_sample_offsets_mt19937(unsigned int* key, int* pos, int radius, int ND, long long number_offsets,
+                               long long* offsets, int* rounds);
 /* HOST function (host pointers, no stream): sklearn MeanShift.fit's post-processing of the converged seeds —
  * identical centre tuples collapse (the last count wins), sort by (count, centre) descending, greedy removal of every
  * centre within `bandwidth` (squared distance <= bandwidth^2) of a kept one

@@ -1032,3 +1032,41 @@ def test_infer_chunk_sizes_and_shared_device_rule(monkeypatch):
     assert parallel.ranks_sharing_device() == 8
     monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")
     assert parallel.ranks_sharing_device() == 4
+
+
+# ------------------------------------------------- pair sampler: numpy's legacy stream restated in libclx
+def test_native_pair_offsets_are_numpys_stream_value_for_value_and_leave_its_state():
+    """clx_sample_offsets_mt19937 (host function: MT19937 + numpy's masked rejection + the reference's filter) against
+    np.random itself: the same offsets, and the global generator in the same state afterwards — so a seeded run draws the
+    reference's pairs whichever form ran (zarr_dataset.py:185-198)."""
+    from cellulus_amd.datasets.zarr_dataset import ZarrDataset
+
+    class Bare(ZarrDataset):
+        def __init__(self, nd):
+            self.num_spatial_dims = nd
+
+    for nd in (2, 3):
+        d = Bare(nd)
+        for seed in (0, 3, 12345):
+            for radius, n in ((10, 196850 if nd == 2 else 20000), (3 if nd == 2 else 5, 1000), (10.0, 5000),
+                              (4 if nd == 2 else 6, 17), (40, 3000), (10, 1), (10, 311), (10, 312), (10, 313)):
+                np.random.seed(seed)
+                np.random.rand(seed % 7 + 1)                   # somewhere inside a block of the generator
+                want = d._sample_offsets_numpy(radius, n)
+                state_want = np.random.get_state()
+                np.random.seed(seed)
+                np.random.rand(seed % 7 + 1)
+                got = d.sample_offsets_within_radius(radius, n)
+                state_got = np.random.get_state()
+                assert got.dtype == want.dtype and got.shape == want.shape
+                np.testing.assert_array_equal(got, want)
+                assert state_got[2] == state_want[2] and np.array_equal(state_got[1], state_want[1])
+                assert np.random.randint(0, 1 << 30) == (np.random.set_state(state_want) or np.random.randint(0, 1 << 30))
+    # a Gaussian draw cached in the generator survives the hand-over
+    np.random.seed(5)
+    np.random.standard_normal(1)
+    before = np.random.get_state()
+    assert before[3] == 1
+    Bare(2).sample_offsets_within_radius(10, 100)
+    after = np.random.get_state()
+    assert after[3] == 1 and after[4] == before[4]
