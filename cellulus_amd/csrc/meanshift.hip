@@ -826,16 +826,22 @@ __device__ __forceinline__ void ms_search_2d_multi(const double (&x)[U][2], cons
       arg[u] = ms_ring_search<2>(x[u], cx[u], cy[u], 0, 2, cs, order, cell_start, h, nx, ny, 1);
 }
 
+#ifndef CLX_DENSE_WAVES
+#define CLX_DENSE_WAVES 1
+#endif
+constexpr int DENSE_WAVES = CLX_DENSE_WAVES;          // wave-tiles per block: 1 / 2 / 4 measured 111 / 115 / 116 us at 8192^2
 template <int ND, int PXL, int G, int U>
-__global__ __launch_bounds__(64) void ms_assign_dense_kernel(
+__global__ __launch_bounds__(64 * DENSE_WAVES) void ms_assign_dense_kernel(
     const double* __restrict__ X, const double* __restrict__ cs, int ncenters, const int* __restrict__ order,
     const int* __restrict__ cell_start, double ox, double oy, double oz, double h, double inv, int nx, int ny, int nz,
     const unsigned long long* __restrict__ flags, const int* __restrict__ counts, const int* __restrict__ tile_start,
     long long npix, int vec, int* __restrict__ labels) {
   constexpr int WT = 64 * G * PXL;
-  __shared__ int lab[WT];
-  const int lane = threadIdx.x;
-  const int wt = blockIdx.x;
+  __shared__ int lab_all[DENSE_WAVES * WT];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int* lab = lab_all + wave * WT;                      // (a wavefront's own tile: no barrier between wavefronts)
+  const int wt = blockIdx.x * DENSE_WAVES + wave;
   // wave-uniform words first: the tile's points, its flag words (scalar loads, in flight under phase 1)
   const int p0 = tile_start[wt];
   const int total = counts[wt];
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(64) void ms_assign_dense_kernel(
       lab[q] = ms_ring_search<ND>(x, cx, cy, cz, 1, cs, order, cell_start, h, nx, ny, nz) + 1;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();                     // the wavefront's LDS operations execute in order
   const long long base = (long long)wt * WT;
   if (base >= npix) return;
   const unsigned long long lower = (1ull << lane) - 1ull;
@@ -1093,7 +1099,7 @@ static void launch_assign_dense(const double* X, const double* cs, int ncenters,
   const int* tile_start = counts + 2 * nwt;
   const int vec = (npix % PXL == 0) && (((uintptr_t)labels) & 15) == 0 ? 1 : 0;
   static const int u = getenv("CLX_MS_DENSE_U") ? atoi(getenv("CLX_MS_DENSE_U")) : 2;      // (sweep: 104 us at 8192^2; 1: 128, 3: 117, 4: 127)
-#define CLX_DENSE(UU) CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_dense_kernel<ND, PXL, G, UU>), dim3(nwt), dim3(64), 0, st, X, cs, ncenters, order, \
+#define CLX_DENSE(UU) CLX_LAUNCH_KIND(CLX_PROF_MS_ASSIGN, (ms_assign_dense_kernel<ND, PXL, G, UU>), dim3(nwt / DENSE_WAVES), dim3(64 * DENSE_WAVES), 0, st, X, cs, ncenters, order, \
                   cell_start, origin[0], origin[1], ND == 3 ? origin[2] : 0.0, cell, 1.0 / cell, nx, ny, nz, flags, counts, \
                   tile_start, npix, vec, labels)
   if (ND == 2 && u == 1) CLX_DENSE(1); else if (ND == 2 && u == 2) CLX_DENSE(2); else if (ND == 2 && u == 3) CLX_DENSE(3); else if (ND == 2 && u == 4) CLX_DENSE(4); else CLX_DENSE(2);
