@@ -869,8 +869,8 @@ def main():
         try:
             torch.cuda.empty_cache()
             out["train_e2e"] = train_e2e(args.workload, device, iterations=args.e2e_iterations)
-            # the reference's default of 8 loader processes bounds train() near 230 crops/s (27 ms of np.random pair
-            # sampling per crop); the same run with 16 says what the device side of train() does
+            # 8 loader processes are the reference's default; the same run with 16 says whether the host side (6 ms per
+            # crop per process since the pair offsets come from libclx's restatement of numpy's stream) bounds it
             more = train_e2e(args.workload, device, iterations=args.e2e_iterations, workers=16)
             out["train_e2e"]["with_16_loader_procs"] = {k: more[k] for k in ("value", "unit", "ms_per_iteration", "loader_procs")}
         except Exception as e:

@@ -226,7 +226,11 @@ __global__ __launch_bounds__(256, BLOCKS) void ms_scatter_kernel(TIn* __restrict
             val[c] = (double)e4[c][e] + (double)co[c];
             if (WB) e4[c][e] = (TIn)val[c];
           }
+#ifdef CLX_SCATTER_NOSTORE      // EXPERIMENT: the pass without its point stores
+          if (((gb >> e) & 1u) && val[0] == 1e300) {
+#else
           if ((gb >> e) & 1u) {
+#endif
 #pragma unroll
             for (int c = 0; c < ND; ++c) Xout[(long long)pos * ND + c] = val[c];
             if (index) index[pos] = (int)(i + e);
