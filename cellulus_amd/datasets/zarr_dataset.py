@@ -38,6 +38,24 @@ def default_normalization_factor(dtype):
                        "set normalization_factor")
 
 
+_BLAS_LIMIT = None
+
+
+def _single_threaded_blas():
+    """Inside a loader process: numpy's BLAS on ONE thread.  The augmentation's small matrix products (a 2 x 2 rotation
+    over 65 536 grid points, the spline matrices over the jitter grids) are enough for OpenBLAS to wake its whole
+    pool — one thread per host core, per loader process — and eight such pools spinning beside each other made the
+    crops' times jitter: `train()` lost 4 % against the step rate on some hosts and nothing on others (round 5)."""
+    global _BLAS_LIMIT
+    if _BLAS_LIMIT is None:
+        try:
+            from threadpoolctl import threadpool_limits
+
+            _BLAS_LIMIT = threadpool_limits(limits=1)
+        except Exception:            # (threadpoolctl absent: nothing to limit with)
+            _BLAS_LIMIT = False
+
+
 class ZarrDataset(IterableDataset):  # type: ignore
     def __init__(
         self,
@@ -71,6 +89,10 @@ class ZarrDataset(IterableDataset):  # type: ignore
         self.skip_pairs = False
 
     def __iter__(self):
+        import torch.utils.data
+
+        if torch.utils.data.get_worker_info() is not None:
+            _single_threaded_blas()
         return iter(self.__yield_sample())
 
     # ------------------------------------------------------------------ source

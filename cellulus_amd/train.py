@@ -108,7 +108,7 @@ def train(experiment_config):
     )
 
     # the input pipeline's share of the host: every loader process draws the np.random pair stream of its
-    # crops (27 ms of one core per 256^2 crop) next to the zarr reads and the augmentation
+    # crops (3 ms of one core per 256^2 crop since libclx restates that stream) next to the zarr reads and the augmentation
     policy = loader_policy(world, train_config.num_workers)
     if is_main:
         print(f"[cellulus_amd] input pipeline: {policy['loader_procs']} loader processes per rank "
@@ -130,6 +130,8 @@ def train(experiment_config):
         drop_last=True,
         num_workers=policy["loader_procs"],
         pin_memory=True,
+        # batches come back in worker order: a deeper queue per worker absorbs one slow crop (15 MB per batch)
+        prefetch_factor=4 if policy["loader_procs"] > 0 else None,
         collate_fn=_collate_narrow if max(train_config.crop_size) < 32768 else None,
     )
 
