@@ -6,6 +6,11 @@
 // Replaces cellulus/utils/mean_shift.py:6-121 -> sklearn.cluster.MeanShift
 // (fit: _mean_shift_single_seed per seed; predict: nearest centre).
 #include <stdlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
 #include "clx_common.h"
 
 namespace {
@@ -1143,10 +1148,6 @@ extern "C" int clx_ms_assign_dense(const double* X, const double* centers_sorted
 // definition; in numpy it was the largest single cost of the detect stage per 512^2 sample (a Python trip per kept
 // centre over all ~4 500 seeds).  Here: two sorts and the greedy pass over a hash grid of edge `bandwidth`.
 // ---------------------------------------------------------------------------------------------
-#include <algorithm>
-#include <cmath>
-#include <vector>
-
 extern "C" int clx_ms_dedup_centers(const double* centers, const int* counts, int n, int ND, double bandwidth,
                                     double* out, int* n_out) {
   CLX_REQUIRE(n_out != nullptr && n >= 0 && (ND == 2 || ND == 3) && (n == 0 || (centers && counts && out)),
