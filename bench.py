@@ -571,8 +571,14 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8, rank=0, worl
     settle = min(settle, iterations // 3)
     tmp = _shared_tmpdir("clx_e2e_", rank, world)
     cwd = os.getcwd()
-    stamps, mem = [], []
+    stamps, mem, waits = [], [], []
     real = T.train_iteration
+    real_stage = T._DevicePrefetcher._stage
+
+    def stage_spy(self):
+        t = time.perf_counter()
+        real_stage(self)
+        waits.append(time.perf_counter() - t)
 
     def spy(*a, **k):
         out = real(*a, **k)
@@ -602,18 +608,22 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8, rank=0, worl
                               train_data_config=dict(container_path="data.zarr", dataset_name="train/raw")))
         policy = T.loader_policy(world, cfg.train_config.num_workers)
         T.train_iteration = spy
+        T._DevicePrefetcher._stage = stage_spy
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
             T.train(cfg)
         total = time.perf_counter() - t0
     finally:
         T.train_iteration = real
+        T._DevicePrefetcher._stage = real_stage
         os.chdir(cwd)
         if world > 1:
             torch.distributed.barrier()
         if rank == 0:
             shutil.rmtree(tmp, ignore_errors=True)
     steady = (stamps[-1] - stamps[settle]) / (len(stamps) - 1 - settle)
+    gaps = np.diff(np.asarray(stamps[settle:]))
+    w = np.asarray(waits[settle + 1:]) if len(waits) > settle + 1 else np.zeros(1)
     if world > 1:
         t = torch.tensor([steady], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -623,6 +633,10 @@ def train_e2e(wl_key, device, iterations=140, settle=40, workers=8, rank=0, worl
     return dict(
         value=round(world * wl["batch"] / steady, 3), unit="crops/s", ms_per_iteration=round(steady * 1e3, 3),
         iterations=iterations, steady_from_iteration=settle, seconds_total=round(total, 2), ranks=world,
+        iteration_ms_p95=round(float(np.percentile(gaps, 95)) * 1e3, 2), iteration_ms_max=round(float(gaps.max()) * 1e3, 2),
+        # the main thread's wait for the loader's next batch + the H2D enqueue, per iteration (rank 0)
+        loader_wait_ms=dict(mean=round(float(w.mean()) * 1e3, 3), p95=round(float(np.percentile(w, 95)) * 1e3, 3),
+                            max=round(float(w.max()) * 1e3, 3)),
         loader_procs=policy["loader_procs"], loader_procs_note="per rank",
         pair_sampler="device (clx_sample_pairs)" if policy["device_pairs"] else "np.random in the loader processes (reference stream)",
         loader_policy=policy["why"],

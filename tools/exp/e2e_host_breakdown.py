@@ -17,6 +17,22 @@ from cellulus_amd import train as T  # noqa: E402
 from cellulus_amd.configs import ExperimentConfig  # noqa: E402
 from cellulus_amd.utils import zarr_io  # noqa: E402
 
+# what ran in this process before train(): bench.py's CPU legs change the loaders' environment (CLX_HB_PRE=sklearn|oracle)
+pre = os.environ.get("CLX_HB_PRE", "")
+if "sklearn" in pre:
+    from sklearn.cluster import MeanShift
+
+    MeanShift(bandwidth=15.0, cluster_all=False).fit(np.random.rand(2000, 2) * 200).predict(np.random.rand(50000, 2) * 200)
+if "oracle" in pre:
+    from bench_infer import synthetic_embeddings
+    from oracle import infer_oracle as IO
+
+    mean_, std_ = synthetic_embeddings((512, 512), spacing=48, radius=12, noise=0.3, seed=1)
+    IO.mean_shift_segmentation(mean_.copy(), std_, 15.0, 70, 0.1, IO.threshold_otsu(std_), None)
+if "threads" in pre:
+    torch.set_num_threads(32)
+    a = torch.randn(2048, 2048)
+    (a @ a).sum()
 workers = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 iterations = int(sys.argv[2]) if len(sys.argv) > 2 else 140
 wl = bench.WORKLOADS["train2d"]
@@ -69,7 +85,7 @@ s = 40
 it = np.diff(acc["stamp"][s:])
 st = np.array(acc["stage"][s + 1:len(it) + s + 1])
 sp = np.array(acc["step"][s + 1:])
-print(f"workers {workers}: iteration {it.mean() * 1e3:.2f} ms (p95 {np.percentile(it, 95) * 1e3:.2f}, max {it.max() * 1e3:.2f}) | "
+print(f"pre [{pre}] workers {workers}: iteration {it.mean() * 1e3:.2f} ms (p95 {np.percentile(it, 95) * 1e3:.2f}, max {it.max() * 1e3:.2f}) | "
       f"host in train_iteration {sp.mean() * 1e3:.2f} ms | in _stage (next batch + H2D enqueue) {st.mean() * 1e3:.2f} ms "
       f"(p95 {np.percentile(st, 95) * 1e3:.2f}, max {st.max() * 1e3:.2f}) | "
       f"rest of the loop (print, logger) {(it.mean() - sp.mean() - st.mean()) * 1e3:.2f} ms | host cores {os.cpu_count()}")
