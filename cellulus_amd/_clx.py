@@ -247,6 +247,17 @@ def zero_many(*tensors):
     call("clx_zero_many", ptrs, sizes, len(ts), stream_ptr(ts[0].device))
 
 
+def zeros(shape, dtype, device):
+    """torch.zeros on a HIP device without a torch fill kernel: an uninitialised tensor + clx_zero_many."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if t.is_cuda and t.numel() > 0 and t.element_size() % 4 == 0:
+        with torch.cuda.device(t.device):
+            zero_many(t)
+    else:
+        t.zero_()
+    return t
+
+
 def require_device(t, name="tensor"):
     if not t.is_cuda:
         raise ClxError(

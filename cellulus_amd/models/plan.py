@@ -329,7 +329,7 @@ class UNetPlan:
         t = self.topo
         for name, (shape, c) in t.shapes.items():
             n = self.B * shape[0] * shape[1] * shape[2]
-            self.buf[name] = torch.zeros((n, pad4(c)), dtype=torch.float32, device=self.device)
+            self.buf[name] = _clx.zeros((n, pad4(c)), torch.float32, self.device)
         # per-layer algorithm (direct implicit GEMM / Winograd) for forward, dgrad and wgrad
         self.algo = {}
         self.workspace = None
@@ -368,7 +368,7 @@ class UNetPlan:
             if sp is not None:
                 self.subpixel[info["conv0"].name] = sp
                 n = self.B * sp["zshape"][0] * sp["zshape"][1] * sp["zshape"][2]
-                self.buf[sp["zname"]] = torch.zeros((n, sp["P"] * sp["N"]), dtype=torch.float32, device=self.device)
+                self.buf[sp["zname"]] = _clx.zeros((n, sp["P"] * sp["N"]), torch.float32, self.device)
                 # the 2x2 convolution over the low-res tensor as Winograd F(4x4, 2x2)
                 sp["wino"] = 0
                 sp["fused_z"] = sp["fused_skip"] = False    # forward halves in the one-launch form (wino_fused.hip)
@@ -495,18 +495,16 @@ class UNetPlan:
             if name == "raw":
                 continue
             n = self.B * shape[0] * shape[1] * shape[2]
-            self.gbuf[name] = torch.zeros((n, pad4(c)), dtype=torch.float32, device=self.device)
+            self.gbuf[name] = _clx.zeros((n, pad4(c)), torch.float32, self.device)
         for info in t.r_info:
             layer = info["conv0"]
             n = self.B * layer.in_shape[0] * layer.in_shape[1] * layer.in_shape[2]
             sp = self.subpixel.get(layer.name)
             if sp is None:
-                self.gbuf["cat%d" % info["level"]] = torch.zeros(
-                    (n, layer.cin_pad), dtype=torch.float32, device=self.device)
+                self.gbuf["cat%d" % info["level"]] = _clx.zeros((n, layer.cin_pad), torch.float32, self.device)
             else:
-                self.gbuf["dskip%d" % info["level"]] = torch.zeros(
-                    (n, sp["C0p"]), dtype=torch.float32, device=self.device)
-                self.gbuf[sp["zname"]] = torch.zeros_like(self.buf[sp["zname"]])
+                self.gbuf["dskip%d" % info["level"]] = _clx.zeros((n, sp["C0p"]), torch.float32, self.device)
+                self.gbuf[sp["zname"]] = _clx.zeros(tuple(self.buf[sp["zname"]].shape), torch.float32, self.device)
                 sp["wp_skip_dgrad"] = torch.empty(sp["C0p"] * (36 * layer.kernel[0] if sp["wino_skip_dgrad"] else layer.taps)
                                                   * sp["N"], dtype=torch.float32,
                                                   device=self.device)
@@ -538,8 +536,7 @@ class UNetPlan:
                     continue
                 if layer.relu and layer.param_index > 0 and pad4(layer.cout) % 32 == 0:
                     n = self.B * layer.out_shape[0] * layer.out_shape[1] * layer.out_shape[2]
-                    self.gate[layer.out] = torch.zeros((n, pad4(layer.cout) // 32), dtype=torch.int32,
-                                                       device=self.device)
+                    self.gate[layer.out] = _clx.zeros((n, pad4(layer.cout) // 32), torch.int32, self.device)
         # F(4x4, 3x3[x3]) layers whose weight AND data gradient are Winograd: the data gradient in its ADJOINT form,
         # dX = sum over tiles of B [U^T (A dY A^T)] B^T — its operand A dY A^T is what the weight gradient has just left
         # in the workspace, so dY is transformed once and the (K-1)-padded input transform of dY is never written
@@ -595,11 +592,11 @@ class UNetPlan:
         for name, sp in self.subpixel.items():
             sp_off[name] = (total, total + sp["_dw_skip_n"])
             total += sp["_dw_skip_n"] + sp["_dw_z_n"]
-        self.dwpack = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.dwpack = _clx.zeros(total, torch.float32, self.device)
         if self.deterministic:
             lib = _clx.load()
             width = max(pad4(layer.cout) for layer in t.convs)
-            self._det_turns = torch.zeros(1 << 20, dtype=torch.int32, device=self.device)     # 4 MB of turn counters
+            self._det_turns = _clx.zeros(1 << 20, torch.int32, self.device)     # 4 MB of turn counters
             self._det_colsum = torch.empty(int(lib.clx_colsum_scratch_bytes(width)) // 4, dtype=torch.float32,
                                            device=self.device)
         for name, sp in self.subpixel.items():
@@ -1016,7 +1013,7 @@ class UNetPlan:
             return
         need = int(_clx.load().clx_conv_wgrad_turns_bytes(ctypes.byref(d)))
         if need > self._det_turns.numel() * 4:
-            self._det_turns = torch.zeros(need // 4 + 1, dtype=torch.int32, device=self.device)
+            self._det_turns = _clx.zeros(need // 4 + 1, torch.int32, self.device)
         d.det_turns = self._det_turns.data_ptr()
         _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), ld_dy, _clx.ptr(dwp), None, st)
         if gb is not None:

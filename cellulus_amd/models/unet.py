@@ -124,8 +124,8 @@ class _HeadFunction(torch.autograd.Function):
         Cp, Fp, Dp = pad4(C), pad4(F), pad4(Dout)
         xp = torch.empty((B * n, Cp), dtype=torch.float32, device=dev)
         _clx.call("clx_planar_to_pixel", _clx.ptr(x.contiguous()), _clx.ptr(xp), B, C, n, Cp, st)
-        h0 = torch.zeros((B * n, Fp), dtype=torch.float32, device=dev)
-        h1 = torch.zeros((B * n, Dp), dtype=torch.float32, device=dev)
+        h0 = _clx.zeros((B * n, Fp), torch.float32, dev)
+        h1 = _clx.zeros((B * n, Dp), torch.float32, dev)
         packs = []
         for w, cin, cin_p, cout, cout_p, src, dst, bias, relu in (
                 (w0, C, Cp, F, Fp, xp, h0, b0, 1), (w1, F, Fp, Dout, Dp, h0, h1, b1, 0)):
@@ -156,14 +156,14 @@ class _HeadFunction(torch.autograd.Function):
         Cp, Fp, Dp = pad4(C), pad4(F), pad4(Dout)
         dh1 = torch.empty((B * n, Dp), dtype=torch.float32, device=dev)
         _clx.call("clx_planar_to_pixel", _clx.ptr(dout.contiguous()), _clx.ptr(dh1), B, Dout, n, Dp, st)
-        dh0 = torch.zeros((B * n, Fp), dtype=torch.float32, device=dev)
-        dxp = torch.zeros((B * n, Cp), dtype=torch.float32, device=dev)
+        dh0 = _clx.zeros((B * n, Fp), torch.float32, dev)
+        dxp = _clx.zeros((B * n, Cp), torch.float32, dev)
         grads = {}
         for tag, w, cin, cin_p, cout, cout_p, src, dy, gate, dsrc, has_b in (
                 ("1", w1, F, Fp, Dout, Dp, h0, dh1, h0, dh0, has_b1),
                 ("0", w0, C, Cp, F, Fp, xp, dh0, None, dxp, has_b0)):
-            dwp = torch.zeros(cout_p * cin_p, dtype=torch.float32, device=dev)
-            gb = torch.zeros(cout, dtype=torch.float32, device=dev) if has_b else None
+            dwp = _clx.zeros(cout_p * cin_p, torch.float32, dev)
+            gb = _clx.zeros(cout, torch.float32, dev) if has_b else None
             d = _pointwise_desc(src, B, shape3, cin_p, cout_p)
             _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), cout_p, _clx.ptr(dwp), _clx.ptr(gb), st)
             gw = torch.empty_like(w)
@@ -268,7 +268,7 @@ class UNetModel(nn.Module):  # type: ignore
                 p.data = flat[off:off + n].view(p.shape)
                 off += n
             self._flat = flat
-            self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+            self._flat_grad = _clx.zeros(total, torch.float32, dev)
         return self._flat, self._flat_grad
 
     def _grad_views(self):

@@ -40,8 +40,8 @@ class Adam(Optimizer):
         """exp_avg / exp_avg_sq live in flat buffers (one per group) with per-parameter views."""
         total = sum(p.numel() for p in params)
         dev = params[0].device
-        m = torch.zeros(total, dtype=torch.float32, device=dev)
-        v = torch.zeros(total, dtype=torch.float32, device=dev)
+        m = _clx.zeros(total, torch.float32, dev)
+        v = _clx.zeros(total, torch.float32, dev)
         off = 0
         for p in params:
             n = p.numel()
