@@ -1032,3 +1032,25 @@ def test_rows_extent_equals_numpy_min_max(n, nd, device):
     _clx.call("clx_rows_extent_f64", _clx.ptr(src), n, nd, _clx.ptr(ext), _clx.stream_ptr(device))
     got = ext[:2 * nd].cpu().numpy().reshape(2, nd)
     np.testing.assert_array_equal(got, np.stack([src_np.min(axis=0), src_np.max(axis=0)]))
+
+
+@pytest.mark.parametrize("lo,hi", [(0.0, 1.0), (-3.5, 7.25), (1e6, 1e6 + 1e-3), (-1e-9, 1e-9), (5.0, 5.0 + 2.0 ** -30)])
+def test_histogram_bins_equal_numpy_on_and_next_to_the_edges(lo, hi, device):
+    """clx_histogram_f64 / _f32 guess a value's bin by one multiplication and look at the edges only near a boundary:
+    values exactly on every edge, one ulp to either side of it, and a range that is tiny against its offset (where an edge's
+    own rounding is many bins' worth of 1e-6) must land where np.histogram puts them."""
+    rng = np.random.default_rng(7)
+    edges = np.linspace(lo, hi, 257)
+    vals = np.concatenate([edges, np.nextafter(edges, -np.inf), np.nextafter(edges, np.inf),
+                           rng.uniform(lo, hi, size=200001), np.full(33, lo), np.full(33, hi)])
+    vals = np.clip(vals, lo, hi)
+    rng.shuffle(vals)
+    want, want_edges = np.histogram(vals, bins=256)
+    got, got_edges = histogram_on_device(torch.from_numpy(vals).to(device))
+    np.testing.assert_array_equal(got_edges, want_edges)
+    np.testing.assert_array_equal(got, want)
+    v32 = vals.astype(np.float32)
+    if np.unique(v32).size > 300:                       # (the float32 form: the widened floats, their own range)
+        want32, _ = np.histogram(v32.astype(np.float64), bins=256)
+        got32, _ = histogram_on_device(torch.from_numpy(v32).to(device))
+        np.testing.assert_array_equal(got32, want32)
