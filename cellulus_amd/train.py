@@ -53,7 +53,8 @@ def loader_policy(world, num_workers):
       it is unset, i.e. one node).  The loader processes are capped to
       that share minus one (the rank's own Python), and the pair coordinates are drawn on the device by
       default (``CLX_DEVICE_PAIRS=0`` keeps the np.random stream): at 8 ranks x 8 crops x 5 steps/s the
-      np.random stream alone needs 8 cores PER RANK, the device sampler 2.5 for crops + augmentation."""
+      np.random stream alone needed 8 cores PER RANK when numpy drew it (about 1 since libclx restates it), the
+      device sampler 2.5 for crops + augmentation."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
