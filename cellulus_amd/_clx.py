@@ -112,6 +112,10 @@ PROTOTYPES = {
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
+    "clx_planes_bytes": (c_size_t, [_LL, _I]),
+    "clx_split_planes": (_I, [_P, _LL, _LL, _I, _P, _P]),
+    "clx_join_planes": (_I, [_P, _LL, _I, _P, _LL, _P]),
+    "clx_gemm_planes": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P]),
     "clx_conv_fused_applicable": (_I, [POINTER(ClxConvDesc)]),
     "clx_conv_fused_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc)]),
     "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),

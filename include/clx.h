@@ -50,7 +50,10 @@ enum clx_profile_kind {
   CLX_PROF_IGEMM_WIDE = 0,   /* conv_igemm_kernel<128,128> */
   CLX_PROF_IGEMM_NARROW = 1, /* conv_igemm_kernel<128,64>  */
   CLX_PROF_WGRAD = 2,        /* conv_wgrad_kernel<...>     */
-  /* (3, 4, 5: the opt-in f32x3bf16 GEMMs and the transposed-operand GEMM of rounds 2-4, removed in round 5) */
+  CLX_PROF_GEMM_SP = 3,      /* gemm_sp_kernel: split-precision products (clx_conv_desc.precision = CLX_PREC_F32X3BF16;
+                                FLOPs = the f32-equivalent 2*M*N*K) */
+  CLX_PROF_WGRAD_SP = 4,     /* wgrad_sp_kernel: the weight gradient of the same precision */
+  CLX_PROF_SPLIT_PLANES = 5, /* sp_split_kernel (HBM-bound: no FLOPs) */
   CLX_PROF_CHAIN64 = 6,      /* chain64_fwd / _bwd kernels (fused pairs of 64-channel 1x1 layers) */
   /* the HBM-bound kernels of detect / segment (no FLOPs: total_flops of these kinds is 0; the caller prices them by bytes) */
   CLX_PROF_MS_PREPARE = 7,   /* ms_prepare_kernel */
@@ -209,6 +212,28 @@ enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
  * need for descriptor `d` with algo = CLX_ALGO_WINOGRAD / _WINOGRAD4; 0 if Winograd does not apply to
  * the geometry (the caller must then use CLX_ALGO_DIRECT). */
 size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass);
+
+/* ---- Split-precision operands ("P3 planes", round 6) ----
+ * The precision CLX_PREC_F32X3BF16 of clx_conv_desc computes float32 products on the bf16 matrix cores: every operand
+ * element is split EXACTLY into three bfloat16 pieces x = h0 + h1 + h2 (truncation, 8 + 8 + 8 significand bits) and
+ * the six products a_i b_j, i + j <= 2, are accumulated in float32 (v_mfma_f32_32x32x16_bf16) — the dropped terms are
+ * <= 2^-24 relative, one float32 rounding.  The pieces are made ONCE where a tensor is produced, in the layout the
+ * matrix core consumes ("P3"): an [R][K] operand (K % 16 == 0) as 1-KB fragments, fragment (rb, ks, p) = piece p of
+ * rows 32 rb .. 32 rb + 31, k = 16 ks .. 16 ks + 15 at byte ((rb * K/16 + ks) * 3 + p) * 1024; inside a fragment the 16 bytes
+ * at 512 h + 16 r hold x_p[32 rb + r][16 ks + 8 h .. + 7].  Rows up to the next multiple of 32 exist and are ZERO.  6 bytes
+ * per element.  (No reference counterpart: the reference's torch.nn.Conv{2,3}d keep float32 operands,
+ * cellulus/models/unet.py:24-63.) */
+/* bytes of the P3 planes of an [rows][K] operand (0 if K % 16 != 0) */
+size_t clx_planes_bytes(long long rows, int K);
+/* planes <- split(x[rows][ld], columns [0, K)).  x and planes 16-byte aligned, ld % 4 == 0, K % 16 == 0. */
+int clx_split_planes(const float* x, long long ld, long long rows, int K, void* planes, clx_stream stream);
+/* x[rows][ld] <- h0 + h1 + h2 of the planes (exact; tests and diagnostics) */
+int clx_join_planes(const void* planes, long long rows, int K, float* x, long long ld, clx_stream stream);
+/* out[m][n] = act(sum_k A[m][k] B[n][k] + bias[n]) from the P3 planes of A ([M][K]) and B ([N][K]): N % 128 == 0,
+ * K % 64 == 0, ld_out % 4 == 0.  The plain-product form of clx_conv_fwd with precision = CLX_PREC_F32X3BF16 (which
+ * splits / reuses planes by itself); exported for tests and for callers that keep planes of their own. */
+int clx_gemm_planes(const void* a_planes, const void* b_planes, int M, int N, int K, const float* bias, int relu,
+                    float* out, int ld_out, clx_stream stream);
 
 /* out = act(conv(in) + bias).  f32 MFMA implicit GEMM (M = output pixels,
  * N = output channels, K = taps x channels). Also used for the data gradient
