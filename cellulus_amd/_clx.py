@@ -87,6 +87,9 @@ class ClxConvDesc(Structure):
         ("ld_pool", c_int),
         ("tile_list", c_void_p),
         ("tile_count", c_int),
+        ("precision", c_int),
+        ("wplanes", c_void_p),
+        ("aplanes", c_void_p),
     ]
 
 
@@ -112,10 +115,12 @@ PROTOTYPES = {
     "clx_unpack_wgrad": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
+    "clx_conv_vcache_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
     "clx_planes_bytes": (c_size_t, [_LL, _I]),
     "clx_split_planes": (_I, [_P, _LL, _LL, _I, _P, _P]),
     "clx_join_planes": (_I, [_P, _LL, _I, _P, _LL, _P]),
     "clx_gemm_planes": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "clx_wgrad_planes": (_I, [_P, _P, _LL, _I, _I, _P, _I, _P]),
     "clx_conv_fused_applicable": (_I, [POINTER(ClxConvDesc)]),
     "clx_conv_fused_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc)]),
     "clx_planar_to_pixel": (_I, [_P, _P, _I, _I, _LL, _I, _P]),

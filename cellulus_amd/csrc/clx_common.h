@@ -69,6 +69,16 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
                      long long bs_out, hipStream_t st);
 int clx_wgrad_launch(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,
                      int batch, long long bs_x, long long bs_dy, long long bs_out, hipStream_t st);
+// split-precision products (gemm_sp.hip): true if the plain product `d` describes — one source read pixel by pixel, 1x1x1
+// kernel — is one gemm_sp_kernel covers (precision switch set, N % 128 == 0, K % 64 == 0, K >= 128) and has its weight planes
+bool clx_sp_applicable(const clx_conv_desc* d);
+// `batch` products out[b] = epilogue(A[b] B[b]^T) from P3 planes (strides: bytes, bytes, floats); the epilogue fields of
+// `ep` (out, ld_out, bias, relu, accumulate, mask, mask_bits, gate_out and their strides) are honoured
+int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long rows_a, int batch, long long bs_a, long long bs_b,
+                  long long bs_out, const clx_conv_desc* ep, hipStream_t st);
+// dW[b][n][c] += sum_rows dY[b][row][n] x[b][row][c] from planes (strides: bytes, bytes, floats); N, C multiples of 128
+int clx_sp_wgrad_launch(const void* dy_planes, const void* x_planes, long long rows, int N, int C, int batch, long long bs_dy,
+                        long long bs_x, long long bs_out, float* dw, int ld_dw, hipStream_t st);
 // Winograd F(2x2, 3x3) / F(4x4, 3x3) path (wino.hip)
 int clx_wino_fwd(const clx_conv_desc* d, hipStream_t st);
 int clx_wino_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpack, float* dbias,

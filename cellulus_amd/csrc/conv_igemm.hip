@@ -687,6 +687,15 @@ extern "C" int clx_conv_fwd(const clx_conv_desc* d, clx_stream stream) {
 // wpack + b*bs_w and writes out + b*bs_out (mask is not batched).  Used by the Winograd path.
 int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long long bs_w,
                      long long bs_out, hipStream_t st) {
+  // opt-in precision: a 1x1 layer as split pass + product from planes (the Winograd paths call clx_sp_launch themselves,
+  // with planes their transforms wrote)
+  if (batch == 1 && d->aplanes != nullptr && clx_sp_applicable(d)) {
+    const clx_src& S = d->src[0];
+    const long long M = (long long)d->B * d->ID * d->IH * d->IW;
+    int rc = clx_split_planes(S.ptr, S.ld, M, S.C, d->aplanes, (clx_stream)st);
+    if (rc) return rc;
+    return clx_sp_launch(d->aplanes, d->wplanes, (int)M, d->N, S.C, M, 1, 0, 0, 0, d, st);
+  }
   ConvP p;
   fill_params(d, p);
   p.zeros = zero_buffer();

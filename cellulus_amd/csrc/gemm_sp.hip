@@ -11,7 +11,7 @@
 // split happens ONCE where a tensor is produced (clx_split_planes, the Winograd transforms, the weight packing), into
 // the "P3" plane format below, and the K loop is nothing but LDS-DMA (global_load_lds_dwordx4), ds_read_b128 and MFMAs.
 //
-// P3 format of an [R rows][K] operand (K % 16 == 0; rows padded to a multiple of 32, the padding rows ZERO):
+// P3 format of an [R rows][K] operand (K % 16 == 0; rows padded to a multiple of 64, the padding rows ZERO):
 //   1-KB fragments in the MFMA's operand order — fragment (rb, ks, p) = plane p of rows 32 rb .. + 31, k = 16 ks .. + 15,
 //   at byte ((rb * K/16 + ks) * 3 + p) * 1024; inside it lane l = 32 h + r of the wavefront owns the 16 bytes
 //   x_p[32 rb + r][16 ks + 8 h .. + 7].  One global_load_lds_dwordx4 per fragment moves 1 KB of CONTIGUOUS memory
@@ -20,7 +20,7 @@
 //
 // gemm_sp_kernel: out[m][n] = epilogue( sum_k A[m][k] B[n][k] ), 256 x 128 tile, 512 threads = 8 waves (4 x 2) of
 // 64 x 64, K walked in 16-deep steps through a ring of FOUR 36-KB stages (three steps in flight, one barrier per step,
-// counted vmcnt).  Two-level summation as in conv_igemm.hip — fresh accumulators every 64 products, added into a second
+// counted vmcnt; operand fragments double-buffered in registers).  Two-level summation as in conv_igemm.hip — fresh accumulators every 64 products, added into a second
 // set — with the sign of A alternating between periods: the matrix core adds the 16 products of an instruction to the
 // accumulator with a floor-like truncation (a bias of ~1e-7 of the output's rms with the same sign everywhere, which
 // is common-mode over the 5e5 pixels a weight gradient sums over; docs/HISTORY.md 6b), and -(A B) carries the same
@@ -29,16 +29,23 @@
 // Replaces nn.Conv{2,3}d 1x1 (+ReLU) and the transform-domain products of the 3x3 layers, forward and data gradient
 // (cellulus/models/unet.py:24-63, cellulus/train.py:178) when clx_conv_desc.precision = CLX_PREC_F32X3BF16.
 #include "clx_common.h"
+#include "sp_planes.h"
 #include <stdlib.h>
+#include <type_traits>
+
+// timing-only ablations (tools/build_variant.sh sp<k> gemm_sp.hip -DSP_ABL=<k>; results are wrong): 1 = no loads in the K
+// loop, 2 = no barriers / waits, 3 = fragments read once, 4 = no epilogue
+#ifndef SP_ABL
+#define SP_ABL 0
+#endif
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-constexpr int FRAG = 1024;                 // bytes of one fragment
-constexpr int KSTEP = 3 * FRAG;            // the three planes of one (row block, k step)
+using sp::u32x2;
+using sp::u32x4;
+using sp::FRAG;
+using sp::KSTEP;
 constexpr int SP_BM = 256, SP_BN = 128;
 constexpr int A_FRAGS = SP_BM / 32 * 3;    // 24 fragments of A per stage
 constexpr int B_FRAGS = SP_BN / 32 * 3;    // 12 of B
@@ -51,28 +58,10 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-// x = h0 + h1 + h2 exactly, each h_i with <= 8 significant bits (the top half of an f32 word); four elements at a time,
-// packed two per word (element 0 in the low half)
-__device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
-  unsigned int u[4], a1[4], a2[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    u[e] = __float_as_uint(v[e]);
-    const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
-    a1[e] = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(a1[e] & 0xffff0000u);
-    a2[e] = __float_as_uint(r2);
-  }
-  p0[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
-  p0[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
-  p1[0] = __builtin_amdgcn_perm(a1[1], a1[0], 0x07060302u);
-  p1[1] = __builtin_amdgcn_perm(a1[3], a1[2], 0x07060302u);
-  p2[0] = __builtin_amdgcn_perm(a2[1], a2[0], 0x07060302u);
-  p2[1] = __builtin_amdgcn_perm(a2[3], a2[2], 0x07060302u);
-}
+using sp::split4;
 
 // f32 [rows][ld] -> P3 planes of its columns [0, K).  A wavefront writes whole fragments (three contiguous 1-KB
-// stores); rows in [rows, 32 ceil(rows / 32)) are written as zeros.
+// stores); rows in [rows, 64 ceil(rows / 64)) are written as zeros.
 __global__ __launch_bounds__(256) void sp_split_kernel(const float* __restrict__ x, long long ld, long long rows, int ksteps,
                                                        char* __restrict__ out, long long nfrag) {
   const int lane = threadIdx.x & 63;
@@ -124,12 +113,25 @@ __global__ __launch_bounds__(256) void sp_join_kernel(const char* __restrict__ i
   }
 }
 
+// the padding rows [rows, 64 ceil(rows / 64)) of `batch` plane sets
+__global__ __launch_bounds__(256) void sp_zero_tail_kernel(char* __restrict__ planes, long long bs, long long rows, int ksteps) {
+  const long long rb0 = rows >> 5, rb1 = (rows + 63) / 64 * 2;          // row blocks that hold padding
+  const int per_rb = ksteps * 6 * 32;                                   // 16-byte pieces of one row block
+  const long long total = (rb1 - rb0) * per_rb;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long rb = rb0 + i / per_rb;
+    const int k = (int)(i % per_rb), r = k & 31, q = k >> 5;            // q = (k step, piece, half)
+    if (rb * 32 + r >= rows)
+      *reinterpret_cast<u32x4*>(planes + blockIdx.y * bs + rb * ksteps * (long long)KSTEP + (long long)q * 512 + r * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
 struct SpP {
-  const char* A;                      // P3 planes of the [M][K] operand (rows = output pixels)
-  const char* B;                      // P3 planes of the [N][K] operand (rows = output channels)
-  long long bs_a, bs_b, bs_out;       // batch strides (gridDim.y problems): bytes, bytes, floats
+  const char* A;                      // forward: P3 planes of the [M][K] operand (rows = output pixels).  Weight gradient: of dY [pixels][N]
+  const char* B;                      // forward: planes of the [N][K] operand (rows = output channels).  Weight gradient: of x [pixels][C]
+  long long bs_a, bs_b, bs_out;       // batch strides (problems of one launch): bytes, bytes, floats
   float* out;
-  int M, N, ksteps;                   // ksteps = K / 16, a multiple of 4
+  int M, N, ksteps;                   // forward: ksteps = K / 16, a multiple of 4.  Weight gradient: M = N of dY (rows of dW), N = C
   int rb_a;                           // 32-row blocks A holds (row blocks past it are clamped: their results are never stored)
   const float* bias;
   const float* mask;
@@ -138,50 +140,102 @@ struct SpP {
   const float* zeros;
   int relu, accumulate, ld_out, ld_mask, ld_mask_bits, ld_gate;
   int nbm, nbn;
+  // weight gradient: the contraction runs over pixel steps of 16; a block takes `steps_per_slice` of them
+  unsigned int stride_a, stride_b;    // bytes of one 32-pixel row block of the dY / x planes
+  int total_steps, steps_per_slice, nslices;
 };
 
+// MODE 0: out[m][n] = epilogue( sum_k A[m][k] B[n][k] )             (forward / data gradient)
+// MODE 1: out[n][c] += sum_pixels dY[pixel][n] x[pixel][c]            (weight gradient; float atomics, split over pixel slices)
+// Both operands of MODE 1 are pixel-major, and the MFMA wants eight consecutive k (= pixels) of one channel per lane: the
+// LDS image of a 16-pixel step is [pixel][32 channels] per 32-channel block and piece (1 KB: one LDS-DMA instruction whose
+// lanes gather 16-byte pieces — 256-byte runs of memory), and a fragment is two ds_read_b64_tr_b16, the transposing LDS read
+// of gfx950: a 16-lane group reads 4 pixels x 16 channels and every lane receives the 4 pixels of ITS channel.  4 pixels x
+// 64 bytes = one 256-byte bank row per 32-lane half: conflict-free.
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
   __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];       // 144 KB; the C tile (132 KB) in the epilogue
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w >> 1, wn = w & 1;
-  const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
-  const int tile_n = v % p.nbn, tile_m = v / p.nbn;
+  int tile_m, tile_n, batch, step0 = 0, ksteps;
+  if constexpr (MODE == 0) {
+    const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+    tile_n = v % p.nbn; tile_m = v / p.nbn;
+    batch = blockIdx.y;
+    ksteps = p.ksteps;
+  } else {
+    const int T = p.nbm * p.nbn;
+    const int u = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_batch = T * p.nslices;
+    batch = u / per_batch;
+    const int v = u % per_batch;
+    const int slice = v / T, t = v % T;
+    tile_n = t % p.nbn; tile_m = t / p.nbn;
+    step0 = slice * p.steps_per_slice;
+    ksteps = p.total_steps - step0 < p.steps_per_slice ? p.total_steps - step0 : p.steps_per_slice;
+  }
   const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
-  const int ksteps = p.ksteps;
 
   // ---- this wave's share of a stage's 36 fragments: f = w + 8 q, q = 0..3, and a fifth one, 32 + (w & 3), for waves 0-3
   // in even steps and waves 4-7 in odd steps: any two consecutive steps are NINE loads for every wave, so the counted
   // wait in front of a step is the same instruction for all of them.  A fragment's address is wave-uniform up to
-  // 16 * lane: scalar bases, one 32-bit vector offset.
-  const char* const Ab = p.A + blockIdx.y * p.bs_a;
-  const char* const Bb = p.B + blockIdx.y * p.bs_b;
-  auto frag_base = [&](int f) -> const char* {
-    if (f < A_FRAGS) {
-      int rb = tile_m * (SP_BM / 32) + f / 3;
-      if (rb > p.rb_a - 1) rb = p.rb_a - 1;
-      return Ab + ((long long)rb * ksteps * 3 + f % 3) * FRAG;
+  // a lane term: scalar bases, one 32-bit vector offset per operand.
+  const char* const Ab = p.A + batch * p.bs_a;
+  const char* const Bb = p.B + batch * p.bs_b;
+  auto frag_base = [&](int f) __attribute__((always_inline)) -> const char* {
+    if constexpr (MODE == 0) {
+      if (f < A_FRAGS) {
+        int rb = tile_m * (SP_BM / 32) + f / 3;
+        if (rb > p.rb_a - 1) rb = p.rb_a - 1;
+        return Ab + ((long long)rb * ksteps * 3 + f % 3) * FRAG;
+      }
+      const int g = f - A_FRAGS;
+      const int nb = tile_n * (SP_BN / 32) + g / 3;
+      return Bb + ((long long)nb * ksteps * 3 + g % 3) * FRAG;
+    } else {
+      // 32-channel block cb of an operand = its k steps 2 cb, 2 cb + 1 (both halves): the lane term picks the octet
+      if (f < A_FRAGS) {
+        int cb = tile_m * (SP_BM / 32) + f / 3;
+        if (cb > p.M / 32 - 1) cb = p.M / 32 - 1;          // (rows of dW past N: computed, never added)
+        return Ab + ((long long)(2 * cb) * 3 + f % 3) * FRAG;
+      }
+      const int g = f - A_FRAGS;
+      const int cb = tile_n * (SP_BN / 32) + g / 3;
+      return Bb + ((long long)(2 * cb) * 3 + g % 3) * FRAG;
     }
-    const int g = f - A_FRAGS;
-    const int nb = tile_n * (SP_BN / 32) + g / 3;
-    return Bb + ((long long)nb * ksteps * 3 + g % 3) * FRAG;
   };
   const char* gsrc[5];
 #pragma unroll
   for (int q = 0; q < 4; ++q) gsrc[q] = frag_base(w + 8 * q);
   gsrc[4] = frag_base(32 + (w & 3));
-  const unsigned int lane16 = (unsigned int)lane * 16u;
+  // MODE 0: lane l owns the 16 bytes at 16 l of its fragment.  MODE 1: lane l fetches the piece (pixel l >> 2, octet l & 3 of
+  // the 32-channel block) = k step (l >> 1) & 1, half l & 1, row l >> 2 of the row block's half that step t covers
+  const unsigned int lane16 = MODE == 0 ? (unsigned int)lane * 16u
+                                        : (unsigned int)(((lane >> 1) & 1) * KSTEP + (lane & 1) * 512 + (lane >> 2) * 16);
   const bool low_half = w < 4;
-  auto issue = [&](int t, int slot, bool odd) {
-    const unsigned int voff = lane16 + (unsigned int)t * KSTEP;        // (K * 192 bytes per row block: far below 4 GB)
+  auto issue = [&](int t, int slot, bool odd) __attribute__((always_inline)) {
+    if (SP_ABL == 1 && t > 2) return;
     char* const dst = smem + slot * STAGE;
+    if constexpr (MODE == 0) {
+      const unsigned int voff = lane16 + (unsigned int)t * KSTEP;        // (K * 192 bytes per row block: far below 4 GB)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) glds16(gsrc[q] + (size_t)voff, dst + (w + 8 * q) * FRAG);
-    if (low_half != odd) glds16(gsrc[4] + (size_t)voff, dst + (32 + (w & 3)) * FRAG);
+      for (int q = 0; q < 4; ++q) glds16(gsrc[q] + (size_t)voff, dst + (w + 8 * q) * FRAG);
+      if (low_half != odd) glds16(gsrc[4] + (size_t)voff, dst + (32 + (w & 3)) * FRAG);
+    } else {
+      const unsigned int ts = (unsigned int)(step0 + t);
+      const unsigned int va = lane16 + (ts >> 1) * p.stride_a + (ts & 1u) * 256u;
+      const unsigned int vb = lane16 + (ts >> 1) * p.stride_b + (ts & 1u) * 256u;
+      // fragments w, w + 8, w + 16 are dY's (f < 24), w + 24 and the fifth (32 + ...) are x's
+#pragma unroll
+      for (int q = 0; q < 3; ++q) glds16(gsrc[q] + (size_t)va, dst + (w + 8 * q) * FRAG);
+      glds16(gsrc[3] + (size_t)vb, dst + (w + 24) * FRAG);
+      if (low_half != odd) glds16(gsrc[4] + (size_t)vb, dst + (32 + (w & 3)) * FRAG);
+    }
   };
   // own loads of the step about to be multiplied have landed when at most the two steps behind it are in flight
-  auto wait_two = [&]() { asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); };
-  auto wait_one = [&]() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
+  auto wait_two = [&]() __attribute__((always_inline)) { if (SP_ABL != 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); };
+  auto wait_one = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); };
 
   f32x16 acc[2][2], tot[2][2];
 #pragma unroll
@@ -199,123 +253,206 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
     bias_v[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
   }
 
-  const char* const afr = smem + (wm * 2 * 3) * FRAG + lane * 16;
-  const char* const bfr = smem + (A_FRAGS + wn * 2 * 3) * FRAG + lane * 16;
+  // LDS addresses of this wave's fragments per ring slot: eight registers, made opaque so that the compiler keeps exactly
+  // these and reaches the pieces by instruction offsets (left to itself it materialised — and spilled — one address per
+  // read: the slots lie beyond the 64-KB offset field)
+  unsigned int la[RING], lb[RING];
+#pragma unroll
+  for (int k = 0; k < RING; ++k) {
+    // MODE 1: the transposing read — lane 4 q + p of a 16-lane group addresses pixel q, channels 4 p .. 4 p + 3 of the group's
+    // 16 channels; group g = lane >> 4 holds channels 16 (g & 1) .. and the k half g >> 1 (pixels 8 (g >> 1) ..)
+    const int lterm = MODE == 0 ? lane * 16
+                                : (8 * (lane >> 5) + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    la[k] = k * STAGE + (wm * 2 * 3) * FRAG + lterm;
+    lb[k] = k * STAGE + (A_FRAGS + wn * 2 * 3) * FRAG + lterm;
+    asm volatile("" : "+v"(la[k]), "+v"(lb[k]));
+  }
 
-  // one 16-deep step out of ring slot `slot`; NEG: the A fragments negated
-  auto step = [&](int slot, auto neg_tag) {
+  // ---- the K loop.  Phase t of a wave:
+  //     wait until its own loads of step t have landed (at most the 9 loads of steps t + 1, t + 2 outstanding)
+  //     barrier      -> step t is complete in LDS, and every wave is past its reads of step t - 1: that slot is free
+  //     request step t + 3 into it, read the fragments of step t, 24 MFMAs
+  // The two waves of a SIMD run the same program between the same barriers: left alone both issue their loads (~100
+  // cycles per LDS-DMA instruction) and wait for their fragment reads at the same time, with the matrix pipe idle — a
+  // third of the kernel (205 -> 310 TFLOP/s at K = 2304 with the reads taken out).  Waves 4-7 therefore run HALF A STEP
+  // LATE: they keep the second half of a step's products for after the next barrier, so one wave of every SIMD
+  // multiplies while the other talks to memory (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  (Fragments
+  // double-buffered in registers, the textbook answer, do not fit: 128 accumulators + 96 > 256.)
+  u32x4 fa[2][3], fb[2][3];               // [tile][piece]
+  auto read_frags = [&](int slot) __attribute__((always_inline)) {
+#if SP_ABL != 3
+    const char* const as = smem + la[slot];
+    const char* const bs = smem + lb[slot];
+    auto rd = [&](const char* ptr) __attribute__((always_inline)) -> u32x4 {
+      if constexpr (MODE == 0) {
+        return *reinterpret_cast<const u32x4*>(ptr);
+      } else {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ptr));             // pixels 8 h + 0 .. 3
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ptr + 256));       // pixels 8 h + 4 .. 7
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{l2[0], l2[1], h2[0], h2[1]};
+      }
+    };
+    // (in the order the products consume them: the first MFMA needs a[0][2] and b[0][0] only)
+    fa[0][2] = rd(as + 2 * FRAG);
+    fb[0][0] = rd(bs);
+    fa[0][0] = rd(as);
+    fb[0][2] = rd(bs + 2 * FRAG);
+    fa[0][1] = rd(as + FRAG);
+    fb[0][1] = rd(bs + FRAG);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fb[1][q] = rd(bs + (3 + q) * FRAG);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fa[1][q] = rd(as + (3 + q) * FRAG);
+#endif
+  };
+#if SP_ABL == 3
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { fa[i][q] = u32x4{(unsigned)lane, 1u, 2u, 3u}; fb[i][q] = u32x4{4u, (unsigned)lane, 6u, 7u}; }
+#endif
+  // the 12 MFMAs of tile row i; NEG: the A fragments negated (in place: they are dead afterwards)
+  auto mfma_row = [&](auto i_tag, auto neg_tag) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_tag)::value;
     constexpr bool NEG = decltype(neg_tag)::value;
-    u32x4 a[2][3], b[2][3];
-    const char* const as = afr + slot * STAGE;
-    const char* const bs = bfr + slot * STAGE;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) a[0][q] = *reinterpret_cast<const u32x4*>(as + q * FRAG);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) b[0][q] = *reinterpret_cast<const u32x4*>(bs + q * FRAG);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) b[1][q] = *reinterpret_cast<const u32x4*>(bs + (3 + q) * FRAG);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) a[1][q] = *reinterpret_cast<const u32x4*>(as + (3 + q) * FRAG);
     if constexpr (NEG) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a[i][q] ^= 0x80008000u;
+      for (int q = 0; q < 3; ++q) fa[i][q] ^= 0x80008000u;
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x16 c = acc[i][j];
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][1]),
+                   a2 = __builtin_bit_cast(bf16x8, fa[i][2]);
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]),
+                   b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
+      // smallest terms first
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+      acc[i][j] = c;
+    }
+  };
+  // end of a period of four steps: the period's sums go into `tot` with the period's sign, `acc` restarts from zero.
+  // In place, spelled as instructions (conv_igemm.hip found the same: written as `tot += acc; acc = 0` the compiler starts the
+  // next period's products in a third register set).  The s_nops cover the 11 wait states an 8-pass MFMA result needs
+  // before a VALU read, which nobody inserts for an asm block.
+  auto flush = [&](auto neg_tag) __attribute__((always_inline)) {
+    constexpr bool NEG = decltype(neg_tag)::value;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        f32x16 c = acc[i][j];
-        // smallest terms first
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][2]), __builtin_bit_cast(bf16x8, b[j][0]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][0]), __builtin_bit_cast(bf16x8, b[j][2]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][1]), __builtin_bit_cast(bf16x8, b[j][1]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][1]), __builtin_bit_cast(bf16x8, b[j][0]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][0]), __builtin_bit_cast(bf16x8, b[j][1]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i][0]), __builtin_bit_cast(bf16x8, b[j][0]), c, 0, 0, 0);
-        acc[i][j] = c;
+        if constexpr (NEG) tot[i][j] -= acc[i][j];
+        else tot[i][j] += acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
       }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  // end of a period of four steps: the period's sums go into `tot` with the period's sign, `acc` restarts from zero
-  // In place, spelled as instructions (conv_igemm.hip found the same: written as `tot += acc; acc = 0` the compiler starts the
-  // next period's products in a third register set).  The MFMAs that wrote `acc` were issued at least a barrier ago; the
-  // s_nops cover the 11 wait states an 8-pass MFMA result needs before a VALU read, which nobody inserts for an asm block.
-  auto flush = [&](auto neg_tag) {
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // phase S (0..3) of the period that starts at step t0.  KIND 0: somewhere in the middle (requests step t + 3); 1 .. 4:
+  // phases 0 .. 3 of the LAST period (only its first phase has a step left to request; the waits count down).
+  // FIRST: the kernel's first period (a late wave has no half step pending in its phase 0).
+  auto phase = [&](int t0, auto s_tag, auto kind_tag, auto late_tag, auto neg_tag, auto first_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_tag)::value;
+    constexpr int KIND = decltype(kind_tag)::value;
+    constexpr bool LATE = decltype(late_tag)::value;       // waves 4-7
     constexpr bool NEG = decltype(neg_tag)::value;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7\n\ts_nop 4" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          f32x2 t = {tot[i][j][r], tot[i][j][r + 1]}, x = {acc[i][j][r], acc[i][j][r + 1]};
-          if constexpr (NEG) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\tv_mov_b64 %1, 0" : "+v"(t), "+v"(x));
-          else asm volatile("v_pk_add_f32 %0, %0, %1\n\tv_mov_b64 %1, 0" : "+v"(t), "+v"(x));
-          tot[i][j][r] = t[0]; tot[i][j][r + 1] = t[1];
-          acc[i][j][r] = x[0]; acc[i][j][r + 1] = x[1];
-        }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // a period in the middle of the K loop: every step requests the step three ahead of it into the slot the previous
-  // step has just left (all waves are past that step's reads once they have met at this step's barrier)
-  auto period_mid = [&](int t0, auto neg_tag) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      wait_two();
-      __builtin_amdgcn_s_barrier();
-      issue(t0 + s + 3, (s + 3) & 3, ((s + 3) & 1) != 0);
+    constexpr bool FIRST = decltype(first_tag)::value;
+    if constexpr (KIND <= 2) wait_two();
+    else if constexpr (KIND == 3) wait_one();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (SP_ABL != 2) __builtin_amdgcn_s_barrier();
+    if constexpr (LATE && !(FIRST && S == 0)) {
+      // the second half of the step before this one: the last step of the previous period — opposite sign — in phase 0
+      if constexpr (S == 0) { mfma_row(I1{}, std::integral_constant<bool, !NEG>{}); flush(std::integral_constant<bool, !NEG>{}); }
+      else mfma_row(I1{}, neg_tag);
       __builtin_amdgcn_sched_barrier(0);
-      step(s, neg_tag);
-      __builtin_amdgcn_sched_barrier(0);     // the step's LDS reads stay in front of the next step's barrier
     }
-    flush(neg_tag);
+    if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
+    read_frags(S);
+#ifdef SP_FENCE_READS
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    mfma_row(I0{}, neg_tag);
+    if constexpr (!LATE) {
+      mfma_row(I1{}, neg_tag);
+      if constexpr (S == 3) flush(neg_tag);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
-  // the last period: only its first step has anything left to request
-  auto period_last = [&](int t0, auto neg_tag) {
-    wait_two();
-    __builtin_amdgcn_s_barrier();
-    issue(t0 + 3, 3, true);
-    __builtin_amdgcn_sched_barrier(0);
-    step(0, neg_tag);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_two();
-    __builtin_amdgcn_s_barrier();
-    step(1, neg_tag);
-    __builtin_amdgcn_sched_barrier(0);
-    wait_one();
-    __builtin_amdgcn_s_barrier();
-    step(2, neg_tag);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    step(3, neg_tag);
-    flush(neg_tag);
+  using K0 = std::integral_constant<int, 0>;
+  auto period_mid = [&](int t0, auto late_tag, auto neg_tag, auto first_tag) __attribute__((always_inline)) {
+    phase(t0, std::integral_constant<int, 0>{}, K0{}, late_tag, neg_tag, first_tag);
+    phase(t0, std::integral_constant<int, 1>{}, K0{}, late_tag, neg_tag, first_tag);
+    phase(t0, std::integral_constant<int, 2>{}, K0{}, late_tag, neg_tag, first_tag);
+    phase(t0, std::integral_constant<int, 3>{}, K0{}, late_tag, neg_tag, first_tag);
+  };
+  auto period_last = [&](int t0, auto late_tag, auto neg_tag, auto first_tag) __attribute__((always_inline)) {
+    phase(t0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, late_tag, neg_tag, first_tag);
+    phase(t0, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, late_tag, neg_tag, first_tag);
+    phase(t0, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, late_tag, neg_tag, first_tag);
+    phase(t0, std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, late_tag, neg_tag, first_tag);
+    if constexpr (decltype(late_tag)::value) {       // the half step a late wave still owes
+      mfma_row(I1{}, neg_tag);
+      flush(neg_tag);
+    }
+  };
+  // periods alternate in sign, starting with +; the first and the last one are peeled (K >= 128: at least two periods)
+  auto k_loop = [&](auto late_tag) __attribute__((always_inline)) {
+    const int nper = ksteps >> 2;
+    period_mid(0, late_tag, std::false_type{}, std::true_type{});
+    int per = 1;
+    for (; per + 2 < nper; per += 2) {
+      period_mid(4 * per, late_tag, std::true_type{}, std::false_type{});
+      period_mid(4 * per + 4, late_tag, std::false_type{}, std::false_type{});
+    }
+    if (per + 2 == nper) {
+      period_mid(4 * per, late_tag, std::true_type{}, std::false_type{});
+      period_last(4 * per + 4, late_tag, std::false_type{}, std::false_type{});
+    } else {
+      period_last(4 * per, late_tag, std::true_type{}, std::false_type{});
+    }
   };
 
   issue(0, 0, false);
   issue(1, 1, true);
   issue(2, 2, false);
-  const int nper = ksteps >> 2;
-  int per = 0;
-  for (; per + 2 < nper; per += 2) {
-    period_mid(4 * per, std::false_type{});
-    period_mid(4 * per + 4, std::true_type{});
-  }
-  if (per + 2 == nper) {
-    period_mid(4 * per, std::false_type{});
-    period_last(4 * per + 4, std::true_type{});
-  } else {
-    period_last(4 * per, std::false_type{});
-  }
+  if (w < 4) k_loop(std::false_type{});
+  else k_loop(std::true_type{});
 
+  if (SP_ABL == 4) { if (tot[0][0][0] == 123.f) p.out[0] = tot[1][1][3] + tot[0][1][2] + tot[1][0][1]; return; }
+  if constexpr (MODE == 1) {
+    // combine: float atomics into out[n][c] — per accumulator register two 128-byte row segments, the full-rate shape
+    float* const ob = p.out + batch * p.bs_out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + (wn * 2 + j) * 32 + li;
+        if (col < p.N) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < p.M) atomicAdd(ob + (size_t)row * p.ld_out + col, tot[i][j][r]);
+          }
+        }
+      }
+    return;
+  }
   // ---- epilogue (conv_igemm.hip's): plain products on whole tiles store straight from the accumulators, everything else
   // goes through an LDS transpose so that every lane stores — and reads the optional operands as — 16-byte channel runs
   if (!p.bias && !p.relu && !p.accumulate && !p.mask && !p.mask_bits && !p.gate_out && m0 + SP_BM <= p.M) {
-    float* const ob = p.out + blockIdx.y * p.bs_out;
+    float* const ob = p.out + batch * p.bs_out;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -361,7 +498,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
       live[j] = mrow[j] < p.M && n_live;
       val[j] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
     }
-    float* const out_base = p.out + blockIdx.y * p.bs_out + n;
+    float* const out_base = p.out + batch * p.bs_out + n;
     if (p.accumulate) {
       f32x4 prev[PH];
 #pragma unroll
@@ -430,16 +567,24 @@ static const float* sp_zero_buffer() {
   return cache[dev];
 }
 
+int clx_sp_zero_tail(void* planes, long long rows, int K, int batch, long long bs, hipStream_t st) {
+  if (rows % 64 == 0 || batch <= 0) return CLX_OK;
+  const int ksteps = K / 16;
+  const long long total = ((rows + 63) / 64 * 2 - rows / 32) * ksteps * 6 * 32;
+  sp_zero_tail_kernel<<<dim3((unsigned)cdiv(total, 256), (unsigned)batch), 256, 0, st>>>((char*)planes, bs, rows, ksteps);
+  return CLX_OK;
+}
+
 extern "C" size_t clx_planes_bytes(long long rows, int K) {
   if (rows <= 0 || K <= 0 || K % 16 != 0) return 0;
-  return (size_t)((rows + 31) / 32) * (size_t)(K / 16) * KSTEP;
+  return (size_t)sp::planes_bytes(rows, K);
 }
 
 extern "C" int clx_split_planes(const float* x, long long ld, long long rows, int K, void* planes, clx_stream stream) {
   CLX_REQUIRE(x != nullptr && planes != nullptr, "clx_split_planes: null pointer");
   CLX_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0, "clx_split_planes: K must be a multiple of 16, ld >= K a multiple of 4");
   CLX_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0, "clx_split_planes: pointers must be 16-byte aligned");
-  const long long nfrag = (rows + 31) / 32 * (K / 16);
+  const long long nfrag = (rows + 63) / 64 * 2 * (K / 16);
   long long blocks = (nfrag + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   CLX_LAUNCH_KIND(CLX_PROF_SPLIT_PLANES, sp_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, K / 16,
@@ -451,7 +596,7 @@ extern "C" int clx_split_planes(const float* x, long long ld, long long rows, in
 extern "C" int clx_join_planes(const void* planes, long long rows, int K, float* x, long long ld, clx_stream stream) {
   CLX_REQUIRE(x != nullptr && planes != nullptr, "clx_join_planes: null pointer");
   CLX_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K, "clx_join_planes: K must be a multiple of 16, ld >= K");
-  const long long nfrag = (rows + 31) / 32 * (K / 16);
+  const long long nfrag = (rows + 63) / 64 * 2 * (K / 16);
   long long blocks = (nfrag + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   sp_join_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const char*)planes, ld, rows, K / 16, x, nfrag);
@@ -459,18 +604,27 @@ extern "C" int clx_join_planes(const void* planes, long long rows, int K, float*
   return CLX_OK;
 }
 
+bool clx_sp_applicable(const clx_conv_desc* d) {
+  if (d->precision != CLX_PREC_F32X3BF16 || d->wplanes == nullptr || d->nsrc != 1) return false;
+  if (d->KD != 1 || d->KH != 1 || d->KW != 1 || d->PD || d->PH || d->PW) return false;
+  const clx_src& S = d->src[0];
+  if (S.fz != 1 || S.fy != 1 || S.fx != 1 || S.oz || S.oy || S.ox) return false;
+  if (S.D != d->ID || S.H != d->IH || S.W != d->IW) return false;
+  return d->N % SP_BN == 0 && S.C % 64 == 0 && S.C >= 128 && d->ld_out % 4 == 0;
+}
+
 // the batched product behind clx_gemm_planes and the precision switch of clx_conv_fwd: `batch` problems, operand b at
 // A + b * bs_a / B + b * bs_b (bytes), result at out + b * bs_out (floats)
 int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long rows_a, int batch, long long bs_a, long long bs_b,
                   long long bs_out, const clx_conv_desc* ep, hipStream_t st) {
-  CLX_REQUIRE(M > 0 && N > 0 && N % SP_BN == 0 && K >= 64 && K % 64 == 0, "clx_gemm_planes: needs N %% 128 == 0 and K %% 64 == 0");
+  CLX_REQUIRE(M > 0 && N > 0 && N % SP_BN == 0 && K >= 128 && K % 64 == 0, "clx_gemm_planes: needs N %% 128 == 0, K %% 64 == 0 and K >= 128");
   CLX_REQUIRE(rows_a >= M, "clx_gemm_planes: the A planes hold fewer rows than M");
   SpP p;
   p.A = (const char*)A; p.B = (const char*)B;
   p.bs_a = bs_a; p.bs_b = bs_b; p.bs_out = bs_out;
   p.out = ep->out; p.ld_out = ep->ld_out;
   p.M = M; p.N = N; p.ksteps = K / 16;
-  p.rb_a = (int)((rows_a + 31) / 32);
+  p.rb_a = (int)((rows_a + 63) / 64 * 2);
   p.bias = ep->bias; p.mask = ep->mask; p.mask_bits = ep->mask_bits; p.gate_out = ep->gate_out;
   p.relu = ep->relu; p.accumulate = ep->accumulate; p.ld_mask = ep->ld_mask; p.ld_mask_bits = ep->ld_mask_bits; p.ld_gate = ep->ld_gate;
   p.zeros = sp_zero_buffer();
@@ -478,7 +632,54 @@ int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long r
   p.nbm = cdiv(M, SP_BM); p.nbn = N / SP_BN;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled()) clx_prof_events(CLX_PROF_GEMM_SP, 2.0 * M * N * K * batch, &e0, &e1);
-  CLX_LAUNCH_TIMED(gemm_sp_kernel, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
+  CLX_LAUNCH_TIMED(gemm_sp_kernel<0>, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
+  return CLX_OK;
+}
+
+// dW[b][n][c] += sum_pixels dY[b][pixel][n] x[b][pixel][c] from the planes of dY ([rows][N]) and x ([rows][C]); `batch` problems
+int clx_sp_wgrad_launch(const void* dy_planes, const void* x_planes, long long rows, int N, int C, int batch, long long bs_dy,
+                        long long bs_x, long long bs_out, float* dw, int ld_dw, hipStream_t st) {
+  CLX_REQUIRE(rows > 0 && N > 0 && C > 0 && N % 128 == 0 && C % 128 == 0, "clx_wgrad_planes: needs N %% 128 == 0 and C %% 128 == 0");
+  SpP p = {};
+  p.A = (const char*)dy_planes; p.B = (const char*)x_planes;
+  p.bs_a = bs_dy; p.bs_b = bs_x; p.bs_out = bs_out;
+  p.out = dw; p.ld_out = ld_dw;
+  p.M = N; p.N = C;
+  p.stride_a = (unsigned int)(N / 16) * KSTEP; p.stride_b = (unsigned int)(C / 16) * KSTEP;
+  CLX_REQUIRE(sp::planes_bytes(rows, N) < (1ll << 32) && sp::planes_bytes(rows, C) < (1ll << 32), "clx_wgrad_planes: operand planes beyond 4 GB");
+  p.total_steps = (int)((rows + 63) / 64 * 4);
+  p.nbm = cdiv(N, SP_BM); p.nbn = C / SP_BN;
+  const int tiles = p.nbm * p.nbn * batch;
+  // pixel slices: the grid that costs the fewest rounds of co-resident blocks (one per CU), a block's prologue + atomics
+  // priced as 12 steps
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  int best_ns = 1;
+  double best = 1e30;
+  const int max_ns = p.total_steps / 8 > 0 ? p.total_steps / 8 : 1;
+  for (int ns = 1; ns <= max_ns && ns <= 4096; ++ns) {
+    const int sps = (cdiv(p.total_steps, ns) + 3) / 4 * 4;
+    const int real_ns = cdiv(p.total_steps, sps);
+    if (p.total_steps - (real_ns - 1) * sps < 8) continue;              // the last slice keeps two periods
+    const double cost = (double)cdiv((long long)tiles * real_ns, cus) * (sps + 12);
+    if (cost < best) { best = cost; best_ns = ns; }
+    if ((long long)tiles * ns > 16ll * cus) break;
+  }
+  p.steps_per_slice = (cdiv(p.total_steps, best_ns) + 3) / 4 * 4;
+  p.nslices = cdiv(p.total_steps, p.steps_per_slice);
+  CLX_REQUIRE(p.total_steps >= 8 && p.total_steps - (p.nslices - 1) * p.steps_per_slice >= 8, "clx_wgrad_planes: fewer than 128 pixels");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (clx_prof_enabled()) clx_prof_events(CLX_PROF_WGRAD_SP, 2.0 * rows * N * C * batch, &e0, &e1);
+  CLX_LAUNCH_TIMED(gemm_sp_kernel<1>, dim3(p.nbm * p.nbn * p.nslices * batch), dim3(512), st, e0, e1, p);
+  return CLX_OK;
+}
+
+extern "C" int clx_wgrad_planes(const void* dy_planes, const void* x_planes, long long rows, int N, int C, float* dw, int ld_dw,
+                                clx_stream stream) {
+  CLX_REQUIRE(dy_planes && x_planes && dw && ld_dw >= C, "clx_wgrad_planes: null pointer / ld_dw < C");
+  const int rc = clx_sp_wgrad_launch(dy_planes, x_planes, rows, N, C, 1, 0, 0, 0, dw, ld_dw, (hipStream_t)stream);
+  if (rc) return rc;
+  CLX_CHECK_LAUNCH("clx_wgrad_planes");
   return CLX_OK;
 }
 

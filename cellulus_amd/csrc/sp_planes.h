@@ -1,0 +1,69 @@
+// "P3" operand planes of the split-precision products (gemm_sp.hip; format: include/clx.h): helpers shared by the
+// kernels that WRITE planes (the split pass, the Winograd transforms, the product epilogue).
+#pragma once
+#include "clx_common.h"
+
+namespace sp {
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FRAG = 1024;          // bytes of one fragment: 32 rows x 16 k x bf16
+constexpr int KSTEP = 3 * FRAG;     // the three pieces of one (32-row block, 16-k step)
+
+// bytes of the planes of an [rows][K] operand: rows padded to a multiple of 64 (two row blocks: the weight gradient
+// walks the pixels in periods of four 16-pixel steps)
+__host__ __device__ inline long long planes_bytes(long long rows, int K) { return (rows + 63) / 64 * 2 * (long long)(K / 16) * KSTEP; }
+
+// byte offset of the 16 bytes x_0[row][8 * octet .. + 7] (piece 0; pieces 1, 2 follow at + FRAG, + 2 FRAG)
+__host__ __device__ inline long long piece_offset(long long row, int octet, int ksteps) {
+  return ((row >> 5) * ksteps + (octet >> 1)) * (long long)KSTEP + (octet & 1) * 512 + (row & 31) * 16;
+}
+
+// x = h0 + h1 + h2 exactly, each h_i a bfloat16 (<= 8 significant bits: the top half of an f32 word, by truncation);
+// four elements at a time, packed two per word (element 0 in the low half)
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
+  unsigned int u[4], a1[4], a2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    u[e] = __float_as_uint(v[e]);
+    const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
+    a1[e] = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(a1[e] & 0xffff0000u);
+    a2[e] = __float_as_uint(r2);
+  }
+  p0[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
+  p0[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+  p1[0] = __builtin_amdgcn_perm(a1[1], a1[0], 0x07060302u);
+  p1[1] = __builtin_amdgcn_perm(a1[3], a1[2], 0x07060302u);
+  p2[0] = __builtin_amdgcn_perm(a2[1], a2[0], 0x07060302u);
+  p2[1] = __builtin_amdgcn_perm(a2[3], a2[2], 0x07060302u);
+}
+
+// the three pieces of x[row][c .. c + 3] (c % 4 == 0) into the planes at `base`: three 8-byte stores
+__device__ __forceinline__ void store4(char* base, long long row, int c, int ksteps, const f32x4 v) {
+  u32x2 p0, p1, p2;
+  split4(v, p0, p1, p2);
+  char* dst = base + piece_offset(row, c >> 3, ksteps) + ((c >> 2) & 1) * 8;
+  *reinterpret_cast<u32x2*>(dst) = p0;
+  *reinterpret_cast<u32x2*>(dst + FRAG) = p1;
+  *reinterpret_cast<u32x2*>(dst + 2 * FRAG) = p2;
+}
+
+// Work items of a kernel that makes planes out of (row, 4-channel group) items, C % 32 == 0: a wavefront takes 8
+// consecutive rows x 32 consecutive channels, so that it READS whole 128-byte lines of a channels-last tensor and
+// WRITES, per piece, four 128-byte runs (8 rows x 16 bytes of four octets).  item -> (row, c); rows are dealt out in
+// groups of 8: the caller sizes its grid for 8 * ceil(rows / 8) * C / 4 items and skips row >= rows.
+__device__ __forceinline__ void item_to_row_channel(long long i, int C, long long& row, int& c) {
+  const int lane = (int)(i & 63);
+  const long long wv = i >> 6;
+  const int nblk = C >> 5;
+  const int cblk = (int)(wv % nblk);
+  row = (wv / nblk) * 8 + (lane >> 3);
+  c = cblk * 32 + (lane & 7) * 4;
+}
+
+}  // namespace sp
+
+// zero the rows [rows, 64 ceil(rows / 64)) of `batch` plane sets (stride bs bytes) of an [rows][K] operand
+int clx_sp_zero_tail(void* planes, long long rows, int K, int batch, long long bs, hipStream_t st);

@@ -15,6 +15,7 @@
 // Replaces the same reference calls as conv_igemm.hip / conv_wgrad.hip (nn.Conv2d 3x3 and
 // its autograd backward, cellulus/models/unet.py:24-51, cellulus/train.py:178).
 #include "clx_common.h"
+#include "sp_planes.h"
 #include "wino_tables.h"
 
 namespace {
@@ -39,19 +40,30 @@ struct Geom {
 };
 
 // V[xi][t][c] = (B^T d B)[xi] for the A x A input patch of tile t (stride MT)
-template <int MT, int R>
+// PL: V as the P3 planes of the split-precision products (sp_planes.h; one plane set per xi, `plane_bytes` apart) — the
+// work items are dealt out so that a wavefront reads whole lines and writes 128-byte runs of every piece
+template <int MT, int R, bool PL = false>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ld_x, int C4, Geom g,
                                                          float* __restrict__ V, long long total,
-                                                         const int* __restrict__ tile_list = nullptr, long long Tc = 0) {
+                                                         const int* __restrict__ tile_list = nullptr, long long Tc = 0,
+                                                         long long plane_bytes = 0) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   const int C = C4 * 4;
   // (tile_list: only the listed tiles, stored compactly — V[xi][i][c] for the i-th listed tile)
-  const long long plane = (tile_list ? Tc : g.T) * C;
+  const long long Trows = tile_list ? Tc : g.T;
+  const long long plane = Trows * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4) * 4;
-    const long long t = i / C4;
+    int c;
+    long long t;
+    if constexpr (PL) {
+      sp::item_to_row_channel(i, C, t, c);
+      if (t >= Trows) continue;
+    } else {
+      c = (int)(i % C4) * 4;
+      t = i / C4;
+    }
     const long long tg = tile_list ? (long long)tile_list[t] : t;
     const int tx = (int)(tg % g.tw);
     const long long q = tg / g.tw;
@@ -95,7 +107,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
         bool first = true;
 #pragma unroll
         for (int k = 0; k < A; ++k) axpy(acc, first, W::BT[qq][k], w[r][k]);
-        st4(dst + (r * A + qq) * plane, acc);
+        if constexpr (PL) sp::store4(reinterpret_cast<char*>(V) + (r * A + qq) * plane_bytes, t, c, C >> 4, acc);
+        else st4(dst + (r * A + qq) * plane, acc);
       }
   }
 }
@@ -338,11 +351,11 @@ __global__ __launch_bounds__(256) void wino_adjoint_output_kernel(const float* _
 
 // Mdy[xi][t][n] = (A dy A^T)[xi] with A = (A^T)^T (A x MT); dbias[n] += sum of dy
 // (block-private LDS accumulator, then one global atomic per channel per block)
-template <int MT, int R>
+template <int MT, int R, bool PL = false>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, int ld_dy, int N4,
                                                       Geom g, float* __restrict__ Md,
                                                       float* __restrict__ dbias, int Nreal,
-                                                      long long total) {
+                                                      long long total, long long plane_bytes = 0) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   extern __shared__ float bacc[];
@@ -354,8 +367,15 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % N4) * 4;
-    long long t = i / N4;
+    int n;
+    long long t;
+    if constexpr (PL) {
+      sp::item_to_row_channel(i, N, t, n);
+      if (t >= g.T) continue;
+    } else {
+      n = (int)(i % N4) * 4;
+      t = i / N4;
+    }
     const int tx = (int)(t % g.tw);
     const long long q = t / g.tw;
     const int ty = (int)(q % g.th);
@@ -397,7 +417,8 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
         bool first = true;
 #pragma unroll
         for (int c = 0; c < MT; ++c) axpy(acc, first, W::AT[c][qq], w[r][c]);
-        st4(dst + (r * A + qq) * plane, acc);
+        if constexpr (PL) sp::store4(reinterpret_cast<char*>(Md) + (r * A + qq) * plane_bytes, t, n, N >> 4, acc);
+        else st4(dst + (r * A + qq) * plane, acc);
       }
   }
   if (dbias) {
@@ -412,11 +433,11 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 // the weight gradient's Mdy = A dy A^T of the MT x MT tile at MT t — which is rows / columns
 // P .. P + MT - 1 of that same patch.  gd: geometry of the data gradient's transform (over the dX
 // tiles), gw: the weight gradient's (over the dY tiles); dbias as in wino_dy_kernel.
-template <int MT, int R>
+template <int MT, int R, bool PL = false>
 __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restrict__ dy, int ld_dy, int N4,
                                                            Geom gd, Geom gw, float* __restrict__ Vd,
                                                            float* __restrict__ Md, float* __restrict__ dbias,
-                                                           int Nreal, long long total) {
+                                                           int Nreal, long long total, long long pb_d = 0, long long pb_w = 0) {
   using W = WT<MT, R>;
   constexpr int A = W::A;
   constexpr int P = R - 1;
@@ -429,8 +450,15 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
   }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % N4) * 4;
-    long long t = i / N4;
+    int n;
+    long long t;
+    if constexpr (PL) {
+      sp::item_to_row_channel(i, N, t, n);
+      if (t >= gd.T) continue;
+    } else {
+      n = (int)(i % N4) * 4;
+      t = i / N4;
+    }
     const int tx = (int)(t % gd.tw);
     const long long q = t / gd.tw;
     const int ty = (int)(q % gd.th);
@@ -466,7 +494,8 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
           for (int a = 0; a < MT; ++a) axpy(acc, first, W::AT[a][r], dd[a][c]);
           w[r][c] = acc;
         }
-      float* dst = Md + (((long long)b * gw.th + ty) * gw.tw + tx) * N + n;
+      const long long tw_lin = ((long long)b * gw.th + ty) * gw.tw + tx;
+      float* dst = Md + tw_lin * N + n;
 #pragma unroll
       for (int r = 0; r < A; ++r)
 #pragma unroll
@@ -475,7 +504,8 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
           bool first = true;
 #pragma unroll
           for (int c = 0; c < MT; ++c) axpy(acc, first, W::AT[c][qq], w[r][c]);
-          st4(dst + (r * A + qq) * plane_w, acc);
+          if constexpr (PL) sp::store4(reinterpret_cast<char*>(Md) + (r * A + qq) * pb_w, tw_lin, n, N >> 4, acc);
+          else st4(dst + (r * A + qq) * plane_w, acc);
         }
     }
     f32x4 d[A][A];
@@ -512,7 +542,8 @@ __global__ __launch_bounds__(256) void wino_dy_dual_kernel(const float* __restri
         bool first = true;
 #pragma unroll
         for (int k = 0; k < A; ++k) axpy(acc, first, W::BT[qq][k], w2[r][k]);
-        st4(dstv + (r * A + qq) * plane_d, acc);
+        if constexpr (PL) sp::store4(reinterpret_cast<char*>(Vd) + (r * A + qq) * pb_d, t, n, N >> 4, acc);
+        else st4(dstv + (r * A + qq) * plane_d, acc);
       }
   }
   if (dbias) {
@@ -701,6 +732,15 @@ inline int out_planes(const clx_conv_desc* d) { return d->ID + 2 * d->PD - (d->K
 
 inline int pad4(int n) { return (n + 3) / 4 * 4; }
 
+// Does this layer's transform-domain arithmetic run in the split precision (clx_conv_desc.precision; gemm_sp.hip)?  ONE
+// rule for the forward, data-gradient and weight-gradient calls of a layer — they hand V and A dY A^T to each other as
+// P3 planes (vcache, dy_vcache, the workspace) —: 2-D layer, both channel counts multiples of 128.
+inline bool wino_sp(const clx_conv_desc* d) {
+  return d->precision == CLX_PREC_F32X3BF16 && d->KD == 1 && d->ID == 1 && d->N % 128 == 0 && d->src[0].C % 128 == 0;
+}
+// grid of a plane-writing transform: 8 ceil(rows / 8) rows x C / 4 items, whole wavefronts
+inline long long sp_items(long long rows, int C) { return (rows + 7) / 8 * 8 * (C / 4); }
+
 // the batched GEMM descriptor: A^2 problems over the transformed tensor V [B][ID planes][tiles][C]:
 // a (KD, 1, 1) "convolution" along z — a plain [T x C] . [C x N] product for 2-D layers
 clx_conv_desc gemm_desc(float* V, int C, const clx_conv_desc* d, const Geom& gin) {
@@ -721,6 +761,8 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   const Geom gin = geom(d, MT, d->ID), gout = geom(d, MT, out_planes(d));
   const clx_src& S = d->src[0];
   const int C = S.C, Np = pad4(d->N);
+  const bool spx = wino_sp(d);
+  CLX_REQUIRE(!spx || d->wplanes != nullptr, "clx_conv_fwd(winograd): precision f32x3bf16 needs wplanes (the planes of wpack)");
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
   const int* list = d->tile_list;
   if (list != nullptr) {
@@ -732,19 +774,37 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
   }
   // (with a tile list the transforms and the products see tile_count tiles, stored compactly)
   const long long Tin = list ? d->tile_count : gin.T, Tout = list ? d->tile_count : gout.T;
-  float* M = (float*)d->workspace + AA * Tin * C;
+  // split precision: V as P3 planes (6 bytes per element), one plane set per xi
+  const long long pbV = spx ? sp::planes_bytes(Tin, C) : 0;
+  float* M = spx ? (float*)((char*)d->workspace + AA * sp::planes_bytes(gin.T, C)) : (float*)d->workspace + AA * Tin * C;
   if (!(d->vcache && d->vcache_valid)) {     // (a weight-gradient call may have left V: dy_vcache)
-    const long long tot_in = Tin * (C / 4);
-    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in, list, Tin);
+    if (spx) {
+      const long long tot_in = sp_items(Tin, C);
+      int rc = clx_sp_zero_tail(V, Tin, C, AA, pbV, st);
+      if (rc) return rc;
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_input_kernel<MT, R, true>), dim3(grid_for(tot_in, 256)), dim3(256), 0, st, S.ptr, S.ld, C / 4,
+                      gin, V, tot_in, list, Tin, pbV);
+    } else {
+      const long long tot_in = Tin * (C / 4);
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_input_kernel<MT, R>), dim3(grid_for(tot_in, 256)), dim3(256), 0, st, S.ptr, S.ld, C / 4, gin, V,
+                      tot_in, list, Tin, 0ll);
+    }
   }
-  clx_conv_desc gd = gemm_desc(V, C, d, gin);
-  if (list) {                                // the listed tiles as one row of tiles of one image
-    gd.B = 1;
-    gd.src[0].W = gd.IW = (int)Tin;
+  if (spx) {
+    clx_conv_desc ep = {};
+    ep.out = M; ep.ld_out = Np;
+    const int rc = clx_sp_launch(V, d->wplanes, (int)Tin, d->N, C, Tin, AA, pbV, sp::planes_bytes(Np, C), Tout * Np, &ep, st);
+    if (rc) return rc;
+  } else {
+    clx_conv_desc gd = gemm_desc(V, C, d, gin);
+    if (list) {                                // the listed tiles as one row of tiles of one image
+      gd.B = 1;
+      gd.src[0].W = gd.IW = (int)Tin;
+    }
+    gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
+    const int rc = clx_igemm_launch(&gd, AA, Tin * C, (long long)Np * d->KD * C, Tout * Np, st);
+    if (rc) return rc;
   }
-  gd.N = d->N; gd.wpack = d->wpack; gd.out = M; gd.ld_out = Np;
-  const int rc = clx_igemm_launch(&gd, AA, Tin * C, (long long)Np * d->KD * C, Tout * Np, st);
-  if (rc) return rc;
   const long long tot_out = Tout * (Np / 4);
   // the bit forms need whole words per lane group: channel count a multiple of 32
   CLX_REQUIRE((d->gate_out == nullptr && d->mask_bits == nullptr) || Np % 32 == 0,
@@ -757,11 +817,9 @@ int wino_fwd_t(const clx_conv_desc* d, hipStream_t st) {
                     d->mask == nullptr && d->mask_bits == nullptr && !d->accumulate,
                 "clx_conv_fwd(winograd): pool_out needs N %% 4 == 0, an aligned ld_pool >= N, and no mask / accumulate");
   }
-  wino_output_kernel<MT, R><<<grid_for(tot_out, 256), 256, 0, st>>>(M, Np / 4, gout, d->bias, d->relu, d->mask,
-                                                                      d->ld_mask, d->out, d->ld_out, d->N, d->accumulate,
-                                                                      d->gate_out, d->ld_gate, d->mask_bits,
-                                                                      d->ld_mask_bits, d->pool_out, d->ld_pool, tot_out,
-                                                                      list, Tout);
+  CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_output_kernel<MT, R>), dim3(grid_for(tot_out, 256)), dim3(256), 0, st, M, Np / 4, gout, d->bias,
+                  d->relu, d->mask, d->ld_mask, d->out, d->ld_out, d->N, d->accumulate, d->gate_out, d->ld_gate, d->mask_bits,
+                  d->ld_mask_bits, d->pool_out, d->ld_pool, tot_out, list, Tout);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd)");
   return CLX_OK;
 }
@@ -772,11 +830,26 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
   const Geom gin = geom(d, MT, d->ID), gout = geom(d, MT, out_planes(d));
   const clx_src& S = d->src[0];
   const int C = S.C, N = d->N;     // N is a multiple of 4 (validated by clx_conv_wgrad)
+  const bool spx = wino_sp(d);
   float* V = d->vcache ? (float*)d->vcache : (float*)d->workspace;
-  float* Md = (float*)d->workspace + AA * gin.T * C;
+  const long long pbV = spx ? sp::planes_bytes(gin.T, C) : 0, pbM = spx ? sp::planes_bytes(gout.T, N) : 0;
+  float* Md = spx ? (float*)((char*)d->workspace + AA * pbV) : (float*)d->workspace + AA * gin.T * C;
   if (!(d->vcache && d->vcache_valid)) {
-    const long long tot_in = gin.T * (C / 4);
-    wino_input_kernel<MT, R><<<grid_for(tot_in, 256), 256, 0, st>>>(S.ptr, S.ld, C / 4, gin, V, tot_in);
+    if (spx) {
+      const long long tot_in = sp_items(gin.T, C);
+      int rc = clx_sp_zero_tail(V, gin.T, C, AA, pbV, st);
+      if (rc) return rc;
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_input_kernel<MT, R, true>), dim3(grid_for(tot_in, 256)), dim3(256), 0, st, S.ptr, S.ld, C / 4,
+                      gin, V, tot_in, (const int*)nullptr, 0ll, pbV);
+    } else {
+      const long long tot_in = gin.T * (C / 4);
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_input_kernel<MT, R>), dim3(grid_for(tot_in, 256)), dim3(256), 0, st, S.ptr, S.ld, C / 4, gin, V,
+                      tot_in, (const int*)nullptr, 0ll, 0ll);
+    }
+  }
+  if (spx) {
+    const int rc = clx_sp_zero_tail(Md, gout.T, N, AA, pbM, st);
+    if (rc) return rc;
   }
   if (d->dy_vcache) {
     // the data gradient of this layer follows: its input transform of dY comes out of the same pass
@@ -787,16 +860,37 @@ int wino_wgrad_t(const clx_conv_desc* d, const float* dy, int ld_dy, float* dwpa
     gd.OH = gout.OH + R - 1; gd.OW = gout.OW + R - 1;
     gd.th = (gd.OH + MT - 1) / MT; gd.tw = (gd.OW + MT - 1) / MT;
     gd.T = (long long)gd.B * gd.th * gd.tw;
-    const long long tot = gd.T * (N / 4);
+    const long long tot = spx ? sp_items(gd.T, N) : gd.T * (N / 4);
     int blocks = grid_for(tot, 256);
     if (dbias && blocks > 2048) blocks = 2048;
-    wino_dy_dual_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, gd, gout,
-                                                                               (float*)d->dy_vcache, Md, dbias, N, tot);
+    if (spx) {
+      const long long pbD = sp::planes_bytes(gd.T, N);
+      const int rc = clx_sp_zero_tail(d->dy_vcache, gd.T, N, AA, pbD, st);
+      if (rc) return rc;
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_dy_dual_kernel<MT, R, true>), dim3(blocks), dim3(256), (size_t)N * sizeof(float), st, dy, ld_dy,
+                      N / 4, gd, gout, (float*)d->dy_vcache, Md, dbias, N, tot, pbD, pbM);
+    } else {
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_dy_dual_kernel<MT, R>), dim3(blocks), dim3(256), (size_t)N * sizeof(float), st, dy, ld_dy, N / 4,
+                      gd, gout, (float*)d->dy_vcache, Md, dbias, N, tot, 0ll, 0ll);
+    }
   } else {
-    const long long tot_dy = gout.T * (N / 4);
+    const long long tot_dy = spx ? sp_items(gout.T, N) : gout.T * (N / 4);
     int blocks = grid_for(tot_dy, 256);
     if (blocks > 2048) blocks = 2048;
-    wino_dy_kernel<MT, R><<<blocks, 256, (size_t)N * sizeof(float), st>>>(dy, ld_dy, N / 4, gout, Md, dbias, N, tot_dy);
+    if (spx)
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_dy_kernel<MT, R, true>), dim3(blocks), dim3(256), (size_t)N * sizeof(float), st, dy, ld_dy, N / 4,
+                      gout, Md, dbias, N, tot_dy, pbM);
+    else
+      CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_dy_kernel<MT, R>), dim3(blocks), dim3(256), (size_t)N * sizeof(float), st, dy, ld_dy, N / 4, gout,
+                      Md, dbias, N, tot_dy, 0ll);
+  }
+  if (spx) {
+    CLX_REQUIRE(gin.T == gout.T, "clx_conv_wgrad(winograd): tile counts of input and output differ");
+    CLX_REQUIRE(d->det_turns == nullptr, "clx_conv_wgrad: the reproducible mode exists for the float32 precision only");
+    const int rc = clx_sp_wgrad_launch(Md, V, gin.T, N, C, AA, pbM, pbV, (long long)N * C, dwpack, C, st);
+    if (rc) return rc;
+    CLX_CHECK_LAUNCH("clx_conv_wgrad(winograd, split precision)");
+    return CLX_OK;
   }
   clx_conv_desc gd = gemm_desc(V, C, d, gin);
   gd.N = N;
@@ -817,7 +911,26 @@ extern "C" size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass) {
   const Geom gin = geom(d, mt, d->ID), gout = geom(d, mt, out_planes(d));
   if (gout.OH <= 0 || gout.OW <= 0 || out_planes(d) <= 0 || gin.T >= (1ll << 31) || gout.T >= (1ll << 31)) return 0;
   const long long C = d->src[0].C, N = pad4(d->N);
+  if (wino_sp(d)) {
+    // V (and, for the weight gradient, A dY A^T) as P3 planes; the products' results stay float32.  (The adjoint data
+    // gradient's products [36][tiles][C] float32 fit the V region: 4 <= 6 bytes per element.)
+    const long long v = sp::planes_bytes(gin.T, (int)C);
+    const long long m = pass == CLX_PASS_WGRAD ? sp::planes_bytes(gout.T, (int)N) : gout.T * N * (long long)sizeof(float);
+    return (size_t)(a * a * (v + m));
+  }
   return (size_t)(a * a * (gin.T * C + gout.T * N)) * sizeof(float);
+}
+
+extern "C" size_t clx_conv_vcache_bytes(const clx_conv_desc* d, int which) {
+  if (d == nullptr || !applicable(d)) return 0;
+  const int mt = tile_of(d), a = mt + d->KH - 1, R = d->KH;
+  const Geom gin = geom(d, mt, d->ID), gout = geom(d, mt, out_planes(d));
+  const long long C = d->src[0].C, N = pad4(d->N);
+  if (which == 0) return wino_sp(d) ? (size_t)(a * a * sp::planes_bytes(gin.T, (int)C)) : (size_t)(a * a * gin.T * C) * sizeof(float);
+  // dy_vcache: the (K - 1)-padded input transform of dY over the tiles of dX
+  const long long th = (gout.OH + R - 1 + mt - 1) / mt, tw = (gout.OW + R - 1 + mt - 1) / mt;
+  const long long Td = (long long)gout.B * th * tw;
+  return wino_sp(d) ? (size_t)(a * a * sp::planes_bytes(Td, (int)N)) : (size_t)(a * a * Td * N) * sizeof(float);
 }
 
 // the adjoint data gradient (clx_conv_desc.adjoint): d is the data-gradient descriptor — source dY (C = the layer's
@@ -835,13 +948,25 @@ static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
   const int planes_dy = d->ID, planes_dx = d->ID + 2 * d->PD - (d->KD - 1);      // z planes of dY / of dX
   const long long Tdy = (long long)d->B * planes_dy * th * tw, Tdx = (long long)d->B * planes_dx * th * tw;
   const int Nf = d->src[0].C, Cp = d->N;
-  const size_t need = (size_t)36 * (Tdx * Cp + Tdy * Nf) * sizeof(float);
+  const bool spx = d->precision == CLX_PREC_F32X3BF16 && d->KD == 1 && d->ID == 1 && Cp % 128 == 0 && Nf % 128 == 0;   // = wino_sp of the layer
+  const size_t need = spx ? (size_t)36 * (sp::planes_bytes(Tdx, Cp) + sp::planes_bytes(Tdy, Nf))
+                          : (size_t)36 * (Tdx * Cp + Tdy * Nf) * sizeof(float);
   CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0,
               "clx_conv_fwd(adjoint): needs the %zu workspace bytes of the layer's weight gradient (%zu given)", need,
               d->workspace_bytes);
   CLX_REQUIRE(d->mask_bits == nullptr || Cp % 32 == 0, "clx_conv_fwd(adjoint): mask_bits needs whole words per pixel");
   float* P = (float*)d->workspace;                     // [36][Tdx][Cp], over what was the weight gradient's V region
   float* Mdy = P + (size_t)36 * Tdx * Cp;              // [36][Tdy][Nf]: left there by clx_conv_wgrad
+  if (spx) {
+    // A dY A^T lies behind the V region as planes; the products from them, float32 results over the V region
+    CLX_REQUIRE(d->wplanes != nullptr, "clx_conv_fwd(adjoint): precision f32x3bf16 needs wplanes");
+    const char* Mp = (const char*)d->workspace + 36 * sp::planes_bytes(Tdx, Cp);
+    clx_conv_desc ep = {};
+    ep.out = P; ep.ld_out = Cp;
+    const int rc = clx_sp_launch(Mp, d->wplanes, (int)Tdy, Cp, Nf, Tdy, 36, sp::planes_bytes(Tdy, Nf), sp::planes_bytes(Cp, Nf),
+                                 Tdx * Cp, &ep, st);
+    if (rc) return rc;
+  } else {
   // the batched product as a (KD, 1, 1) transposed convolution along z over the tiles
   clx_conv_desc gd = {};
   gd.nsrc = 1;
@@ -853,12 +978,12 @@ static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
   gd.N = Cp; gd.wpack = d->wpack; gd.out = P; gd.ld_out = Cp;
   const int rc = clx_igemm_launch(&gd, 36, Tdy * Nf, (long long)Cp * d->KD * Nf, Tdx * Cp, st);
   if (rc) return rc;
+  }
   const int IH = OHf + 2, IW = OWf + 2;
   const int nseg = ((IH + 3) / 4 + ADJ_SEG - 1) / ADJ_SEG;
   const long long total = (long long)d->B * planes_dx * nseg * ((IW + 3) / 4) * (Cp / 4);
-  wino_adjoint_output_kernel<<<grid_for(total, 256), 256, 0, st>>>(P, Cp / 4, d->B * planes_dx, th, tw, IH, IW, d->mask,
-                                                                   d->ld_mask, d->mask_bits, d->ld_mask_bits, d->out,
-                                                                   d->ld_out, Cp, total);
+  CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, wino_adjoint_output_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, P, Cp / 4,
+                  d->B * planes_dx, th, tw, IH, IW, d->mask, d->ld_mask, d->mask_bits, d->ld_mask_bits, d->out, d->ld_out, Cp, total);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd adjoint)");
   return CLX_OK;
 }

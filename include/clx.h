@@ -63,7 +63,8 @@ enum clx_profile_kind {
   CLX_PROF_MINMAX = 11,      /* minmax_init + minmax_kernel */
   CLX_PROF_HISTOGRAM = 12,   /* histogram_kernel */
   CLX_PROF_NOISE_STATS = 13, /* noise_stats kernels */
-  CLX_PROF_WINO_FUSED = 14   /* wino_fused_kernel (CLX_ALGO_WINOGRAD4_FUSED; FLOPs = 2 * a^2 * tiles * N * C executed) */
+  CLX_PROF_WINO_FUSED = 14,  /* wino_fused_kernel (CLX_ALGO_WINOGRAD4_FUSED; FLOPs = 2 * a^2 * tiles * N * C executed) */
+  CLX_PROF_WINO_TRANSFORM = 15 /* the HBM-bound transform kernels of CLX_ALGO_WINOGRAD / _WINOGRAD4 (no FLOPs) */
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);
@@ -167,7 +168,23 @@ typedef struct clx_conv_desc {
    * vcache / accumulate with a list. */
   const int* tile_list;
   int tile_count;
+  /* clx_conv_precision.  CLX_PREC_F32 (0, default): float32 MFMA — the reference's arithmetic.  CLX_PREC_F32X3BF16: where the
+   * convolution is a plain matrix product — 1x1 layers, the transform-domain products of the 2-D Winograd layers,
+   * forward, data gradient and weight gradient; N % 128 == 0, contraction length % 64 == 0 and >= 128 — the operands
+   * are split exactly into three bfloat16 pieces and six exact products per float32 product are accumulated in float32
+   * on the bf16 matrix cores ("P3 planes" above; csrc/gemm_sp.hip).  Everything else stays on the float32 kernels.
+   * The planes of the weights come from the caller (wplanes: clx_split_planes of `wpack` seen as [rows][K], K = the
+   * product's contraction length — Ctot for a 1x1 layer, KD * C per transform point for a Winograd layer — refreshed
+   * whenever wpack is); those of the activations are made by the library: by the Winograd transforms themselves inside
+   * `workspace` / `vcache` (clx_conv_workspace_bytes and clx_conv_vcache_bytes grow accordingly), by a split pass into
+   * `aplanes` (clx_planes_bytes(M, C) bytes of scratch) for a 1x1 layer.  A layer without wplanes (or a 1x1 layer
+   * without aplanes) runs in float32. */
+  int precision;
+  const void* wplanes;
+  void* aplanes;
 } clx_conv_desc;
+
+enum clx_conv_precision { CLX_PREC_F32 = 0, CLX_PREC_F32X3BF16 = 1 };
 
 enum clx_conv_algo {
   CLX_ALGO_DIRECT = 0,
@@ -212,6 +229,11 @@ enum clx_conv_pass { CLX_PASS_FWD = 0, CLX_PASS_WGRAD = 1 };
  * need for descriptor `d` with algo = CLX_ALGO_WINOGRAD / _WINOGRAD4; 0 if Winograd does not apply to
  * the geometry (the caller must then use CLX_ALGO_DIRECT). */
 size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass);
+/* Bytes of the buffers a caller may hand to a Winograd layer to carry transformed tensors from one call to the next:
+ * which = 0: clx_conv_desc.vcache (V = B^T d B of the layer's input: written by clx_conv_fwd, reused by clx_conv_wgrad);
+ * which = 1: clx_conv_desc.dy_vcache (the data gradient's input transform of dY, written by clx_conv_wgrad).  Float32
+ * tensors, or P3 planes — 1.5x the bytes — where the layer runs in the split precision.  0 if Winograd does not apply. */
+size_t clx_conv_vcache_bytes(const clx_conv_desc* d, int which);
 
 /* ---- Split-precision operands ("P3 planes", round 6) ----
  * The precision CLX_PREC_F32X3BF16 of clx_conv_desc computes float32 products on the bf16 matrix cores: every operand
@@ -220,7 +242,7 @@ size_t clx_conv_workspace_bytes(const clx_conv_desc* d, int pass);
  * <= 2^-24 relative, one float32 rounding.  The pieces are made ONCE where a tensor is produced, in the layout the
  * matrix core consumes ("P3"): an [R][K] operand (K % 16 == 0) as 1-KB fragments, fragment (rb, ks, p) = piece p of
  * rows 32 rb .. 32 rb + 31, k = 16 ks .. 16 ks + 15 at byte ((rb * K/16 + ks) * 3 + p) * 1024; inside a fragment the 16 bytes
- * at 512 h + 16 r hold x_p[32 rb + r][16 ks + 8 h .. + 7].  Rows up to the next multiple of 32 exist and are ZERO.  6 bytes
+ * at 512 h + 16 r hold x_p[32 rb + r][16 ks + 8 h .. + 7].  Rows up to the next multiple of 64 exist and are ZERO.  6 bytes
  * per element.  (No reference counterpart: the reference's torch.nn.Conv{2,3}d keep float32 operands,
  * cellulus/models/unet.py:24-63.) */
 /* bytes of the P3 planes of an [rows][K] operand (0 if K % 16 != 0) */
@@ -234,6 +256,12 @@ int clx_join_planes(const void* planes, long long rows, int K, float* x, long lo
  * splits / reuses planes by itself); exported for tests and for callers that keep planes of their own. */
 int clx_gemm_planes(const void* a_planes, const void* b_planes, int M, int N, int K, const float* bias, int relu,
                     float* out, int ld_out, clx_stream stream);
+/* dw[n][c] += sum over rows of dY[row][n] * x[row][c] from the P3 planes of dY ([rows][N]) and x ([rows][C]), N % 128 == 0,
+ * C % 128 == 0, rows >= 128: float atomics into the caller's (zeroed or accumulating) dw[N][ld_dw].  The plain-product form
+ * of clx_conv_wgrad with precision = CLX_PREC_F32X3BF16 (replaces the autograd weight gradient of nn.Conv{2,3}d,
+ * cellulus/train.py:178). */
+int clx_wgrad_planes(const void* dy_planes, const void* x_planes, long long rows, int N, int C, float* dw, int ld_dw,
+                     clx_stream stream);
 
 /* out = act(conv(in) + bias).  f32 MFMA implicit GEMM (M = output pixels,
  * N = output channels, K = taps x channels). Also used for the data gradient

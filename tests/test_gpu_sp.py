@@ -33,26 +33,25 @@ def test_planes_are_an_exact_split(rows, K, ld):
     full[0, :4] = torch.tensor([0.0, -0.0, 1.0, -1.5], device=dev)
     x = full[:, :K]
     buf = _planes(x)
-    assert buf.numel() == (rows + 31) // 32 * (K // 16) * 3072
+    assert buf.numel() == (rows + 63) // 64 * 2 * (K // 16) * 3072
     # the inverse (h0 + h1 + h2 in float32) gives the operand back bit for bit
     back = torch.full((rows, K), float("nan"), device=dev)
     _clx.call("clx_join_planes", _clx.ptr(buf), rows, K, _clx.ptr(back), K, _clx.stream_ptr(dev))
-    assert torch.equal(back.view(torch.int32), x.contiguous().view(torch.int32))
+    assert torch.equal(back, x.contiguous())            # (values: -0.0 comes back as +0.0)
     # ... and the layout is the documented one: fragment (rb, ks, p), 16 bytes at 512 h + 16 r
-    h = buf.cpu().numpy().view(np.uint16).reshape((rows + 31) // 32, K // 16, 3, 2, 32, 8)
+    h = buf.cpu().numpy().view(np.uint16).reshape((rows + 63) // 64 * 2, K // 16, 3, 2, 32, 8)
     pieces = (h.astype(np.uint32) << 16).view(np.float32)                    # bf16 -> f32
-    xs = np.zeros(((rows + 31) // 32 * 32, K), np.float32)
+    xs = np.zeros(((rows + 63) // 64 * 64, K), np.float32)
     xs[:rows] = x.cpu().numpy()
     want = xs.reshape(-1, 32, K // 16, 2, 8).transpose(0, 2, 3, 1, 4)        # [rb][ks][h][r][8]
     got = (pieces[:, :, 0].astype(np.float64) + pieces[:, :, 1] + pieces[:, :, 2])
     assert np.array_equal(got.astype(np.float32), want)
     # (every piece has at most 8 significant bits by construction: it IS a bfloat16); the padding rows are zero
     assert not np.isnan(pieces).any()
-    if rows % 32:
-        assert np.all(h[-1, :, :, :, rows % 32:, :] == 0)
+    assert np.all(h.transpose(0, 4, 1, 2, 3, 5).reshape(-1, K // 16 * 48)[rows:] == 0)
 
 
-@pytest.mark.parametrize("M,N,K,relu", [(256, 128, 64, 0), (1000, 256, 256, 1), (70000, 256, 768, 1), (257, 768, 2304, 0)])
+@pytest.mark.parametrize("M,N,K,relu", [(256, 128, 128, 0), (1000, 256, 256, 1), (70000, 256, 768, 1), (257, 768, 2304, 0)])
 def test_product_from_planes_against_float64(M, N, K, relu):
     _clx, lib = _lib()
     dev = torch.device("cuda:0")
@@ -77,6 +76,25 @@ def test_product_from_planes_against_float64(M, N, K, relu):
     assert rel < 3e-7, (rel, err)
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
     assert bias_err < 2e-8, bias_err                               # the alternating sign removes the accumulation bias
+
+
+@pytest.mark.parametrize("rows,N,C", [(128, 128, 128), (1000, 256, 128), (70001, 768, 256), (33000, 128, 768)])
+def test_weight_gradient_from_planes_against_float64(rows, N, C):
+    _clx, lib = _lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows + N)
+    x = torch.relu(torch.randn(rows, C, device=dev))
+    dy = torch.randn(rows, N, device=dev) * (torch.rand(rows, N, device=dev) < 0.5)          # a gated gradient
+    dw = torch.full((N, C + 4), 1.0, device=dev)                                              # += into what is there
+    pdy, px = _planes(dy), _planes(x)              # (kept alive: a temporary's memory would be handed to the next allocation)
+    _clx.call("clx_wgrad_planes", _clx.ptr(pdy), _clx.ptr(px), rows, N, C, _clx.ptr(dw), C + 4, _clx.stream_ptr(dev))
+    ref = dy.double().t() @ x.double() + 1.0
+    got = dw[:, :C].double()
+    assert torch.equal(dw[:, C:], torch.ones(N, 4, device=dev))
+    rms = (ref - 1.0).pow(2).mean().sqrt().item()
+    rel = ((got - ref).pow(2).mean().sqrt() / rms).item()
+    assert rel < 3e-7, rel
+    assert abs(((got - ref).mean() / rms).item()) < 3e-8
 
 
 def test_rejects_what_it_cannot_do():

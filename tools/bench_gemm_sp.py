@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cellulus_amd import _clx
 from cellulus_amd._clx import ClxConvDesc, ClxSrc
 
+if os.environ.get("CLX_LIB"):
+    _clx.LIB_PATH = os.path.abspath(os.environ["CLX_LIB"])
 dev = torch.device("cuda:0")
 st = _clx.stream_ptr(dev)
 lib = _clx.load()
@@ -71,6 +73,9 @@ def one(M, N, K, relu_in=True):
         _clx.call("clx_conv_fwd", ctypes.byref(d), st)
 
     t_sp, t_split, t_f32 = timed(run_sp), timed(run_split), timed(run_f32)
+    if os.environ.get("SP_TIME_ONLY"):
+        print(f"M={M:7d} N={N:4d} K={K:5d}  sp {t_sp:7.3f} ms {2.0 * M * N * K / t_sp / 1e9:6.1f} TF/s", flush=True)
+        return
     rows = min(M, 4096)
     ref = torch.relu(x[:rows].double() @ w.double().t() + bias.double())
     ref_t = torch.relu(x[M - rows:].double() @ w.double().t() + bias.double())
@@ -94,3 +99,35 @@ if __name__ == "__main__":
         (129032, 256, 256), (31752, 768, 768), (30976, 768, 256), (29768, 256, 768)]
     for M, N, K in shapes:
         one(M, N, K)
+
+
+def one_wgrad(rows, N, C):
+    """the weight-gradient product from planes against conv_wgrad_kernel on the same 1x1 layer"""
+    torch.manual_seed(1)
+    x = torch.relu(torch.randn(rows, C, device=dev))
+    dy = torch.randn(rows, N, device=dev)
+    pdy, px = planes_of(dy), planes_of(x)
+    dw = torch.zeros(N, C, device=dev)
+    dw32 = torch.zeros(N, C, device=dev)
+
+    def run_sp():
+        _clx.call("clx_wgrad_planes", _clx.ptr(pdy), _clx.ptr(px), rows, N, C, _clx.ptr(dw), C, st)
+
+    d = ClxConvDesc()
+    d.nsrc = 1
+    s = ClxSrc()
+    s.ptr = x.data_ptr(); s.C = C; s.ld = C; s.D, s.H, s.W = 1, 1, rows; s.oz = s.oy = s.ox = 0; s.fz = s.fy = s.fx = 1
+    d.src[0] = s
+    d.B = 1; d.ID, d.IH, d.IW = 1, 1, rows; d.KD = d.KH = d.KW = 1; d.PD = d.PH = d.PW = 0; d.N = N; d.algo = 0
+
+    def run_f32():
+        _clx.call("clx_conv_wgrad", ctypes.byref(d), _clx.ptr(dy), N, _clx.ptr(dw32), None, st)
+
+    t_sp, t_f32 = timed(run_sp), timed(run_f32)
+    fl = 2.0 * rows * N * C
+    print(f"wgrad rows={rows:7d} N={N:4d} C={C:4d}  sp {t_sp:7.3f} ms {fl / t_sp / 1e9:6.1f} TF/s | f32 {t_f32:7.3f} ms {fl / t_f32 / 1e9:6.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__" and os.environ.get("SP_WGRAD"):
+    for rows, N, C in [(516128, 256, 256), (258064, 256, 256), (123008, 768, 768), (61504, 768, 768)]:
+        one_wgrad(rows, N, C)
