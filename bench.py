@@ -45,6 +45,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA; the split precision f32x3bf16 spends six bf16 products per f32 product
+SP_KERNELS = ("gemm_sp_kernel", "wgrad_sp_kernel")          # priced against BF16_MFMA_PEAK_TFLOPS / 6 (f32-equivalent FLOPs)
 
 WORKLOADS = {
     "train2d": dict(
@@ -340,7 +342,9 @@ def run_workload(wl_key, args, rank, world, device):
 
     lib = _clx.load()
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-             6: "chain64_kernels", 14: "wino_fused_kernels"}
+             3: "gemm_sp_kernel", 4: "wgrad_sp_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
+    hbm_kinds = {5: "sp_split_kernel", 15: "wino_transform_kernels"}       # HBM-bound launches libclx stamps as well (no FLOPs)
+    hbm_prof = {}
 
     def read_clock(reset=True):
         """MHz the MFMA kernels ran at since the last reset (clx_profile_clock), None if nothing was recorded"""
@@ -354,6 +358,10 @@ def run_workload(wl_key, args, rank, world, device):
             n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
             lib.clx_profile_read(kind, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
             prof[kname] = (n_l.value, ms_l.value, fl_l.value)
+        for kind, kname in hbm_kinds.items():
+            n_l, ms_l, fl_l = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            lib.clx_profile_read(kind, ctypes.byref(n_l), ctypes.byref(ms_l), ctypes.byref(fl_l))
+            hbm_prof[kname] = (n_l.value, ms_l.value)
         _clx.call("clx_profile_enable", 0)
         return prof
 
@@ -445,9 +453,15 @@ def run_workload(wl_key, args, rank, world, device):
     # HIP-event durations (events recorded inside libclx around the kernel launch itself)
     dom_name, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    peak = F32_MFMA_PEAK_TFLOPS
+
+    def peak_of(kname):
+        return BF16_MFMA_PEAK_TFLOPS / 6 if kname in SP_KERNELS else F32_MFMA_PEAK_TFLOPS
+
+    peak = peak_of(dom_name)
     mfma_ms = sum(v[1] for v in prof.values())
     mfma_fl = sum(v[2] for v in prof.values())
+    # what the step makes of the matrix cores: every kernel's FLOPs priced against ITS peak (seconds at peak / step time)
+    peak_seconds = sum(v[2] / (peak_of(k) * 1e12) for k, v in prof.items())
     plan_algo = getattr(plan, "algo", {})
     n_wino = sum(1 for a in plan_algo.values() if a.get("fwd"))
     wino_tile = max([{1: 2, 2: 4}.get(a.get("fwd"), 0) for a in plan_algo.values()] or [0])
@@ -463,12 +477,15 @@ def run_workload(wl_key, args, rank, world, device):
         avg_launch_ms=round(ms / max(launches, 1), 4),
         note="achieved = FLOPs the kernel executes (2*M*N*K per GEMM, real extents) / HIP-event time of "
              "its launches; Winograd F(2x2) / F(4x4) layers execute 4/9 / 1/4 of the direct-convolution FLOPs",
-        step_mfma_frac=round(mfma_fl / args.steps / (dt / args.steps) / 1e12 / peak, 4),
+        step_mfma_frac=round(peak_seconds / dt, 4),
         all_mfma_kernels=dict(tflops=round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else 0.0,
                               ms_per_step=round(mfma_ms / args.steps, 3)),
         per_kernel={k: dict(launches_per_step=int(v[0] // args.steps), ms_per_step=round(v[1] / args.steps, 3),
-                            tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0)
+                            tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[1] else 0.0,
+                            **({"peak": round(peak_of(k), 1)} if k in SP_KERNELS else {}))
                     for k, v in prof.items() if v[0]},
+        hbm_bound_kernels={k: dict(launches_per_step=int(v[0] // args.steps), ms_per_step=round(v[1] / args.steps, 3))
+                           for k, v in hbm_prof.items() if v[0]},
         winograd_layers=n_wino, winograd_tile=wino_tile,
         direct_equivalent_tflops=round(crops_per_s / world * train_flops / 1e12, 2),
     )
@@ -807,9 +824,16 @@ def main():
                     help="0 (default): the product's default, two half batches on two streams per GPU (CLX_STREAMS "
                          "unset).  1: one stream — every kernel alone on the device, the run the roofline numbers and "
                          "the PMC profiles are taken from")
+    ap.add_argument("--precision", default="both", choices=["f32", "f32x3bf16", "both"],
+                    help="both (default): the headline workload in float32 MFMA, then AGAIN with CLX_PRECISION=f32x3bf16 (the "
+                         "plain products on the bf16 matrix cores from an exact three-way split of the float32 operands, "
+                         "csrc/gemm_sp.hip) as the extra objects `train2d_f32x3bf16` / `infer_f32x3bf16`; f32: the first "
+                         "only; f32x3bf16: the whole line in that precision (its `dtype` says so)")
     args = ap.parse_args()
     if args.streams:
         os.environ["CLX_STREAMS"] = str(args.streams)
+    if args.precision == "f32x3bf16":
+        os.environ["CLX_PRECISION"] = "f32x3bf16"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -826,7 +850,21 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
+    env_precision = os.environ.get("CLX_PRECISION", "f32") or "f32"
     res = run_workload(args.workload, args, rank, world, device)
+    res_sp = infer_sp = None
+    if args.precision == "both" and env_precision == "f32" and args.workload == "train2d":
+        os.environ["CLX_PRECISION"] = "f32x3bf16"
+        torch.cuda.empty_cache()
+        try:
+            res_sp = run_workload(args.workload, args, rank, world, device)
+            if world == 1 and not args.no_infer:
+                from bench_infer import infer_bench
+
+                torch.cuda.empty_cache()
+                infer_sp = infer_bench(device, with_cpu=False, with_e2e=True, with_streaming=False)
+        finally:
+            os.environ["CLX_PRECISION"] = env_precision
     res3d = None
     if args.workload == "train2d" and not args.no_train3d:
         torch.cuda.empty_cache()
@@ -864,6 +902,18 @@ def main():
         "data": "synthetic",
     }
     out.update({k: v for k, v in res.items() if k not in out})
+    sp_dtype = "f32 (exact 3xbf16 operand split, 6 products, f32 accumulate)"
+    if env_precision != "f32":
+        out["dtype"] = sp_dtype
+        out["note"] = f"CLX_PRECISION={env_precision}: every number of this line is that precision's"
+    if res_sp is not None:
+        out["train2d_f32x3bf16"] = dict(
+            metric="train crops/sec, the same workload with CLX_PRECISION=f32x3bf16 (results are float32: six exact bf16 "
+                   "products per float32 product on the plain GEMMs, float32 accumulation; everything else unchanged)",
+            dtype=sp_dtype, steps=args.steps, warmup=args.warmup, **res_sp)
+    if infer_sp is not None:
+        out["infer_f32x3bf16"] = dict(infer_sp, dtype=sp_dtype,
+                                      metric=infer_sp["metric"] + " with CLX_PRECISION=f32x3bf16 on the embedding network")
     if res3d is not None:
         out["train3d"] = dict(metric="train crops/sec, BASELINE configs[3]", steps=args.steps, warmup=args.warmup,
                               **res3d)

@@ -25,6 +25,8 @@ import torch
 
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 MFMA; the split precision spends six bf16 products per float32 product
+SP_KERNELS = ("gemm_sp_kernel", "wgrad_sp_kernel")
 
 
 def _sync_time(fn, reps):
@@ -330,7 +332,7 @@ def infer_sharded(device, rank, world, samples_per_rank=16):
 
 
 MFMA_KINDS = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-              6: "chain64_kernels", 14: "wino_fused_kernels"}
+              3: "gemm_sp_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
 
 
 def embed_stage(model, device, size, n_it, reps):
@@ -468,16 +470,21 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
     def roofline_of(prof, t_embed_tile, t_value_pass, nstreams, plan_batch):
         dom, (launches, ms, flops) = max(prof.items(), key=lambda kv: kv[1][1])
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        peak = F32_MFMA_PEAK_TFLOPS
+
+        def peak_of(kname):
+            return BF16_MFMA_PEAK_TFLOPS / 6 if kname in SP_KERNELS else F32_MFMA_PEAK_TFLOPS
+
+        peak = peak_of(dom)
         mfma_ms = sum(v[1] for v in prof.values())
         mfma_fl = sum(v[2] for v in prof.values())
+        peak_seconds = sum(v[2] / (peak_of(k) * 1e12) for k, v in prof.items())     # every kernel priced against ITS peak
         traffic, traffic_source = traffic_lookup(dom, "infer")
         return dict(bound="mfma", kernel=dom, achieved=round(achieved, 2), peak=round(peak, 1),
                     unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=traffic, traffic_source=traffic_source,
                     launches_per_tile=int(round(launches)), avg_launch_ms=round(ms / max(launches, 1), 4),
                     forwards_per_launch=int(plan_batch),
                     share_of_embed_stage=round(ms * 1e-3 / t_embed_tile, 4),
-                    step_mfma_frac=round(mfma_fl / t_embed_tile / 1e12 / peak, 4),
+                    step_mfma_frac=round(peak_seconds / t_embed_tile, 4),
                     all_mfma_kernels=dict(tflops=round(mfma_fl / (mfma_ms * 1e-3) / 1e12, 2) if mfma_ms else 0.0,
                                           ms_per_tile=round(mfma_ms, 3),
                                           share_of_embed_stage=round(mfma_ms * 1e-3 / t_embed_tile, 4)),
@@ -487,7 +494,7 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
                     timed_in=f"a second pass on ONE stream (every kernel alone on the device: {t_embed_tile * 1e3:.2f} ms per tile); "
                              f"the `value` pass runs the chunks on {nstreams} stream(s): {t_value_pass * 1e3:.2f} ms per tile",
                     one_stream_embed_ms=round(t_embed_tile * 1e3, 2), streams_value_pass=nstreams,
-                    step_mfma_frac_value_pass=round(mfma_fl / t_value_pass / 1e12 / peak, 4),
+                    step_mfma_frac_value_pass=round(peak_seconds / t_value_pass, 4),
                     note="achieved = FLOPs the dominant kernel executes / HIP-event time of its launches; "
                          "share_of_embed_stage = its launches' time / the embedding stage's wall time per tile (the "
                          "rest: the other MFMA kernels under all_mfma_kernels, Winograd transforms, first-layer and "

@@ -90,6 +90,8 @@ class ClxConvDesc(Structure):
         ("precision", c_int),
         ("wplanes", c_void_p),
         ("aplanes", c_void_p),
+        ("aplanes_valid", c_int),
+        ("dyplanes", c_void_p),
     ]
 
 

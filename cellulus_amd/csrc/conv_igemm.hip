@@ -692,8 +692,10 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   if (batch == 1 && d->aplanes != nullptr && clx_sp_applicable(d)) {
     const clx_src& S = d->src[0];
     const long long M = (long long)d->B * d->ID * d->IH * d->IW;
-    int rc = clx_split_planes(S.ptr, S.ld, M, S.C, d->aplanes, (clx_stream)st);
-    if (rc) return rc;
+    if (!d->aplanes_valid) {
+      const int rc = clx_sp_split(S.ptr, S.ld, M, S.C, d->aplanes, nullptr, 0, st);
+      if (rc) return rc;
+    }
     return clx_sp_launch(d->aplanes, d->wplanes, (int)M, d->N, S.C, M, 1, 0, 0, 0, d, st);
   }
   ConvP p;

@@ -506,6 +506,25 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   CLX_REQUIRE(d->algo == CLX_ALGO_DIRECT || d->algo == CLX_ALGO_WINOGRAD || d->algo == CLX_ALGO_WINOGRAD4,
               "clx_conv_wgrad: bad algo");
   if (d->algo != CLX_ALGO_DIRECT) return clx_wino_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
+  // opt-in precision: a 1x1 layer over one plain source, both channel counts multiples of 128 — planes of x (left by the
+  // forward pass, or split here) and of dY (split here; the bias gradient is that pass's column sums)
+  if (d->precision == CLX_PREC_F32X3BF16 && d->aplanes != nullptr && d->dyplanes != nullptr && d->det_turns == nullptr &&
+      d->nsrc == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->PD == 0 && d->PH == 0 && d->PW == 0 &&
+      d->N % 128 == 0 && d->src[0].C % 128 == 0 && ld_dy >= d->N) {
+    const clx_src& S = d->src[0];
+    if (S.fz == 1 && S.fy == 1 && S.fx == 1 && S.oz == 0 && S.oy == 0 && S.ox == 0 && S.D == d->ID && S.H == d->IH && S.W == d->IW) {
+      const long long M = (long long)d->B * d->ID * d->IH * d->IW;
+      int rc = 0;
+      if (!d->aplanes_valid) rc = clx_sp_split(S.ptr, S.ld, M, S.C, d->aplanes, nullptr, 0, (hipStream_t)stream);
+      if (rc) return rc;
+      rc = clx_sp_split(dy, ld_dy, M, d->N, d->dyplanes, dbias, d->N, (hipStream_t)stream);
+      if (rc) return rc;
+      rc = clx_sp_wgrad_launch(d->dyplanes, d->aplanes, M, d->N, S.C, 1, 0, 0, 0, dwpack, S.C, (hipStream_t)stream);
+      if (rc) return rc;
+      CLX_CHECK_LAUNCH("clx_conv_wgrad(split precision)");
+      return CLX_OK;
+    }
+  }
   if (clx_smallc_applicable(d) && d->det_turns == nullptr) {
     clx_smallc_wgrad(d, dy, ld_dy, dwpack, dbias, (hipStream_t)stream);
     CLX_CHECK_LAUNCH("clx_conv_wgrad(small-channel)");

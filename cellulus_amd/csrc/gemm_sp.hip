@@ -11,7 +11,7 @@
 // split happens ONCE where a tensor is produced (clx_split_planes, the Winograd transforms, the weight packing), into
 // the "P3" plane format below, and the K loop is nothing but LDS-DMA (global_load_lds_dwordx4), ds_read_b128 and MFMAs.
 //
-// P3 format of an [R rows][K] operand (K % 16 == 0; rows padded to a multiple of 64, the padding rows ZERO):
+// P3 format of an [R rows][K] operand (K % 16 == 0; rows padded to a multiple of 64 and at least 128, the padding rows ZERO):
 //   1-KB fragments in the MFMA's operand order — fragment (rb, ks, p) = plane p of rows 32 rb .. + 31, k = 16 ks .. + 15,
 //   at byte ((rb * K/16 + ks) * 3 + p) * 1024; inside it lane l = 32 h + r of the wavefront owns the 16 bytes
 //   x_p[32 rb + r][16 ks + 8 h .. + 7].  One global_load_lds_dwordx4 per fragment moves 1 KB of CONTIGUOUS memory
@@ -61,12 +61,16 @@ __device__ __forceinline__ void glds16(const char* g, char* l) {
 using sp::split4;
 
 // f32 [rows][ld] -> P3 planes of its columns [0, K).  A wavefront writes whole fragments (three contiguous 1-KB
-// stores); rows in [rows, 64 ceil(rows / 64)) are written as zeros.
+// stores); the padding rows are written as zeros.  COLSUM: also colsum[k] += sum over rows of x[row][k]
+// (the bias gradient of a layer whose dY is split here): the grid's wavefront count is a multiple of the k steps, so a
+// wavefront keeps its k step and sums in registers; one shuffle reduction and 16 atomics per wavefront at the end.
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void sp_split_kernel(const float* __restrict__ x, long long ld, long long rows, int ksteps,
-                                                       char* __restrict__ out, long long nfrag) {
+                                                       char* __restrict__ out, long long nfrag, float* __restrict__ colsum, int nreal) {
   const int lane = threadIdx.x & 63;
   const long long w0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long long)gridDim.x * blockDim.x) >> 6;
   const int r = lane & 31, h = lane >> 5;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   for (long long f = w0; f < nfrag; f += nw) {
     const int ks = (int)(f % ksteps);
     const long long rb = f / ksteps;
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(256) void sp_split_kernel(const float* __restrict__
       v0 = *reinterpret_cast<const f32x4*>(src);
       v1 = *reinterpret_cast<const f32x4*>(src + 4);
     }
+    if constexpr (COLSUM) { s0 += v0; s1 += v1; }
     u32x2 a0, a1, a2, b0, b1, b2;
     split4(v0, a0, a1, a2);
     split4(v1, b0, b1, b2);
@@ -84,6 +89,24 @@ __global__ __launch_bounds__(256) void sp_split_kernel(const float* __restrict__
     *reinterpret_cast<u32x4*>(dst) = u32x4{a0[0], a0[1], b0[0], b0[1]};
     *reinterpret_cast<u32x4*>(dst + FRAG) = u32x4{a1[0], a1[1], b1[0], b1[1]};
     *reinterpret_cast<u32x4*>(dst + 2 * FRAG) = u32x4{a2[0], a2[1], b2[0], b2[1]};
+  }
+  if constexpr (COLSUM) {
+    if (w0 < nfrag) {
+      const int ks = (int)(w0 % ksteps);                 // (nw % ksteps == 0: the same k step every trip)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int m = 1; m < 32; m <<= 1) { s0[e] += __shfl_xor(s0[e], m, 64); s1[e] += __shfl_xor(s1[e], m, 64); }
+      }
+      if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k0 = ks * 16 + h * 8 + e;
+          if (k0 < nreal) atomicAdd(colsum + k0, s0[e]);
+          if (k0 + 4 < nreal) atomicAdd(colsum + k0 + 4, s1[e]);
+        }
+      }
+    }
   }
 }
 
@@ -113,9 +136,9 @@ __global__ __launch_bounds__(256) void sp_join_kernel(const char* __restrict__ i
   }
 }
 
-// the padding rows [rows, 64 ceil(rows / 64)) of `batch` plane sets
+// the padding rows [rows, padded_rows(rows)) of `batch` plane sets
 __global__ __launch_bounds__(256) void sp_zero_tail_kernel(char* __restrict__ planes, long long bs, long long rows, int ksteps) {
-  const long long rb0 = rows >> 5, rb1 = (rows + 63) / 64 * 2;          // row blocks that hold padding
+  const long long rb0 = rows >> 5, rb1 = sp::padded_rows(rows) / 32;    // row blocks that hold padding
   const int per_rb = ksteps * 6 * 32;                                   // 16-byte pieces of one row block
   const long long total = (rb1 - rb0) * per_rb;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -568,9 +591,9 @@ static const float* sp_zero_buffer() {
 }
 
 int clx_sp_zero_tail(void* planes, long long rows, int K, int batch, long long bs, hipStream_t st) {
-  if (rows % 64 == 0 || batch <= 0) return CLX_OK;
+  if (sp::padded_rows(rows) == rows || batch <= 0) return CLX_OK;
   const int ksteps = K / 16;
-  const long long total = ((rows + 63) / 64 * 2 - rows / 32) * ksteps * 6 * 32;
+  const long long total = (sp::padded_rows(rows) / 32 - rows / 32) * ksteps * 6 * 32;
   sp_zero_tail_kernel<<<dim3((unsigned)cdiv(total, 256), (unsigned)batch), 256, 0, st>>>((char*)planes, bs, rows, ksteps);
   return CLX_OK;
 }
@@ -580,15 +603,32 @@ extern "C" size_t clx_planes_bytes(long long rows, int K) {
   return (size_t)sp::planes_bytes(rows, K);
 }
 
-extern "C" int clx_split_planes(const float* x, long long ld, long long rows, int K, void* planes, clx_stream stream) {
+// colsum != NULL: colsum[k] += sum_rows x[row][k] for k < nreal as well (the bias gradient, when x is a layer's dY)
+int clx_sp_split(const float* x, long long ld, long long rows, int K, void* planes, float* colsum, int nreal, hipStream_t st) {
   CLX_REQUIRE(x != nullptr && planes != nullptr, "clx_split_planes: null pointer");
   CLX_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0, "clx_split_planes: K must be a multiple of 16, ld >= K a multiple of 4");
   CLX_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 15) == 0, "clx_split_planes: pointers must be 16-byte aligned");
-  const long long nfrag = (rows + 63) / 64 * 2 * (K / 16);
+  const int ksteps = K / 16;
+  const long long nfrag = sp::padded_rows(rows) / 32 * ksteps;
   long long blocks = (nfrag + 3) / 4;
   if (blocks > 8192) blocks = 8192;
-  CLX_LAUNCH_KIND(CLX_PROF_SPLIT_PLANES, sp_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, K / 16,
-                  (char*)planes, nfrag);
+  if (colsum != nullptr) {
+    // wavefronts (4 per block) a multiple of the k steps: blocks a multiple of ksteps / gcd(ksteps, 4)
+    int g = ksteps % 4 == 0 ? 4 : ksteps % 2 == 0 ? 2 : 1;
+    const long long unit = ksteps / g;
+    blocks = (blocks + unit - 1) / unit * unit;
+    CLX_LAUNCH_KIND(CLX_PROF_SPLIT_PLANES, sp_split_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, rows, ksteps, (char*)planes,
+                    nfrag, colsum, nreal);
+  } else {
+    CLX_LAUNCH_KIND(CLX_PROF_SPLIT_PLANES, sp_split_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, x, ld, rows, ksteps, (char*)planes,
+                    nfrag, (float*)nullptr, 0);
+  }
+  return CLX_OK;
+}
+
+extern "C" int clx_split_planes(const float* x, long long ld, long long rows, int K, void* planes, clx_stream stream) {
+  const int rc = clx_sp_split(x, ld, rows, K, planes, nullptr, 0, (hipStream_t)stream);
+  if (rc) return rc;
   CLX_CHECK_LAUNCH("clx_split_planes");
   return CLX_OK;
 }
@@ -596,7 +636,7 @@ extern "C" int clx_split_planes(const float* x, long long ld, long long rows, in
 extern "C" int clx_join_planes(const void* planes, long long rows, int K, float* x, long long ld, clx_stream stream) {
   CLX_REQUIRE(x != nullptr && planes != nullptr, "clx_join_planes: null pointer");
   CLX_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K, "clx_join_planes: K must be a multiple of 16, ld >= K");
-  const long long nfrag = (rows + 63) / 64 * 2 * (K / 16);
+  const long long nfrag = sp::padded_rows(rows) / 32 * (K / 16);
   long long blocks = (nfrag + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   sp_join_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>((const char*)planes, ld, rows, K / 16, x, nfrag);
@@ -624,7 +664,7 @@ int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long r
   p.bs_a = bs_a; p.bs_b = bs_b; p.bs_out = bs_out;
   p.out = ep->out; p.ld_out = ep->ld_out;
   p.M = M; p.N = N; p.ksteps = K / 16;
-  p.rb_a = (int)((rows_a + 63) / 64 * 2);
+  p.rb_a = (int)(sp::padded_rows(rows_a) / 32);
   p.bias = ep->bias; p.mask = ep->mask; p.mask_bits = ep->mask_bits; p.gate_out = ep->gate_out;
   p.relu = ep->relu; p.accumulate = ep->accumulate; p.ld_mask = ep->ld_mask; p.ld_mask_bits = ep->ld_mask_bits; p.ld_gate = ep->ld_gate;
   p.zeros = sp_zero_buffer();
@@ -647,7 +687,7 @@ int clx_sp_wgrad_launch(const void* dy_planes, const void* x_planes, long long r
   p.M = N; p.N = C;
   p.stride_a = (unsigned int)(N / 16) * KSTEP; p.stride_b = (unsigned int)(C / 16) * KSTEP;
   CLX_REQUIRE(sp::planes_bytes(rows, N) < (1ll << 32) && sp::planes_bytes(rows, C) < (1ll << 32), "clx_wgrad_planes: operand planes beyond 4 GB");
-  p.total_steps = (int)((rows + 63) / 64 * 4);
+  p.total_steps = (int)(sp::padded_rows(rows) / 16);
   p.nbm = cdiv(N, SP_BM); p.nbn = C / SP_BN;
   const int tiles = p.nbm * p.nbn * batch;
   // pixel slices: the grid that costs the fewest rounds of co-resident blocks (one per CU), a block's prologue + atomics
@@ -667,7 +707,7 @@ int clx_sp_wgrad_launch(const void* dy_planes, const void* x_planes, long long r
   }
   p.steps_per_slice = (cdiv(p.total_steps, best_ns) + 3) / 4 * 4;
   p.nslices = cdiv(p.total_steps, p.steps_per_slice);
-  CLX_REQUIRE(p.total_steps >= 8 && p.total_steps - (p.nslices - 1) * p.steps_per_slice >= 8, "clx_wgrad_planes: fewer than 128 pixels");
+  CLX_REQUIRE(p.total_steps >= 8 && p.total_steps - (p.nslices - 1) * p.steps_per_slice >= 8, "clx_wgrad_planes: internal: a slice of fewer than 8 steps");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled()) clx_prof_events(CLX_PROF_WGRAD_SP, 2.0 * rows * N * C * batch, &e0, &e1);
   CLX_LAUNCH_TIMED(gemm_sp_kernel<1>, dim3(p.nbm * p.nbn * p.nslices * batch), dim3(512), st, e0, e1, p);

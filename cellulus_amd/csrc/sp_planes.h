@@ -11,9 +11,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int FRAG = 1024;          // bytes of one fragment: 32 rows x 16 k x bf16
 constexpr int KSTEP = 3 * FRAG;     // the three pieces of one (32-row block, 16-k step)
 
-// bytes of the planes of an [rows][K] operand: rows padded to a multiple of 64 (two row blocks: the weight gradient
-// walks the pixels in periods of four 16-pixel steps)
-__host__ __device__ inline long long planes_bytes(long long rows, int K) { return (rows + 63) / 64 * 2 * (long long)(K / 16) * KSTEP; }
+// rows the planes of an [rows][K] operand hold: padded to a multiple of 64, at least 128 (the weight gradient walks the
+// pixels in periods of four 16-pixel steps, at least two of them); the padding rows are zero
+__host__ __device__ inline long long padded_rows(long long rows) { return rows <= 128 ? 128 : (rows + 63) / 64 * 64; }
+// bytes of those planes
+__host__ __device__ inline long long planes_bytes(long long rows, int K) { return padded_rows(rows) / 32 * (long long)(K / 16) * KSTEP; }
 
 // byte offset of the 16 bytes x_0[row][8 * octet .. + 7] (piece 0; pieces 1, 2 follow at + FRAG, + 2 FRAG)
 __host__ __device__ inline long long piece_offset(long long row, int octet, int ksteps) {
@@ -65,5 +67,5 @@ __device__ __forceinline__ void item_to_row_channel(long long i, int C, long lon
 
 }  // namespace sp
 
-// zero the rows [rows, 64 ceil(rows / 64)) of `batch` plane sets (stride bs bytes) of an [rows][K] operand
+// zero the padding rows [rows, padded_rows(rows)) of `batch` plane sets (stride bs bytes) of an [rows][K] operand
 int clx_sp_zero_tail(void* planes, long long rows, int K, int batch, long long bs, hipStream_t st);

@@ -948,7 +948,7 @@ static int wino_adjoint(const clx_conv_desc* d, hipStream_t st) {
   const int planes_dy = d->ID, planes_dx = d->ID + 2 * d->PD - (d->KD - 1);      // z planes of dY / of dX
   const long long Tdy = (long long)d->B * planes_dy * th * tw, Tdx = (long long)d->B * planes_dx * th * tw;
   const int Nf = d->src[0].C, Cp = d->N;
-  const bool spx = d->precision == CLX_PREC_F32X3BF16 && d->KD == 1 && d->ID == 1 && Cp % 128 == 0 && Nf % 128 == 0;   // = wino_sp of the layer
+  const bool spx = wino_sp(d);           // (N = Cp, C = Nf, extent of dY: the rule gives what it gave the layer's forward form)
   const size_t need = spx ? (size_t)36 * (sp::planes_bytes(Tdx, Cp) + sp::planes_bytes(Tdy, Nf))
                           : (size_t)36 * (Tdx * Cp + Tdy * Nf) * sizeof(float);
   CLX_REQUIRE(d->workspace != nullptr && d->workspace_bytes >= need && ((uintptr_t)d->workspace & 15) == 0,

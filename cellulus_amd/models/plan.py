@@ -60,6 +60,19 @@ def wino_min_channels(kernel):
     return WINO_MIN_CHANNELS_3D if kernel[0] > 1 else WINO_MIN_CHANNELS
 
 
+def precision_code() -> int:
+    """clx_conv_precision of the plain products (1x1 layers, the transform-domain products of the 2-D Winograd layers;
+    forward, data gradient and weight gradient): 0 = float32 MFMA; 1 = CLX_PRECISION=f32x3bf16, the exact three-way
+    bfloat16 split of the float32 operands with six products per float32 product on the bf16 matrix cores
+    (csrc/gemm_sp.hip)."""
+    name = os.environ.get("CLX_PRECISION", "f32") or "f32"
+    if name == "f32":
+        return 0
+    if name == "f32x3bf16":
+        return 1
+    raise ValueError(f"CLX_PRECISION must be 'f32' or 'f32x3bf16', got {name!r}")
+
+
 def winograd_enabled() -> bool:
     return os.environ.get("CLX_WINOGRAD", "1") != "0"
 
@@ -315,12 +328,22 @@ class UNetPlan:
         self.B = int(batch)
         self.device = device
         self.keep = keep_activations
-        self.fused = fused_wanted(keep_activations)
+        self.precision = precision_code()
+        # (the one-launch Winograd kernels multiply in float32: with the split precision the three-launch form, whose
+        #  products run on the bf16 matrix cores, is the faster one)
+        self.fused = fused_wanted(keep_activations) and self.precision == 0
         # opt-in: run-to-run reproducible training (CLX_DETERMINISTIC=1; the reference's CPU autograd is
         # deterministic, cellulus/train.py:177-179).  Weight-gradient slices add in a fixed order, bias
         # gradients come from ordered column sums, the first layer takes the generic kernel and the fused
         # 1x1 pairs are off (their block sums meet in float atomics); train._fused_step switches the loss.
         self.deterministic = os.environ.get("CLX_DETERMINISTIC", "0") == "1"
+        if self.deterministic and self.precision:
+            raise ValueError("CLX_DETERMINISTIC=1 is implemented for the default precision (float32 MFMA) only")
+        self._wplanes = {}          # data_ptr of a packed-weight tensor -> (tensor, its P3 planes, rows, K)
+        self.aplanes = None         # scratch for the planes of a 1x1 layer's input (inference) ...
+        self.xplanes = {}           # ... or one buffer per layer (training: the weight gradient reuses them)
+        self._xplanes_fresh = set()
+        self.dyplanes = None        # planes of the dY a 1x1 layer's weight gradient has split, reused by its data gradient
         self.buf = {}
         self._alloc()
 
@@ -441,6 +464,20 @@ class UNetPlan:
             taps = wino_taps(code, layer.kernel) if code else layer.taps
             self.wpack_fwd[layer.name] = torch.empty(
                 pad4(layer.cout) * taps * layer.cin_pad, dtype=torch.float32, device=self.device)
+            if code and layer.kernel[0] == 1:
+                self._register_wplanes(self.wpack_fwd[layer.name], pad4(layer.cout), WINO_TAPS[code], layer.cin_pad)
+            elif not code and self._pointwise_sp(layer)[0]:
+                self._register_wplanes(self.wpack_fwd[layer.name], pad4(layer.cout), 1, layer.cin_pad)
+        for sp in self.subpixel.values():
+            if sp["wino"] and sp["zk"][0] == 1:
+                self._register_wplanes(sp["wp_z_fwd"], sp["P"] * sp["N"], 25, sp["C1p"])
+        if self.precision:
+            # scratch for the planes of a 1x1 layer's input (a training plan keeps one buffer per layer instead)
+            rows_k = [(self.B * layer.in_shape[0] * layer.in_shape[1] * layer.in_shape[2], layer.cin_pad)
+                      for layer in t.convs if self._pointwise_sp(layer)[0]]
+            if rows_k:
+                self.aplanes = torch.empty(max(int(_clx.load().clx_planes_bytes(r, k)) for r, k in rows_k),
+                                           dtype=torch.uint8, device=self.device)
         self._packed_version = None
         self._bwd_ready = False
         self.vcache = {}
@@ -464,6 +501,7 @@ class UNetPlan:
         assert other._bwd_ready and self._bwd_ready and other.B == self.B and other.algo == self.algo
         assert other.dw_off == self.dw_off and other.dwpack.numel() == self.dwpack.numel()
         self.wpack_fwd, self.wpack_dgrad, self.dwpack = other.wpack_fwd, other.wpack_dgrad, other.dwpack
+        self._wplanes = other._wplanes
         for name, sp in self.subpixel.items():
             for key in ("w_skip", "weff", "wp_skip_fwd", "wp_z_fwd", "wp_skip_dgrad", "wp_z_dgrad", "dw_skip", "dw_z"):
                 sp[key] = other.subpixel[name][key]
@@ -472,6 +510,7 @@ class UNetPlan:
         """Forward-only version of share_from: this plan reads `other`'s packed weights and never packs."""
         assert other.B == self.B and other.algo == self.algo and other.keep == self.keep
         self.wpack_fwd = other.wpack_fwd
+        self._wplanes = other._wplanes
         for name, sp in self.subpixel.items():
             for key in ("w_skip", "weff", "wp_skip_fwd", "wp_z_fwd"):
                 sp[key] = other.subpixel[name][key]
@@ -517,12 +556,14 @@ class UNetPlan:
                                         device=self.device)
                 if sp["wino_skip"] and not sp["fused_skip"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     tiles = self.B * layer.in_shape[0] * -(-layer.out_shape[1] // 4) * -(-layer.out_shape[2] // 4)
-                    sp["vcache_skip"] = torch.empty(36 * tiles * sp["C0p"], dtype=torch.float32, device=self.device)
+                    sp["vcache_skip"] = torch.empty(self._vfloats(36, tiles, sp["C0p"]), dtype=torch.float32, device=self.device)
                 sp["_dw_z_n"] = ztaps * sp["P"] * sp["N"] * sp["C1p"]
                 if sp["wino"] and not sp["fused_z"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                     zs = sp["zshape"]
                     tiles = self.B * (zs[0] + sp["zk"][0] - 1) * -(-zs[1] // 4) * -(-zs[2] // 4)
-                    sp["vcache"] = torch.empty(25 * tiles * sp["C1p"], dtype=torch.float32, device=self.device)
+                    sp["vcache"] = torch.empty(self._vfloats(25, tiles, sp["C1p"]), dtype=torch.float32, device=self.device)
+                if sp["wino"] and sp["zk"][0] == 1:
+                    self._register_wplanes(sp["wp_z_dgrad"], sp["C1p"], 25, sp["P"] * sp["N"])
         # ReLU gates as bits: written by the epilogue that produces a layer's output, read by the data
         # gradient that passes through that ReLU — 1/32 of the float tensor it would otherwise read (the
         # 64-channel 1x1 layers of the 3-D network are HBM-bound).  Whole words per pixel (channels %
@@ -556,7 +597,8 @@ class UNetPlan:
 
             def dual_floats(code, out_shape, k, chans):
                 a2, m = (WINO_TAPS[code], WINO_TILE[code]) if k == 3 else (25, 4)
-                return a2 * self.B * out_shape[0] * (-(-(out_shape[1] + k - 1) // m)) * (-(-(out_shape[2] + k - 1) // m)) * chans
+                return self._vfloats(a2, self.B * out_shape[0] * (-(-(out_shape[1] + k - 1) // m)) * (-(-(out_shape[2] + k - 1) // m)),
+                                     chans)
 
             for layer in t.convs:
                 a = self.algo[layer.name]
@@ -574,7 +616,7 @@ class UNetPlan:
             if a["fwd"] and a["fwd"] == a["wgrad"] and os.environ.get("CLX_WINOGRAD_VCACHE", "1") != "0":
                 m = WINO_TILE[a["fwd"]]
                 tiles = self.B * layer.in_shape[0] * -(-layer.out_shape[1] // m) * -(-layer.out_shape[2] // m)
-                self.vcache[layer.name] = torch.empty(WINO_TAPS[a["fwd"]] * tiles * layer.cin_pad,
+                self.vcache[layer.name] = torch.empty(self._vfloats(WINO_TAPS[a["fwd"]], tiles, layer.cin_pad),
                                                       dtype=torch.float32, device=self.device)
         total = 0
         self.dw_off = {}
@@ -587,6 +629,24 @@ class UNetPlan:
                 taps = wino_taps(code, layer.kernel) if code else layer.taps
                 self.wpack_dgrad[layer.name] = torch.empty(
                     layer.cin_pad * taps * pad4(layer.cout), dtype=torch.float32, device=self.device)
+                if code and layer.kernel[0] == 1:
+                    self._register_wplanes(self.wpack_dgrad[layer.name], layer.cin_pad, WINO_TAPS[code], pad4(layer.cout))
+                elif not code and self._pointwise_sp(layer)[1]:
+                    self._register_wplanes(self.wpack_dgrad[layer.name], layer.cin_pad, 1, pad4(layer.cout))
+        if self.precision:
+            # training: the planes of a 1x1 layer's input stay for its weight gradient; one scratch for the planes of dY
+            need_dy = 0
+            for layer in t.convs:
+                fwd_sp, dgrad_sp, wgrad_sp = self._pointwise_sp(layer)
+                if layer.name in self.chains or layer.name in self.chain_second:
+                    continue
+                rows = self.B * layer.in_shape[0] * layer.in_shape[1] * layer.in_shape[2]
+                if fwd_sp or wgrad_sp:
+                    self.xplanes[layer.name] = self._planes_scratch(rows, layer.cin_pad)
+                if (dgrad_sp and layer.param_index > 0) or wgrad_sp:
+                    need_dy = max(need_dy, int(_clx.load().clx_planes_bytes(rows, pad4(layer.cout))))
+            if need_dy:
+                self.dyplanes = torch.empty(need_dy, dtype=torch.uint8, device=self.device)
         # the sub-pixel layers' weight-gradient accumulators live behind the others: one fill zeroes all
         sp_off = {}
         for name, sp in self.subpixel.items():
@@ -720,6 +780,7 @@ class UNetPlan:
         ds.KD, ds.KH, ds.KW = layer.kernel
         ds.PD = ds.PH = ds.PW = 0
         for d in (dz, ds):
+            d.precision = self.precision
             d.algo = 0
             d.accumulate = 0
             d.workspace = None
@@ -759,7 +820,7 @@ class UNetPlan:
     def _sp_forward(self, layer, sp, bias, st):
         dz, ds = self._sp_descs(layer, sp)
         zbuf = self.buf[sp["zname"]]
-        dz.wpack = sp["wp_z_fwd"].data_ptr()
+        self._set_wpack(dz, sp["wp_z_fwd"])
         dz.out = zbuf.data_ptr()
         dz.ld_out = sp["P"] * sp["N"]
         sp["_v_fresh"] = False
@@ -776,7 +837,7 @@ class UNetPlan:
         _clx.call("clx_depth_to_space", _clx.ptr(zbuf), sp["P"] * sp["N"], _clx.ptr(out), sp["N"], self.B,
                   zs[0], zs[1], zs[2], sp["N"], *sp["fac"], st)
         ds.N = layer.cout
-        ds.wpack = sp["wp_skip_fwd"].data_ptr()
+        self._set_wpack(ds, sp["wp_skip_fwd"])
         ds.bias = bias.data_ptr() if bias is not None else None
         ds.relu = 1 if layer.relu else 0
         ds.accumulate = 1
@@ -847,7 +908,7 @@ class UNetPlan:
         dskip = self.gbuf["dskip%d" % sp["level"]]
         dd = self._dgrad_desc(layer, dy)
         dd.N = sp["C0p"]
-        dd.wpack = sp["wp_skip_dgrad"].data_ptr()
+        self._set_wpack(dd, sp["wp_skip_dgrad"])
         dd.mask = None
         dd.ld_mask = 0
         dd.out = dskip.data_ptr()
@@ -857,7 +918,7 @@ class UNetPlan:
         _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
         # data gradient of the low-res tensor straight from dZ (replaces upsample backward)
         dl = self._sp_low_dgrad_desc(layer, sp, dzbuf)
-        dl.wpack = sp["wp_z_dgrad"].data_ptr()
+        self._set_wpack(dl, sp["wp_z_dgrad"])
         if sp["wino"]:
             self._use_workspace(dl, sp["wino"])
             if self.dycache is not None:       # written by the weight-gradient call on dZ above
@@ -893,6 +954,7 @@ class UNetPlan:
         dl.algo = 0
         dl.workspace = None
         dl.workspace_bytes = 0
+        dl.precision = self.precision
         if dzbuf is not None:
             self._set_mask(dl, up_s.tensor)                 # ReLU gate of the low-res tensor
         else:                                               # geometry-only query
@@ -925,6 +987,7 @@ class UNetPlan:
         d.algo = 0
         d.workspace = None
         d.workspace_bytes = 0
+        d.precision = self.precision
         # a raw image with 1-3 channels is stored padded to 4: tell the first-layer kernels
         d.c_real = layer.sources[0].channels if len(layer.sources) == 1 else 0
         return d
@@ -956,6 +1019,50 @@ class UNetPlan:
         d.workspace = self.workspace.data_ptr()
         d.workspace_bytes = self.workspace.numel() * 4
 
+    # ------------------------------------------------- split precision (CLX_PRECISION=f32x3bf16; csrc/gemm_sp.hip)
+    def _register_wplanes(self, wp, n, batch, k):
+        """planes for the packed weights `wp` seen as `batch` matrices [n][k] (the B operand of a plain product), if
+        the split-precision kernels cover that product"""
+        if not self.precision or n % 128 or k % 64 or k < 128 or wp.data_ptr() in self._wplanes:
+            return
+        nbytes = int(_clx.load().clx_planes_bytes(batch * n, k))
+        self._wplanes[wp.data_ptr()] = (wp, torch.empty(nbytes, dtype=torch.uint8, device=self.device), batch * n, k)
+
+    def _set_wpack(self, d, wp):
+        d.wpack = wp.data_ptr()
+        e = self._wplanes.get(wp.data_ptr())
+        d.wplanes = e[1].data_ptr() if e is not None else None
+
+    def _split_wplanes(self, st):
+        """the planes of every registered packed-weight tensor, after a (re)packing"""
+        for wp, planes, rows, k in self._wplanes.values():
+            _clx.call("clx_split_planes", _clx.ptr(wp), k, rows, k, _clx.ptr(planes), st)
+
+    def _pointwise_sp(self, layer: ConvLayer):
+        """(forward product, data-gradient product, weight-gradient product) of a 1x1 layer over one plain source in the
+        split precision?  The rules of clx_sp_applicable / clx_conv_wgrad."""
+        if not self.precision or tuple(layer.kernel) != (1, 1, 1) or len(layer.sources) != 1:
+            return False, False, False
+        s = layer.sources[0]
+        shape, _c = self.topo.shapes[s.tensor]
+        if tuple(s.crop) != (0, 0, 0) or tuple(s.factor) != (1, 1, 1) or tuple(shape) != tuple(layer.in_shape):
+            return False, False, False
+        n, c = pad4(layer.cout), layer.cin_pad
+        if layer.cout != n:
+            return False, False, False
+        return (n % 128 == 0 and c % 64 == 0 and c >= 128, c % 128 == 0 and n % 64 == 0 and n >= 128,
+                n % 128 == 0 and c % 128 == 0)
+
+    def _vfloats(self, a2, tiles, chans):
+        """floats of a buffer for `a2` transformed tensors [tiles][chans]: float32, or P3 planes (6 bytes per element,
+        rows padded to 64) where the layer may run in the split precision"""
+        if not self.precision:
+            return a2 * tiles * chans
+        return a2 * max(128, (tiles + 63) // 64 * 64) * chans * 3 // 2 + 16
+
+    def _planes_scratch(self, rows, k):
+        return torch.empty(int(_clx.load().clx_planes_bytes(rows, k)), dtype=torch.uint8, device=self.device)
+
     def _dgrad_desc(self, layer: ConvLayer, dy):
         """Data gradient as a convolution of dy (zero padding k-1, flipped transposed weights)."""
         dd = ClxConvDesc()
@@ -979,6 +1086,7 @@ class UNetPlan:
         dd.algo = 0
         dd.workspace = None
         dd.workspace_bytes = 0
+        dd.precision = self.precision
         return dd
 
     def _expand_cin(self, layer, w):
@@ -1153,6 +1261,7 @@ class UNetPlan:
             _clx.call("clx_pack_weights_batch", _clx.ptr(cache["table"]), cache["njobs"], cache["biggest"], st)
         for layer in cache["singles"]:
             self._pack_layer(layer, params[2 * layer.param_index], need_dgrad, st)
+        self._split_wplanes(st)
 
     def pack_weights(self, params, version, need_dgrad):
         """(Re)pack weights when the parameters changed (version = tuple of tensor versions)."""
@@ -1173,6 +1282,7 @@ class UNetPlan:
                 self._sp_pack(layer, self.subpixel[layer.name], w, need_dgrad, st)
                 continue
             self._pack_layer(layer, w, need_dgrad, st)
+        self._split_wplanes(st)
         self._packed_version = key
 
     # ----------------------------------------------------------------- forward
@@ -1265,7 +1375,7 @@ class UNetPlan:
         listed output tiles only)"""
         d = self._desc(op)
         d.N = op.cout
-        d.wpack = self.wpack_fwd[op.name].data_ptr()
+        self._set_wpack(d, self.wpack_fwd[op.name])
         b = params[2 * op.param_index + 1]
         d.bias = b.data_ptr() if b is not None else None
         d.relu = 1 if op.relu else 0
@@ -1275,6 +1385,11 @@ class UNetPlan:
         d.ld_out = pad4(op.cout)
         if op.relu and self.keep:
             self._set_gate_out(d, op.out)
+        if self.precision and not self.algo[op.name]["fwd"] and self._pointwise_sp(op)[0]:
+            xp = self.xplanes.get(op.name) if self.keep and self._bwd_ready and tiles is None else None
+            d.aplanes = (xp if xp is not None else self.aplanes).data_ptr()
+            if xp is not None:
+                self._xplanes_fresh.add(op.name)
         if self.algo[op.name]["fwd"]:
             self._use_workspace(d, self.algo[op.name]["fwd"])
             if self.keep and self._bwd_ready and op.name in self.vcache:
@@ -1343,7 +1458,10 @@ class UNetPlan:
                 d.KD = d.KH = d.KW = 1
                 d.PD = d.PH = d.PW = 0
                 d.N = op.cout
-                d.wpack = self.wpack_fwd[op.name].data_ptr()
+                self._set_wpack(d, self.wpack_fwd[op.name])
+                d.precision = self.precision
+                if self.precision and self.aplanes is not None:       # (n <= the dense tensor's rows: the scratch fits)
+                    d.aplanes = self.aplanes.data_ptr()
                 b = params[2 * op.param_index + 1]
                 d.bias = b.data_ptr() if b is not None else None
                 d.relu = 1 if op.relu else 0
@@ -1369,6 +1487,7 @@ class UNetPlan:
         st = _clx.stream_ptr(self.device)
         sparse_tail = self.pointwise_prefix()[1] if sparse is not None else None
         self._vcache_fresh = set()      # Winograd layers whose V this forward left in self.vcache
+        self._xplanes_fresh = set()     # 1x1 layers whose input planes this forward left in self.xplanes
         npix_in = t.in_shape[0] * t.in_shape[1] * t.in_shape[2]
         raw = raw.contiguous()
         rows_only_first = sparse is not None and self.first_layer_on_rows()
@@ -1504,13 +1623,22 @@ class UNetPlan:
                     d.vcache_valid = 1
                 if dual:
                     d.dy_vcache = self.dycache.data_ptr()
+            dy_split = False
+            if not wino_w and self._pointwise_sp(layer)[2] and layer.name in self.xplanes and self.dyplanes is not None:
+                d.aplanes = self.xplanes[layer.name].data_ptr()
+                d.aplanes_valid = 1 if layer.name in self._xplanes_fresh else 0
+                d.dyplanes = self.dyplanes.data_ptr()
+                dy_split = True
             self._wgrad(d, dy, pad4(layer.cout), dwp, gb, layer.cout, st)
             yield (layer.param_index,), self._unpack_step(layer, dwp, grads[2 * layer.param_index], wino_w)
             # ---- data gradient
             if layer.param_index == 0:
                 continue
             dd = self._dgrad_desc(layer, dy)
-            dd.wpack = self.wpack_dgrad[layer.name].data_ptr()
+            self._set_wpack(dd, self.wpack_dgrad[layer.name])
+            if not self.algo[layer.name]["dgrad"] and self._pointwise_sp(layer)[1] and self.dyplanes is not None:
+                dd.aplanes = self.dyplanes.data_ptr()
+                dd.aplanes_valid = 1 if dy_split else 0          # the weight gradient above has just split this dY
             if self.algo[layer.name]["dgrad"]:
                 self._use_workspace(dd, self.algo[layer.name]["dgrad"])
                 if adjoint:                    # A dY A^T was left in the workspace by the weight-gradient call above

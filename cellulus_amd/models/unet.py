@@ -412,6 +412,7 @@ class UNetModel(nn.Module):  # type: ignore
         if tiles is not None and not cp[2]:
             tiles = None
         one.wpack_fwd = plan.wpack_fwd
+        one._wplanes = plan._wplanes
         clean_rows = one.forward_prefix(clean, params, len(tail) + (1 if tiles is not None else 0))
         clean_tile_rows = clean_pool_rows = None
         if tiles is not None:

@@ -178,10 +178,16 @@ typedef struct clx_conv_desc {
    * whenever wpack is); those of the activations are made by the library: by the Winograd transforms themselves inside
    * `workspace` / `vcache` (clx_conv_workspace_bytes and clx_conv_vcache_bytes grow accordingly), by a split pass into
    * `aplanes` (clx_planes_bytes(M, C) bytes of scratch) for a 1x1 layer.  A layer without wplanes (or a 1x1 layer
-   * without aplanes) runs in float32. */
+   * without aplanes) runs in float32.
+   * aplanes_valid = 1: `aplanes` already holds the planes of src[0] (an earlier call of the same layer left them: the
+   * forward pass for the weight gradient, the weight gradient's dyplanes for the data gradient) — no split pass.
+   * dyplanes (clx_conv_wgrad of a 1x1 layer only): clx_planes_bytes(M, N) bytes that receive the planes of dY; the bias
+   * gradient comes out of that split pass. */
   int precision;
   const void* wplanes;
   void* aplanes;
+  int aplanes_valid;
+  void* dyplanes;
 } clx_conv_desc;
 
 enum clx_conv_precision { CLX_PREC_F32 = 0, CLX_PREC_F32X3BF16 = 1 };
@@ -242,7 +248,7 @@ size_t clx_conv_vcache_bytes(const clx_conv_desc* d, int which);
  * <= 2^-24 relative, one float32 rounding.  The pieces are made ONCE where a tensor is produced, in the layout the
  * matrix core consumes ("P3"): an [R][K] operand (K % 16 == 0) as 1-KB fragments, fragment (rb, ks, p) = piece p of
  * rows 32 rb .. 32 rb + 31, k = 16 ks .. 16 ks + 15 at byte ((rb * K/16 + ks) * 3 + p) * 1024; inside a fragment the 16 bytes
- * at 512 h + 16 r hold x_p[32 rb + r][16 ks + 8 h .. + 7].  Rows up to the next multiple of 64 exist and are ZERO.  6 bytes
+ * at 512 h + 16 r hold x_p[32 rb + r][16 ks + 8 h .. + 7].  Rows up to the next multiple of 64 (at least 128 rows) exist and are ZERO.  6 bytes
  * per element.  (No reference counterpart: the reference's torch.nn.Conv{2,3}d keep float32 operands,
  * cellulus/models/unet.py:24-63.) */
 /* bytes of the P3 planes of an [rows][K] operand (0 if K % 16 != 0) */
