@@ -92,6 +92,9 @@ class ClxConvDesc(Structure):
         ("aplanes", c_void_p),
         ("aplanes_valid", c_int),
         ("dyplanes", c_void_p),
+        ("dyplanes_valid", c_int),
+        ("out_planes", c_void_p),
+        ("out_colsum", c_void_p),
     ]
 
 
@@ -118,6 +121,7 @@ PROTOTYPES = {
     "clx_unpack_wgrad_wino": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "clx_conv_workspace_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
     "clx_conv_vcache_bytes": (c_size_t, [POINTER(ClxConvDesc), _I]),
+    "clx_conv_sp_covers": (_I, [POINTER(ClxConvDesc)]),
     "clx_planes_bytes": (c_size_t, [_LL, _I]),
     "clx_split_planes": (_I, [_P, _LL, _LL, _I, _P, _P]),
     "clx_join_planes": (_I, [_P, _LL, _I, _P, _LL, _P]),

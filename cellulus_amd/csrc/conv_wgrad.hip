@@ -517,7 +517,7 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
       int rc = 0;
       if (!d->aplanes_valid) rc = clx_sp_split(S.ptr, S.ld, M, S.C, d->aplanes, nullptr, 0, (hipStream_t)stream);
       if (rc) return rc;
-      rc = clx_sp_split(dy, ld_dy, M, d->N, d->dyplanes, dbias, d->N, (hipStream_t)stream);
+      if (!d->dyplanes_valid) rc = clx_sp_split(dy, ld_dy, M, d->N, d->dyplanes, dbias, d->N, (hipStream_t)stream);
       if (rc) return rc;
       rc = clx_sp_wgrad_launch(d->dyplanes, d->aplanes, M, d->N, S.C, 1, 0, 0, 0, dwpack, S.C, (hipStream_t)stream);
       if (rc) return rc;

@@ -163,6 +163,8 @@ struct SpP {
   const float* zeros;
   int relu, accumulate, ld_out, ld_mask, ld_mask_bits, ld_gate;
   int nbm, nbn;
+  char* out_planes;                   // forward, one problem per launch: ALSO the P3 planes of out ([M][N]), or NULL
+  float* colsum; int colsum_n;        // forward: colsum[n] += sum_m out[m][n], n < colsum_n, or NULL
   // weight gradient: the contraction runs over pixel steps of 16; a block takes `steps_per_slice` of them
   unsigned int stride_a, stride_b;    // bytes of one 32-pixel row block of the dY / x planes
   int total_steps, steps_per_slice, nslices;
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
   }
   // ---- epilogue (conv_igemm.hip's): plain products on whole tiles store straight from the accumulators, everything else
   // goes through an LDS transpose so that every lane stores — and reads the optional operands as — 16-byte channel runs
-  if (!p.bias && !p.relu && !p.accumulate && !p.mask && !p.mask_bits && !p.gate_out && m0 + SP_BM <= p.M) {
+  if (!p.bias && !p.relu && !p.accumulate && !p.mask && !p.mask_bits && !p.gate_out && !p.out_planes && !p.colsum && m0 + SP_BM <= p.M) {
     float* const ob = p.out + batch * p.bs_out;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -503,12 +505,18 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
       }
     }
   __syncthreads();
-  constexpr int F4_PER_ROW = SP_BN / 4;                 // 32
-  constexpr int ITERS = SP_BM * F4_PER_ROW / 512;       // 16
+  // A wavefront takes 8 rows x 32 channels per pass (the eight lanes of a row hold one gate word; the float32 stores are
+  // 128-byte runs, and so are the stores of every piece of the output's own planes: sp_planes.h); the 8 waves of a pass
+  // cover 16 rows x 128 channels, 16 passes the tile.
+  constexpr int ITERS = SP_BM / 16;                     // 16
   constexpr int PH = 8;
-  const int c4 = (tid % F4_PER_ROW) * 4;
+  const int wv = tid >> 6;
+  const int c4 = (wv & 3) * 32 + (lane & 7) * 4;
+  const int row0 = (wv >> 2) * 8 + (lane >> 3);
   const int n = n0 + c4;
   const bool n_live = n < p.N;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const long long prow = p.out_planes ? sp::padded_rows(p.M) : 0;
 #pragma unroll 1
   for (int h0 = 0; h0 < ITERS; h0 += PH) {
     f32x4 val[PH];
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
     bool live[PH];
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
-      const int row = (tid + 512 * (h0 + j)) / F4_PER_ROW;
+      const int row = row0 + 16 * (h0 + j);
       mrow[j] = m0 + row;
       live[j] = mrow[j] < p.M && n_live;
       val[j] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
@@ -571,6 +579,34 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
 #pragma unroll
     for (int j = 0; j < PH; ++j)
       if (live[j]) *reinterpret_cast<f32x4*>(out_base + (size_t)mrow[j] * p.ld_out) = val[j];      // N % 128 == 0: whole groups
+    if (p.out_planes) {
+      // the result as the next product's operand: its three pieces, split here instead of by a pass of its own; the
+      // padding rows of the planes (all inside the last tile of rows) as zeros
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        if (n_live && mrow[j] < prow)
+          sp::store4(p.out_planes, mrow[j], n, p.N >> 4, live[j] ? val[j] : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    if (p.colsum) {
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        if (live[j]) csum += val[j];
+    }
+  }
+  if (p.colsum) {
+    // column sums of the stored tile (the bias gradient of the layer whose dY this launch produces): over the 8 rows of
+    // the wavefront by shuffles, then one float atomic per channel and wavefront
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      csum[e] += __shfl_xor(csum[e], 8, 64);
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    if ((lane >> 3) == 0 && n_live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.colsum_n) atomicAdd(p.colsum + n + e, csum[e]);
+    }
   }
 }
 
@@ -653,13 +689,17 @@ bool clx_sp_applicable(const clx_conv_desc* d) {
   return d->N % SP_BN == 0 && S.C % 64 == 0 && S.C >= 128 && d->ld_out % 4 == 0;
 }
 
+extern "C" int clx_conv_sp_covers(const clx_conv_desc* d) {
+  return d != nullptr && d->algo == CLX_ALGO_DIRECT && d->aplanes != nullptr && clx_sp_applicable(d) ? 1 : 0;
+}
+
 // the batched product behind clx_gemm_planes and the precision switch of clx_conv_fwd: `batch` problems, operand b at
 // A + b * bs_a / B + b * bs_b (bytes), result at out + b * bs_out (floats)
 int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long rows_a, int batch, long long bs_a, long long bs_b,
                   long long bs_out, const clx_conv_desc* ep, hipStream_t st) {
   CLX_REQUIRE(M > 0 && N > 0 && N % SP_BN == 0 && K >= 128 && K % 64 == 0, "clx_gemm_planes: needs N %% 128 == 0, K %% 64 == 0 and K >= 128");
   CLX_REQUIRE(rows_a >= M, "clx_gemm_planes: the A planes hold fewer rows than M");
-  SpP p;
+  SpP p = {};
   p.A = (const char*)A; p.B = (const char*)B;
   p.bs_a = bs_a; p.bs_b = bs_b; p.bs_out = bs_out;
   p.out = ep->out; p.ld_out = ep->ld_out;
@@ -669,6 +709,9 @@ int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long r
   p.relu = ep->relu; p.accumulate = ep->accumulate; p.ld_mask = ep->ld_mask; p.ld_mask_bits = ep->ld_mask_bits; p.ld_gate = ep->ld_gate;
   p.zeros = sp_zero_buffer();
   CLX_REQUIRE(p.zeros != nullptr, "clx_gemm_planes: cannot resolve the device zero buffer");
+  p.out_planes = batch == 1 ? (char*)ep->out_planes : nullptr;
+  p.colsum = batch == 1 ? ep->out_colsum : nullptr; p.colsum_n = N;
+  CLX_REQUIRE(p.out_planes == nullptr || ep->ld_out == N, "clx_gemm_planes: out_planes needs a dense output (ld_out == N)");
   p.nbm = cdiv(M, SP_BM); p.nbn = N / SP_BN;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled()) clx_prof_events(CLX_PROF_GEMM_SP, 2.0 * M * N * K * batch, &e0, &e1);

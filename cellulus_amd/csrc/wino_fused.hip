@@ -637,8 +637,9 @@ int clx_wino_fused_fwd(const clx_conv_desc* d, hipStream_t st) {
     const long long total = (long long)p.ntb * ((p.C + 31) / 32) * 256;
     long long gx = (total + 255) / 256;
     if (gx > 32768) gx = 32768;
-    if (d->KH == 3) wino_input_frag_kernel<3><<<(unsigned)gx, 256, 0, st>>>(p, Vf, total);
-    else wino_input_frag_kernel<2><<<(unsigned)gx, 256, 0, st>>>(p, Vf, total);
+    // (the input transform of the two-launch form: an HBM-bound launch, timed with the other transforms)
+    if (d->KH == 3) CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_input_frag_kernel<3>), dim3((unsigned)gx), dim3(256), 0, st, p, Vf, total);
+    else CLX_LAUNCH_KIND(CLX_PROF_WINO_TRANSFORM, (wino_input_frag_kernel<2>), dim3((unsigned)gx), dim3(256), 0, st, p, Vf, total);
     p.vf = Vf;
     static const int order_env = getenv("CLX_FUSED_ORDER") ? atoi(getenv("CLX_FUSED_ORDER")) : 2;
     p.order = order_env;
@@ -652,6 +653,8 @@ int clx_wino_fused_fwd(const clx_conv_desc* d, hipStream_t st) {
     CLX_CHECK_LAUNCH("clx_conv_fwd(winograd fused, two launches)");
     return CLX_OK;
   }
+  // (the one-launch form executes the same products — its FLOPs count; the transforms it repeats per channel block do not)
+  if (clx_prof_enabled()) clx_prof_events(CLX_PROF_WINO_FUSED, 2.0 * nxi * p.T * (double)p.N * p.C, &e0, &e1);
   if (d->KH == 3) CLX_LAUNCH_TIMED((wino_fused_kernel<3>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p);
   else CLX_LAUNCH_TIMED((wino_fused_kernel<2>), dim3((unsigned)blocks), dim3(512), st, e0, e1, p);
   CLX_CHECK_LAUNCH("clx_conv_fwd(winograd fused)");

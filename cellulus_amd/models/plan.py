@@ -344,6 +344,8 @@ class UNetPlan:
         self.xplanes = {}           # ... or one buffer per layer (training: the weight gradient reuses them)
         self._xplanes_fresh = set()
         self.dyplanes = None        # planes of the dY a 1x1 layer's weight gradient has split, reused by its data gradient
+        self.dyplanes2 = None
+        self._pointwise_reader = {}
         self.buf = {}
         self._alloc()
 
@@ -646,7 +648,14 @@ class UNetPlan:
                 if (dgrad_sp and layer.param_index > 0) or wgrad_sp:
                     need_dy = max(need_dy, int(_clx.load().clx_planes_bytes(rows, pad4(layer.cout))))
             if need_dy:
+                # two of them: a data gradient reads the planes of its dY out of one while its epilogue writes the planes
+                # of the next layer's dY into the other
                 self.dyplanes = torch.empty(need_dy, dtype=torch.uint8, device=self.device)
+                self.dyplanes2 = torch.empty(need_dy, dtype=torch.uint8, device=self.device)
+            # tensor -> the 1x1 layer that reads it as its one plain source and keeps planes of it
+            for layer in t.convs:
+                if layer.name in self.xplanes and pad4(t.shapes[layer.sources[0].tensor][1]) == layer.cin_pad:
+                    self._pointwise_reader[layer.sources[0].tensor] = layer
         # the sub-pixel layers' weight-gradient accumulators live behind the others: one fill zeroes all
         sp_off = {}
         for name, sp in self.subpixel.items():
@@ -1389,7 +1398,14 @@ class UNetPlan:
             xp = self.xplanes.get(op.name) if self.keep and self._bwd_ready and tiles is None else None
             d.aplanes = (xp if xp is not None else self.aplanes).data_ptr()
             if xp is not None:
+                # (planes the layer before this one has already written in its epilogue: no split pass)
+                d.aplanes_valid = 1 if op.name in self._xplanes_fresh else 0
                 self._xplanes_fresh.add(op.name)
+                # ... and this layer's epilogue writes the planes of the 1x1 layer that reads its output
+                nxt = self._pointwise_reader.get(op.out)
+                if nxt is not None and nxt.name in self.xplanes and os.environ.get("CLX_SP_EPILOGUE_PLANES", "1") != "0":
+                    d.out_planes = self.xplanes[nxt.name].data_ptr()
+                    self._xplanes_fresh.add(nxt.name)
         if self.algo[op.name]["fwd"]:
             self._use_workspace(d, self.algo[op.name]["fwd"])
             if self.keep and self._bwd_ready and op.name in self.vcache:
@@ -1585,6 +1601,7 @@ class UNetPlan:
         pool_by_out = {p.out: p for p in t.pools}
         r_by_conv0 = {info["conv0"].name: info for info in t.r_info}
         pending_skip = {}   # skip tensor name -> (cat gbuf name, conv0 layer)
+        dy_planes_of = {}   # tensor name -> buffer that holds the P3 planes of its gradient (split precision)
 
         # reverse execution order; gbuf[x] holds dL/d(pre-activation of x)
         for op in reversed(t.fwd_order):
@@ -1623,12 +1640,23 @@ class UNetPlan:
                     d.vcache_valid = 1
                 if dual:
                     d.dy_vcache = self.dycache.data_ptr()
-            dy_split = False
-            if not wino_w and self._pointwise_sp(layer)[2] and layer.name in self.xplanes and self.dyplanes is not None:
+            # split precision, 1x1 layers: the planes of this layer's dY — written by the epilogue of the data gradient that
+            # produced dY (dy_planes_of, with the bias gradient as that epilogue's column sums), or split by the weight
+            # gradient below — serve the weight gradient and the data gradient
+            dy_planes = dy_planes_of.pop(layer.out, None)
+            dy_ready = dy_planes is not None
+            if dy_planes is None and self.dyplanes is not None:
+                dy_planes = self.dyplanes
+            if not wino_w and self._pointwise_sp(layer)[2] and layer.name in self.xplanes and dy_planes is not None:
                 d.aplanes = self.xplanes[layer.name].data_ptr()
                 d.aplanes_valid = 1 if layer.name in self._xplanes_fresh else 0
-                d.dyplanes = self.dyplanes.data_ptr()
-                dy_split = True
+                d.dyplanes = dy_planes.data_ptr()
+                d.dyplanes_valid = 1 if dy_ready else 0
+                if dy_ready:
+                    gb = None                       # (the bias gradient is in already)
+                dy_ready = True
+            elif dy_ready:
+                raise AssertionError("planes of dY were written for a layer whose weight gradient does not read them")
             self._wgrad(d, dy, pad4(layer.cout), dwp, gb, layer.cout, st)
             yield (layer.param_index,), self._unpack_step(layer, dwp, grads[2 * layer.param_index], wino_w)
             # ---- data gradient
@@ -1636,9 +1664,10 @@ class UNetPlan:
                 continue
             dd = self._dgrad_desc(layer, dy)
             self._set_wpack(dd, self.wpack_dgrad[layer.name])
-            if not self.algo[layer.name]["dgrad"] and self._pointwise_sp(layer)[1] and self.dyplanes is not None:
-                dd.aplanes = self.dyplanes.data_ptr()
-                dd.aplanes_valid = 1 if dy_split else 0          # the weight gradient above has just split this dY
+            dgrad_sp = not self.algo[layer.name]["dgrad"] and self._pointwise_sp(layer)[1] and dy_planes is not None
+            if dgrad_sp:
+                dd.aplanes = dy_planes.data_ptr()
+                dd.aplanes_valid = 1 if dy_ready else 0          # (left by the weight gradient above, or by the layer behind)
             if self.algo[layer.name]["dgrad"]:
                 self._use_workspace(dd, self.algo[layer.name]["dgrad"])
                 if adjoint:                    # A dY A^T was left in the workspace by the weight-gradient call above
@@ -1687,6 +1716,15 @@ class UNetPlan:
                     self._set_mask(dd, prev.out, relu=prev.relu)
                     dd.out = self.gbuf[prev.out].data_ptr()
                     dd.ld_out = pad4(prev.cout)
+                    if (dgrad_sp and prev.name in self.xplanes and self._pointwise_sp(prev)[2] and prev.name not in self.chains
+                            and prev.name not in self.chain_second and prev.cout == pad4(prev.cout)
+                            and os.environ.get("CLX_SP_EPILOGUE_PLANES", "1") != "0"):
+                        # the epilogue writes the planes of prev's dY and adds prev's bias gradient (its column sums)
+                        other = self.dyplanes2 if dy_planes is self.dyplanes else self.dyplanes
+                        dd.out_planes = other.data_ptr()
+                        gbp = grads[2 * prev.param_index + 1]
+                        dd.out_colsum = gbp.data_ptr() if gbp is not None else None
+                        dy_planes_of[prev.out] = other
                     _clx.call("clx_conv_fwd", ctypes.byref(dd), st)
         assert not pending_skip
 

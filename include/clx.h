@@ -182,12 +182,20 @@ typedef struct clx_conv_desc {
    * aplanes_valid = 1: `aplanes` already holds the planes of src[0] (an earlier call of the same layer left them: the
    * forward pass for the weight gradient, the weight gradient's dyplanes for the data gradient) — no split pass.
    * dyplanes (clx_conv_wgrad of a 1x1 layer only): clx_planes_bytes(M, N) bytes that receive the planes of dY; the bias
-   * gradient comes out of that split pass. */
+   * gradient comes out of that split pass.
+   * out_planes / out_colsum (clx_conv_fwd of a 1x1 layer that runs in this precision, dense output ld_out == N): the
+   * epilogue ALSO writes the P3 planes of `out` (clx_planes_bytes(M, N) bytes: the operand planes of the layer that reads
+   * `out` next — its aplanes with aplanes_valid = 1, or a weight gradient's dyplanes with dyplanes_valid = 1) and adds the
+   * column sums of `out` into out_colsum[N] (the bias gradient of the layer whose dY this data-gradient call produces).
+   * clx_conv_sp_covers(d) says whether a call will honour them. */
   int precision;
   const void* wplanes;
   void* aplanes;
   int aplanes_valid;
   void* dyplanes;
+  int dyplanes_valid;   /* clx_conv_wgrad: dyplanes already hold the planes of dY (and dbias has been taken care of) */
+  void* out_planes;
+  float* out_colsum;
 } clx_conv_desc;
 
 enum clx_conv_precision { CLX_PREC_F32 = 0, CLX_PREC_F32X3BF16 = 1 };
@@ -268,6 +276,10 @@ int clx_gemm_planes(const void* a_planes, const void* b_planes, int M, int N, in
  * cellulus/train.py:178). */
 int clx_wgrad_planes(const void* dy_planes, const void* x_planes, long long rows, int N, int C, float* dw, int ld_dw,
                      clx_stream stream);
+
+/* 1 if clx_conv_fwd(d) runs as the split-precision product from planes (1x1 layer, precision / wplanes / aplanes set, N % 128
+ * == 0, C % 64 == 0, C >= 128) — the form that honours out_planes / out_colsum —, else 0 */
+int clx_conv_sp_covers(const clx_conv_desc* d);
 
 /* out = act(conv(in) + bias).  f32 MFMA implicit GEMM (M = output pixels,
  * N = output channels, K = taps x channels). Also used for the data gradient
