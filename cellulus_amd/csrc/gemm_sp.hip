@@ -234,10 +234,13 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) gsrc[q] = frag_base(w + 8 * q);
   gsrc[4] = frag_base(32 + (w & 3));
-  // MODE 0: lane l owns the 16 bytes at 16 l of its fragment.  MODE 1: lane l fetches the piece (pixel l >> 2, octet l & 3 of
-  // the 32-channel block) = k step (l >> 1) & 1, half l & 1, row l >> 2 of the row block's half that step t covers
+  // MODE 0: lane l owns the 16 bytes at 16 l of its fragment.  MODE 1: lane l fetches the piece (octet o = l >> 4 of the
+  // 32-channel block, pixel (l & 15) ^ 4 o): sixteen consecutive lanes read 256 consecutive bytes (consecutive lanes on
+  // different octets — four 16-byte requests per lane quad — cost the kernel a third of its time), and the XOR spreads the four
+  // octets' 4-pixel groups over the LDS banks for the transposing reads.  Octet o = k step o >> 1, half o & 1 of the row block.
+  const int l_oct = lane >> 4, l_pix = (lane & 15) ^ (4 * (lane >> 4));
   const unsigned int lane16 = MODE == 0 ? (unsigned int)lane * 16u
-                                        : (unsigned int)(((lane >> 1) & 1) * KSTEP + (lane & 1) * 512 + (lane >> 2) * 16);
+                                        : (unsigned int)((l_oct >> 1) * KSTEP + (l_oct & 1) * 512 + l_pix * 16);
   const bool low_half = w < 4;
   auto issue = [&](int t, int slot, bool odd) __attribute__((always_inline)) {
     if (SP_ABL == 1 && t > 2) return;
@@ -285,9 +288,10 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
 #pragma unroll
   for (int k = 0; k < RING; ++k) {
     // MODE 1: the transposing read — lane 4 q + p of a 16-lane group addresses pixel q, channels 4 p .. 4 p + 3 of the group's
-    // 16 channels; group g = lane >> 4 holds channels 16 (g & 1) .. and the k half g >> 1 (pixels 8 (g >> 1) ..)
-    const int lterm = MODE == 0 ? lane * 16
-                                : (8 * (lane >> 5) + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    // 16 channels; group g = lane >> 4 holds channels 16 (g & 1) .. and the k half g >> 1 (pixels P = 8 (g >> 1) + q, + 4 for the
+    // second read: address ^ 64).  LDS image of a (32-channel block, piece): [octet o][slot = pixel ^ 4 o][8 channels].
+    const int r_oct = 2 * ((lane >> 4) & 1) + ((lane & 3) >> 1), r_pix = 8 * (lane >> 5) + ((lane >> 2) & 3);
+    const int lterm = MODE == 0 ? lane * 16 : r_oct * 256 + (r_pix ^ (4 * r_oct)) * 16 + (lane & 1) * 8;
     la[k] = k * STAGE + (wm * 2 * 3) * FRAG + lterm;
     lb[k] = k * STAGE + (A_FRAGS + wn * 2 * 3) * FRAG + lterm;
     asm volatile("" : "+v"(la[k]), "+v"(lb[k]));
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ptr));             // pixels 8 h + 0 .. 3
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ptr + 256));       // pixels 8 h + 4 .. 7
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((uintptr_t)ptr ^ 64));   // pixels 8 h + 4 .. 7 (slot ^ 4)
         const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
         return u32x4{l2[0], l2[1], h2[0], h2[1]};
       }
