@@ -255,11 +255,24 @@ def zero_many(*tensors):
     ts = [t for t in tensors if t is not None and t.numel() > 0]
     if not ts:
         return
+    dev = ts[0].device
+    fast = []
     for t in ts:
-        assert t.is_cuda and t.is_contiguous() and t.element_size() % 4 == 0, "zero_many: contiguous 4/8-byte device tensors"
-    ptrs = (_P * len(ts))(*[t.data_ptr() for t in ts])
-    sizes = (_LL * len(ts))(*[t.numel() * t.element_size() for t in ts])
-    call("clx_zero_many", ptrs, sizes, len(ts), stream_ptr(ts[0].device))
+        if not t.is_cuda:
+            raise ClxError(f"zero_many: tensor on {t.device}; there is no CPU path")
+        if t.device != dev:
+            raise ClxError(f"zero_many: tensors on different devices ({dev} and {t.device}) in one call")
+        nbytes = t.numel() * t.element_size()
+        # (the kernel wants 16-byte-aligned buffers of whole 4-byte words: a sliced view or an odd size takes torch's fill)
+        if t.is_contiguous() and t.data_ptr() % 16 == 0 and nbytes % 4 == 0:
+            fast.append(t)
+        else:
+            t.zero_()
+    if not fast:
+        return
+    ptrs = (_P * len(fast))(*[t.data_ptr() for t in fast])
+    sizes = (_LL * len(fast))(*[t.numel() * t.element_size() for t in fast])
+    call("clx_zero_many", ptrs, sizes, len(fast), stream_ptr(dev))
 
 
 def zeros(shape, dtype, device):

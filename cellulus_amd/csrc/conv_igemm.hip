@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
   constexpr int A_PASSES = BM / 32;
   constexpr int B_PASSES = BN / 32;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(TM * TN >= 2, "the accumulator flush relies on another tile's MFMAs between a tile's last MFMA and its flush");
 
   // one LDS arena: A/B double buffers during the K loop, the C tile in the epilogue
   // C tile rows: 16 lanes read one 64-float row of the narrow tile, and ds_read_b128 serves the lane groups
@@ -350,6 +351,10 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv_igemm_kernel(const
 #pragma unroll
         for (int c = 0; c < TN; ++c) {
           if (e == 0 && flush) {
+            // (the asm block reads MFMA results as VALU operands, and nobody inserts the MFMA -> VALU wait states for an
+            //  asm block: 18 for a 16-pass v_mfma_f32_32x32x2_f32.  This tile's last MFMA is at least TM * TN - 1 MFMAs of the
+            //  other tiles back — the static_assert below keeps it that way — and the s_nop covers the rest for the first tile.)
+            if (a == 0 && c == 0) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1" ::: "memory");
 #pragma unroll
 #if CLX_FLUSH_FORM == 1        // four 32-bit instructions per pair (the first version of this flush)
             for (int r = 0; r < 16; ++r) {
@@ -704,7 +709,7 @@ int clx_igemm_launch(const clx_conv_desc* d, int batch, long long bs_in, long lo
   CLX_REQUIRE(p.zeros != nullptr, "clx_conv_fwd: cannot resolve the device zero buffer");
   p.bs_in = bs_in; p.bs_w = bs_w; p.bs_out = bs_out;
   static const int flush_env = getenv("CLX_IGEMM_FLUSH") ? atoi(getenv("CLX_IGEMM_FLUSH")) : 2;
-  p.flush_every = flush_env;
+  p.flush_every = flush_env > 0 ? flush_env : 0;
   // 128-wide N tiles unless padding N up to a multiple of 128 wastes > 20 % of the MFMAs
   const bool wide = d->N > 64 && (double)(cdiv(d->N, 128) * 128) / d->N <= 1.2;
   hipEvent_t e0 = nullptr, e1 = nullptr;

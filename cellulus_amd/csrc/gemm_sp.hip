@@ -308,6 +308,13 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
   // multiplies while the other talks to memory (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).  (Fragments
   // double-buffered in registers, the textbook answer, do not fit: 128 accumulators + 96 > 256.)
   u32x4 fa[2][3], fb[2][3];               // [tile][piece]
+#if SP_ABL == 6
+  u32x4 sa[2][3], sb[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { sa[i][q] = u32x4{(unsigned)lane, 1u, 2u, 3u}; sb[i][q] = u32x4{4u, (unsigned)lane, 6u, 7u}; }
+#endif
   auto read_frags = [&](int slot) __attribute__((always_inline)) {
 #if SP_ABL != 3
     const char* const as = smem + la[slot];
@@ -324,6 +331,15 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
         return u32x4{l2[0], l2[1], h2[0], h2[1]};
       }
     };
+#if SP_ABL == 5 || SP_ABL == 7          // timing only: a third / two thirds of the fragment reads
+    fa[0][0] = rd(as); fb[0][0] = rd(bs); fb[1][0] = rd(bs + 3 * FRAG); fa[1][0] = rd(as + 3 * FRAG);
+#if SP_ABL == 7
+    fa[0][1] = rd(as + FRAG); fb[0][1] = rd(bs + FRAG); fb[1][1] = rd(bs + 4 * FRAG); fa[1][1] = rd(as + 4 * FRAG);
+#else
+    fa[0][1] = fa[0][0] + 1u; fb[0][1] = fb[0][0] + 1u; fb[1][1] = fb[1][0] + 1u; fa[1][1] = fa[1][0] + 1u;
+#endif
+    fa[0][2] = fa[0][1] + 3u; fb[0][2] = fb[0][1] + 3u; fb[1][2] = fb[1][1] + 3u; fa[1][2] = fa[1][1] + 3u;
+#else
     // (in the order the products consume them: the first MFMA needs a[0][2] and b[0][0] only)
     fa[0][2] = rd(as + 2 * FRAG);
     fb[0][0] = rd(bs);
@@ -335,6 +351,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
     for (int q = 0; q < 3; ++q) fb[1][q] = rd(bs + (3 + q) * FRAG);
 #pragma unroll
     for (int q = 0; q < 3; ++q) fa[1][q] = rd(as + (3 + q) * FRAG);
+#endif
 #endif
   };
 #if SP_ABL == 3
@@ -354,10 +371,18 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x16 c = acc[i][j];
+#if SP_ABL == 6
+      if (j == 0) asm volatile("" :: "v"(fa[i][0]), "v"(fa[i][1]), "v"(fa[i][2]), "v"(fb[i][0]), "v"(fb[i][1]), "v"(fb[i][2]));
+      const bf16x8 a0 = __builtin_bit_cast(bf16x8, sa[i][0]), a1 = __builtin_bit_cast(bf16x8, sa[i][1]),
+                   a2 = __builtin_bit_cast(bf16x8, sa[i][2]);
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, sb[j][0]), b1 = __builtin_bit_cast(bf16x8, sb[j][1]),
+                   b2 = __builtin_bit_cast(bf16x8, sb[j][2]);
+#else
       const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][1]),
                    a2 = __builtin_bit_cast(bf16x8, fa[i][2]);
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]),
                    b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
+#endif
       // smallest terms first
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);

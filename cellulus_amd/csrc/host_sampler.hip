@@ -60,7 +60,13 @@ extern "C" int clx_sample_offsets_mt19937(unsigned int* key, int* pos, int radiu
   mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
   const long long L = (long long)ND * number_offsets;
   const int r2 = radius * radius;
-  std::vector<int16_t> draws((size_t)ND * (size_t)L);
+  std::vector<int16_t> draws;
+  try {        // (an allocation failure must not cross the C boundary: ctypes would std::terminate the process)
+    draws.resize((size_t)ND * (size_t)L);
+  } catch (const std::exception& e) {
+    clx_set_error("clx_sample_offsets_mt19937: %s", e.what());
+    return CLX_ERR_WORKSPACE;
+  }
   int trips = 0;
   for (;;) {
     ++trips;

@@ -1153,6 +1153,12 @@ extern "C" int clx_ms_dedup_centers(const double* centers, const int* counts, in
   CLX_REQUIRE(n_out != nullptr && n >= 0 && (ND == 2 || ND == 3) && (n == 0 || (centers && counts && out)),
               "clx_ms_dedup_centers: bad arguments");
   CLX_REQUIRE(bandwidth > 0.0, "clx_ms_dedup_centers: bandwidth must be positive");
+  // a NaN coordinate breaks the strict weak ordering std::sort requires (undefined behaviour, not just a garbage order)
+  for (int i = 0; i < n; ++i)
+    if (counts[i] > 0)
+      for (int d = 0; d < ND; ++d)
+        CLX_REQUIRE(std::isfinite(centers[(size_t)i * ND + d]), "clx_ms_dedup_centers: centre %d has a non-finite coordinate", i);
+  try {        // (allocation failures must not cross the C boundary: ctypes would std::terminate the process)
   auto at = [&](int i, int d) { return centers[(size_t)i * ND + d]; };
   // dict semantics: identical centre tuples are one key (first occurrence), the LAST count wins
   struct Item { double c[3]; int src; int count; };
@@ -1266,6 +1272,10 @@ extern "C" int clx_ms_dedup_centers(const double* centers, const int* counts, in
     }
   *n_out = kept;
   return CLX_OK;
+  } catch (const std::exception& e) {
+    clx_set_error("clx_ms_dedup_centers: %s", e.what());
+    return CLX_ERR_WORKSPACE;
+  }
 }
 
 extern "C" size_t clx_ms_bucket_workspace(int n, long long ncells) {

@@ -22,24 +22,29 @@ __host__ __device__ inline long long piece_offset(long long row, int octet, int 
   return ((row >> 5) * ksteps + (octet >> 1)) * (long long)KSTEP + (octet & 1) * 512 + (row & 31) * 16;
 }
 
-// x = h0 + h1 + h2 exactly, each h_i a bfloat16 (<= 8 significant bits: the top half of an f32 word, by truncation);
-// four elements at a time, packed two per word (element 0 in the low half)
+// x = h0 + h1 + h2 exactly, each h_i a bfloat16: h0 = rn(x), h1 = rn(x - h0), h2 = x - h0 - h1 (<= 8 significant bits left:
+// exact).  Round-to-nearest pieces (v_cvt_pk_bf16_f32) keep |h1| <= 2^-9 |x| and |h2| <= 2^-17 |x| with either sign, so the three
+// products the kernels drop (h1 g2, h2 g1, h2 g2: <= 2^-25 of the product) are smaller than with truncated pieces and have
+// no preferred sign (truncation left a relative bias of -8e-9 on the products).  Four elements at a time, packed two per
+// word (element 0 in the low half).
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& p0, u32x2& p1, u32x2& p2) {
-  unsigned int u[4], a1[4], a2[4];
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  auto pack = [](float a, float b) -> unsigned int {
+    const bf16x2_ h = __builtin_convertvector(f32x2_{a, b}, bf16x2_);
+    return __builtin_bit_cast(unsigned int, h);
+  };
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    u[e] = __float_as_uint(v[e]);
-    const float r1 = v[e] - __uint_as_float(u[e] & 0xffff0000u);
-    a1[e] = __float_as_uint(r1);
-    const float r2 = r1 - __uint_as_float(a1[e] & 0xffff0000u);
-    a2[e] = __float_as_uint(r2);
+  for (int e = 0; e < 2; ++e) {
+    const float x0 = v[2 * e], x1 = v[2 * e + 1];
+    const unsigned int w0 = pack(x0, x1);
+    const float r0 = x0 - __uint_as_float(w0 << 16), r1 = x1 - __uint_as_float(w0 & 0xffff0000u);
+    const unsigned int w1 = pack(r0, r1);
+    const float s0 = r0 - __uint_as_float(w1 << 16), s1 = r1 - __uint_as_float(w1 & 0xffff0000u);
+    p0[e] = w0;
+    p1[e] = w1;
+    p2[e] = pack(s0, s1);
   }
-  p0[0] = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u);
-  p0[1] = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
-  p1[0] = __builtin_amdgcn_perm(a1[1], a1[0], 0x07060302u);
-  p1[1] = __builtin_amdgcn_perm(a1[3], a1[2], 0x07060302u);
-  p2[0] = __builtin_amdgcn_perm(a2[1], a2[0], 0x07060302u);
-  p2[1] = __builtin_amdgcn_perm(a2[3], a2[2], 0x07060302u);
 }
 
 // the three pieces of x[row][c .. c + 3] (c % 4 == 0) into the planes at `base`: three 8-byte stores

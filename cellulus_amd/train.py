@@ -132,7 +132,8 @@ def train(experiment_config):
         num_workers=policy["loader_procs"],
         pin_memory=True,
         # batches come back in worker order: a deeper queue per worker absorbs one slow crop (15 MB per batch)
-        prefetch_factor=4 if policy["loader_procs"] > 0 else None,
+        # (CLX_LOADER_PREFETCH: hosts with a small /dev/shm — loader processes x this many batches live there)
+        prefetch_factor=max(1, int(os.environ.get("CLX_LOADER_PREFETCH", "4"))) if policy["loader_procs"] > 0 else None,
         collate_fn=_collate_narrow if max(train_config.crop_size) < 32768 else None,
     )
 
@@ -245,9 +246,13 @@ def _collate_narrow(samples):
     processes' shared memory, the pinning thread and the H2D copy.  ``_DevicePrefetcher`` widens them on the device:
     ``train_iteration`` sees the reference's int64 tensors (``cellulus/train.py:166-173``)."""
     raw = torch.from_numpy(np.stack([s[0] for s in samples]))
-    anchor = torch.from_numpy(np.stack([s[1] for s in samples]).astype(np.int16))
-    reference = torch.from_numpy(np.stack([s[2] for s in samples]).astype(np.int16))
-    return raw, anchor, reference
+    anchor = np.stack([s[1] for s in samples])
+    reference = np.stack([s[2] for s in samples])
+    # (a dataset that yields coordinates outside an int16 keeps its int64 arrays: the bad-coordinate check of the gather
+    #  must see the values as they are, not wrapped)
+    if min(anchor.min(initial=0), reference.min(initial=0)) >= 0 and max(anchor.max(initial=0), reference.max(initial=0)) < 32768:
+        anchor, reference = anchor.astype(np.int16), reference.astype(np.int16)
+    return raw, torch.from_numpy(anchor), torch.from_numpy(reference)
 
 
 class _DevicePrefetcher:

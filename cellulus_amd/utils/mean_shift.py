@@ -115,17 +115,12 @@ def _dedup_centers_numpy(centers, counts, bandwidth):
     return centers[unique]
 
 
-_PREP_WS = {}
-
-
 def _prepare_workspace(nbytes, dev):
-    """clx_ms_prepare's scratch (flags, tile counts and prefix; no state between calls): one buffer per (device, stream),
-    grown when a larger image comes."""
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
-    ws = _PREP_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _PREP_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    return ws
+    """clx_ms_prepare's scratch: the flag words, the tile counts and their prefix — which clx_ms_assign_dense of the SAME
+    call reads again after host-side work (de-duplication, uploads).  Allocated per call (npix / 8 + 12 bytes per tile:
+    32 KB for a 512^2 image, from torch's caching allocator) and held by the caller until the assignment has been
+    enqueued: a second detection on the same stream — another thread, a pipelined caller — cannot overwrite it."""
+    return torch.empty(nbytes, dtype=torch.uint8, device=dev)
 
 
 def mean_shift_on_device(emb, std, bandwidth, reduction_probability, threshold, seeds=None):
