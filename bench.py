@@ -825,15 +825,16 @@ def main():
                          "unset).  1: one stream — every kernel alone on the device, the run the roofline numbers and "
                          "the PMC profiles are taken from")
     ap.add_argument("--precision", default="both", choices=["f32", "f32x3bf16", "both"],
-                    help="both (default): the headline workload in float32 MFMA, then AGAIN with CLX_PRECISION=f32x3bf16 (the "
-                         "plain products on the bf16 matrix cores from an exact three-way split of the float32 operands, "
-                         "csrc/gemm_sp.hip) as the extra objects `train2d_f32x3bf16` / `infer_f32x3bf16`; f32: the first "
-                         "only; f32x3bf16: the whole line in that precision (its `dtype` says so)")
+                    help="both (default): the line in the product's default arithmetic (f32x3bf16: the plain products on the "
+                         "bf16 matrix cores from an exact three-way split of the float32 operands, csrc/gemm_sp.hip), then the "
+                         "2-D workload and the inference tile AGAIN with CLX_PRECISION=f32 (float32 MFMA everywhere, the "
+                         "arithmetic of rounds 1-5) as the objects `train2d_f32_mfma` / `infer_f32_mfma`; f32 / f32x3bf16: "
+                         "the whole line in that precision only")
     args = ap.parse_args()
     if args.streams:
         os.environ["CLX_STREAMS"] = str(args.streams)
-    if args.precision == "f32x3bf16":
-        os.environ["CLX_PRECISION"] = "f32x3bf16"
+    if args.precision != "both":
+        os.environ["CLX_PRECISION"] = args.precision
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
@@ -850,21 +851,27 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    env_precision = os.environ.get("CLX_PRECISION", "f32") or "f32"
+    from cellulus_amd.models.plan import precision_name
+
+    line_precision = precision_name()
     res = run_workload(args.workload, args, rank, world, device)
-    res_sp = infer_sp = None
-    if args.precision == "both" and env_precision == "f32" and args.workload == "train2d":
-        os.environ["CLX_PRECISION"] = "f32x3bf16"
+    res_f32 = infer_f32 = None
+    if args.precision == "both" and line_precision != "f32" and args.workload == "train2d":
+        keep_env = os.environ.get("CLX_PRECISION")
+        os.environ["CLX_PRECISION"] = "f32"
         torch.cuda.empty_cache()
         try:
-            res_sp = run_workload(args.workload, args, rank, world, device)
+            res_f32 = run_workload(args.workload, args, rank, world, device)
             if world == 1 and not args.no_infer:
                 from bench_infer import infer_bench
 
                 torch.cuda.empty_cache()
-                infer_sp = infer_bench(device, with_cpu=False, with_e2e=True, with_streaming=False)
+                infer_f32 = infer_bench(device, with_cpu=False, with_e2e=True, with_streaming=False)
         finally:
-            os.environ["CLX_PRECISION"] = env_precision
+            if keep_env is None:
+                del os.environ["CLX_PRECISION"]
+            else:
+                os.environ["CLX_PRECISION"] = keep_env
     res3d = None
     if args.workload == "train2d" and not args.no_train3d:
         torch.cuda.empty_cache()
@@ -902,18 +909,22 @@ def main():
         "data": "synthetic",
     }
     out.update({k: v for k, v in res.items() if k not in out})
-    sp_dtype = "f32 (exact 3xbf16 operand split, 6 products, f32 accumulate)"
-    if env_precision != "f32":
-        out["dtype"] = sp_dtype
-        out["note"] = f"CLX_PRECISION={env_precision}: every number of this line is that precision's"
-    if res_sp is not None:
-        out["train2d_f32x3bf16"] = dict(
-            metric="train crops/sec, the same workload with CLX_PRECISION=f32x3bf16 (results are float32: six exact bf16 "
-                   "products per float32 product on the plain GEMMs, float32 accumulation; everything else unchanged)",
-            dtype=sp_dtype, steps=args.steps, warmup=args.warmup, **res_sp)
-    if infer_sp is not None:
-        out["infer_f32x3bf16"] = dict(infer_sp, dtype=sp_dtype,
-                                      metric=infer_sp["metric"] + " with CLX_PRECISION=f32x3bf16 on the embedding network")
+    if line_precision == "f32x3bf16":
+        out["dtype"] = "f32 (exact 3xbf16 operand split, 6 products, f32 accumulate)"
+        out["dtype_note"] = ("results and every tensor in HBM are float32; the plain products (1x1 layers, the transform-domain "
+                             "products of the 2-D Winograd layers: forward, data gradient, weight gradient) multiply an exact "
+                             "three-way bfloat16 split of their float32 operands on the bf16 matrix cores, six products per "
+                             "float32 product, float32 accumulation (roofline peak of those kernels: 2516.6 / 6 = 419.4 TFLOP/s "
+                             "f32-equivalent); |HIP - float64 oracle| at a trained network's output scale 7.2e-5, the float32 "
+                             "MFMA kernels' 7.3e-5 (profiles/r06_parity_trained_scale_2d*.txt); CLX_PRECISION=f32 = float32 MFMA "
+                             "everywhere: the objects train2d_f32_mfma / infer_f32_mfma of this line")
+    if res_f32 is not None:
+        out["train2d_f32_mfma"] = dict(
+            metric="train crops/sec, the same workload with CLX_PRECISION=f32 (float32 MFMA everywhere: the arithmetic of "
+                   "rounds 1-5)", dtype="f32", steps=args.steps, warmup=args.warmup, **res_f32)
+    if infer_f32 is not None:
+        out["infer_f32_mfma"] = dict(infer_f32, dtype="f32",
+                                     metric=infer_f32["metric"] + " with CLX_PRECISION=f32 (float32 MFMA) on the embedding network")
     if res3d is not None:
         out["train3d"] = dict(metric="train crops/sec, BASELINE configs[3]", steps=args.steps, warmup=args.warmup,
                               **res3d)

@@ -60,17 +60,28 @@ def wino_min_channels(kernel):
     return WINO_MIN_CHANNELS_3D if kernel[0] > 1 else WINO_MIN_CHANNELS
 
 
+# The arithmetic of the plain products (1x1 layers, the transform-domain products of the 2-D Winograd layers; forward, data
+# gradient and weight gradient), clx_conv_precision:
+#   "f32x3bf16" (default since round 6): every float32 operand split EXACTLY into three bfloat16 pieces, six exact products
+#       per float32 product accumulated in float32 on the bf16 matrix cores (csrc/gemm_sp.hip).  Results
+#       are float32; distance from the float64 oracle at a trained network's output scale 7.2e-5 (float32 MFMA: 7.3e-5).
+#   "f32": float32 MFMA everywhere (v_mfma_f32_32x32x2_f32), the only arithmetic of rounds 1-5; CLX_PRECISION=f32.
+DEFAULT_PRECISION = "f32x3bf16"
+
+
+def precision_name() -> str:
+    name = os.environ.get("CLX_PRECISION", "") or DEFAULT_PRECISION
+    if name not in ("f32", "f32x3bf16"):
+        raise ValueError(f"CLX_PRECISION must be 'f32' or 'f32x3bf16', got {name!r}")
+    return name
+
+
 def precision_code() -> int:
-    """clx_conv_precision of the plain products (1x1 layers, the transform-domain products of the 2-D Winograd layers;
-    forward, data gradient and weight gradient): 0 = float32 MFMA; 1 = CLX_PRECISION=f32x3bf16, the exact three-way
-    bfloat16 split of the float32 operands with six products per float32 product on the bf16 matrix cores
-    (csrc/gemm_sp.hip)."""
-    name = os.environ.get("CLX_PRECISION", "f32") or "f32"
-    if name == "f32":
+    """clx_conv_precision: 0 = float32 MFMA, 1 = the three-way bfloat16 split (CLX_PREC_F32X3BF16).  The run-to-run
+    reproducible mode (CLX_DETERMINISTIC=1) exists in float32 only and selects it."""
+    if os.environ.get("CLX_DETERMINISTIC", "0") == "1":
         return 0
-    if name == "f32x3bf16":
-        return 1
-    raise ValueError(f"CLX_PRECISION must be 'f32' or 'f32x3bf16', got {name!r}")
+    return 1 if precision_name() == "f32x3bf16" else 0
 
 
 def winograd_enabled() -> bool:
@@ -337,8 +348,6 @@ class UNetPlan:
         # gradients come from ordered column sums, the first layer takes the generic kernel and the fused
         # 1x1 pairs are off (their block sums meet in float atomics); train._fused_step switches the loss.
         self.deterministic = os.environ.get("CLX_DETERMINISTIC", "0") == "1"
-        if self.deterministic and self.precision:
-            raise ValueError("CLX_DETERMINISTIC=1 is implemented for the default precision (float32 MFMA) only")
         self._wplanes = {}          # data_ptr of a packed-weight tensor -> (tensor, its P3 planes, rows, K)
         self.aplanes = None         # scratch for the planes of a 1x1 layer's input (inference) ...
         self.xplanes = {}           # ... or one buffer per layer (training: the weight gradient reuses them)

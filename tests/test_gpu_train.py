@@ -375,7 +375,6 @@ def test_deterministic_mode_is_bit_reproducible(nd, device, monkeypatch):
     column sums, the pair-gradient scatter is fixed-point.  The result equals the default mode's to
     rounding (same arithmetic, another summation order).  Wide enough for Winograd layers, the sub-pixel
     upsample convolution and split-K slices."""
-    monkeypatch.delenv("CLX_PRECISION", raising=False)      # (the reproducible mode exists in float32 only: the plan refuses the pair)
     cfg = dict(in_channels=1, out_channels=nd, num_fmaps=64 if nd == 2 else 32, fmap_inc_factor=2,
                features_in_last_layer=64, downsampling_factors=[[2] * nd], num_spatial_dims=nd)
     spatial = (76, 84) if nd == 2 else (28, 28, 32)

@@ -64,6 +64,15 @@ CONFIGS = {
     "3d_small": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=8, fmap_inc_factor=2,
                               features_in_last_layer=16, downsampling_factors=[[2, 2, 2]],
                               num_spatial_dims=3), spatial=(28, 24, 32), batch=2),
+    # 128 / 256 channels: every 1x1 layer and every wide Winograd layer (incl. the 2x2 low-resolution half of the
+    # sub-pixel convolution) in the split precision (csrc/gemm_sp.hip): planes written by the transforms, the split
+    # pass and the product's own epilogue; odd extents: ragged row blocks and tile counts that are no multiple of 64
+    "2d_sp128": dict(cfg=dict(in_channels=1, out_channels=2, num_fmaps=128, fmap_inc_factor=2,
+                              features_in_last_layer=64, downsampling_factors=[[2, 2]],
+                              num_spatial_dims=2), spatial=(52, 44), batch=3),
+    "3d_sp128": dict(cfg=dict(in_channels=1, out_channels=3, num_fmaps=128, fmap_inc_factor=1,
+                              features_in_last_layer=64, downsampling_factors=[[2, 2, 2]],
+                              num_spatial_dims=3), spatial=(20, 20, 24), batch=1),
 }
 
 
@@ -151,7 +160,9 @@ def test_fused_1x1_pairs_are_used_and_equal_the_layer_by_layer_path(name, device
     inference (where the pair keeps nothing of its first layer)."""
     # (a seed whose two runs happen to make the same ReLU decisions: one flipped gate — an activation within rounding of
     #  zero — moves a gradient by 1e-4 .. 1e-3, in either precision: tools/exp/sp_chain_seeds.py)
-    seed = 5 if os.environ.get("CLX_PRECISION", "f32") == "f32x3bf16" and name == "2d_chain64" else 4
+    from cellulus_amd.models.plan import precision_name
+
+    seed = 5 if precision_name() == "f32x3bf16" and name == "2d_chain64" else 4
     oracle, model, raw = _make(name, device, seed=seed)
     x = raw.to(device)
     got = model(x)
@@ -177,7 +188,7 @@ def test_fused_1x1_pairs_are_used_and_equal_the_layer_by_layer_path(name, device
         assert l2 < 1e-5, (n, l2)
 
 
-@pytest.mark.parametrize("name", ["2d_wide", "2d_chain64", "3d_small", "2d_odd_channels"])
+@pytest.mark.parametrize("name", ["2d_wide", "2d_chain64", "3d_small", "2d_odd_channels", "2d_sp128"])
 def test_two_stream_half_batches_equal_the_one_stream_step(name, device, monkeypatch):
     """DualPlan: the batch as two halves on two streams over one set of packed weights and one set of gradient
     accumulators.  Same outputs (bit for bit: the forward kernels see the same rows) and the same gradients up to the
@@ -330,7 +341,7 @@ def test_infer_chunks_on_two_streams_equal_one_stream_bit_for_bit(name, device, 
     assert torch.equal(model.infer_on_device(x, noise=noise), one_b)
 
 
-@pytest.mark.parametrize("name", ["2d_wide", "2d_odd_channels", "3d_small", "2d_chain64", "2d_96"])
+@pytest.mark.parametrize("name", ["2d_wide", "2d_odd_channels", "3d_small", "2d_chain64", "2d_96", "2d_sp128"])
 def test_noisy_copies_through_changed_rows_equal_the_dense_forward_bit_for_bit(name, device, monkeypatch):
     """The noisy copies of infer mode (unet.py:73-100) differ from the image in p_salt_pepper of their pixels: the 1x1
     layers behind the first convolution run once on the clean image and on the CHANGED rows of each copy
@@ -374,8 +385,8 @@ def test_noisy_copies_through_changed_rows_equal_the_dense_forward_bit_for_bit(n
             assert torch.equal(dense, model.infer_on_device(x, noise=noise))
             monkeypatch.delenv("CLX_SPARSE_FIRST", raising=False)
             # the Winograd layer behind the 1x1 layers takes a tile list where there is one (2d_96) ...
-            assert ("tile_fraction" in info) == (name == "2d_96"), info
-            if name == "2d_96":
+            assert ("tile_fraction" in info) == (name in ("2d_96", "2d_sp128")), info
+            if name in ("2d_96", "2d_sp128"):
                 assert plan.tiled_layer_behind_prefix()[1] == 4 and 0.0 < info["tile_fraction"] < 0.7
                 # ... and CLX_SPARSE_TILES=0 keeps that layer dense: the same bits again
                 monkeypatch.setenv("CLX_SPARSE_TILES", "0")
