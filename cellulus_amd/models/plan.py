@@ -340,9 +340,9 @@ class UNetPlan:
         self.device = device
         self.keep = keep_activations
         self.precision = precision_code()
-        # (the one-launch Winograd kernels multiply in float32: with the split precision the three-launch form, whose
-        #  products run on the bf16 matrix cores, is the faster one)
-        self.fused = fused_wanted(keep_activations) and self.precision == 0
+        # (the one-launch Winograd kernels multiply in float32: a layer whose products can run in the split precision takes
+        #  the three-launch form — _fused_ok —, the narrow layers keep the one-launch form)
+        self.fused = fused_wanted(keep_activations)
         # opt-in: run-to-run reproducible training (CLX_DETERMINISTIC=1; the reference's CPU autograd is
         # deterministic, cellulus/train.py:177-179).  Weight-gradient slices add in a fixed order, bias
         # gradients come from ordered column sums, the first layer takes the generic kernel and the fused
@@ -357,6 +357,14 @@ class UNetPlan:
         self._pointwise_reader = {}
         self.buf = {}
         self._alloc()
+
+    def _fused_ok(self, cin_pad, cout):
+        """the one-launch (float32) Winograd form for a 2-D layer cin_pad -> cout?  Where it pays (fused_pays) — unless the
+        layer's products run in the split precision (both channel counts multiples of 128: csrc/wino.hip::wino_sp), which
+        beats it"""
+        if not self.fused or not fused_pays(cin_pad, cout):
+            return False
+        return not (self.precision and cin_pad % 128 == 0 and cout % 128 == 0)
 
     # ------------------------------------------------------------------ memory
     def _alloc(self):
@@ -380,7 +388,7 @@ class UNetPlan:
                 nf = int(lib.clx_conv_workspace_bytes(ctypes.byref(d), 0))
                 if nf:
                     a["fwd"], ws_bytes = code, max(ws_bytes, nf)
-                    if (code == 2 and self.fused and layer.cout == pad4(layer.cout) and fused_pays(layer.cin_pad, layer.cout)
+                    if (code == 2 and self._fused_ok(layer.cin_pad, layer.cout) and layer.cout == pad4(layer.cout)
                             and int(lib.clx_conv_fused_applicable(ctypes.byref(d)))):
                         a["fwd"] = 3
                         ws_bytes = max(ws_bytes, int(lib.clx_conv_fused_workspace_bytes(ctypes.byref(d))))
@@ -420,7 +428,7 @@ class UNetPlan:
                     if all(need):
                         sp["wino"] = 2
                         ws_bytes = max([ws_bytes] + need)
-                        sp["fused_z"] = bool(self.fused and fused_pays(sp["C1p"], sp["P"] * sp["N"])
+                        sp["fused_z"] = bool(self._fused_ok(sp["C1p"], sp["P"] * sp["N"])
                                              and int(lib.clx_conv_fused_applicable(ctypes.byref(dz))))
                         if sp["fused_z"]:
                             ws_bytes = max(ws_bytes, int(lib.clx_conv_fused_workspace_bytes(ctypes.byref(dz))))
@@ -444,7 +452,7 @@ class UNetPlan:
                         sp["wino_skip"] = 2
                         ws_bytes = max([ws_bytes] + need)
                         ds.N = conv0.cout
-                        sp["fused_skip"] = bool(self.fused and conv0.cout == sp["N"] and fused_pays(sp["C0p"], conv0.cout)
+                        sp["fused_skip"] = bool(self._fused_ok(sp["C0p"], conv0.cout) and conv0.cout == sp["N"]
                                                 and int(lib.clx_conv_fused_applicable(ctypes.byref(ds))))
                 # its data gradient contracts over z taps x output channels: long enough only in 3-D
                 sp["wino_skip_dgrad"] = 0
