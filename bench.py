@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA; the split precision f32x3bf16 spends six bf16 products per f32 product
-SP_KERNELS = ("gemm_sp_kernel", "wgrad_sp_kernel")          # priced against BF16_MFMA_PEAK_TFLOPS / 6 (f32-equivalent FLOPs)
+SP_KERNELS = ("gemm_sp_kernel<0>", "gemm_sp_kernel<1>")   # forward / data gradient, weight gradient          # priced against BF16_MFMA_PEAK_TFLOPS / 6 (f32-equivalent FLOPs)
 
 WORKLOADS = {
     "train2d": dict(
@@ -342,7 +342,7 @@ def run_workload(wl_key, args, rank, world, device):
 
     lib = _clx.load()
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-             3: "gemm_sp_kernel", 4: "wgrad_sp_kernel", 6: "chain64_kernels", 14: "wino_fused_kernels"}
+             3: "gemm_sp_kernel<0>", 4: "gemm_sp_kernel<1>", 6: "chain64_kernels", 14: "wino_fused_kernels"}
     hbm_kinds = {5: "sp_split_kernel", 15: "wino_transform_kernels"}       # HBM-bound launches libclx stamps as well (no FLOPs)
     hbm_prof = {}
 
@@ -498,8 +498,9 @@ def run_workload(wl_key, args, rank, world, device):
         roofline["frac_at_measured_clock"] = round(achieved / (peak * mhz / 2400.0), 4)
         roofline["shader_clock_note"] = ("s_memtime / s_memrealtime ticks of the middle block of every GEMM launch of the pass the "
                                          "kernel numbers are from; `frac` stays against the 2.4-GHz peak")
-    roofline["step_mfma_frac_note"] = ("FLOPs all MFMA kernels execute in one step / the step's wall time (the `value` "
-                                       "pass) / peak: what the whole step makes of the matrix cores")
+    roofline["step_mfma_frac_note"] = ("every MFMA kernel's FLOPs priced against ITS peak (157.3 TFLOP/s float32 MFMA; 419.4 "
+                                       "f32-equivalent for the split-precision products): seconds at peak / the step's wall time (the "
+                                       "`value` pass): what the whole step makes of the matrix cores")
     if overlapped is not None:
         o_l, o_ms, o_fl = overlapped[dom_name]
         roofline["timed_in"] = ("a second pass of the same K steps on ONE stream inside this run (each kernel alone on the "

@@ -76,6 +76,8 @@ bool clx_sp_applicable(const clx_conv_desc* d);
 // `ep` (out, ld_out, bias, relu, accumulate, mask, mask_bits, gate_out and their strides) are honoured
 int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long rows_a, int batch, long long bs_a, long long bs_b,
                   long long bs_out, const clx_conv_desc* ep, hipStream_t st);
+// shader-clock / wall-clock ticks recorded by the split-precision product kernels (added by clx_profile_clock)
+int clx_sp_clock_read(double* shader_ticks, double* wall_ticks, int reset);
 // planes <- split(x[rows][ld], columns [0, K)); colsum != NULL: colsum[k] += the column sums of x, k < nreal
 int clx_sp_split(const float* x, long long ld, long long rows, int K, void* planes, float* colsum, int nreal, hipStream_t st);
 // dW[b][n][c] += sum_rows dY[b][row][n] x[b][row][c] from planes (strides: bytes, bytes, floats); N, C multiples of 128

@@ -11,7 +11,7 @@ void clx_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* clx_last_error(void) { return g_err; }
-extern "C" int clx_abi_version(void) { return 12; }
+extern "C" int clx_abi_version(void) { return 13; }
 extern "C" int clx_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {

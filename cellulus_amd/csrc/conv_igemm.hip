@@ -38,8 +38,13 @@ extern "C" int clx_profile_clock(double* shader_ticks, double* wall_ticks_100mhz
     clx_set_error("clx_profile_clock: copy failed");
     return CLX_ERR_LAUNCH;
   }
-  if (shader_ticks) *shader_ticks = (double)h[0];
-  if (wall_ticks_100mhz) *wall_ticks_100mhz = (double)h[1];
+  double sc = 0.0, sw = 0.0;                     // the split-precision products' counters (gemm_sp.hip)
+  if (clx_sp_clock_read(&sc, &sw, reset) != CLX_OK) {
+    clx_set_error("clx_profile_clock: copy failed");
+    return CLX_ERR_LAUNCH;
+  }
+  if (shader_ticks) *shader_ticks = (double)h[0] + sc;
+  if (wall_ticks_100mhz) *wall_ticks_100mhz = (double)h[1] + sw;
   if (reset) {
     const unsigned long long z[2] = {0ull, 0ull};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_clk_ticks), z, sizeof(z)) != hipSuccess) {

@@ -39,6 +39,21 @@
 #define SP_ABL 0
 #endif
 
+// shader clock under load (as conv_igemm.hip): the middle block of every launch adds the shader-clock and 100-MHz wall-clock
+// ticks of its own life to two counters; clx_profile_clock (conv_igemm.hip) adds them to its own
+__device__ unsigned long long g_sp_clk_ticks[2];
+int clx_sp_clock_read(double* shader_ticks, double* wall_ticks, int reset) {
+  unsigned long long h[2] = {0ull, 0ull};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sp_clk_ticks), sizeof(h)) != hipSuccess) return CLX_ERR_LAUNCH;
+  *shader_ticks = (double)h[0];
+  *wall_ticks = (double)h[1];
+  if (reset) {
+    const unsigned long long z[2] = {0ull, 0ull};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_sp_clk_ticks), z, sizeof(z)) != hipSuccess) return CLX_ERR_LAUNCH;
+  }
+  return CLX_OK;
+}
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -201,6 +216,9 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
     ksteps = p.total_steps - step0 < p.steps_per_slice ? p.total_steps - step0 : p.steps_per_slice;
   }
   const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
+  const bool clk_block = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0;   // mid-launch
+  unsigned long long clk_c0 = 0, clk_w0 = 0;
+  if (clk_block) { clk_c0 = clock64(); clk_w0 = wall_clock64(); }
 
   // ---- this wave's share of a stage's 36 fragments: f = w + 8 q, q = 0..3, and a fifth one, 32 + (w & 3), for waves 0-3
   // in even steps and waves 4-7 in odd steps: any two consecutive steps are NINE loads for every wave, so the counted
@@ -481,9 +499,12 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
   issue(0, 0, false);
   issue(1, 1, true);
   issue(2, 2, false);
+  // (a static s_setprio 1 for the late half — MI355X_MICROARCH.md "Two waves per SIMD", item 4 — changes nothing here:
+  //  125.0 / 199.7 / 228.0 against 125.4 / 199.4 / 228.1 TFLOP/s on the three benchmark shapes)
   if (w < 4) k_loop(std::false_type{});
   else k_loop(std::true_type{});
 
+  if (clk_block) { atomicAdd(&g_sp_clk_ticks[0], clock64() - clk_c0); atomicAdd(&g_sp_clk_ticks[1], wall_clock64() - clk_w0); }
   if (SP_ABL == 4) { if (tot[0][0][0] == 123.f) p.out[0] = tot[1][1][3] + tot[0][1][2] + tot[1][0][1]; return; }
   if constexpr (MODE == 1) {
     // combine: float atomics into out[n][c] — per accumulator register two 128-byte row segments, the full-rate shape

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/clx.h but not exported"
     assert sorted(_clx.PROTOTYPES) == declared, "ctypes prototypes and clx.h disagree"
-    assert _clx.load().clx_abi_version() == 12
+    assert _clx.load().clx_abi_version() == 13
 
 
 def test_argument_validation_without_gpu():
@@ -1070,3 +1070,34 @@ def test_native_pair_offsets_are_numpys_stream_value_for_value_and_leave_its_sta
     Bare(2).sample_offsets_within_radius(10, 100)
     after = np.random.get_state()
     assert after[3] == 1 and after[4] == before[4]
+
+
+def test_planes_geometry_and_argument_validation_without_gpu():
+    """The P3 plane format of the split-precision products (include/clx.h, csrc/sp_planes.h): 6 bytes per element, rows
+    padded to a multiple of 64 and at least 128; the entry points refuse what the kernels do not cover before any launch."""
+    from cellulus_amd import _clx
+
+    lib = _clx.load()
+    assert lib.clx_planes_bytes(1, 16) == 128 * 16 * 6
+    assert lib.clx_planes_bytes(128, 64) == 128 * 64 * 6
+    assert lib.clx_planes_bytes(129, 64) == 192 * 64 * 6
+    assert lib.clx_planes_bytes(516128, 256) == (516128 + 63) // 64 * 64 * 256 * 6
+    assert lib.clx_planes_bytes(100, 40) == 0 and lib.clx_planes_bytes(0, 64) == 0
+    null = ctypes.c_void_p(0)
+    p = ctypes.c_void_p(4096)
+    with pytest.raises(_clx.ClxError, match="null"):
+        _clx.call("clx_split_planes", null, 64, 10, 64, p, null)
+    with pytest.raises(_clx.ClxError, match="multiple of 16"):
+        _clx.call("clx_split_planes", p, 64, 10, 40, p, null)
+    with pytest.raises(_clx.ClxError, match="N %% 128|N % 128"):
+        _clx.call("clx_gemm_planes", p, p, 64, 96, 128, null, 0, p, 96, null)
+    with pytest.raises(_clx.ClxError, match="K"):
+        _clx.call("clx_gemm_planes", p, p, 64, 128, 64, null, 0, p, 128, null)
+    with pytest.raises(_clx.ClxError, match="128"):
+        _clx.call("clx_wgrad_planes", p, p, 1000, 128, 64, p, 64, null)
+    d = _clx.ClxConvDesc()
+    assert lib.clx_conv_sp_covers(ctypes.byref(d)) == 0
+    # the switch of the Python layer
+    from cellulus_amd.models import plan as P
+
+    assert P.DEFAULT_PRECISION == "f32x3bf16"

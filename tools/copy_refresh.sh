@@ -37,5 +37,9 @@ cp $R/pmc_lds_conflicts_f32.txt profiles/${P}_pmc_lds_conflicts_f32.txt
 [ -f $R/wino_fused_layers.txt ] && cp $R/wino_fused_layers.txt profiles/${P}_wino_fused_layers.txt
 [ -f $R/parity_trained_scale_2d.txt ] && cp $R/parity_trained_scale_2d.txt profiles/${P}_parity_trained_scale_2d.txt
 [ -f $R/parity_trained_scale_3d.txt ] && cp $R/parity_trained_scale_3d.txt profiles/${P}_parity_trained_scale_3d.txt
+[ -f $R/parity_trained_scale_2d_f32_mfma.txt ] && cp $R/parity_trained_scale_2d_f32_mfma.txt profiles/${P}_parity_trained_scale_2d_f32_mfma.txt
+[ -f $R/pmc_sp_counters.txt ] && cp $R/pmc_sp_counters.txt profiles/${P}_pmc_sp_counters.txt
+[ -f $R/gemm_sp_shapes.txt ] && cp $R/gemm_sp_shapes.txt profiles/${P}_gemm_sp_shapes.txt
+[ -f $R/trained_e2e.txt ] && cp $R/trained_e2e.txt profiles/${P}_trained_e2e.txt
 
 true

@@ -23,13 +23,14 @@ export CLX_STREAMS=1      # every PMC pass and per-layer table below: kernels al
 # matrix-pipe busy per kernel
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc -o t -- python3 bench.py --steps 2 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
 python3 tools/pmc_digest.py $O/pmc conv_ > $O/pmc_conv_kernels.txt
+python3 tools/pmc_digest.py $O/pmc gemm_sp >> $O/pmc_conv_kernels.txt
 python3 tools/pmc_digest.py $O/pmc chain64 >> $O/pmc_conv_kernels.txt
 python3 tools/pmc_digest.py $O/pmc wino_ > $O/pmc_wino_kernels.txt
 rm -rf $O/pmc
 # HBM bytes per launch: training kernels ...
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o t -- python3 bench.py --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e --no-train3d > /dev/null 2>&1
-python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train2d.json conv_ wino_ chain64 > $O/hbm_traffic_train2d.txt
+python3 tools/hbm_traffic.py $O/pmc_rd $O/pmc_wr $O/hbm_traffic_train2d.json conv_ gemm_sp sp_split wino_ chain64 > $O/hbm_traffic_train2d.txt
 rm -rf $O/pmc_rd $O/pmc_wr
 # ... the 3-D workload ...
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o t -- python3 bench.py --workload train3d --steps 1 --warmup 1 --no-infer --no-cpu-baseline --no-train-e2e > /dev/null 2>&1
@@ -73,5 +74,13 @@ cp gpurun_out/gpu_library/miopen_cmds.txt $O/gpu_library_baseline_miopen_cmds.tx
 cp gpurun_out/gpu_library/line.json $O/gpu_library_baseline_line.json 2>/dev/null
 timeout 300 python tools/exp/fused_bench.py 2>/dev/null | grep "^{" > $O/wino_fused_layers.txt
 timeout 300 python tools/parity_trained_scale.py 2d 2>/dev/null | grep -v amdgpu > $O/parity_trained_scale_2d.txt
+CLX_PRECISION=f32 timeout 300 python tools/parity_trained_scale.py 2d 2>/dev/null | grep -v amdgpu > $O/parity_trained_scale_2d_f32_mfma.txt
+# issue / LDS / wait counters of the split-precision product on one long-K shape, and the product kernels alone
+bash tools/pmc_sp.sh > /dev/null 2>&1
+cp gpurun_out/pmc_sp/counters.txt $O/pmc_sp_counters.txt 2>/dev/null
+python tools/bench_gemm_sp.py > $O/gemm_sp_shapes.txt 2>/dev/null
+SP_WGRAD=1 SP_TIME_ONLY=1 python tools/bench_gemm_sp.py 256 128 128 2>/dev/null | grep wgrad >> $O/gemm_sp_shapes.txt
+# the measured lines of the trained-network tests (error, instances, pixels that differ)
+timeout 900 python -m pytest tests/test_gpu_trained_e2e.py -q -s 2>&1 | grep -v "Warning\|warnings\|pin_memory\|^$" > $O/trained_e2e.txt
 timeout 300 python tools/parity_trained_scale.py 3d 2>/dev/null | grep -v amdgpu > $O/parity_trained_scale_3d.txt
 echo refresh complete
