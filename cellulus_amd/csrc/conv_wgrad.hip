@@ -510,7 +510,8 @@ extern "C" int clx_conv_wgrad(const clx_conv_desc* d, const float* dy, int ld_dy
   // forward pass, or split here) and of dY (split here; the bias gradient is that pass's column sums)
   if (d->precision == CLX_PREC_F32X3BF16 && d->aplanes != nullptr && d->dyplanes != nullptr && d->det_turns == nullptr &&
       d->nsrc == 1 && d->KD == 1 && d->KH == 1 && d->KW == 1 && d->PD == 0 && d->PH == 0 && d->PW == 0 &&
-      d->N % 128 == 0 && d->src[0].C % 128 == 0 && ld_dy >= d->N) {
+      d->N % 128 == 0 && d->src[0].C % 128 == 0 && ld_dy >= d->N &&
+      (long long)d->B * d->ID * d->IH * d->IW * (d->N > d->src[0].C ? d->N : d->src[0].C) * 6 < (1ll << 32) - (1 << 24)) {
     const clx_src& S = d->src[0];
     if (S.fz == 1 && S.fy == 1 && S.fx == 1 && S.oz == 0 && S.oy == 0 && S.ox == 0 && S.D == d->ID && S.H == d->IH && S.W == d->IW) {
       const long long M = (long long)d->B * d->ID * d->IH * d->IW;

@@ -736,7 +736,15 @@ inline int pad4(int n) { return (n + 3) / 4 * 4; }
 // rule for the forward, data-gradient and weight-gradient calls of a layer — they hand V and A dY A^T to each other as
 // P3 planes (vcache, dy_vcache, the workspace) —: 2-D layer, both channel counts multiples of 128.
 inline bool wino_sp(const clx_conv_desc* d) {
-  return d->precision == CLX_PREC_F32X3BF16 && d->KD == 1 && d->ID == 1 && d->N % 128 == 0 && d->src[0].C % 128 == 0;
+  if (d->precision != CLX_PREC_F32X3BF16 || d->KD != 1 || d->ID != 1 || d->N % 128 != 0 || d->src[0].C % 128 != 0) return false;
+  // the weight-gradient product addresses its operand planes with 32-bit offsets: one transform point's planes stay below
+  // 4 GB (the tiles of the layer's LARGER grid — the data-gradient form's — decide for all three calls)
+  const int mt = d->algo == CLX_ALGO_WINOGRAD ? 2 : 4;
+  // (the layer's forward INPUT extent, whichever form `d` is: >= every grid one of its calls tiles)
+  const long long eh = d->IH + (d->PH ? d->KH - 1 : 0), ew = d->IW + (d->PW ? d->KW - 1 : 0);
+  const long long tiles = (long long)d->B * ((eh + mt - 1) / mt) * ((ew + mt - 1) / mt);
+  const int ch = d->N > d->src[0].C ? d->N : d->src[0].C;
+  return sp::planes_bytes(tiles, ch) < (1ll << 32);
 }
 // grid of a plane-writing transform: 8 ceil(rows / 8) rows x C / 4 items, whole wavefronts
 inline long long sp_items(long long rows, int C) { return (rows + 7) / 8 * 8 * (C / 4); }

@@ -359,12 +359,13 @@ class UNetPlan:
         self._alloc()
 
     def _fused_ok(self, cin_pad, cout):
-        """the one-launch (float32) Winograd form for a 2-D layer cin_pad -> cout?  Where it pays (fused_pays) — unless the
-        layer's products run in the split precision (both channel counts multiples of 128: csrc/wino.hip::wino_sp), which
-        beats it"""
-        if not self.fused or not fused_pays(cin_pad, cout):
-            return False
-        return not (self.precision and cin_pad % 128 == 0 and cout % 128 == 0)
+        """the one-launch (float32) Winograd form for a 2-D layer cin_pad -> cout?  Where it pays (fused_pays) — in the
+        float32-MFMA precision only: its 36 x 32 x 64 accumulators are ONE chain over the contraction (no room for the
+        second set of the two-level summation), and with it on the 64-channel layers the default precision's inference
+        plan sat at 8.26e-5 from float64 at a trained network's output scale where the three-launch forms give 7.20e-5
+        and float32 MFMA 8.16e-5 (profiles/r06_parity_trained_scale_2d*.txt) — the promotion rule of DESIGN.md 4 asks
+        for <=, so the default precision runs every Winograd layer in three launches (-4 % on an inference tile)."""
+        return bool(self.fused and not self.precision and fused_pays(cin_pad, cout))
 
     # ------------------------------------------------------------------ memory
     def _alloc(self):
@@ -1076,8 +1077,10 @@ class UNetPlan:
         n, c = pad4(layer.cout), layer.cin_pad
         if layer.cout != n:
             return False, False, False
+        rows = self.B * layer.in_shape[0] * layer.in_shape[1] * layer.in_shape[2]
         return (n % 128 == 0 and c % 64 == 0 and c >= 128, c % 128 == 0 and n % 64 == 0 and n >= 128,
-                n % 128 == 0 and c % 128 == 0)
+                # (the weight-gradient product addresses its operand planes with 32-bit offsets: clx_conv_wgrad's rule)
+                n % 128 == 0 and c % 128 == 0 and rows * max(n, c) * 6 < (1 << 32) - (1 << 24))
 
     def _vfloats(self, a2, tiles, chans):
         """floats of a buffer for `a2` transformed tensors [tiles][chans]: float32, or P3 planes (6 bytes per element,
