@@ -1,5 +1,5 @@
 """Layer-level timing of the one-launch Winograd forward (CLX_ALGO_WINOGRAD4_FUSED, csrc/wino_fused.hip) against the
-three-launch form (CLX_ALGO_WINOGRAD4) on the Winograd layers of the benchmark configurations: the inference chunk
+three-launch form (CLX_ALGO_WINOGRAD4), in float32 MFMA and in the split precision, on the Winograd layers of the benchmark configurations: the inference chunk
 (8 noisy copies of a 512^2 tile, cfg-5) and the training half batch (4 crops of 256^2, cfg-2).
 
     python tools/exp/fused_bench.py [--only NAME] [--reps 5] > gpurun_out/fused_bench.txt
@@ -52,9 +52,14 @@ def main():
         for mode in (4, 7):
             packs[mode] = torch.empty(nxi * N * C, device=dev)
             _clx.call("clx_pack_weights", _clx.ptr(w), _clx.ptr(packs[mode]), N, C, k * k, C, N, mode, st)
-        out = {a: torch.zeros(B, OH, OH, N, device=dev) for a in (2, 3)}
+        out = {a: torch.zeros(B, OH, OH, N, device=dev) for a in (2, 3, "sp")}
+        # the three-launch form in the split precision: planes of the packed weights
+        sp_ok = N % 128 == 0 and C % 128 == 0
+        if sp_ok:
+            wplanes = torch.empty(int(lib.clx_planes_bytes(nxi * N, C)), dtype=torch.uint8, device=dev)
+            _clx.call("clx_split_planes", _clx.ptr(packs[4]), C, nxi * N, C, _clx.ptr(wplanes), st)
 
-        def desc(algo):
+        def desc(algo, sp=False):
             d = ClxConvDesc()
             d.nsrc = 1
             s = ClxSrc()
@@ -68,8 +73,11 @@ def main():
             d.N = N
             d.algo = algo
             d.bias, d.relu, d.accumulate = bias.data_ptr(), 1, acc
-            d.out, d.ld_out = out[algo].data_ptr(), N
+            d.out, d.ld_out = out["sp" if sp else algo].data_ptr(), N
             d.wpack = packs[4 if algo == 2 else 7].data_ptr()
+            if sp:
+                d.precision = 1
+                d.wplanes = wplanes.data_ptr()
             return d
 
         d2 = desc(2)
@@ -84,7 +92,14 @@ def main():
         tiles = B * (-(-OH // 4)) ** 2
         flops = 2.0 * nxi * tiles * N * C
         res = dict(layer=name, tiles=tiles, gflop_executed=flops / 1e9)
-        for algo, d in ((2, d2), (3, d3)):
+        runs = [("three_launch", d2), ("fused", d3)]
+        if sp_ok:
+            dsp = desc(2, sp=True)
+            need_sp = int(lib.clx_conv_workspace_bytes(ctypes.byref(dsp), 0))
+            ws_sp = torch.empty(need_sp // 4 + 4, device=dev)
+            dsp.workspace, dsp.workspace_bytes = ws_sp.data_ptr(), ws_sp.numel() * 4
+            runs.append(("three_launch_sp", dsp))
+        for key, d in runs:
             for _ in range(2):
                 _clx.call("clx_conv_fwd", ctypes.byref(d), st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -94,12 +109,15 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / args.reps
-            key = "three_launch" if algo == 2 else "fused"
             res[key + "_ms"] = round(ms, 4)
             res[key + "_tflops"] = round(flops / ms / 1e9, 1)
         if not acc:
             res["max_abs_diff"] = float((out[2] - out[3]).abs().max())
         res["speedup"] = round(res["three_launch_ms"] / res["fused_ms"], 3)
+        if sp_ok:
+            res["fused_over_sp"] = round(res["fused_ms"] / res["three_launch_sp_ms"], 3)
+            if not acc:
+                res["max_abs_diff_sp"] = float((out[2] - out["sp"]).abs().max())
         print(json.dumps(res), flush=True)
         del x, w, ws, out, packs
 

@@ -81,6 +81,6 @@ cp gpurun_out/pmc_sp/counters.txt $O/pmc_sp_counters.txt 2>/dev/null
 python tools/bench_gemm_sp.py > $O/gemm_sp_shapes.txt 2>/dev/null
 SP_WGRAD=1 SP_TIME_ONLY=1 python tools/bench_gemm_sp.py 256 128 128 2>/dev/null | grep wgrad >> $O/gemm_sp_shapes.txt
 # the measured lines of the trained-network tests (error, instances, pixels that differ)
-timeout 900 python -m pytest tests/test_gpu_trained_e2e.py -q -s 2>&1 | grep -v "Warning\|warnings\|pin_memory\|^$" > $O/trained_e2e.txt
+timeout 900 python -m pytest tests/test_gpu_trained_e2e.py -q -s 2>&1 | tr "\r" "\n" | grep -v "Warning\|warnings\|pin_memory\|^$\|it/s\]\|===> loss\|Checkpoint saved\|amdgpu.ids\|ExperimentConfig(\|Created logger" > $O/trained_e2e.txt
 timeout 300 python tools/parity_trained_scale.py 3d 2>/dev/null | grep -v amdgpu > $O/parity_trained_scale_3d.txt
 echo refresh complete
