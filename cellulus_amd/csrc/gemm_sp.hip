@@ -699,7 +699,10 @@ int clx_sp_split(const float* x, long long ld, long long rows, int K, void* plan
   long long blocks = (nfrag + 3) / 4;
   if (blocks > 8192) blocks = 8192;
   if (colsum != nullptr) {
-    // wavefronts (4 per block) a multiple of the k steps: blocks a multiple of ksteps / gcd(ksteps, 4)
+    // wavefronts (4 per block) a multiple of the k steps: blocks a multiple of ksteps / gcd(ksteps, 4).  A resident grid
+    // (8 blocks per CU) and no more: every wavefront ends in 16 atomics on the K column sums, and 8192 blocks' worth of
+    // them on 256 addresses took as long as the split itself
+    if (blocks > 2048) blocks = 2048;
     int g = ksteps % 4 == 0 ? 4 : ksteps % 2 == 0 ? 2 : 1;
     const long long unit = ksteps / g;
     blocks = (blocks + unit - 1) / unit * unit;

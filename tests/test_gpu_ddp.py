@@ -131,7 +131,11 @@ def test_ranks_equal_one_process_at_global_batch(tmp_path, device, world, bucket
     np.testing.assert_allclose(got["losses"], losses, rtol=1e-5)
     # the all-reduced gradient of the first step IS the global batch's gradient (sums of the same terms in another order)
     scale = np.abs(grad0).max()
-    np.testing.assert_allclose(got["grad0"] / scale, grad0 / scale, atol=1e-4)
+    # (terms of 1e3 cancel in a weight's gradient, so the order of the additions is worth ~1e-4 of the largest element on a
+    # few of them: round 6 saw 4 of 16762 at 1.3e-4 with eight ranks once in some forty runs.  Nearly all within 1e-4,
+    # none further than 5e-4)
+    gdiff = np.abs(got["grad0"] - grad0) / scale
+    assert (gdiff > 1e-4).mean() < 1e-3 and gdiff.max() < 5e-4, ((gdiff > 1e-4).sum(), gdiff.max())
     # ... and two Adam steps later the parameters are the one-process parameters.  Adam's first steps move a parameter by
     # lr * g / (|g| + eps) ~ +-lr whatever |g| is, so where a gradient element is smaller than the float noise of its
     # sum (terms of 1e3 cancelling) the ORDER of the additions decides its sign — atomics: it changes from run to run,
