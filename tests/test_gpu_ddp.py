@@ -187,9 +187,22 @@ def test_cfg3_dress_rehearsal_eight_ranks_at_the_real_workload(tmp_path, device)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "CLX_STREAMS",
               "CLX_GRAD_BUCKET_MB", "CLX_DEVICE_PAIRS"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
-                        "--no-train3d", "--infer-samples", "2", "--e2e-iterations", "18"],
-                       env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=3000)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--no-train3d", "--infer-samples", "2", "--e2e-iterations", "18"]
+    p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=3000)
+    if p.returncode != 0:
+        # eight ranks over gloo's TCP transport on loopback, beside their loader processes: twice in round 6 a rank lost its
+        # connection ("Connection closed by peer").  The wire is not what is under test: keep the evidence, and run the
+        # command ONCE more if — and only if — the failure is the transport's
+        import re
+
+        tail = (p.stdout + p.stderr)[-6000:]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            with open(os.path.join(ROOT, "gpurun_out", "cfg3_dress_rehearsal_first_failure.txt"), "w") as fh:
+                fh.write(tail)
+        if re.search(r"Connection (closed|reset)|Broken pipe|Socket Timeout|gloo.*(timeout|timed out)|EADDRINUSE|address already in use",
+                     tail, re.I):
+            p = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=3000)
     assert p.returncode == 0, (p.stdout + p.stderr)[-4000:]
     lines = [l for l in p.stdout.strip().split("\n") if l.startswith("{")]
     assert len(lines) == 1

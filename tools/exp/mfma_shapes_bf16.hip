@@ -90,10 +90,14 @@ static void run(const unsigned int* rnd, int iters) {
   hipFree(out);
 }
 
-int main() {
+// argument "const": every operand the same value (what a timing-only ablation of a product kernel multiplies) instead of
+// random bits — the same instruction stream at a lower switching power
+int main(int argc, char** argv) {
+  const bool constant = argc > 1 && argv[1][0] == 'c';
   unsigned int* h = (unsigned int*)malloc(512 * 12 * 4 * 4);
   srand(1);
-  for (int i = 0; i < 512 * 12 * 4; ++i) h[i] = (unsigned)rand() ^ ((unsigned)rand() << 16);
+  for (int i = 0; i < 512 * 12 * 4; ++i) h[i] = constant ? 0u : (unsigned)rand() ^ ((unsigned)rand() << 16);
+  printf("operands: %s\n", constant ? "constant" : "random");
   unsigned int* rnd;
   hipMalloc(&rnd, 512 * 12 * 4 * 4);
   hipMemcpy(rnd, h, 512 * 12 * 4 * 4, hipMemcpyHostToDevice);

@@ -22,4 +22,7 @@ for key, c in sorted(acc.items()):
         busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(c["SQ_VALU_MFMA_BUSY_CYCLES"])
         act = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
         parts.append(f"mfma_busy={busy / (act / 8 * 1024):.3f}")
+    if "GRBM_GUI_ACTIVE" in c and "_us" in c:
+        act = sum(c["GRBM_GUI_ACTIVE"]) / len(c["GRBM_GUI_ACTIVE"])
+        parts.append(f"grbm_mhz={act / 8 / (sum(c['_us']) / len(c['_us'])):.0f}")
     print("  ".join(parts))
