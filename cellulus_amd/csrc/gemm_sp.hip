@@ -33,7 +33,7 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// timing-only ablations (tools/build_variant.sh sp<k> gemm_sp.hip -DSP_ABL=<k>; results are wrong): 1 = no loads in the K
+// timing-only ablations (tools/build_variant.sh sp<k> gemm_sp.hip -DSP_ABL=<k>; results are wrong; 8 = the products as 16x16x32 MFMAs): 1 = no loads in the K
 // loop, 2 = no barriers / waits, 3 = fragments read once, 4 = no epilogue
 #ifndef SP_ABL
 #define SP_ABL 0
@@ -53,6 +53,15 @@ int clx_sp_clock_read(double* shader_ticks, double* wall_ticks, int reset) {
   }
   return CLX_OK;
 }
+
+#ifdef SP16_STAMP
+// diagnostic build (tools/build_variant.sh stamp gemm_sp.hip -DSP16_STAMP): s_memtime stamps of waves 0 and 4 of block 0 around the
+// segments of double steps 16 .. 19 of gemm_sp16_kernel; tools/exp/sp16_stamps.py prints them
+__device__ unsigned long long g_sp16_stamps[2][64];
+extern "C" int clx_sp16_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sp16_stamps), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : 1;
+}
+#endif
 
 namespace {
 
@@ -184,6 +193,114 @@ struct SpP {
   unsigned int stride_a, stride_b;    // bytes of one 32-pixel row block of the dY / x planes
   int total_steps, steps_per_slice, nslices;
 };
+
+// The tile's epilogue out of LDS (Cs: [SP_BM][LDC] floats, bias added, written and barrier-synchronised by the caller):
+// previous output, ReLU, gates, masks, the float32 store, the output's own planes, its column sums.
+__device__ __forceinline__ void sp_epilogue_from_lds(const SpP& p, const float* Cs, int m0, int n0, int batch, int tid, int lane) {
+  // A wavefront takes 8 rows x 32 channels per pass (the eight lanes of a row hold one gate word; the float32 stores are
+  // 128-byte runs, and so are the stores of every piece of the output's own planes: sp_planes.h); the 8 waves of a pass
+  // cover 16 rows x 128 channels, 16 passes the tile.
+  constexpr int ITERS = SP_BM / 16;                     // 16
+  constexpr int PH = 8;
+  const int wv = tid >> 6;
+  const int c4 = (wv & 3) * 32 + (lane & 7) * 4;
+  const int row0 = (wv >> 2) * 8 + (lane >> 3);
+  const int n = n0 + c4;
+  const bool n_live = n < p.N;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+  const long long prow = p.out_planes ? sp::padded_rows(p.M) : 0;
+#pragma unroll 1
+  for (int h0 = 0; h0 < ITERS; h0 += PH) {
+    f32x4 val[PH];
+    int mrow[PH];
+    bool live[PH];
+#pragma unroll
+    for (int j = 0; j < PH; ++j) {
+      const int row = row0 + 16 * (h0 + j);
+      mrow[j] = m0 + row;
+      live[j] = mrow[j] < p.M && n_live;
+      val[j] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
+    }
+    float* const out_base = p.out + batch * p.bs_out + n;
+    if (p.accumulate) {
+      f32x4 prev[PH];
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        prev[j] = *reinterpret_cast<const f32x4*>(live[j] ? out_base + (size_t)mrow[j] * p.ld_out : p.zeros);
+#pragma unroll
+      for (int j = 0; j < PH; ++j) val[j] += prev[j];
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[j][e] = fmaxf(val[j][e], 0.f);
+    }
+    if (p.mask_bits) {
+      unsigned int wd[PH];
+#pragma unroll
+      for (int j = 0; j < PH; ++j) wd[j] = live[j] ? p.mask_bits[(size_t)mrow[j] * p.ld_mask_bits + (n >> 5)] : 0u;
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[j][e] = ((wd[j] >> ((n & 31) + e)) & 1u) ? val[j][e] : 0.f;
+    }
+    if (p.gate_out) {
+#pragma unroll
+      for (int j = 0; j < PH; ++j) {
+        unsigned int nib = 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nib |= (live[j] && val[j][e] > 0.f) ? (1u << e) : 0u;
+        unsigned int word = nib << (4 * (lane & 7));
+        word |= __shfl_xor(word, 1, 64);
+        word |= __shfl_xor(word, 2, 64);
+        word |= __shfl_xor(word, 4, 64);
+        if ((lane & 7) == 0 && mrow[j] < p.M && n < p.ld_out) p.gate_out[(size_t)mrow[j] * p.ld_gate + (n >> 5)] = word;
+      }
+    }
+    if (p.mask) {
+      f32x4 mk[PH];
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        mk[j] = *reinterpret_cast<const f32x4*>(live[j] ? p.mask + (size_t)mrow[j] * p.ld_mask + n : p.zeros);
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[j][e] = (!live[j] || mk[j][e] > 0.f) ? val[j][e] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < PH; ++j)
+      if (live[j]) *reinterpret_cast<f32x4*>(out_base + (size_t)mrow[j] * p.ld_out) = val[j];      // N % 128 == 0: whole groups
+    if (p.out_planes) {
+      // the result as the next product's operand: its three pieces, split here instead of by a pass of its own; the
+      // padding rows of the planes (all inside the last tile of rows) as zeros
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        if (n_live && mrow[j] < prow)
+          sp::store4(p.out_planes, mrow[j], n, p.N >> 4, live[j] ? val[j] : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+    if (p.colsum) {
+#pragma unroll
+      for (int j = 0; j < PH; ++j)
+        if (live[j]) csum += val[j];
+    }
+  }
+  if (p.colsum) {
+    // column sums of the stored tile (the bias gradient of the layer whose dY this launch produces): over the 8 rows of
+    // the wavefront by shuffles, then one float atomic per channel and wavefront
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      csum[e] += __shfl_xor(csum[e], 8, 64);
+      csum[e] += __shfl_xor(csum[e], 16, 64);
+      csum[e] += __shfl_xor(csum[e], 32, 64);
+    }
+    if ((lane >> 3) == 0 && n_live) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < p.colsum_n) atomicAdd(p.colsum + n + e, csum[e]);
+    }
+  }
+}
 
 // MODE 0: out[m][n] = epilogue( sum_k A[m][k] B[n][k] )             (forward / data gradient)
 // MODE 1: out[n][c] += sum_pixels dY[pixel][n] x[pixel][c]            (weight gradient; float atomics, split over pixel slices)
@@ -402,12 +519,24 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
                    b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
 #endif
       // smallest terms first
+#if SP_ABL == 8                            // timing only: the same FLOPs as pairs of v_mfma_f32_16x16x32_bf16 (the shape the chip
+      {                                    // clocks higher on, profiles/r06_mfma_ceiling_bf16.txt) on the same fragment registers
+        f32x4 lo = {c[0], c[1], c[2], c[3]}, hi = {c[4], c[5], c[6], c[7]};
+#define SP_PAIR(a, b)                                                  \
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0); \
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
+        SP_PAIR(a2, b0) SP_PAIR(a0, b2) SP_PAIR(a1, b1) SP_PAIR(a1, b0) SP_PAIR(a0, b1) SP_PAIR(a0, b0)
+#undef SP_PAIR
+        c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3]; c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+      }
+#else
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+#endif
       acc[i][j] = c;
     }
   };
@@ -450,8 +579,17 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
       else mfma_row(I1{}, neg_tag);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // (-DSP_READS_FIRST: the fragment reads in front of the LDS-DMA requests.  In gemm_sp16_kernel a wave's ds_reads behind
+    //  its own global_load_lds wait 1000-1800 cycles and the order matters a lot; here the requests' lead is worth more:
+    //  reads first measured -2 ... -4 % on the eight benchmark shapes)
+#ifdef SP_READS_FIRST
+    read_frags(S);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
+#else
     if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
     read_frags(S);
+#endif
 #ifdef SP_FENCE_READS
     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -555,109 +693,330 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
       }
     }
   __syncthreads();
-  // A wavefront takes 8 rows x 32 channels per pass (the eight lanes of a row hold one gate word; the float32 stores are
-  // 128-byte runs, and so are the stores of every piece of the output's own planes: sp_planes.h); the 8 waves of a pass
-  // cover 16 rows x 128 channels, 16 passes the tile.
-  constexpr int ITERS = SP_BM / 16;                     // 16
-  constexpr int PH = 8;
-  const int wv = tid >> 6;
-  const int c4 = (wv & 3) * 32 + (lane & 7) * 4;
-  const int row0 = (wv >> 2) * 8 + (lane >> 3);
-  const int n = n0 + c4;
-  const bool n_live = n < p.N;
-  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
-  const long long prow = p.out_planes ? sp::padded_rows(p.M) : 0;
-#pragma unroll 1
-  for (int h0 = 0; h0 < ITERS; h0 += PH) {
-    f32x4 val[PH];
-    int mrow[PH];
-    bool live[PH];
-#pragma unroll
-    for (int j = 0; j < PH; ++j) {
-      const int row = row0 + 16 * (h0 + j);
-      mrow[j] = m0 + row;
-      live[j] = mrow[j] < p.M && n_live;
-      val[j] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
+  sp_epilogue_from_lds(p, Cs, m0, n0, batch, tid, lane);
+}
+
+// ---- the forward / data-gradient product on v_mfma_f32_16x16x32_bf16 (opt-in: CLX_SP_MFMA=16) -------------------------------
+// The same tile, ring, planes, two-level summation and epilogue as gemm_sp_kernel<0>; the six products of a fragment pair as
+// 16 x 16 x 32 instructions.  Why: the chip holds a higher clock on this shape (an accumulator register is read and written
+// once per 32 products instead of once per 16: profiles/r06_mfma_ceiling_bf16.txt, 2.03 against 1.80 GHz on random operands;
+// in this kernel 1.96 against 1.64 GHz on the K = 2304 launch).
+// A 16 x 16 x 32 operand is 16 rows x 32 k: lane l holds row l % 16, k = 8 (l / 16) .. + 7 — the 16 bytes the P3 fragment of the
+// k step (l / 32 of a PAIR of ring stages), half (l / 16) & 1, keeps for that row: the LDS image and the LDS-DMA stay as they
+// are, a DOUBLE step (two ring stages, 32 k) is multiplied between barriers, and the ring is two double stages.
+// Registers: 64 + 64 accumulators, the A fragments of the double step (4 row groups x 3 pieces: 48) and two of the four
+// column groups of B at a time (2 x 12).  Waves 4-7 run half a double step late, as in gemm_sp_kernel.
+// What the stamps of the diagnostic build (-DSP16_STAMP, tools/exp/sp16_stamps.py) taught:
+//   * a wave's ds_reads BEHIND its own global_load_lds return 1000-1800 cycles later than in front of them (18 reads: 1050
+//     behind three requests, 570 in front): every segment reads first and requests afterwards;
+//   * back-to-back 16 x 16 x 32 instructions hold the SIMD's vector issue half of the time: the partner wave's 18 ds_read_b128
+//     take 700-1000 cycles beside them (400 beside nothing), and the older wave wins every issue slot it wants — without
+//     priorities the early half's products ran INSIDE the late half's instead of behind them and the late half's reads were
+//     covered by nothing: s_setprio 1 for the late half, 3 around the early half's reads, 0 for its products.
+// Measured (one MI355X, TFLOP/s f32-equivalent, this kernel / gemm_sp_kernel<0>): K = 2304: 209-213 / 201-205; K = 768:
+// 161 / 167-170; K = 256: 98 / 124 (the longer fill of the two-double-stage ring and the LDS epilogue of every tile).  The
+// contraction lengths of the benchmark networks are 256 and 768: NOT the default.  The matrix pipe is busy 0.57-0.62 of the
+// cycles here against 0.71 there — what the late half's burst of 18 reads at the end of every first half step costs.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512, 1) void gemm_sp16_kernel(const SpP p) {
+  __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SP16_STAMP
+  __shared__ unsigned long long stamp_lds[2][64];
+  int stamp_n = 0;
+  const bool stamp_wave = blockIdx.x == 0 && blockIdx.y == 0 && (w == 0 || w == 4);
+  auto stamp = [&](int d) __attribute__((always_inline)) {
+    if (stamp_wave && d >= 16 && d < 20) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (lane == 0) stamp_lds[w >> 2][stamp_n & 63] = t;
+      ++stamp_n;
     }
-    float* const out_base = p.out + batch * p.bs_out + n;
-    if (p.accumulate) {
-      f32x4 prev[PH];
+  };
+#define SP_STAMP(d) stamp(d)
+#else
+#define SP_STAMP(d)
+#endif
+  const int wm = w >> 1, wn = w & 1;
+  const int v = xcd_remap(blockIdx.x, p.nbm * p.nbn);
+  const int tile_n = v % p.nbn, tile_m = v / p.nbn;
+  const int batch = blockIdx.y;
+  const int ksteps = p.ksteps;
+  const int m0 = tile_m * SP_BM, n0 = tile_n * SP_BN;
+  const bool clk_block = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0;
+  unsigned long long clk_c0 = 0, clk_w0 = 0;
+  if (clk_block) { clk_c0 = clock64(); clk_w0 = wall_clock64(); }
+
+  // ---- loads of a double step: 48 fragments of A (six per wave: f = w + 8 q; stage f / 24 of the pair, fragment f % 24 of it)
+  // and 24 of B (three per wave: stage f / 12, fragment f % 12), requested at different times (below)
+  const char* const Ab = p.A + batch * p.bs_a;
+  const char* const Bb = p.B + batch * p.bs_b;
+  const char* gsrc_a[6];
+  const char* gsrc_b[3];
+  int ldst_a[6], ldst_b[3];
 #pragma unroll
-      for (int j = 0; j < PH; ++j)
-        prev[j] = *reinterpret_cast<const f32x4*>(live[j] ? out_base + (size_t)mrow[j] * p.ld_out : p.zeros);
+  for (int q = 0; q < 6; ++q) {
+    const int f = w + 8 * q, sub = f / A_FRAGS, idx = f % A_FRAGS;
+    int rb = tile_m * (SP_BM / 32) + idx / 3;
+    if (rb > p.rb_a - 1) rb = p.rb_a - 1;
+    gsrc_a[q] = Ab + ((long long)rb * ksteps * 3 + idx % 3) * FRAG + sub * KSTEP;
+    ldst_a[q] = sub * STAGE + idx * FRAG;
+  }
 #pragma unroll
-      for (int j = 0; j < PH; ++j) val[j] += prev[j];
+  for (int q = 0; q < 3; ++q) {
+    const int f = w + 8 * q, sub = f / B_FRAGS, idx = f % B_FRAGS;
+    const int nb = tile_n * (SP_BN / 32) + idx / 3;
+    gsrc_b[q] = Bb + ((long long)nb * ksteps * 3 + idx % 3) * FRAG + sub * KSTEP;
+    ldst_b[q] = sub * STAGE + (A_FRAGS + idx) * FRAG;
+  }
+  const unsigned int lane16 = (unsigned int)lane * 16u;
+#ifndef SP16_ABL
+#define SP16_ABL 0
+#endif
+  auto issue_a = [&](int d, int pair) __attribute__((always_inline)) {
+    if (SP16_ABL == 1 && d > 1) return;
+    char* const dst = smem + pair * 2 * STAGE;
+    const unsigned int voff = lane16 + (unsigned int)d * (2u * KSTEP);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) glds16(gsrc_a[q] + (size_t)voff, dst + ldst_a[q]);
+  };
+  auto issue_b = [&](int d, int pair) __attribute__((always_inline)) {
+    if (SP16_ABL == 1 && d > 1) return;
+    char* const dst = smem + pair * 2 * STAGE;
+    const unsigned int voff = lane16 + (unsigned int)d * (2u * KSTEP);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) glds16(gsrc_b[q] + (size_t)voff, dst + ldst_b[q]);
+  };
+
+  f32x4_ acc[4][4], tot[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+
+  // LDS addresses of this wave's operands per double stage (opaque: two registers per operand, the rest instruction offsets)
+  unsigned int la[2], lb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int g = lane >> 4;
+    const int lterm = (g >> 1) * STAGE + (g & 1) * 512 + (lane & 15) * 16;
+    la[u] = u * 2 * STAGE + (wm * 2 * 3) * FRAG + lterm;
+    lb[u] = u * 2 * STAGE + (A_FRAGS + wn * 2 * 3) * FRAG + lterm;
+    asm volatile("" : "+v"(la[u]), "+v"(lb[u]));
+  }
+  u32x4 fa[4][3], fb[2][2][3];            // A: [row group][piece]; B: [buffer][column group of the pair][piece]
+  // group G of 16 rows (columns) = row block G >> 1 of the wave's two, rows 16 (G & 1) .. of it
+  auto read_a = [&](int pair) __attribute__((always_inline)) {
+    const char* const as = smem + la[pair];
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[G][q] = *reinterpret_cast<const u32x4*>(as + ((G >> 1) * 3 + q) * FRAG + (G & 1) * 256);
+  };
+  auto read_b = [&](int pair, auto half_tag, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int H = decltype(half_tag)::value, BUF = decltype(buf_tag)::value;
+    const char* const bs = smem + lb[pair];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fb[BUF][jj][q] = *reinterpret_cast<const u32x4*>(bs + (H * 3 + q) * FRAG + jj * 256);
+  };
+  auto negate_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int G = 0; G < 4; ++G)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) fa[G][q] ^= 0x80008000u;
+  };
+  // the 48 MFMAs of two column groups (half H of the wave's 64 columns): product-major, so that the four row groups'
+  // instructions lie between two that accumulate into the same registers
+  auto mfma_half = [&](auto half_tag, auto buf_tag) __attribute__((always_inline)) {
+    constexpr int H = decltype(half_tag)::value, BUF = decltype(buf_tag)::value;
+#if SP16_ABL == 4                           // timing only: no products (the fragments still have to arrive)
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) asm volatile("" :: "v"(fb[BUF][jj][q]), "v"(fa[jj][q]), "v"(fa[2 + jj][q]));
+    return;
+#endif
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};      // smallest terms first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int G = 0; G < 4; ++G)
+          acc[G][2 * H + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[G][PA[t]]),
+                                                                        __builtin_bit_cast(bf16x8, fb[BUF][jj][PB[t]]),
+                                                                        acc[G][2 * H + jj], 0, 0, 0);
     }
-    if (p.relu) {
+  };
+  auto flush = [&](auto neg_tag) __attribute__((always_inline)) {
+    constexpr bool NEG = decltype(neg_tag)::value;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < PH; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[j][e] = fmaxf(val[j][e], 0.f);
-    }
-    if (p.mask_bits) {
-      unsigned int wd[PH];
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (NEG) tot[i][j] -= acc[i][j];
+        else tot[i][j] += acc[i][j];
 #pragma unroll
-      for (int j = 0; j < PH; ++j) wd[j] = live[j] ? p.mask_bits[(size_t)mrow[j] * p.ld_mask_bits + (n >> 5)] : 0u;
-#pragma unroll
-      for (int j = 0; j < PH; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[j][e] = ((wd[j] >> ((n & 31) + e)) & 1u) ? val[j][e] : 0.f;
-    }
-    if (p.gate_out) {
-#pragma unroll
-      for (int j = 0; j < PH; ++j) {
-        unsigned int nib = 0u;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) nib |= (live[j] && val[j][e] > 0.f) ? (1u << e) : 0u;
-        unsigned int word = nib << (4 * (lane & 7));
-        word |= __shfl_xor(word, 1, 64);
-        word |= __shfl_xor(word, 2, 64);
-        word |= __shfl_xor(word, 4, 64);
-        if ((lane & 7) == 0 && mrow[j] < p.M && n < p.ld_out) p.gate_out[(size_t)mrow[j] * p.ld_gate + (n >> 5)] = word;
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
       }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  // Double step d of a period (S = 0: its first, 1: its second and last; it lives in double stage S) is two half steps
+  // between three barriers:
+  //   OPEN  — A(d + 1) excepted, this wave's loads have landed; every wave is past its reads of double step d - 1:
+  //           request B(d + 1) into the other double stage.  An early wave reads A, B0, B1 and multiplies the first half of
+  //           the columns; a late wave (4-7) multiplies the second half of double step d - 1 from registers, then reads.
+  //   MID   — every wave holds A(d) in registers: request A(d + 2) into THIS double stage (a lead of one and a half double
+  //           steps for two thirds of the bytes; the B fragments — weights, shared by every block — have one).  An early
+  //           wave reads B2, B3 and multiplies the second half; a late wave multiplies the first half, then reads B2, B3
+  //           and keeps them.
+  // The two waves of a SIMD thus alternate between reading and multiplying, as in gemm_sp_kernel.
+  // A1: double step d + 1 exists (its A fragments are this wave's six loads still in flight at OPEN); A2: d + 2 exists.
+  auto dstep = [&](int d, auto s_tag, auto late_tag, auto neg_tag, auto first_tag, auto a1_tag, auto a2_tag) __attribute__((always_inline)) {
+    constexpr int S = decltype(s_tag)::value;
+    constexpr bool LATE = decltype(late_tag)::value, NEG = decltype(neg_tag)::value, FIRST = decltype(first_tag)::value;
+    constexpr bool A1 = decltype(a1_tag)::value, A2 = decltype(a2_tag)::value;
+    if constexpr (A1) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    SP_STAMP(d);                                                  // 0: at OPEN (after the wait for the loads)
+    if (SP16_ABL != 2) __builtin_amdgcn_s_barrier();
+    SP_STAMP(d);                                                  // 1: through OPEN
+    // (an LDS-DMA instruction costs its wave 60-180 cycles of issue: the half that multiplies first requests afterwards,
+    //  so that one wave of every SIMD feeds the matrix pipe while the other talks to memory)
+    if constexpr (!LATE) {
+#ifndef SP16_NO_PRIO
+      __builtin_amdgcn_s_setprio(3);         // an early wave's READS go in front of the late half's products, its products behind
+#endif
+      read_a(S);
+      read_b(S, H0{}, H0{});
+#ifndef SP16_NO_PRIO
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 2: reads issued
+      if constexpr (A1) issue_b(d + 1, S ^ 1);
+#ifdef SP16_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 3: B requested, fragments in registers
+      if constexpr (NEG) negate_a();
+      mfma_half(H0{}, H0{});
+    } else {
+      if constexpr (!(FIRST && S == 0)) {
+        mfma_half(H1{}, H1{});
+        if constexpr (S == 0) flush(std::integral_constant<bool, !NEG>{});       // (the previous period's last half)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 2: products issued
+      read_a(S);
+      read_b(S, H0{}, H0{});
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 3: reads issued
+      if constexpr (A1) issue_b(d + 1, S ^ 1);
+      if constexpr (NEG) negate_a();
     }
-    if (p.mask) {
-      f32x4 mk[PH];
-#pragma unroll
-      for (int j = 0; j < PH; ++j)
-        mk[j] = *reinterpret_cast<const f32x4*>(live[j] ? p.mask + (size_t)mrow[j] * p.ld_mask + n : p.zeros);
-#pragma unroll
-      for (int j = 0; j < PH; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) val[j][e] = (!live[j] || mk[j][e] > 0.f) ? val[j][e] : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    SP_STAMP(d);                                                  // 4: at MID
+    if (SP16_ABL != 2) __builtin_amdgcn_s_barrier();
+    SP_STAMP(d);                                                  // 5: through MID
+    if constexpr (!LATE) {
+#ifndef SP16_NO_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
+      read_b(S, H1{}, H1{});
+#ifndef SP16_NO_PRIO
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 6: reads issued
+      if constexpr (A2) issue_a(d + 2, S);
+#ifdef SP16_STAMP
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 7: A requested, fragments in registers
+      mfma_half(H1{}, H1{});
+      if constexpr (S == 1) flush(neg_tag);
+    } else {
+      mfma_half(H0{}, H0{});
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 6: products issued
+      read_b(S, H1{}, H1{});
+      __builtin_amdgcn_sched_barrier(0); SP_STAMP(d); __builtin_amdgcn_sched_barrier(0);      // 7: reads issued
+      if constexpr (A2) issue_a(d + 2, S);
     }
-#pragma unroll
-    for (int j = 0; j < PH; ++j)
-      if (live[j]) *reinterpret_cast<f32x4*>(out_base + (size_t)mrow[j] * p.ld_out) = val[j];      // N % 128 == 0: whole groups
-    if (p.out_planes) {
-      // the result as the next product's operand: its three pieces, split here instead of by a pass of its own; the
-      // padding rows of the planes (all inside the last tile of rows) as zeros
-#pragma unroll
-      for (int j = 0; j < PH; ++j)
-        if (n_live && mrow[j] < prow)
-          sp::store4(p.out_planes, mrow[j], n, p.N >> 4, live[j] ? val[j] : f32x4{0.f, 0.f, 0.f, 0.f});
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // a period of 64 k = two double steps.  TAIL: 0 = two more periods follow at least, 1 = the last but one, 2 = the last
+  auto period = [&](int per, auto late_tag, auto neg_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
+    constexpr int TAIL = decltype(tail_tag)::value;
+    using T = std::true_type;
+    dstep(2 * per, H0{}, late_tag, neg_tag, first_tag, T{}, std::integral_constant<bool, TAIL != 2>{});
+    dstep(2 * per + 1, H1{}, late_tag, neg_tag, first_tag, std::integral_constant<bool, TAIL != 2>{},
+          std::integral_constant<bool, TAIL != 2>{});
+    if constexpr (TAIL == 2 && decltype(late_tag)::value) {     // the half double step a late wave still owes
+      mfma_half(H1{}, H1{});
+      flush(neg_tag);
     }
-    if (p.colsum) {
-#pragma unroll
-      for (int j = 0; j < PH; ++j)
-        if (live[j]) csum += val[j];
+  };
+  // periods alternate in sign, starting with +; the first and the last one are peeled (K >= 128: at least two periods)
+  using P0 = std::integral_constant<int, 0>;
+  using P2 = std::integral_constant<int, 2>;
+  auto k_loop = [&](auto late_tag) __attribute__((always_inline)) {
+    const int nper = ksteps >> 2;
+    using T = std::true_type;
+    using F = std::false_type;
+    period(0, late_tag, F{}, T{}, P0{});
+    int per = 1;
+    for (; per + 2 < nper; per += 2) {
+      period(per, late_tag, T{}, F{}, P0{});
+      period(per + 1, late_tag, F{}, F{}, P0{});
     }
+    if (per + 2 == nper) {
+      period(per, late_tag, T{}, F{}, P0{});
+      period(per + 1, late_tag, F{}, F{}, P2{});
+    } else {
+      period(per, late_tag, T{}, F{}, P2{});
+    }
+  };
+  issue_a(0, 0);
+  issue_b(0, 0);
+  issue_a(1, 1);
+  // The late half multiplies FIRST behind every barrier, from registers, while the early half reads; it has to be through
+  // its products when the early half's fragments arrive, or the two blocks of products run side by side and the late
+  // half's reads behind them are covered by nothing: priority for its instructions (measured with the stamps of the
+  // diagnostic build: the late half's 48 products took 1650 cycles beside the early half's, its reads 600 more)
+#ifndef SP16_NO_PRIO
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+  if (w < 4) k_loop(std::false_type{});
+  else k_loop(std::true_type{});
+  __builtin_amdgcn_s_setprio(0);
+
+#ifdef SP16_STAMP
+  if (stamp_wave && lane < 64) g_sp16_stamps[w >> 2][lane] = lane < stamp_n ? stamp_lds[w >> 2][lane] : 0ull;
+#endif
+  if (clk_block) { atomicAdd(&g_sp_clk_ticks[0], clock64() - clk_c0); atomicAdd(&g_sp_clk_ticks[1], wall_clock64() - clk_w0); }
+  // ---- epilogue: through the LDS transpose (accumulator register r of lane l: row 4 (l / 16) + r, column l % 16 of its 16 x 16)
+  __syncthreads();
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = wn * 64 + 16 * j + (lane & 15);
+    const int n = n0 + col;
+    const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cs[(wm * 64 + 16 * i + 4 * (lane >> 4) + r) * LDC + col] = tot[i][j][r] + bv;
   }
-  if (p.colsum) {
-    // column sums of the stored tile (the bias gradient of the layer whose dY this launch produces): over the 8 rows of
-    // the wavefront by shuffles, then one float atomic per channel and wavefront
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      csum[e] += __shfl_xor(csum[e], 8, 64);
-      csum[e] += __shfl_xor(csum[e], 16, 64);
-      csum[e] += __shfl_xor(csum[e], 32, 64);
-    }
-    if ((lane >> 3) == 0 && n_live) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (n + e < p.colsum_n) atomicAdd(p.colsum + n + e, csum[e]);
-    }
-  }
+  __syncthreads();
+  sp_epilogue_from_lds(p, Cs, m0, n0, batch, tid, lane);
 }
 
 __device__ __attribute__((aligned(16))) float g_sp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -768,7 +1127,11 @@ int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long r
   p.nbm = cdiv(M, SP_BM); p.nbn = N / SP_BN;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled()) clx_prof_events(CLX_PROF_GEMM_SP, 2.0 * M * N * K * batch, &e0, &e1);
-  CLX_LAUNCH_TIMED(gemm_sp_kernel<0>, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
+  // CLX_SP_MFMA=16: the 16 x 16 x 32 form of the kernel (gemm_sp16_kernel: faster from K ~ 2000 on, slower on the contraction
+  // lengths of the benchmark networks, 256 and 768; read per launch so that a test can switch it)
+  const char* const shape_env = getenv("CLX_SP_MFMA");
+  if (shape_env != nullptr && atoi(shape_env) == 16) CLX_LAUNCH_TIMED(gemm_sp16_kernel, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
+  else CLX_LAUNCH_TIMED(gemm_sp_kernel<0>, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
   return CLX_OK;
 }
 

@@ -52,8 +52,12 @@ def test_planes_are_an_exact_split(rows, K, ld):
     assert np.all(h.transpose(0, 4, 1, 2, 3, 5).reshape(-1, K // 16 * 48)[rows:] == 0)
 
 
+@pytest.mark.parametrize("mfma", ["32", "16"])
 @pytest.mark.parametrize("M,N,K,relu", [(256, 128, 128, 0), (1000, 256, 256, 1), (70000, 256, 768, 1), (257, 768, 2304, 0)])
-def test_product_from_planes_against_float64(M, N, K, relu):
+def test_product_from_planes_against_float64(M, N, K, relu, mfma, monkeypatch):
+    """mfma: the kernel on v_mfma_f32_32x32x16_bf16 (the default) and the opt-in one on 16x16x32 (CLX_SP_MFMA=16, read per
+    launch): the same products, the same bars"""
+    monkeypatch.setenv("CLX_SP_MFMA", mfma)
     _clx, lib = _lib()
     dev = torch.device("cuda:0")
     torch.manual_seed(M + K)
