@@ -713,10 +713,10 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
 //     take 700-1000 cycles beside them (400 beside nothing), and the older wave wins every issue slot it wants — without
 //     priorities the early half's products ran INSIDE the late half's instead of behind them and the late half's reads were
 //     covered by nothing: s_setprio 1 for the late half, 3 around the early half's reads, 0 for its products.
-// Measured (one MI355X, TFLOP/s f32-equivalent, this kernel / gemm_sp_kernel<0>): K = 2304: 209-213 / 201-205; K = 768:
-// 161 / 167-170; K = 256: 98 / 124 (the longer fill of the two-double-stage ring and the LDS epilogue of every tile).  The
-// contraction lengths of the benchmark networks are 256 and 768: NOT the default.  The matrix pipe is busy 0.57-0.62 of the
-// cycles here against 0.71 there — what the late half's burst of 18 reads at the end of every first half step costs.
+// Measured (one MI355X, TFLOP/s f32-equivalent, this kernel / gemm_sp_kernel<0>): K = 2304: 212-216 / 204-208; K = 768:
+// 162 / 170; K = 256: 101 / 126 (the longer fill of the two-double-stage ring and the LDS epilogue of every tile).  The
+// contraction lengths of the benchmark networks are 256 and 768: NOT the default.  Matrix pipe 0.71 busy at 1.77 GHz here,
+// 0.73 at 1.67 GHz there (profiles/r06_pmc_sp16_vs_sp32.txt): occupancy won back by the scheduling came off the clock.
 typedef float f32x4_ __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(512, 1) void gemm_sp16_kernel(const SpP p) {
   __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];

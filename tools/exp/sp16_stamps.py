@@ -5,6 +5,7 @@ import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cellulus_amd import _clx
+os.environ["CLX_SP_MFMA"] = "16"
 _clx.LIB_PATH = os.path.abspath(os.environ["CLX_LIB"])
 lib = _clx.load()
 dev = torch.device("cuda:0")
