@@ -5,6 +5,7 @@ weight gradient with linear rows (1x1) and with the general decode (3x3), ragged
 
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -145,3 +146,72 @@ def test_weight_gradient_linear_and_decoded_rows_vs_f64(C, N, k, device):
     err = (dw.cpu().double().reshape(N, C, k, k) - wr.grad).abs().max().item()
     assert err < 3e-5 * wr.grad.abs().max().item(), err
     assert (db.cpu().double() - dy.double().sum((0, 1, 2))).abs().max().item() < 1e-3
+
+
+_FLUSH_SCRIPT = r"""
+import ctypes, sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+from cellulus_amd import _clx
+from cellulus_amd._clx import ClxConvDesc, ClxSrc
+dev = torch.device("cuda:0")
+st = _clx.stream_ptr(dev)
+res = {}
+for C in (32, 256):                       # one K chunk of 32 / eight of them
+    torch.manual_seed(C)
+    B, H, W, N = 2, 40, 36, 64
+    x = torch.relu(torch.randn(B, H, W, C)).to(dev).contiguous()
+    w = (torch.randn(N, C, 1) * 0.2).to(dev).contiguous()
+    wp = torch.empty(N * C, device=dev)
+    _clx.call("clx_pack_weights", _clx.ptr(w), _clx.ptr(wp), N, C, 1, C, N, 0, st)
+    out = torch.empty(B, H, W, N, device=dev)
+    d = ClxConvDesc()
+    d.nsrc = 1
+    s = ClxSrc()
+    s.ptr, s.C, s.ld = x.data_ptr(), C, C
+    s.D, s.H, s.W = 1, H, W
+    s.fz = s.fy = s.fx = 1
+    d.src[0] = s
+    d.B = B
+    d.ID, d.IH, d.IW = 1, H, W
+    d.KD = d.KH = d.KW = 1
+    d.N = N
+    d.algo = 0
+    d.wpack = wp.data_ptr()
+    d.out, d.ld_out = out.data_ptr(), N
+    _clx.call("clx_conv_fwd", ctypes.byref(d), st)
+    torch.cuda.synchronize()
+    res[f"out{C}"] = out.cpu().numpy()
+    res[f"ref{C}"] = (x.double().reshape(-1, C) @ w.double().reshape(N, C).t()).reshape(B, H, W, N).cpu().numpy()
+np.savez(sys.argv[2], **res)
+"""
+
+
+def test_accumulator_flush_against_one_chain(tmp_path, device):
+    """CLX_IGEMM_FLUSH (read once per process: two processes): fresh accumulators every 64 products (the default, 2) against one
+    chain over all of K (0), float32 MFMA kernels.  One 32-deep chunk: the flush never fires, the bits are the same; eight
+    chunks: both within the float32 bar of the float64 product, and the flushed sum no further from it than the chain."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "flush.py"
+    script.write_text(_FLUSH_SCRIPT)
+    got = {}
+    for flush in ("0", "2"):
+        env = dict(os.environ, CLX_IGEMM_FLUSH=flush, CLX_PRECISION="f32")
+        out = tmp_path / f"flush{flush}.npz"
+        p = subprocess.run([sys.executable, str(script), root, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        got[flush] = np.load(out)
+    assert np.array_equal(got["0"]["out32"], got["2"]["out32"])
+    ref = got["0"]["ref256"]
+    scale = np.abs(ref).max()
+    e0 = np.abs(got["0"]["out256"] - ref).max() / scale
+    e2 = np.abs(got["2"]["out256"] - ref).max() / scale
+    assert e0 < 2e-6 and e2 < 2e-6, (e0, e2)
+    r0 = np.sqrt(((got["0"]["out256"] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+    r2 = np.sqrt(((got["2"]["out256"] - ref) ** 2).mean()) / np.sqrt((ref ** 2).mean())
+    assert r2 <= 1.1 * r0, (r0, r2)
