@@ -37,6 +37,13 @@ def init_from_env(backend=None):
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if "CLX_LOCAL_DEVICE" in os.environ and world > 1 and torch.cuda.is_available():
+        # several ranks on one device: a rank may not let torch's caching allocator keep more than its share (blocks cached
+        # from an earlier phase of the run count against the others: the eight-rank rehearsal of BASELINE configs[2] peaks
+        # at 26 GB per rank of live tensors and, uncapped, ran one GPU of 288 GB out of memory now and then).  At the cap
+        # the allocator gives its unused blocks back and retries before it reports out-of-memory
+        share = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        torch.cuda.set_per_process_memory_fraction(min(1.0, 0.92 / share), local_rank)
     return rank, world, local_rank
 
 

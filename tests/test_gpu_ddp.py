@@ -197,6 +197,9 @@ def test_cfg3_dress_rehearsal_eight_ranks_at_the_real_workload(tmp_path, device)
         import re
 
         tail = (p.stdout + p.stderr)[-6000:]
+        free_b, total_b = torch.cuda.mem_get_info()
+        tail += (f"\n[parent process] device free {free_b / 2 ** 30:.1f} of {total_b / 2 ** 30:.1f} GiB after the run; its own tensors "
+                 f"{torch.cuda.memory_allocated() / 2 ** 30:.2f} GiB, reserved {torch.cuda.memory_reserved() / 2 ** 30:.2f} GiB\n")
         if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
             with open(os.path.join(ROOT, "gpurun_out", "cfg3_dress_rehearsal_first_failure.txt"), "w") as fh:
                 fh.write(tail)
