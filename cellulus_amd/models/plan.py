@@ -1047,6 +1047,13 @@ class UNetPlan:
         d.workspace_bytes = self.workspace.numel() * 4
 
     # ------------------------------------------------- split precision (CLX_PRECISION=f32x3bf16; csrc/gemm_sp.hip)
+    def arena_bytes(self):
+        """device bytes of this plan's own activations and scratch (not the packed weights and their planes, which plans of one
+        model share): what a second plan of the same shape on another stream takes"""
+        ts = list(self.buf.values()) + [self.workspace, self.aplanes, self.dyplanes, getattr(self, "dyplanes2", None)]
+        ts += list(self.xplanes.values()) + list(self.vcache.values())
+        return sum(t.numel() * t.element_size() for t in ts if t is not None)
+
     def _register_wplanes(self, wp, n, batch, k):
         """planes for the packed weights `wp` seen as `batch` matrices [n][k] (the B operand of a plain product), if
         the split-precision kernels cover that product"""

@@ -307,6 +307,11 @@ class UNetModel(nn.Module):  # type: ignore
             # one plan (activation arena) per input shape; drop older ones to bound memory
             for k in [k for k in self._plans if k[2] == bool(keep)]:
                 del self._plans[k]
+            if not keep:
+                # (the further plans of the chunk streams and the one-image plan of the changed-rows form belong to the shape
+                #  that goes: they must not stay beside the new arena until _forward_chunks replaces them)
+                self._infer_pair = None
+                self._clean_plan = None
             if dual_stream_wanted(topo, raw.shape[0], keep):
                 plan = DualPlan(topo, raw.shape[0], raw.device, keep)
             else:
@@ -476,9 +481,7 @@ class UNetModel(nn.Module):  # type: ignore
         if pair is None or pair[0] is not plan:
             # every further set of activations must fit beside the first (several ranks may share a device in a rehearsal):
             # as many streams as there is room for
-            need = sum(t.numel() * t.element_size() for t in plan.buf.values())
-            if plan.workspace is not None:
-                need += plan.workspace.numel() * plan.workspace.element_size()
+            need = plan.arena_bytes()
             free = parallel.free_device_memory(noisy.device)
             nstreams = min(nstreams, 1 + int(free // (1.25 * need)))
             if nstreams < 2:
