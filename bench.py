@@ -78,6 +78,18 @@ def _free_port():
     return port
 
 
+
+def release_device_memory():
+    """Between the legs of a run: the previous leg's models and plans hold each other in reference cycles (modules, plans,
+    closures), so their tensors stay LIVE until a generation-2 collection — collect first, then hand torch's cached blocks
+    back (eight ranks rehearsing on one GPU ran it out of memory with the previous leg's 27 GB still allocated)."""
+    import gc
+
+    import torch
+
+    gc.collect()
+    torch.cuda.empty_cache()
+
 def self_launch(n, argv):
     """Start one child per GPU, wait, relay rank 0's stdout.  Children are FRESH processes
     (Popen of this very file), so nothing GPU-initialised is ever replaced or forked."""
@@ -787,7 +799,7 @@ def gpu_library_baseline(workload, device, seed=0, steps=3, with_infer=True):
     if with_infer and len(workload["crop"]) == 2:
         del opt
         model.zero_grad(set_to_none=True)
-        torch.cuda.empty_cache()
+        release_device_memory()
         size, n_it = 512, 16
         model.eval()
         model.set_infer(0.01, n_it)
@@ -860,13 +872,13 @@ def main():
     if args.precision == "both" and line_precision != "f32" and args.workload == "train2d":
         keep_env = os.environ.get("CLX_PRECISION")
         os.environ["CLX_PRECISION"] = "f32"
-        torch.cuda.empty_cache()
+        release_device_memory()
         try:
             res_f32 = run_workload(args.workload, args, rank, world, device)
             if world == 1 and not args.no_infer:
                 from bench_infer import infer_bench
 
-                torch.cuda.empty_cache()
+                release_device_memory()
                 infer_f32 = infer_bench(device, with_cpu=False, with_e2e=True, with_streaming=False)
         finally:
             if keep_env is None:
@@ -875,19 +887,19 @@ def main():
                 os.environ["CLX_PRECISION"] = keep_env
     res3d = None
     if args.workload == "train2d" and not args.no_train3d:
-        torch.cuda.empty_cache()
+        release_device_memory()
         res3d = run_workload("train3d", args, rank, world, device)
     # ---- the other half of the metric and the real train(), on every rank when there are several
     infer_obj = e2e_obj = None
     if world > 1:
         # (no try/except here: a rank that fails must EXIT, so that the launcher ends the ranks waiting in a barrier)
         if not args.no_infer:
-            torch.cuda.empty_cache()
+            release_device_memory()
             from bench_infer import infer_sharded
 
             infer_obj = infer_sharded(device, rank, world, samples_per_rank=args.infer_samples)
         if not args.no_train_e2e and args.workload in ("train2d", "train3d"):
-            torch.cuda.empty_cache()
+            release_device_memory()
             e2e_obj = train_e2e(args.workload, device, iterations=args.e2e_iterations, rank=rank, world=world)
         torch.distributed.barrier()
     if rank != 0:
@@ -935,7 +947,7 @@ def main():
         out["train_e2e"] = e2e_obj
     if world == 1 and not args.no_infer:
         try:
-            torch.cuda.empty_cache()
+            release_device_memory()
             from bench_infer import infer_bench
 
             out["infer"] = infer_bench(device)
@@ -943,7 +955,7 @@ def main():
             out["infer"] = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_train_e2e and args.workload in ("train2d", "train3d"):
         try:
-            torch.cuda.empty_cache()
+            release_device_memory()
             out["train_e2e"] = train_e2e(args.workload, device, iterations=args.e2e_iterations)
             # 8 loader processes are the reference's default; the same run with 16 says whether the host side (6 ms per
             # crop per process since the pair offsets come from libclx's restatement of numpy's stream) bounds it
@@ -959,7 +971,7 @@ def main():
     # (--no-cpu-baseline switches BOTH baselines off: the profiling scripts pass it to keep foreign kernels out of their traces)
     if world == 1 and not args.no_gpu_library_baseline and not args.no_cpu_baseline and args.workload in ("train2d", "train3d"):
         try:
-            torch.cuda.empty_cache()
+            release_device_memory()
             out["gpu_library_baseline"] = gpu_library_baseline(WORKLOADS[args.workload], device)
         except Exception as e:
             out["gpu_library_baseline"] = {"error": f"{type(e).__name__}: {e}"}

@@ -319,6 +319,14 @@ def e2e_infer(device, samples=32, size=512, rank=0, world=1):
                         "time = the slowest rank's between two barriers" if world > 1 else ""))
 
 
+
+def bench_release():
+    """bench.release_device_memory: collect the reference cycles of the previous leg's models and plans, then empty torch's cache"""
+    import gc
+
+    gc.collect()
+    torch.cuda.empty_cache()
+
 def infer_sharded(device, rank, world, samples_per_rank=16):
     """The `infer` object of a multi-rank bench line (every rank calls this): the whole job's Mpixels/s through the
     real infer() at the two tile sizes the metric names (512^2 = BASELINE configs[4], 256^2 = the metric string)."""
@@ -528,11 +536,11 @@ def infer_bench(device, reps=2, with_cpu=True, with_e2e=True, with_streaming=Tru
         "clusters": int(len(centers)),
     }
     del model, plan, emb
-    torch.cuda.empty_cache()
+    bench_release()
     if with_streaming:
         try:
             out["streaming"] = streaming_rooflines(device)
-            torch.cuda.empty_cache()
+            bench_release()
             # the two mean-shift kernels again at 256 samples per launch: what a launch of 64 samples loses is ramp and
             # launch cost, not bandwidth
             out["streaming"]["mean_shift_at_8192"] = streaming_rooflines(device, 8192, only_mean_shift=True)
