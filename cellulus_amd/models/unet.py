@@ -600,6 +600,14 @@ class UNetModel(nn.Module):  # type: ignore
         for s in spatial:
             npix *= int(s)
         want = max(1, (8 * 528 * 528) // max(npix, 1))
+        if parallel.ranks_sharing_device() > 1 and torch.cuda.is_available():
+            # several ranks on one device (the rehearsal hook CLX_LOCAL_DEVICE): a chunk's plan must fit the rank's share twice
+            # (two streams) beside what the rank holds already.  A plan takes ~60 bytes per input pixel and feature map of
+            # the first level (activations, the Winograd operands as planes, their products: 34 GB for eight 528^2 copies
+            # at 256 feature maps)
+            dev = getattr(self, "device", None) or torch.device("cuda", torch.cuda.current_device())
+            room = parallel.free_device_memory(dev)
+            want = max(1, min(want, int(room / (2.5 * 60.0 * self.num_fmaps * max(npix, 1)))))
         if want >= T:
             return T                   # small tiles: all copies in one forward
         best = 1
