@@ -46,7 +46,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6  # dense bf16 MFMA; the split precision f32x3bf16 spends six bf16 products per f32 product
-SP_KERNELS = ("gemm_sp_kernel<0>", "gemm_sp_kernel<1>")   # forward / data gradient, weight gradient          # priced against BF16_MFMA_PEAK_TFLOPS / 6 (f32-equivalent FLOPs)
+SP_KERNELS = ("gemm_sp_kernel<0>", "gemm_sp_kernel<1>", "gemm_sp2_kernel")   # forward / data gradient (K > 1024), weight gradient, forward / data gradient on 128 x 128 tiles          # priced against BF16_MFMA_PEAK_TFLOPS / 6 (f32-equivalent FLOPs)
 
 WORKLOADS = {
     "train2d": dict(
@@ -354,7 +354,8 @@ def run_workload(wl_key, args, rank, world, device):
 
     lib = _clx.load()
     kinds = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-             3: "gemm_sp_kernel<0>", 4: "gemm_sp_kernel<1>", 6: "chain64_kernels", 14: "wino_fused_kernels"}
+             3: "gemm_sp_kernel<0>", 4: "gemm_sp_kernel<1>", 6: "chain64_kernels", 14: "wino_fused_kernels",
+             16: "gemm_sp2_kernel"}
     hbm_kinds = {5: "sp_split_kernel", 15: "wino_transform_kernels"}       # HBM-bound launches libclx stamps as well (no FLOPs)
     hbm_prof = {}
 

@@ -26,7 +26,7 @@ import torch
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md
 F32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # dense bf16 MFMA; the split precision spends six bf16 products per float32 product
-SP_KERNELS = ("gemm_sp_kernel<0>", "gemm_sp_kernel<1>")   # forward / data gradient, weight gradient
+SP_KERNELS = ("gemm_sp_kernel<0>", "gemm_sp_kernel<1>", "gemm_sp2_kernel")   # forward / data gradient, weight gradient
 
 
 def _sync_time(fn, reps):
@@ -340,7 +340,7 @@ def infer_sharded(device, rank, world, samples_per_rank=16):
 
 
 MFMA_KINDS = {0: "conv_igemm_kernel<128,128,2,2>", 1: "conv_igemm_kernel<128,64,4,1>", 2: "conv_wgrad_kernel",
-              3: "gemm_sp_kernel<0>", 6: "chain64_kernels", 14: "wino_fused_kernels"}
+              3: "gemm_sp_kernel<0>", 6: "chain64_kernels", 14: "wino_fused_kernels", 16: "gemm_sp2_kernel"}
 
 
 def embed_stage(model, device, size, n_it, reps):

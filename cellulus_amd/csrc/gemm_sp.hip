@@ -196,11 +196,13 @@ struct SpP {
 
 // The tile's epilogue out of LDS (Cs: [SP_BM][LDC] floats, bias added, written and barrier-synchronised by the caller):
 // previous output, ReLU, gates, masks, the float32 store, the output's own planes, its column sums.
+template <int BM = SP_BM, int NWAVES = 8>
 __device__ __forceinline__ void sp_epilogue_from_lds(const SpP& p, const float* Cs, int m0, int n0, int batch, int tid, int lane) {
   // A wavefront takes 8 rows x 32 channels per pass (the eight lanes of a row hold one gate word; the float32 stores are
-  // 128-byte runs, and so are the stores of every piece of the output's own planes: sp_planes.h); the 8 waves of a pass
-  // cover 16 rows x 128 channels, 16 passes the tile.
-  constexpr int ITERS = SP_BM / 16;                     // 16
+  // 128-byte runs, and so are the stores of every piece of the output's own planes: sp_planes.h); the 8 (4) waves of a pass
+  // cover 16 (8) rows x 128 channels, 16 passes the tile.
+  constexpr int PASS_ROWS = NWAVES / 4 * 8;
+  constexpr int ITERS = BM / PASS_ROWS;                 // 16
   constexpr int PH = 8;
   const int wv = tid >> 6;
   const int c4 = (wv & 3) * 32 + (lane & 7) * 4;
@@ -216,7 +218,7 @@ __device__ __forceinline__ void sp_epilogue_from_lds(const SpP& p, const float* 
     bool live[PH];
 #pragma unroll
     for (int j = 0; j < PH; ++j) {
-      const int row = row0 + 16 * (h0 + j);
+      const int row = row0 + PASS_ROWS * (h0 + j);
       mrow[j] = m0 + row;
       live[j] = mrow[j] < p.M && n_live;
       val[j] = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4]);
@@ -696,6 +698,203 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
   sp_epilogue_from_lds(p, Cs, m0, n0, batch, tid, lane);
 }
 
+// ---- the forward / data-gradient product with TWO workgroups per CU (short contractions) ------------------------------------
+// gemm_sp_kernel<0> keeps one 512-thread workgroup on a CU: nothing runs under a tile's pipeline fill (the first stages come
+// from HBM) or under its epilogue, and on the contractions of the benchmark networks — 256 and 768 deep: 16 and 48 steps —
+// those are a third of a tile's time (125 / 170-190 TFLOP/s where K = 2304 reaches 205-225).  Here a workgroup is 256
+// threads = 4 waves (2 x 2) of 64 x 64 on a 128 x 128 tile with a ring of THREE 24-KB stages (72 KB): two of them share a
+// CU — one wave of each on every SIMD, 256 registers each — and one's fill and epilogue fall under the other's products.
+// No late half: the two workgroups of a CU are out of phase by themselves.  Costs: 24 KB of operands per 0.52 MFLOP
+// instead of 36 KB per 1.05 (a third more traffic out of L2), six LDS-DMA requests per wave and step instead of 4.5.
+constexpr int S2_BM = 128, S2_BN = 128;
+constexpr int S2_A_FRAGS = S2_BM / 32 * 3, S2_B_FRAGS = S2_BN / 32 * 3;      // 12 + 12
+constexpr int S2_STAGE = (S2_A_FRAGS + S2_B_FRAGS) * FRAG;                   // 24 KB
+constexpr int S2_RING = 3;
+__global__ __launch_bounds__(256, 2) void gemm_sp2_kernel(const SpP p) {
+  __shared__ __attribute__((aligned(16))) char smem[S2_RING * S2_STAGE];       // 72 KB; the C tile (66 KB) in the epilogue
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 1, wn = w & 1;
+  const int nbm = (p.M + S2_BM - 1) / S2_BM, nbn = p.N / S2_BN;
+  const int v = xcd_remap(blockIdx.x, nbm * nbn);
+  const int tile_n = v % nbn, tile_m = v / nbn;
+  const int batch = blockIdx.y;
+  const int ksteps = p.ksteps;
+  const int m0 = tile_m * S2_BM, n0 = tile_n * S2_BN;
+  const bool clk_block = blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && threadIdx.x == 0;
+  unsigned long long clk_c0 = 0, clk_w0 = 0;
+  if (clk_block) { clk_c0 = clock64(); clk_w0 = wall_clock64(); }
+
+  // loads: the 24 fragments of a stage, six per wave (f = w + 4 q): A's twelve, then B's
+  const char* const Ab = p.A + batch * p.bs_a;
+  const char* const Bb = p.B + batch * p.bs_b;
+  const char* gsrc[6];
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int f = w + 4 * q;
+    if (f < S2_A_FRAGS) {
+      int rb = tile_m * (S2_BM / 32) + f / 3;
+      if (rb > p.rb_a - 1) rb = p.rb_a - 1;
+      gsrc[q] = Ab + ((long long)rb * ksteps * 3 + f % 3) * FRAG;
+    } else {
+      const int g = f - S2_A_FRAGS;
+      const int nb = tile_n * (S2_BN / 32) + g / 3;
+      gsrc[q] = Bb + ((long long)nb * ksteps * 3 + g % 3) * FRAG;
+    }
+  }
+  const unsigned int lane16 = (unsigned int)lane * 16u;
+  auto issue = [&](int t, int slot) __attribute__((always_inline)) {
+    char* const dst = smem + slot * S2_STAGE;
+    const unsigned int voff = lane16 + (unsigned int)t * KSTEP;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) glds16(gsrc[q] + (size_t)voff, dst + (w + 4 * q) * FRAG);
+  };
+
+  f32x16 acc[2][2], tot[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+  const int li = lane & 31, lh = lane >> 5;
+  unsigned int la[S2_RING], lb[S2_RING];
+#pragma unroll
+  for (int k = 0; k < S2_RING; ++k) {
+    la[k] = k * S2_STAGE + (wm * 2 * 3) * FRAG + lane * 16;
+    lb[k] = k * S2_STAGE + (S2_A_FRAGS + wn * 2 * 3) * FRAG + lane * 16;
+    asm volatile("" : "+v"(la[k]), "+v"(lb[k]));
+  }
+  u32x4 fa[2][3], fb[2][3];
+  auto read_frags = [&](int slot) __attribute__((always_inline)) {
+    const char* const as = smem + la[slot];
+    const char* const bs = smem + lb[slot];
+    fa[0][2] = *reinterpret_cast<const u32x4*>(as + 2 * FRAG);
+    fb[0][0] = *reinterpret_cast<const u32x4*>(bs);
+    fa[0][0] = *reinterpret_cast<const u32x4*>(as);
+    fb[0][2] = *reinterpret_cast<const u32x4*>(bs + 2 * FRAG);
+    fa[0][1] = *reinterpret_cast<const u32x4*>(as + FRAG);
+    fb[0][1] = *reinterpret_cast<const u32x4*>(bs + FRAG);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fb[1][q] = *reinterpret_cast<const u32x4*>(bs + (3 + q) * FRAG);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) fa[1][q] = *reinterpret_cast<const u32x4*>(as + (3 + q) * FRAG);
+  };
+  auto mfma_step = [&](auto neg_tag) __attribute__((always_inline)) {
+    constexpr bool NEG = decltype(neg_tag)::value;
+    if constexpr (NEG) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) fa[i][q] ^= 0x80008000u;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x16 c = acc[i][j];
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, fa[i][0]), a1 = __builtin_bit_cast(bf16x8, fa[i][1]),
+                     a2 = __builtin_bit_cast(bf16x8, fa[i][2]);
+        const bf16x8 b0 = __builtin_bit_cast(bf16x8, fb[j][0]), b1 = __builtin_bit_cast(bf16x8, fb[j][1]),
+                     b2 = __builtin_bit_cast(bf16x8, fb[j][2]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b0, c, 0, 0, 0);       // smallest terms first
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b2, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+  };
+  auto flush = [&](auto neg_tag) __attribute__((always_inline)) {
+    constexpr bool NEG = decltype(neg_tag)::value;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (NEG) tot[i][j] -= acc[i][j];
+        else tot[i][j] += acc[i][j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // step t: this wave's six loads of step t have landed when at most the six of step t + 1 are in flight; behind the barrier
+  // the whole stage is in LDS and every wave is past its reads of step t - 1, whose slot takes step t + 2.
+  // TAIL: 0 = a step t + 2 exists; 1 = the last but one step; 2 = the last
+  auto step = [&](int t, int slot, auto tail_tag, auto neg_tag) __attribute__((always_inline)) {
+    constexpr int TAIL = decltype(tail_tag)::value;
+    if constexpr (TAIL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if constexpr (TAIL == 0) issue(t + 2, slot == 0 ? 2 : slot - 1);
+    read_frags(slot);
+    mfma_step(neg_tag);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T0 = std::integral_constant<int, 0>;
+  using T1 = std::integral_constant<int, 1>;
+  using T2 = std::integral_constant<int, 2>;
+  // a period of four steps (64 k) that starts at step t0, whose slot is s0 (t0 % 3); LAST: the kernel's last period
+  auto period = [&](int t0, int s0, auto neg_tag, auto last_tag) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+    const int s1 = s0 == 2 ? 0 : s0 + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+    step(t0, s0, T0{}, neg_tag);
+    step(t0 + 1, s1, T0{}, neg_tag);
+    if constexpr (LAST) { step(t0 + 2, s2, T1{}, neg_tag); step(t0 + 3, s0, T2{}, neg_tag); }
+    else { step(t0 + 2, s2, T0{}, neg_tag); step(t0 + 3, s0, T0{}, neg_tag); }
+    flush(neg_tag);
+  };
+  issue(0, 0);
+  issue(1, 1);
+  {
+    const int nper = ksteps >> 2;           // K >= 128: at least two periods; signs alternate, starting with +
+    int s0 = 0;                             // slot of the period's first step: (4 per) % 3 = per % 3
+    for (int per = 0; per + 1 < nper; ++per) {
+      if (per & 1) period(4 * per, s0, std::true_type{}, std::false_type{});
+      else period(4 * per, s0, std::false_type{}, std::false_type{});
+      s0 = s0 == 2 ? 0 : s0 + 1;
+    }
+    if ((nper - 1) & 1) period(4 * (nper - 1), s0, std::true_type{}, std::true_type{});
+    else period(4 * (nper - 1), s0, std::false_type{}, std::true_type{});
+  }
+  if (clk_block) { atomicAdd(&g_sp_clk_ticks[0], clock64() - clk_c0); atomicAdd(&g_sp_clk_ticks[1], wall_clock64() - clk_w0); }
+  // ---- epilogue, as gemm_sp_kernel<0>'s
+  if (!p.bias && !p.relu && !p.accumulate && !p.mask && !p.mask_bits && !p.gate_out && !p.out_planes && !p.colsum && m0 + S2_BM <= p.M) {
+    float* const ob = p.out + batch * p.bs_out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + (wn * 2 + j) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          ob[(size_t)row * p.ld_out + col] = tot[i][j][r];
+        }
+      }
+    return;
+  }
+  __syncthreads();
+  float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = (wn * 2 + j) * 32 + li;
+    const int n = n0 + col;
+    const float bv = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        Cs[row * LDC + col] = tot[i][j][r] + bv;
+      }
+  }
+  __syncthreads();
+  sp_epilogue_from_lds<S2_BM, 4>(p, Cs, m0, n0, batch, tid, lane);
+}
+
 // ---- the forward / data-gradient product on v_mfma_f32_16x16x32_bf16 (opt-in: CLX_SP_MFMA=16) -------------------------------
 // The same tile, ring, planes, two-level summation and epilogue as gemm_sp_kernel<0>; the six products of a fragment pair as
 // 16 x 16 x 32 instructions.  Why: the chip holds a higher clock on this shape (an accumulator register is read and written
@@ -1125,12 +1324,18 @@ int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long r
   p.colsum = batch == 1 ? ep->out_colsum : nullptr; p.colsum_n = N;
   CLX_REQUIRE(p.out_planes == nullptr || ep->ld_out == N, "clx_gemm_planes: out_planes needs a dense output (ld_out == N)");
   p.nbm = cdiv(M, SP_BM); p.nbn = N / SP_BN;
+  // CLX_SP_TILE=128: gemm_sp2_kernel (128 x 128 tiles, two workgroups per CU) always; =256: never; unset: up to K = 1024
+  // (measured against gemm_sp_kernel<0>: K = 256 +8 ... +22 %, K = 768 0 ... +6 %, K = 2304 -4 %)
+  const char* const tile_env = getenv("CLX_SP_TILE");
+  const int tile_choice = tile_env != nullptr ? atoi(tile_env) : 0;
+  const bool small_tiles = tile_choice == 128 || (tile_choice != 256 && K <= 1024);
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (clx_prof_enabled()) clx_prof_events(CLX_PROF_GEMM_SP, 2.0 * M * N * K * batch, &e0, &e1);
+  if (clx_prof_enabled()) clx_prof_events(small_tiles ? CLX_PROF_GEMM_SP2 : CLX_PROF_GEMM_SP, 2.0 * M * N * K * batch, &e0, &e1);
   // CLX_SP_MFMA=16: the 16 x 16 x 32 form of the kernel (gemm_sp16_kernel: faster from K ~ 2000 on, slower on the contraction
   // lengths of the benchmark networks, 256 and 768; read per launch so that a test can switch it)
   const char* const shape_env = getenv("CLX_SP_MFMA");
   if (shape_env != nullptr && atoi(shape_env) == 16) CLX_LAUNCH_TIMED(gemm_sp16_kernel, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
+  else if (small_tiles) CLX_LAUNCH_TIMED(gemm_sp2_kernel, dim3(cdiv(M, S2_BM) * (N / S2_BN), batch), dim3(256), st, e0, e1, p);
   else CLX_LAUNCH_TIMED(gemm_sp_kernel<0>, dim3(p.nbm * p.nbn, batch), dim3(512), st, e0, e1, p);
   return CLX_OK;
 }

@@ -64,7 +64,8 @@ enum clx_profile_kind {
   CLX_PROF_HISTOGRAM = 12,   /* histogram_kernel */
   CLX_PROF_NOISE_STATS = 13, /* noise_stats kernels */
   CLX_PROF_WINO_FUSED = 14,  /* wino_fused_kernel (CLX_ALGO_WINOGRAD4_FUSED; FLOPs = 2 * a^2 * tiles * N * C executed) */
-  CLX_PROF_WINO_TRANSFORM = 15 /* the HBM-bound transform kernels of CLX_ALGO_WINOGRAD / _WINOGRAD4 (no FLOPs) */
+  CLX_PROF_WINO_TRANSFORM = 15, /* the HBM-bound transform kernels of CLX_ALGO_WINOGRAD / _WINOGRAD4 (no FLOPs) */
+  CLX_PROF_GEMM_SP2 = 16     /* gemm_sp2_kernel: the split-precision product on 128 x 128 tiles, two workgroups per CU (K <= 1024) */
 };
 int clx_profile_enable(int on);
 int clx_profile_read(int kind, double* launches, double* total_ms, double* total_flops);

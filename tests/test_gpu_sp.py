@@ -52,12 +52,17 @@ def test_planes_are_an_exact_split(rows, K, ld):
     assert np.all(h.transpose(0, 4, 1, 2, 3, 5).reshape(-1, K // 16 * 48)[rows:] == 0)
 
 
-@pytest.mark.parametrize("mfma", ["32", "16"])
+@pytest.mark.parametrize("kernel", ["tile256", "tile128", "mfma16"])
 @pytest.mark.parametrize("M,N,K,relu", [(256, 128, 128, 0), (1000, 256, 256, 1), (70000, 256, 768, 1), (257, 768, 2304, 0)])
-def test_product_from_planes_against_float64(M, N, K, relu, mfma, monkeypatch):
-    """mfma: the kernel on v_mfma_f32_32x32x16_bf16 (the default) and the opt-in one on 16x16x32 (CLX_SP_MFMA=16, read per
-    launch): the same products, the same bars"""
-    monkeypatch.setenv("CLX_SP_MFMA", mfma)
+def test_product_from_planes_against_float64(M, N, K, relu, kernel, monkeypatch):
+    """The three forward kernels on every shape (the library picks by K; the switches are read per launch): 256 x 128 tiles,
+    one workgroup per CU (gemm_sp_kernel<0>: K > 1024); 128 x 128 tiles, two per CU (gemm_sp2_kernel: K <= 1024); the opt-in
+    one on v_mfma_f32_16x16x32_bf16 (CLX_SP_MFMA=16): the same products, the same bars"""
+    if kernel == "mfma16":
+        monkeypatch.setenv("CLX_SP_MFMA", "16")
+    else:
+        monkeypatch.delenv("CLX_SP_MFMA", raising=False)
+        monkeypatch.setenv("CLX_SP_TILE", kernel[4:])
     _clx, lib = _lib()
     dev = torch.device("cuda:0")
     torch.manual_seed(M + K)

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 from bench_infer import embed_stage  # noqa: E402
 from cellulus_amd.models import get_model  # noqa: E402
 
-MFMA = ("conv_igemm_kernel", "conv_wgrad_kernel", "gemm_sp_kernel", "chain64_", "wino_fused_kernel", "wino_pre_kernel")
+MFMA = ("conv_igemm_kernel", "conv_wgrad_kernel", "gemm_sp_kernel", "gemm_sp2_kernel", "chain64_", "wino_fused_kernel", "wino_pre_kernel")
 trace_us = 0.0
 for line in open(sys.argv[1]):
     m = re.match(r"^(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
