@@ -828,8 +828,17 @@ __global__ __launch_bounds__(256, 2) void gemm_sp2_kernel(const SpP p) {
     if constexpr (TAIL == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // the fragment reads in front of the LDS-DMA requests: a wave's ds_reads behind its own global_load_lds return late
+    // (gemm_sp16_kernel's stamps), and with a second workgroup on the CU the requests' lead matters less than in
+    // gemm_sp_kernel<0> (-DSP2_DMA_FIRST, the other order: -1 ... -7 % on the benchmark shapes)
+#ifdef SP2_DMA_FIRST
     if constexpr (TAIL == 0) issue(t + 2, slot == 0 ? 2 : slot - 1);
     read_frags(slot);
+#else
+    read_frags(slot);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TAIL == 0) issue(t + 2, slot == 0 ? 2 : slot - 1);
+#endif
     mfma_step(neg_tag);
     __builtin_amdgcn_sched_barrier(0);
   };
