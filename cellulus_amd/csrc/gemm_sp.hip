@@ -581,17 +581,26 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
       else mfma_row(I1{}, neg_tag);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // (-DSP_READS_FIRST: the fragment reads in front of the LDS-DMA requests.  In gemm_sp16_kernel a wave's ds_reads behind
-    //  its own global_load_lds wait 1000-1800 cycles and the order matters a lot; here the requests' lead is worth more:
-    //  reads first measured -2 ... -4 % on the eight benchmark shapes)
-#ifdef SP_READS_FIRST
-    read_frags(S);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
+    // Which goes first behind the barrier, this step's fragment reads or the LDS-DMA requests of step t + 3?  A wave's
+    // ds_reads BEHIND its own global_load_lds return 1000-1800 cycles later than in front of them (gemm_sp16_kernel's stamps).
+    // The weight gradient (24 transposing reads per step) gains 25-27 % from reading first (132 -> 168 and 176 -> 220 TFLOP/s
+    // on the benchmark's 1x1 layers); the forward product, whose requests' lead is worth more than its 12 plain reads,
+    // loses 2-4 % (-DSP_READS_FIRST / -DSP_DMA_FIRST force one order for both)
+#if defined(SP_READS_FIRST)
+    constexpr bool READS_FIRST = true;
+#elif defined(SP_DMA_FIRST)
+    constexpr bool READS_FIRST = false;
 #else
-    if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
-    read_frags(S);
+    constexpr bool READS_FIRST = MODE == 1;
 #endif
+    if constexpr (READS_FIRST) {
+      read_frags(S);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
+    } else {
+      if constexpr (KIND == 0 || KIND == 1) issue(t0 + S + 3, (S + 3) & 3, ((S + 3) & 1) != 0);
+      read_frags(S);
+    }
 #ifdef SP_FENCE_READS
     __builtin_amdgcn_sched_barrier(0);
 #endif
