@@ -593,6 +593,7 @@ __global__ __launch_bounds__(512, 1) void gemm_sp_kernel(const SpP p) {
 #else
     constexpr bool READS_FIRST = MODE == 1;
 #endif
+    // (the requests BEHIND the first row of products instead: -1 ... -4 % in both modes)
     if constexpr (READS_FIRST) {
       read_frags(S);
       __builtin_amdgcn_sched_barrier(0);
@@ -789,16 +790,19 @@ __global__ __launch_bounds__(256, 2) void gemm_sp2_kernel(const SpP p) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) fa[1][q] = *reinterpret_cast<const u32x4*>(as + (3 + q) * FRAG);
   };
-  auto mfma_step = [&](auto neg_tag) __attribute__((always_inline)) {
+  auto mfma_step = [&](auto neg_tag, auto row_tag) __attribute__((always_inline)) {
     constexpr bool NEG = decltype(neg_tag)::value;
+    constexpr int ROW = decltype(row_tag)::value;             // -1: both rows of tiles
     if constexpr (NEG) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
+        if (ROW < 0 || ROW == i)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) fa[i][q] ^= 0x80008000u;
+          for (int q = 0; q < 3; ++q) fa[i][q] ^= 0x80008000u;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
+      if (ROW < 0 || ROW == i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         f32x16 c = acc[i][j];
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(256, 2) void gemm_sp2_kernel(const SpP p) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (TAIL == 0) issue(t + 2, slot == 0 ? 2 : slot - 1);
 #endif
-    mfma_step(neg_tag);
+    mfma_step(neg_tag, std::integral_constant<int, -1>{});
     __builtin_amdgcn_sched_barrier(0);
   };
   using T0 = std::integral_constant<int, 0>;
