@@ -1,7 +1,7 @@
 // Split-precision products: float32 GEMMs on the bf16 matrix cores, fed from PRE-SPLIT operand planes.
 //
 // gfx950 has no TF32 and its f32 MFMA peak (157 TFLOP/s) is 1/16 of the bf16 one.  Every f32 operand element is split
-// EXACTLY into three bf16 pieces x = h0 + h1 + h2 (8 + 8 + 8 significand bits, by truncation) and the six products
+// EXACTLY into three bf16 pieces x = h0 + h1 + h2 (8 + 8 + 8 significand bits, each piece rounded to nearest) and the six products
 // a_i b_j with i + j <= 2 are accumulated in the f32 accumulators of v_mfma_f32_32x32x16_bf16: each product is exact, the
 // dropped terms (a1 b2, a2 b1, a2 b2) are <= 2^-24 relative — the size of one f32 rounding.  Peak of this form: bf16 MFMA /
 // 6 = 419 TFLOP/s f32-equivalent.
@@ -25,6 +25,10 @@
 // accumulator with a floor-like truncation (a bias of ~1e-7 of the output's rms with the same sign everywhere, which
 // is common-mode over the 5e5 pixels a weight gradient sums over; docs/HISTORY.md 6b), and -(A B) carries the same
 // expected bias as +(A B), so the difference of the two kinds of period has none.
+//
+// Three forward / data-gradient kernels share the format, the arithmetic and the epilogue: gemm_sp_kernel<0> (this one: K >
+// 1024), gemm_sp2_kernel (128 x 128 tiles, two workgroups per CU: the default up to K = 1024, i.e. every product of the
+// benchmark networks) and gemm_sp16_kernel (v_mfma_f32_16x16x32_bf16, opt-in); gemm_sp_kernel<1> is the weight gradient.
 //
 // Replaces nn.Conv{2,3}d 1x1 (+ReLU) and the transform-domain products of the 3x3 layers, forward and data gradient
 // (cellulus/models/unet.py:24-63, cellulus/train.py:178) when clx_conv_desc.precision = CLX_PREC_F32X3BF16.
