@@ -1354,7 +1354,9 @@ int clx_sp_launch(const void* A, const void* B, int M, int N, int K, long long r
   // (measured against gemm_sp_kernel<0>: K = 256 +8 ... +22 %, K = 768 0 ... +6 %, K = 2304 -4 %)
   const char* const tile_env = getenv("CLX_SP_TILE");
   const int tile_choice = tile_env != nullptr ? atoi(tile_env) : 0;
-  const bool small_tiles = tile_choice == 128 || (tile_choice != 256 && K <= 1024);
+  const char* const maxk_env = getenv("CLX_SP_TILE_MAXK");           // (the rule's threshold, for measurements)
+  const int maxk = maxk_env != nullptr ? atoi(maxk_env) : 1024;
+  const bool small_tiles = tile_choice == 128 || (tile_choice != 256 && K <= maxk);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (clx_prof_enabled()) clx_prof_events(small_tiles ? CLX_PROF_GEMM_SP2 : CLX_PROF_GEMM_SP, 2.0 * M * N * K * batch, &e0, &e1);
   // CLX_SP_MFMA=16: the 16 x 16 x 32 form of the kernel (gemm_sp16_kernel: faster from K ~ 2000 on, slower on the contraction
